@@ -1,0 +1,364 @@
+"""Pins the CPU oracle: (1) the reference's exact known answers (test/test_aux.jl:3-117),
+(2) the reference's own C clients compiled from where they lie (only when /root/reference
+exists), (3) independent numpy / scipy / LAPACK restatements, (4) the committed golden
+vectors under tests/golden/."""
+import json
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+# ---- (1) exact known answers of test/test_aux.jl -------------------------------------
+
+def test_sym_givens_known_answers(oracle):
+    g = oracle.sym_givens
+    assert g(0.0, 0.0) == (1.0, 0.0, 0.0)
+    a = 3.14
+    assert g(a, 0.0) == (1.0, 0.0, a)
+    assert g(-a, 0.0) == (-1.0, 0.0, a)
+    assert g(0.0, a) == (0.0, 1.0, a)
+    assert g(0.0, -a) == (0.0, -1.0, a)
+    for (x, y) in [(3.0, 4.0), (-4.0, 3.0), (1e-3, -7.0), (5.0, -1e-9)]:
+        c, s, r = g(x, y)
+        assert abs(c * x + s * y - r) <= 1e-15 * abs(r)
+        assert abs(s * x - c * y) <= 1e-15 * abs(r)
+        assert abs(c * c + s * s - 1) <= 4e-16
+
+
+def test_roots_quadratic_known_answers(oracle):
+    rq = oracle.roots_quadratic
+    assert rq(0.0, 0.0, 0.0) == (0.0, 0.0)
+    with pytest.raises(ValueError):
+        rq(0.0, 0.0, 1.0)
+    assert rq(0.0, 3.14, -1.0) == (1.0 / 3.14, 1.0 / 3.14)
+    with pytest.raises(ValueError):
+        rq(1.0, 0.0, 1.0)
+    assert rq(1.0, 0.0, 0.0) == (0.0, 0.0)
+    r = rq(1.0, 3.0, 2.0)
+    assert math.isclose(r[0], -2.0) and math.isclose(r[1], -1.0)
+    with pytest.raises(ValueError):
+        rq(1.0e8, 1.0, 1.0)
+    assert rq(-1.0e-8, 1.0e5, 1.0, nitref=0) == (1.0e13, 0.0)
+    assert rq(-1.0e-8, 1.0e5, 1.0, nitref=1) == (1.0e13, -1.0e-05)
+    for nit in (0, 1):
+        r = rq(-1.0e-7, 1.0, 1.0, nitref=nit)
+        assert math.isclose(r[0], 1.0e7, rel_tol=1e-6) and math.isclose(r[1], -1.0, rel_tol=1e-6)
+
+
+def test_to_boundary_known_answers(oracle):
+    n = 5
+    x = np.ones(n)
+    d = np.ones(n)
+    d[0:n:2] = -1
+    for bad in (-1.0, 0.5):
+        with pytest.raises(ValueError):
+            oracle.to_boundary(x, d, bad)
+    with pytest.raises(ValueError):
+        oracle.to_boundary(x, np.zeros(n), 1.0)
+    r = oracle.to_boundary(x, d, 5.0)
+    assert math.isclose(max(r), 2.209975124224178, rel_tol=1e-14)
+    assert math.isclose(min(r), -1.8099751242241782, rel_tol=1e-14)
+    r = oracle.to_boundary(x, d, 5.0, flip=True)
+    assert math.isclose(max(r), 1.8099751242241782, rel_tol=1e-14)
+    assert math.isclose(min(r), -2.209975124224178, rel_tol=1e-14)
+
+
+# ---- (2) the reference's own C clients ------------------------------------------------
+
+OUT_OF_SCOPE = ("MINRES", "Float32", "DQGMRES", "block_minres")
+
+
+@pytest.fixture(scope="module")
+def refbin():
+    if not os.path.isdir(os.path.join(REF, "interfaces")):
+        pytest.skip("reference tree absent (GPU box): _ref cannot be (re)built here")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all", "ref"])
+    return os.path.join(ROOT, "oracle", "_ref")
+
+
+def test_ref_basic_cg_example(refbin):
+    # interfaces/examples/C/basic_cg.c:13-15 : niter 3, x = ones
+    out = subprocess.run([os.path.join(refbin, "basic_cg")], capture_output=True, text=True)
+    assert out.returncode == 0
+    assert "Solved: yes" in out.stdout and "niter: 3" in out.stdout
+    assert "x = [ 1.00 1.00 1.00 1.00 1.00 ]" in out.stdout
+
+
+def test_ref_test_api_client(refbin):
+    out = subprocess.run([os.path.join(refbin, "test_api")], capture_output=True, text=True)
+    fails = [l for l in out.stdout.splitlines() if "FAIL" in l]
+    bad = [l for l in fails if not any(k in l for k in OUT_OF_SCOPE)]
+    assert not bad, bad
+    assert len(fails) == 5          # 2 MINRES + 3 Float32 checks: out-of-scope solvers / dtypes
+    assert "36 checks passed" in out.stdout
+
+
+def test_ref_test_all_solvers_client(refbin):
+    out = subprocess.run([os.path.join(refbin, "test_all_solvers")], capture_output=True, text=True)
+    lines = {l.split()[0]: l for l in out.stdout.splitlines() if "..." in l}
+    for s in ("cg", "gmres", "bicgstab"):
+        assert "PASS" in lines[s], lines[s]
+    others = [k for k, l in lines.items() if "PASS" not in l]
+    assert all("returned -2" in lines[k] for k in others)   # unknown (solver,dtype) pair
+
+
+def test_ref_test_block_client(refbin):
+    out = subprocess.run([os.path.join(refbin, "test_block")], capture_output=True, text=True)
+    sections, cur = {}, None
+    for l in out.stdout.splitlines():
+        if l.endswith("..."):
+            cur = l
+            sections[cur] = []
+        elif "FAIL" in l:
+            sections[cur].append(l)
+    for name, fails in sections.items():
+        if "block_minres" in name:
+            continue
+        assert not fails, (name, fails)
+    ex = subprocess.run([os.path.join(refbin, "block_gmres_example")], capture_output=True, text=True)
+    assert "Block solved: yes" in ex.stdout
+
+
+# ---- (3) independent restatements ------------------------------------------------------
+
+def _julia_get_div_grad(n1, n2, n3):
+    """test/get_div_grad.jl:8-25 restated with scipy.sparse.kron (independent of the C stencil code)."""
+    import scipy.sparse as sp
+
+    def ddx(n):
+        e = np.ones(n)
+        return sp.csr_matrix((np.r_[-e, e], (np.r_[0:n, 0:n], np.r_[0:n, 1:n + 1])), shape=(n, n + 1))
+    eye = sp.identity
+    D1 = sp.kron(eye(n3), sp.kron(eye(n2), ddx(n1)))
+    D2 = sp.kron(eye(n3), sp.kron(ddx(n2), eye(n1)))
+    D3 = sp.kron(ddx(n3), sp.kron(eye(n2), eye(n1)))
+    Div = sp.hstack([D1, D2, D3]).tocsr()
+    return (Div @ Div.T).tocsr()
+
+
+def _julia_kron_unsymmetric(n):
+    """test/test_utils.jl:160-169."""
+    import scipy.sparse as sp
+    A = sp.diags([-np.ones(n - 1), 3.0 * np.ones(n), -2.0 * np.ones(n - 1)], [-1, 0, 1]).tocsr()
+    Id = sp.identity(n)
+    A = sp.kron(A, Id) + sp.kron(Id, A)
+    A = sp.kron(A, Id) + sp.kron(Id, A)
+    return A.tocsr()
+
+
+@pytest.mark.parametrize("dims", [(2, 2, 2), (4, 4, 4), (3, 5, 4), (6, 6, 6)])
+def test_poisson_generator_matches_julia_construction(oracle, dims):
+    A = oracle.poisson3d(*dims)
+    ref = _julia_get_div_grad(*dims)
+    ref.eliminate_zeros()
+    ref.sort_indices()
+    S = A.to_scipy()
+    assert A.nnz == ref.nnz
+    assert (S != ref).nnz == 0
+    n1 = dims[0]
+    if dims[0] == dims[1] == dims[2]:
+        assert A.nnz == 7 * n1 ** 3 - 6 * n1 ** 2
+
+
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_kron_unsymmetric_generator_matches_julia_construction(oracle, n):
+    A = oracle.kron_unsymmetric(n)
+    ref = _julia_kron_unsymmetric(n)
+    ref.sort_indices()
+    assert (A.to_scipy() != ref).nnz == 0
+
+
+def test_spmv_and_blas1_against_numpy(oracle):
+    rng = np.random.default_rng(7)
+    A = oracle.poisson3d(9)
+    x = rng.standard_normal(A.n)
+    y = A.matvec(x)
+    assert np.allclose(y, A.to_scipy() @ x, rtol=0, atol=1e-13)
+    a, b = rng.standard_normal(1000), rng.standard_normal(1000)
+    exact = math.fsum(a * b)   # products rounded, sum exact: differs from the long-double dot by O(eps)
+    assert abs(oracle.dot(a, b) - exact) <= 1e-13 * np.abs(a * b).sum()
+    assert math.isclose(oracle.nrm2(a), float(np.linalg.norm(a)), rel_tol=1e-14)
+    y0 = b.copy()
+    oracle.axpy(0.3, a, y0)
+    assert np.allclose(y0, b + 0.3 * a, rtol=1e-15, atol=1e-15)
+    y0 = b.copy()
+    oracle.axpby(0.3, a, -1.7, y0)
+    assert np.allclose(y0, 0.3 * a - 1.7 * b, rtol=1e-15, atol=1e-15)
+
+
+def _numpy_cg(A, b, atol, rtol, itmax):
+    """Independent numpy restatement of src/cg.jl:153-268 (M = I, radius = 0)."""
+    n = b.size
+    x = np.zeros(n)
+    r = b.copy()
+    p = r.copy()
+    gamma = float(r @ r)
+    hist = [math.sqrt(gamma)]
+    eps_tol = atol + rtol * hist[0]
+    it = 0
+    solved = hist[0] <= eps_tol
+    while not (solved or it >= itmax):
+        Ap = A @ p
+        alpha = gamma / float(p @ Ap)
+        x += alpha * p
+        r -= alpha * Ap
+        gn = float(r @ r)
+        hist.append(math.sqrt(gn))
+        solved = hist[-1] <= eps_tol
+        if not solved:
+            beta = gn / gamma
+            gamma = gn
+            p = r + beta * p
+        it += 1
+    return x, it, np.array(hist)
+
+
+@pytest.mark.parametrize("n1,expect", [(16, 38), (32, 78)])
+def test_cg_against_numpy_restatement(oracle, n1, expect):
+    A = oracle.poisson3d(n1)
+    b = np.ones(A.n)
+    res = oracle.cg(A, b, history=True)
+    x, it, hist = _numpy_cg(A.to_scipy(), b, math.sqrt(np.finfo(float).eps), math.sqrt(np.finfo(float).eps), 2 * A.n)
+    assert res.solved and res.status == "solution good enough given atol and rtol"
+    assert res.niter == it == expect            # SURVEY section 8c session values
+    assert np.allclose(res.residuals, hist, rtol=1e-9)
+    assert np.linalg.norm(b - A.to_scipy() @ res.x) / np.linalg.norm(b) <= 1e-6   # test/test_cg.jl:22-28
+
+
+def test_cg_benchmark_tolerances(oracle):
+    # benchmark/benchmarks.jl:14-21 : atol=0, rtol=1e-8, itmax=n ; SURVEY 8c: 39 / 79 iterations
+    for n1, expect in ((16, 39), (32, 79)):
+        A = oracle.poisson3d(n1)
+        res = oracle.cg(A, np.ones(A.n), atol=0.0, rtol=1e-8, itmax=A.n)
+        assert res.niter == expect and res.solved
+
+
+def test_cg_edge_cases(oracle):
+    A = oracle.tridiag(10, -1.0, 4.0, -1.0)                         # symmetric_definite, test_utils.jl:18-23
+    b = A.matvec(np.arange(1.0, 11.0))
+    res = oracle.cg(A, b, itmax=10)
+    assert res.solved and np.linalg.norm(b - A.matvec(res.x)) / np.linalg.norm(b) <= 1e-6
+    res = oracle.cg(A, np.zeros(10))                                 # test/test_cg.jl zero rhs
+    assert res.niter == 0 and res.status == "x is a zero-residual solution" and np.all(res.x == 0)
+    res = oracle.cg(A, b, itmax=2)
+    assert (not res.solved) and res.status == "maximum number of iterations exceeded" and res.niter == 2
+    # warm start from the solution: zero iterations needed beyond tolerance check
+    x_star = oracle.cg(A, b, atol=1e-14, rtol=1e-14).x
+    res = oracle.cg(A, b, x0=x_star)
+    assert res.solved and res.niter <= 1
+    # negative-definite operator: linesearch flags nonpositive curvature at iteration 0
+    Aneg = oracle.tridiag(10, 1.0, -4.0, 1.0)
+    res = oracle.cg(Aneg, b, linesearch=True)
+    assert res.niter == 0 and res.indefinite and res.npcCount == 1 and res.status == "nonpositive curvature"
+    # trust region: lands on the boundary
+    res = oracle.cg(A, b, radius=1.0)
+    assert res.status == "on trust-region boundary" and math.isclose(np.linalg.norm(res.x), 1.0, rel_tol=1e-10)
+
+
+def test_gmres_against_scipy_and_flags(oracle):
+    import scipy.sparse.linalg as spla
+    A = oracle.kron_unsymmetric(8)
+    S = A.to_scipy()
+    b = S @ np.ones(A.n)
+    for kw in ({}, {"restart": True}, {"restart": True, "reorthogonalization": True}):
+        res = oracle.gmres(A, b, memory=10, history=True, **kw)
+        assert res.solved, kw
+        assert np.linalg.norm(b - S @ res.x) / np.linalg.norm(b) <= 1e-6
+        assert res.niter > 10
+        assert np.all(np.diff(res.residuals) <= 1e-12)               # GMRES residual estimates are monotone
+    # Jacobi preconditioners as callables (test/test_gmres.jl:105-128)
+    d = S.diagonal()
+    res = oracle.gmres(A, b, M=lambda v: v / d, memory=10)
+    assert res.solved and np.linalg.norm(b - S @ res.x) / np.linalg.norm(b) <= 1e-6
+    res = oracle.gmres(A, b, N=lambda v: v / d, memory=10, restart=True)
+    assert res.solved and np.linalg.norm(b - S @ res.x) / np.linalg.norm(b) <= 1e-6
+    res = oracle.gmres(A, np.zeros(A.n))
+    assert res.niter == 0 and res.status == "x is a zero-residual solution"
+    # full GMRES residual estimate equals the true residual norm of scipy's least-squares iterate
+    res = oracle.gmres(A, b, memory=20, atol=1e-10, rtol=1e-10, history=True)
+    xs, info = spla.gmres(S, b, rtol=1e-10, atol=1e-10, restart=A.n)
+    assert info == 0 and np.allclose(res.x, xs, atol=1e-7)
+
+
+def test_bicgstab_flags(oracle):
+    A = oracle.kron_unsymmetric(8)
+    S = A.to_scipy()
+    b = S @ np.ones(A.n)
+    res = oracle.bicgstab(A, b, history=True)
+    assert res.solved and np.linalg.norm(b - S @ res.x) / np.linalg.norm(b) <= 1e-6
+    assert len(res.residuals) == res.niter + 1
+    res = oracle.bicgstab(A, np.zeros(A.n))
+    assert res.niter == 0 and res.status == "x is a zero-residual solution"
+    c = np.zeros(A.n)
+    res = oracle.bicgstab(A, b, c=c)
+    assert res.status == "Breakdown bᴴc = 0" and not res.solved
+    d = S.diagonal()
+    res = oracle.bicgstab(A, b, M=lambda v: v / d, N=lambda v: v.copy())
+    assert res.solved and np.linalg.norm(b - S @ res.x) / np.linalg.norm(b) <= 1e-6
+
+
+def test_householder_against_lapack(oracle):
+    import ctypes as C
+    from scipy.linalg import lapack
+    rng = np.random.default_rng(3)
+    L = oracle.lib()
+    for (m, k) in [(40, 6), (32, 16), (7, 7)]:
+        A = np.asfortranarray(rng.standard_normal((m, k)))
+        Q = A.copy(order="F")
+        R = np.zeros((k, k), order="F")
+        tau = np.zeros(k)
+        L.ko_householder(m, k, oracle._dp(Q), oracle._dp(R), oracle._dp(tau), 0)
+        qr, tau_l, _, info = lapack.dgeqrf(A)
+        assert info == 0
+        assert np.allclose(tau, tau_l, rtol=1e-13, atol=1e-15)
+        assert np.allclose(R, np.triu(qr[:k, :]), rtol=1e-12, atol=1e-13)
+        q_l, _, info = lapack.dorgqr(qr, tau_l)
+        assert np.allclose(Q, q_l, rtol=1e-12, atol=1e-13)
+        assert np.allclose(Q @ R, A, atol=1e-12) and np.allclose(Q.T @ Q, np.eye(k), atol=1e-13)
+        # ormqr side L trans T
+        Cm = np.asfortranarray(rng.standard_normal((m, 3)))
+        C1 = Cm.copy(order="F")
+        qrc = np.asfortranarray(qr)
+        L.ko_ormqr_LT(m, 3, k, oracle._dp(qrc), m, oracle._dp(tau_l), oracle._dp(C1), m)
+        c_l, _, info = lapack.dormqr("L", "T", qr, tau_l, Cm, max(1, 3 * 64))
+        assert np.allclose(C1, c_l, rtol=1e-12, atol=1e-13)
+
+
+def test_block_gmres_oracle(oracle):
+    # interfaces/test/C/test_block.c:62-70 style right-hand sides: B = A * X_true, X_true[i,j] = ((i+1)/n)^j
+    A = oracle.kron_unsymmetric(6)
+    S = A.to_scipy()
+    n, p = A.n, 4
+    Xt = np.stack([((np.arange(n) + 1.0) / n) ** j for j in range(p)], axis=1)
+    B = S @ Xt
+    for kw in ({}, {"restart": True}, {"reorthogonalization": True}):
+        res = oracle.block_gmres(A, B, memory=8, history=True, **kw)
+        assert res.solved, kw
+        assert np.linalg.norm(B - S @ res.x) / np.linalg.norm(B) <= 1e-6
+        assert math.isclose(res.residuals[0], np.linalg.norm(B), rel_tol=1e-13)
+
+
+# ---- (4) committed golden vectors ------------------------------------------------------
+
+def test_golden_vectors(oracle):
+    path = os.path.join(GOLD, "oracle_histories.json")
+    if not os.path.exists(path):
+        pytest.skip("golden vectors not generated yet")
+    gold = json.load(open(path))
+    for case in gold["cases"]:
+        A = getattr(oracle, case["matrix"])(case["n1"])
+        if case["rhs"] == "ones":
+            b = np.ones(A.n)
+        else:
+            b = A.matvec(np.ones(A.n))
+        res = getattr(oracle, case["solver"])(A, b, history=True, **case["kwargs"])
+        assert res.niter == case["niter"], case["name"]
+        assert res.status == case["status"]
+        assert np.allclose(res.residuals, np.array(case["residuals"]), rtol=1e-12, atol=0), case["name"]
