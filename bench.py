@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/second (+ achieved HBM GB/s) on the 3-D Poisson 7-point CSR operator.
+
+Workload (BASELINE.json configs[1]): cg! on get_div_grad(512,512,512) (n = 134,217,728, nnz = 937,951,232),
+Float64, b = ones, x0 = 0.  A "step" is one CG iteration (1 SpMV + 2 dots + 2 axpy + 1 axpby, fused into
+3 kernels).  With --gpus N the SAME 512^3 problem is row-partitioned over N ranks (strong scaling, one
+process per GPU, RCCL over xGMI inside libkrylov_hip: all-gather of the (hi, lo) dot partials, neighbour
+halo exchange before each SpMV).  Inputs are generated on the device, so the timed region starts with
+everything resident in HBM.
+
+Prints ONE JSON line on rank 0 (stdout); diagnostics go to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(n1, budget_s=30.0):
+    """Oracle CG loop (the reference's cg! recurrence, src/cg.jl:195-268) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ctypes as C
+    import oracle as ok
+    ncores = os.cpu_count() or 1
+    try:
+        avail_gb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) / 1e6
+    except Exception:
+        avail_gb = 0.0
+    sample_n1 = n1
+    need_gb = 17.0 * (n1 / 512.0) ** 3 * 1.3
+    if avail_gb < need_gb or ncores < 16:
+        sample_n1 = 256 if n1 > 256 else n1     # bounded sample when the host is small
+    t0 = time.time()
+    ok.lib().ko_set_threads(ncores)
+    A = ok.poisson3d(sample_n1)
+    t_gen = time.time() - t0
+    r = C.c_double()
+    iters_all = 3 if sample_n1 >= 512 else 10
+    spi_all = ok.lib().ko_cg_bench(C.byref(A.c), iters_all, ncores, C.byref(r))
+    spi_one = None
+    if time.time() - t0 < budget_s:
+        spi_one = ok.lib().ko_cg_bench(C.byref(A.c), 1 if sample_n1 >= 512 else 3, 1, C.byref(r))
+    best, cores = (spi_all, ncores)
+    if spi_one is not None and spi_one < spi_all:
+        best, cores = spi_one, 1
+    sample = (f"{iters_all} CG iterations of the oracle loop on get_div_grad({sample_n1}^3), OpenMP {ncores} threads: "
+              f"{1.0 / spi_all:.3f} it/s" + (f"; 1 thread (faithful serial SpMV): {1.0 / spi_one:.3f} it/s" if spi_one else "")
+              + f"; matrix generation {t_gen:.1f} s excluded")
+    return {"value": 1.0 / best, "unit": "iter/s", "cores": cores, "kind": "port", "sample": sample,
+            "sample_n1": sample_n1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n1", type=int, default=512, help="grid size per dimension (default: cfg 2, 512^3)")
+    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (khip_ctx_set_option)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch                      # torch FIRST: one shared HIP runtime in the process
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+    import numpy as np
+    import krylov_jl_amd as K
+
+    ctx = K.Context(local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    if world > 1:
+        uid = [K.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, world, uid[0])
+
+    n1 = args.n1
+    n = n1 ** 3
+    starts = K.row_partition(n, world)
+    r0, r1 = starts[rank], starts[rank + 1]
+    nloc = r1 - r0
+    t_setup = time.time()
+    A = K.CsrMatrix.stencil(ctx, "poisson", n1, rows=(r0, r1), distributed=(world > 1))
+    b = ctx.empty(nloc)
+    K.kfill_(b, 1.0)
+    ws = K.CgWorkspace(ctx, nloc, nloc)
+    ctx.sync()
+    log(f"[rank {rank}] setup {time.time() - t_setup:.2f} s, local rows {nloc}, nnz {A.nnz}")
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    # warm-up iterations (untimed)
+    if args.warmup > 0:
+        K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.warmup, fused=bool(args.fused))
+    ctx.set_option("profile_spmv", 1)
+    ctx.profile_spmv()
+    barrier()
+    t0 = time.perf_counter()
+    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.steps, history=True, fused=bool(args.fused))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = ws.stats
+    assert st.niter == args.steps, (st.niter, st.status)
+    launches, spmv_ms = ctx.profile_spmv()
+    ctx.set_option("profile_spmv", 0)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        its = args.steps / elapsed
+        spmv_bytes_local = A.spmv_bytes
+        # algorithmic bytes of one fused iteration on this rank: SpMV(+dot) + (x,r update + r.r: 48n) + (p update: 24n)
+        iter_bytes_local = spmv_bytes_local + 72 * nloc
+        iter_bytes_unfused_local = spmv_bytes_local + 104 * nloc       # as the reference issues it
+        spmv_per_iter = launches / max(args.steps, 1)
+        avg_spmv_ms = spmv_ms / max(args.steps, 1)                    # all SpMV launches of one iteration
+        spmv_gbps = spmv_bytes_local / (avg_spmv_ms * 1e-3) / 1e9 if avg_spmv_ms > 0 else 0.0
+        out = {
+            "metric": "cg_iters_per_sec_poisson3d_csr_512cubed",
+            "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"cg! on get_div_grad({n1},{n1},{n1}) CSR (cfg 2), b=ones, Float64, int32 indices",
+                       "n": n, "nnz_global": 7 * n - 6 * n1 * n1, "fused": bool(args.fused),
+                       "partition": f"1-D rows over {world} GPU(s)", "atol": 0.0, "rtol": 0.0},
+            "hbm_gbps_iteration": its * iter_bytes_local * world / 1e9,
+            "hbm_gbps_iteration_reference_sequence": its * iter_bytes_unfused_local * world / 1e9,
+            "final_residual_norm": float(st.residuals[-1]),
+            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel (CSR SpMV fused with p.Ap)",
+                         "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": None,
+                         "bytes_per_launch": spmv_bytes_local, "avg_ms": avg_spmv_ms,
+                         "launches_per_iteration": spmv_per_iter},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n1)
+            except Exception as e:          # never lose the GPU line to a host-side problem
+                out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

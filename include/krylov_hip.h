@@ -1,0 +1,273 @@
+/*
+ * krylov_hip.h -- C ABI of the MI355X-native Krylov inner-loop engine (libkrylov_hip.so).
+ *
+ * This is the drop-in boundary behind Krylov.jl's own extension contract
+ * (docs/src/custom_workspaces.md:107-300): a Julia device
+ * vector type forwards each `Krylov.k*` method to one entry point below with a
+ * `ccall`; INTEGRATION.md shows that glue.  Plain pointers and sizes only: every
+ * `double*` argument is a DEVICE pointer (gfx950 HBM) unless the name ends in
+ * `_host`.  Element type: Float64 real (T = FC = Float64), int32 column indices.
+ *
+ * Conventions (mirror docs/src/interfaces/reference.md:144-165): every function
+ * returns an int, 0 = success, < 0 = error; nothing is thrown across the ABI;
+ * khip_last_error() holds the message of the last failure on this thread.
+ * All calls on one khip_ctx must come from one host thread (the reference's C
+ * library has the same rule, reference.md:172).  Kernels run on the context's HIP
+ * stream; only the entry points that return a host scalar synchronise.
+ *
+ * "ref:" comments cite the reference interface each entry point replaces
+ * (paths relative to the Krylov.jl v0.10.8 tree).
+ */
+#ifndef KRYLOV_HIP_H
+#define KRYLOV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KHIP_OK               0
+#define KHIP_ERR_INVALID     -1   /* bad argument / inconsistent sizes (Julia error(...)) */
+#define KHIP_ERR_HIP         -2   /* a HIP runtime call failed */
+#define KHIP_ERR_UNSUPPORTED -3
+#define KHIP_ERR_COMM        -4   /* RCCL failure */
+#define KHIP_ERR_NUMERIC     -5   /* e.g. operator not SPD (src/cg.jl:163,243) */
+
+#define KHIP_VERSION_MAJOR 0
+#define KHIP_VERSION_MINOR 1
+
+typedef struct khip_ctx khip_ctx;   /* device + stream + scratch + (optional) communicator */
+typedef struct khip_csr khip_csr;   /* CSR operator resident in HBM */
+
+const char *khip_last_error(void);
+void        khip_version(int *major, int *minor);
+
+/* ---------------------------------------------------------------- context ---- */
+/* stream: a hipStream_t to borrow (e.g. the caller's current stream) or NULL to create one. */
+int   khip_ctx_create(int device, void *stream, khip_ctx **out);
+int   khip_ctx_destroy(khip_ctx *ctx);
+int   khip_ctx_sync(khip_ctx *ctx);
+void *khip_ctx_stream(khip_ctx *ctx);
+/* tuning / behaviour knobs, see DESIGN.md ("spmv_rows", "spmv_vec", "spmv_nt", "spmv_xcd",
+ * "compensated", "blas1_blocks", ...).  Unknown key -> KHIP_ERR_INVALID. */
+int   khip_ctx_set_option(khip_ctx *ctx, const char *key, int value);
+int   khip_ctx_get_option(khip_ctx *ctx, const char *key, int *value);
+
+/* ------------------------------------------------ device buffers ------------- */
+/* ref: S(undef, n) / similar(x) in every workspace constructor
+ *      (src/krylov_workspaces.jl:269-285,1605-1623,2898-2918; allocate_if src/krylov_utils.jl:281-299) */
+int khip_malloc(khip_ctx *ctx, size_t bytes, void **dptr);
+int khip_free(khip_ctx *ctx, void *dptr);
+int khip_memcpy_h2d(khip_ctx *ctx, void *dst, const void *src_host, size_t bytes);
+int khip_memcpy_d2h(khip_ctx *ctx, void *dst_host, const void *src, size_t bytes);
+int khip_memcpy_d2d(khip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int khip_mem_info(khip_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+
+/* ------------------------------------------------ CSR operator --------------- */
+/* ref: the sparse matrix handed to kmul!(y, A, x) = mul!(y, A, x) (src/krylov_utils.jl:305);
+ *      on the existing GPU path a ROCSparseMatrixCSR (docs/src/gpu.md:165-225).
+ * rowptr has m+1 entries of `rowptr_bits` (32 or 64) bits, col/val have nnz entries;
+ * index_base is 0 or 1 (Julia arrays are 1-based).  The arrays are COPIED (from host when
+ * on_device == 0, from device otherwise); the handle owns its HBM copy.  nnz of one handle
+ * must be < 2^31 (one GPU's shard; SURVEY.md section 7 "int32 limits"). */
+int khip_csr_create(khip_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const void *rowptr,
+                    int rowptr_bits, const int32_t *col, const double *val, int index_base,
+                    int on_device, khip_csr **out);
+/* Distributed form (ref recipe docs/src/custom_workspaces.md:477-586):
+ * this rank owns global rows [row0, row0+m) of an n_global-square operator; col[] holds
+ * GLOBAL indices.  Requires khip_comm_init on ctx.  Builds the halo plan (needed remote
+ * columns, send lists) and remaps columns to [owned | ghost] numbering. */
+int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t m, int64_t nnz,
+                         const void *rowptr, int rowptr_bits, const int32_t *col,
+                         const double *val, int index_base, int on_device, khip_csr **out);
+int khip_csr_destroy(khip_csr *A);
+int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
+/* device-side generators of the benchmark operators (rows [row0, row0+m) of the global matrix,
+ * global columns; ref: test/get_div_grad.jl:8-25, test/test_utils.jl:160-169).
+ * kind: 0 = get_div_grad(n1,n2,n3) 7-pt Poisson, 1 = kron_unsymmetric(n1), 2 = 27-pt cfg-5 operator.
+ * Outputs are device arrays owned by the caller (khip_free): rowptr int32[m+1] (local, 0-based),
+ * col int32[nnz] (global, 0-based), val double[nnz]. */
+int khip_gen_stencil(khip_ctx *ctx, int kind, int n1, int n2, int n3, int64_t row0, int64_t m,
+                     int32_t **rowptr_dev, int32_t **col_dev, double **val_dev, int64_t *nnz);
+
+/* y <- A x.  ref: kmul!(y, A, x) src/krylov_utils.jl:305; sites src/cg.jl:155,196,
+ * src/gmres.jl:159,222,257, src/bicgstab.jl:160,221,228.  For a distributed handle x and y are
+ * the owned slices; the halo exchange happens inside. */
+int khip_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y);
+/* Y <- A X for row-major n-by-p panels (ld = p).  ref: mul!(W, A, P) src/block_gmres.jl:242. */
+int khip_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
+/* algorithmic HBM bytes of one khip_spmv on this handle: 12 nnz + 4 (m+1) + 8 n + 8 m */
+int khip_spmv_bytes(const khip_csr *A, int64_t *bytes);
+
+/* Profiling hook used by bench.py's roofline leg: with khip_ctx_set_option(ctx, "profile_spmv", 1)
+ * every SpMV kernel launch is bracketed by HIP events on the context's stream; this call
+ * synchronises, returns the number of launches recorded since the last call and their summed
+ * duration, and resets the counters. */
+int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms);
+
+/* ------------------------------------------------ BLAS-1 shim ---------------- */
+/* ref: src/krylov_utils.jl:309-349.  x and y may alias exactly (BLAS semantics). */
+int khip_dot(khip_ctx *ctx, int64_t n, const double *x, const double *y, double *result_host);      /* kdot  :309-311 (kdotr :313-314) */
+int khip_nrm2(khip_ctx *ctx, int64_t n, const double *x, double *result_host);                      /* knorm :316-317 */
+int khip_scal(khip_ctx *ctx, int64_t n, double s, double *x);                                       /* kscal! :321-323 */
+int khip_div(khip_ctx *ctx, int64_t n, double *x, double s);                                        /* kdiv!  :325-326 (= scal by 1/s) */
+int khip_copy(khip_ctx *ctx, int64_t n, double *y, const double *x);                                /* kcopy! :328-329, (dest, src) */
+int khip_scalcopy(khip_ctx *ctx, int64_t n, double *y, double s, const double *x);                  /* kscalcopy! :331-332 */
+int khip_divcopy(khip_ctx *ctx, int64_t n, double *y, const double *x, double s);                   /* kdivcopy!  :334-335 */
+int khip_axpy(khip_ctx *ctx, int64_t n, double s, const double *x, double *y);                      /* kaxpy!  :337-339 */
+int khip_axpby(khip_ctx *ctx, int64_t n, double s, const double *x, double t, double *y);           /* kaxpby! :341-345 */
+int khip_fill(khip_ctx *ctx, int64_t n, double *x, double val);                                     /* kfill!  :347 */
+int khip_ref(khip_ctx *ctx, int64_t n, double *x, double *y, double c, double s);                   /* kref!   :349 */
+
+/* ------------------------------------------------ fused accelerators --------- */
+/* Each equals its unfused sequence on the device up to the last bit of the reduction
+ * (elementwise results are bit-identical; reductions agree to <= 1 ulp). */
+/* y <- A x ; *result_host = x . y           (src/cg.jl:196-197) */
+int khip_spmv_dot(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, double *result_host);
+/* x <- x + a p ; r <- r - a q ; *result_host = r . r     (src/cg.jl:239-242 with M = I) */
+int khip_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const double *q,
+                   double *x, double *r, double *result_host);
+/* w <- x + b y  written to w (w may alias x or y): copy + axpy in one pass (src/bicgstab.jl:224-225,232-233) */
+int khip_waxpy(khip_ctx *ctx, int64_t n, double *w, const double *x, double b, const double *y);
+/* result_host[0] = x . y ; result_host[1] = x . x      (src/bicgstab.jl:230) */
+int khip_dot2(khip_ctx *ctx, int64_t n, const double *x, const double *y, double *result_host);
+/* Modified Gram-Schmidt cascade against k basis vectors V[0..k) (device pointers in a HOST array),
+ * in the reference's order (src/gmres.jl:259-262): for i: h_i = V_i . q ; q <- q - h_i V_i.
+ * Runs k+1 dependent kernels with device-resident scalars and ONE host sync; h_host gets the k
+ * coefficients, *nrm_host = ||q|| afterwards (src/gmres.jl:274) when nrm_host != NULL.
+ * accumulate != 0 adds the coefficients into h_host instead (reorthogonalisation pass :265-271). */
+int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, double *q,
+             double *h_host, double *nrm_host, int accumulate);
+/* x <- x + sum_i y_i V_i, applied per element in the order i = 0..k-1 (bit-identical to k
+ * kaxpy! calls, src/gmres.jl:348-350) */
+int khip_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *y_host,
+                    const double *const *V_host, double *x);
+
+/* ------------------------------------------------ panel (block-GMRES) -------- */
+/* Panels are n-by-p ROW-MAJOR in HBM (p contiguous; DESIGN.md "panel layout").
+ * ref: mul!(R, V', Q) / mul!(Q, V, R, -1, 1) src/block_gmres.jl:244-247, householder!
+ * src/block_krylov_utils.jl:201-208, X += V*Y src/block_gmres.jl:324-326. */
+int khip_panel_from_colmajor(khip_ctx *ctx, int64_t n, int p, const double *X_colmajor, double *P);
+int khip_panel_to_colmajor(khip_ctx *ctx, int64_t n, int p, const double *P, double *X_colmajor);
+/* Psi_host (p-by-p, column-major, HOST) <- V^T Q */
+int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const double *Q, double *Psi_host);
+/* Q <- beta*Q + alpha * V * Psi  (Psi p-by-p column-major HOST) */
+int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const double *V,
+                       const double *Psi_host, double beta, double *Q);
+/* reduced QR of the panel: Q overwritten by an orthonormal basis, R_host (p-by-p col-major,
+ * upper triangular, positive... sign convention of Householder: see DESIGN.md) */
+int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host);
+int khip_panel_norm(khip_ctx *ctx, int64_t n, int p, const double *Q, double *result_host);
+
+/* ------------------------------------------------ multi-GPU ------------------- */
+/* One process per GPU.  unique_id is the 128-byte ncclUniqueId created by
+ * khip_comm_unique_id on rank 0 and broadcast by the launcher (torch.distributed / MPI). */
+int khip_comm_unique_id(void *id128_host);
+int khip_comm_init(khip_ctx *ctx, int rank, int nranks, const void *id128_host);
+int khip_comm_rank(khip_ctx *ctx, int *rank, int *nranks);
+int khip_comm_barrier(khip_ctx *ctx);
+
+/* Host-only helpers of the partition / halo logic (no GPU needed; used by khip_csr_create_dist and
+ * by the world_size-2 gloo tests).  ghost_columns: sorted unique columns of rows [row0, row0+m)
+ * that fall outside [row0, row0+m) (rowptr is int64, local, 0-based; col global).  halo_plan: given
+ * EVERY rank's sorted ghost list (concatenated, offsets ghost_off[nranks+1]) and the partition
+ * row_starts[nranks+1], derive for `rank` the per-peer receive segments of its own ghost list
+ * (recv_off) and the owned indices it must pack for each peer (send_idx, segments send_off). */
+int khip_ghost_columns_host(const int64_t *rowptr, const int32_t *col, int64_t m, int64_t row0,
+                            int32_t *out, int64_t cap, int64_t *count);
+int khip_halo_plan_host(int rank, int nranks, const int64_t *row_starts, const int32_t *ghost_all,
+                        const int64_t *ghost_off, int64_t *recv_off, int64_t *send_off,
+                        int32_t *send_idx, int64_t send_cap);
+
+/* ------------------------------------------------ solvers --------------------- */
+/* Host control flow of the reference's in-place methods, restated in C++ above the primitives
+ * (Julia is absent in this build environment; with Julia the unmodified src/cg.jl etc. drive the
+ * same primitives through the k* methods).  Operators: a khip_csr, or a user callback on device
+ * pointers (the mul!-based operator contract, docs/src/matrix_free.md:32-34). */
+typedef int (*khip_apply_fn)(void *self, const double *x, double *y);   /* y <- Op x, 0 on success */
+typedef struct {
+  const khip_csr *csr;       /* used when apply == NULL */
+  khip_apply_fn   apply;     /* user operator on device pointers */
+  void           *self;
+} khip_operator;
+
+typedef int (*khip_callback_fn)(void *workspace, void *userdata);       /* callback(workspace)::Bool */
+
+typedef struct {
+  double atol, rtol;          /* NaN -> sqrt(eps)                 (src/cg.jl:104-105) */
+  int    itmax;               /* 0 -> 2n (2*div(n,p) for block)   (src/cg.jl:177) */
+  double timemax;             /* NaN or <= 0 -> Inf */
+  int    history;             /* push residual norms             (src/cg.jl:165,245) */
+  double radius;              /* cg: trust-region radius          (src/cg.jl:215-237) */
+  int    linesearch;          /* cg                               (src/cg.jl:198-211) */
+  int    restart;             /* gmres / block_gmres              (src/gmres.jl:219-226) */
+  int    reorthogonalization; /* gmres / block_gmres              (src/gmres.jl:265-271) */
+  int    fused;               /* 0 = issue primitives exactly as the reference does; 1 = fused kernels */
+  khip_callback_fn callback; void *callback_data;
+} khip_options;
+
+typedef struct {              /* SimpleStats, src/krylov_stats.jl:24-44 */
+  int    niter, solved, inconsistent, indefinite, npcCount;
+  double timer;
+  char   status[96];
+  const double *residuals; int nres;
+  char   error[160];
+} khip_stats;
+
+khip_options khip_default_options(void);
+
+typedef struct khip_cg_workspace          khip_cg_workspace;           /* CgWorkspace       src/krylov_workspaces.jl:236-291 */
+typedef struct khip_gmres_workspace       khip_gmres_workspace;        /* GmresWorkspace    :2857-2924 */
+typedef struct khip_bicgstab_workspace    khip_bicgstab_workspace;     /* BicgstabWorkspace :1568-1629 */
+typedef struct khip_block_gmres_workspace khip_block_gmres_workspace;  /* BlockGmresWorkspace src/block_krylov_workspaces.jl:115-171 */
+
+int khip_cg_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_cg_workspace **out);
+int khip_cg_workspace_destroy(khip_cg_workspace *ws);
+int khip_cg_warm_start(khip_cg_workspace *ws, const double *x0);                   /* warm_start! src/workspace_accessors.jl:193-200 */
+/* cg!(ws, A, b; M, ...)  src/cg.jl:120-291.  M == NULL means M = I; otherwise z <- M r. */
+int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_operator *M,
+                  const double *b, const khip_options *opts);
+double           *khip_cg_solution(khip_cg_workspace *ws);                         /* solution(ws) === ws.x */
+const khip_stats *khip_cg_stats(khip_cg_workspace *ws);
+/* named work vectors for callbacks: "x","r","p","Ap","z","dx","npc_dir" */
+double           *khip_cg_vector(khip_cg_workspace *ws, const char *name);
+size_t            khip_cg_workspace_bytes(khip_cg_workspace *ws);                  /* storage test, test/test_allocations.jl:41-57 */
+
+int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory, khip_gmres_workspace **out);
+int khip_gmres_workspace_destroy(khip_gmres_workspace *ws);
+int khip_gmres_warm_start(khip_gmres_workspace *ws, const double *x0);
+/* gmres!(ws, A, b; M, N, restart, reorthogonalization, ...)  src/gmres.jl:121-384 */
+int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                     const khip_operator *N, const double *b, const khip_options *opts);
+double           *khip_gmres_solution(khip_gmres_workspace *ws);
+const khip_stats *khip_gmres_stats(khip_gmres_workspace *ws);
+size_t            khip_gmres_workspace_bytes(khip_gmres_workspace *ws);
+
+int khip_bicgstab_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_bicgstab_workspace **out);
+int khip_bicgstab_workspace_destroy(khip_bicgstab_workspace *ws);
+int khip_bicgstab_warm_start(khip_bicgstab_workspace *ws, const double *x0);
+/* bicgstab!(ws, A, b; c, M, N, ...)  src/bicgstab.jl:125-277 ; c == NULL -> c = b */
+int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, const khip_operator *M,
+                        const khip_operator *N, const double *b, const double *c,
+                        const khip_options *opts);
+double           *khip_bicgstab_solution(khip_bicgstab_workspace *ws);
+const khip_stats *khip_bicgstab_stats(khip_bicgstab_workspace *ws);
+size_t            khip_bicgstab_workspace_bytes(khip_bicgstab_workspace *ws);
+
+int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p, int memory,
+                                      khip_block_gmres_workspace **out);
+int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws);
+/* block_gmres!(ws, A, B; restart, reorthogonalization, ...) src/block_gmres.jl:110-358.
+ * B and the solution are n-by-p COLUMN-MAJOR device arrays (the reference layout); the
+ * workspace converts to row-major panels internally. */
+int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A,
+                           const double *B_colmajor, const khip_options *opts);
+int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor);
+const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRYLOV_HIP_H */

@@ -1,0 +1,795 @@
+"""krylov.jl_amd -- host-side mirror of Krylov.jl's workspace / solver / operator API over the
+MI355X-native C ABI (include/krylov_hip.h, libkrylov_hip.so).
+
+The directory name contains a dot, so import it through the repo-root shim::
+
+    import krylov_jl_amd as K
+
+Naming follows the reference with Python's trailing-underscore convention for Julia's `!`:
+`cg!` -> `cg_`, `kaxpy!` -> `kaxpy_`, ...  (src/krylov_utils.jl:305-349, src/cg.jl:120,
+src/gmres.jl:121, src/bicgstab.jl:125, src/block_gmres.jl:110).
+
+There is NO CPU fallback: every call goes to hand-written gfx950 kernels; loading fails loudly if
+the extension is missing and context creation fails loudly if no GPU is visible.
+
+PyTorch is optional plumbing.  If it is used in the same process (torch.distributed launchers),
+import torch BEFORE this package so that both share one HIP runtime (same SONAME libamdhip64.so.7).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkrylov_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_void_pp = C.POINTER(C.c_void_p)
+
+APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+CALLBACK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class KhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libkrylov_hip error {code}: {msg}")
+        self.code = code
+
+
+class COperator(C.Structure):
+    _fields_ = [("csr", C.c_void_p), ("apply", APPLY_FN), ("self", C.c_void_p)]
+
+
+class COptions(C.Structure):
+    _fields_ = [("atol", C.c_double), ("rtol", C.c_double), ("itmax", C.c_int), ("timemax", C.c_double),
+                ("history", C.c_int), ("radius", C.c_double), ("linesearch", C.c_int), ("restart", C.c_int),
+                ("reorthogonalization", C.c_int), ("fused", C.c_int), ("callback", CALLBACK_FN),
+                ("callback_data", C.c_void_p)]
+
+
+class CStats(C.Structure):
+    _fields_ = [("niter", C.c_int), ("solved", C.c_int), ("inconsistent", C.c_int), ("indefinite", C.c_int),
+                ("npcCount", C.c_int), ("timer", C.c_double), ("status", C.c_char * 96),
+                ("residuals", c_double_p), ("nres", C.c_int), ("error", C.c_char * 160)]
+
+
+# every symbol include/krylov_hip.h declares: name -> (restype, argtypes)
+_i64, _int, _dbl, _vp, _sz = C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_size_t
+SIGNATURES = {
+    "khip_last_error": (C.c_char_p, []),
+    "khip_version": (None, [C.POINTER(_int), C.POINTER(_int)]),
+    "khip_ctx_create": (_int, [_int, _vp, c_void_pp]),
+    "khip_ctx_destroy": (_int, [_vp]),
+    "khip_ctx_sync": (_int, [_vp]),
+    "khip_ctx_stream": (_vp, [_vp]),
+    "khip_ctx_set_option": (_int, [_vp, C.c_char_p, _int]),
+    "khip_ctx_get_option": (_int, [_vp, C.c_char_p, C.POINTER(_int)]),
+    "khip_malloc": (_int, [_vp, _sz, c_void_pp]),
+    "khip_free": (_int, [_vp, _vp]),
+    "khip_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz]),
+    "khip_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz]),
+    "khip_memcpy_d2d": (_int, [_vp, _vp, _vp, _sz]),
+    "khip_mem_info": (_int, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "khip_csr_create": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, c_void_pp]),
+    "khip_csr_create_dist": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, c_void_pp]),
+    "khip_csr_destroy": (_int, [_vp]),
+    "khip_csr_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "khip_gen_stencil": (_int, [_vp, _int, _int, _int, _int, _i64, _i64, c_void_pp, c_void_pp, c_void_pp,
+                                C.POINTER(_i64)]),
+    "khip_spmv": (_int, [_vp, _vp, _vp, _vp]),
+    "khip_spmm": (_int, [_vp, _vp, _vp, _vp, _int]),
+    "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
+    "khip_profile_spmv": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),
+    "khip_dot": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
+    "khip_nrm2": (_int, [_vp, _i64, _vp, c_double_p]),
+    "khip_scal": (_int, [_vp, _i64, _dbl, _vp]),
+    "khip_div": (_int, [_vp, _i64, _vp, _dbl]),
+    "khip_copy": (_int, [_vp, _i64, _vp, _vp]),
+    "khip_scalcopy": (_int, [_vp, _i64, _vp, _dbl, _vp]),
+    "khip_divcopy": (_int, [_vp, _i64, _vp, _vp, _dbl]),
+    "khip_axpy": (_int, [_vp, _i64, _dbl, _vp, _vp]),
+    "khip_axpby": (_int, [_vp, _i64, _dbl, _vp, _dbl, _vp]),
+    "khip_fill": (_int, [_vp, _i64, _vp, _dbl]),
+    "khip_ref": (_int, [_vp, _i64, _vp, _vp, _dbl, _dbl]),
+    "khip_spmv_dot": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
+    "khip_axpy2_dot": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, c_double_p]),
+    "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
+    "khip_dot2": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
+    "khip_mgs": (_int, [_vp, _i64, _int, c_void_pp, _vp, c_double_p, c_double_p, _int]),
+    "khip_multi_axpy": (_int, [_vp, _i64, _int, c_double_p, c_void_pp, _vp]),
+    "khip_panel_from_colmajor": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "khip_panel_to_colmajor": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "khip_panel_gemm_tn": (_int, [_vp, _i64, _int, _vp, _vp, c_double_p]),
+    "khip_panel_gemm_nn": (_int, [_vp, _i64, _int, _dbl, _vp, c_double_p, _dbl, _vp]),
+    "khip_panel_qr": (_int, [_vp, _i64, _int, _vp, c_double_p]),
+    "khip_panel_norm": (_int, [_vp, _i64, _int, _vp, c_double_p]),
+    "khip_comm_unique_id": (_int, [_vp]),
+    "khip_comm_init": (_int, [_vp, _int, _int, _vp]),
+    "khip_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
+    "khip_comm_barrier": (_int, [_vp]),
+    "khip_default_options": (COptions, []),
+    "khip_cg_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
+    "khip_cg_workspace_destroy": (_int, [_vp]),
+    "khip_cg_warm_start": (_int, [_vp, _vp]),
+    "khip_cg_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _vp, C.POINTER(COptions)]),
+    "khip_cg_solution": (_vp, [_vp]),
+    "khip_cg_stats": (C.POINTER(CStats), [_vp]),
+    "khip_cg_vector": (_vp, [_vp, C.c_char_p]),
+    "khip_cg_workspace_bytes": (_sz, [_vp]),
+    "khip_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, c_void_pp]),
+    "khip_gmres_workspace_destroy": (_int, [_vp]),
+    "khip_gmres_warm_start": (_int, [_vp, _vp]),
+    "khip_gmres_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), C.POINTER(COperator), _vp,
+                                C.POINTER(COptions)]),
+    "khip_gmres_solution": (_vp, [_vp]),
+    "khip_gmres_stats": (C.POINTER(CStats), [_vp]),
+    "khip_gmres_workspace_bytes": (_sz, [_vp]),
+    "khip_bicgstab_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
+    "khip_bicgstab_workspace_destroy": (_int, [_vp]),
+    "khip_bicgstab_warm_start": (_int, [_vp, _vp]),
+    "khip_bicgstab_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), C.POINTER(COperator), _vp, _vp,
+                                   C.POINTER(COptions)]),
+    "khip_bicgstab_solution": (_vp, [_vp]),
+    "khip_bicgstab_stats": (C.POINTER(CStats), [_vp]),
+    "khip_bicgstab_workspace_bytes": (_sz, [_vp]),
+    "khip_block_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, _int, c_void_pp]),
+    "khip_block_gmres_workspace_destroy": (_int, [_vp]),
+    "khip_block_gmres_solve": (_int, [_vp, C.POINTER(COperator), _vp, C.POINTER(COptions)]),
+    "khip_block_gmres_get_X": (_int, [_vp, _vp]),
+    "khip_block_gmres_stats": (C.POINTER(CStats), [_vp]),
+    # host-only helpers (partition / halo plan logic, testable without a GPU)
+    "khip_ghost_columns_host": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "khip_halo_plan_host": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libkrylov_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    script = os.path.join(_HERE, "build.sh")
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "krylov_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["bash", script])
+    return LIB_PATH
+
+
+def lib():
+    """Load the native library (fails loudly when it is missing: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); krylov.jl_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)      # AttributeError here == header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _ck(rc):
+    if rc != 0:
+        raise KhipError(rc, lib().khip_last_error().decode("utf-8", "replace"))
+
+
+def gpu_available() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+# --------------------------------------------------------------------------- context / vectors
+
+class Context:
+    """Device + HIP stream + reduction scratch (+ RCCL communicator when distributed)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        _ck(lib().khip_ctx_create(device, stream, C.byref(self._h)))
+        self.device = device
+        self.rank, self.nranks = 0, 1
+
+    def close(self):
+        if self._h:
+            lib().khip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _ck(lib().khip_ctx_sync(self._h))
+
+    def set_option(self, key: str, value: int):
+        _ck(lib().khip_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int()
+        _ck(lib().khip_ctx_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def mem_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        _ck(lib().khip_mem_info(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    @property
+    def stream(self):
+        return lib().khip_ctx_stream(self._h)
+
+    def profile_spmv(self):
+        """(launches, total_ms) of the SpMV launches recorded since the last call (option profile_spmv=1)."""
+        n, ms = C.c_int64(), C.c_double()
+        _ck(lib().khip_profile_spmv(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # --- multi-GPU (one process per GPU) ---
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _ck(lib().khip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        buf = C.create_string_buffer(unique_id, 128)
+        _ck(lib().khip_comm_init(self._h, rank, nranks, buf))
+        self.rank, self.nranks = rank, nranks
+
+    def barrier(self):
+        _ck(lib().khip_comm_barrier(self._h))
+
+    # --- allocation helpers ---
+    def empty(self, n: int) -> "DeviceVector":
+        return DeviceVector(self, n)
+
+    def zeros(self, n: int) -> "DeviceVector":
+        v = DeviceVector(self, n)
+        kfill_(v, 0.0)
+        return v
+
+    def array(self, host) -> "DeviceVector":
+        a = np.ascontiguousarray(host, dtype=np.float64).ravel()
+        v = DeviceVector(self, a.size)
+        v.copy_from_host(a)
+        return v
+
+
+class DeviceVector:
+    """Float64 vector in HBM: the storage type `S` of the workspaces (`S(undef, n)`, `similar`,
+    `length`; docs/src/custom_workspaces.md:107)."""
+
+    def __init__(self, ctx: Context, n: int, ptr: int | None = None, owner=None):
+        self.ctx, self.n = ctx, int(n)
+        self._owner = owner
+        if ptr is None:
+            p = C.c_void_p()
+            # pad to a multiple of 2 doubles so 16-byte lane accesses never straddle the allocation
+            _ck(lib().khip_malloc(ctx._h, 8 * max(2, (self.n + 1) & ~1), C.byref(p)))
+            self.ptr = p.value
+            self._owned = True
+        else:
+            self.ptr = ptr
+            self._owned = False
+
+    def __len__(self):
+        return self.n
+
+    def similar(self):
+        return DeviceVector(self.ctx, self.n)
+
+    def slice(self, lo: int, hi: int) -> "DeviceVector":
+        return DeviceVector(self.ctx, hi - lo, ptr=self.ptr + 8 * lo, owner=self)
+
+    def copy_from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        assert a.size == self.n
+        _ck(lib().khip_memcpy_h2d(self.ctx._h, self.ptr, a.ctypes.data, 8 * self.n))
+        return self
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        _ck(lib().khip_memcpy_d2h(self.ctx._h, out.ctypes.data, self.ptr, 8 * self.n))
+        return out
+
+    def __del__(self):
+        try:
+            if self._owned and self.ptr and self.ctx._h:
+                lib().khip_free(self.ctx._h, self.ptr)
+        except Exception:
+            pass
+
+
+def _p(v):
+    """device pointer of a DeviceVector / raw int / object with data_ptr() (torch tensor)."""
+    if v is None:
+        return None
+    if isinstance(v, DeviceVector):
+        return v.ptr
+    if isinstance(v, int):
+        return v
+    if hasattr(v, "data_ptr"):
+        return v.data_ptr()
+    raise TypeError(f"not a device buffer: {type(v)}")
+
+
+# --------------------------------------------------------------------------- k* primitives
+# Signatures follow src/krylov_utils.jl:305-349 (n first, scalars as T, return the mutated vector).
+
+def kdot(n, x, y) -> float:
+    r = C.c_double()
+    _ck(lib().khip_dot(x.ctx._h, n, _p(x), _p(y), C.byref(r)))
+    return r.value
+
+
+kdotr = kdot    # real part; identical for Float64 (src/krylov_utils.jl:313-314)
+
+
+def knorm(n, x) -> float:
+    r = C.c_double()
+    _ck(lib().khip_nrm2(x.ctx._h, n, _p(x), C.byref(r)))
+    return r.value
+
+
+def knorm_elliptic(n, x, y) -> float:   # src/krylov_utils.jl:319
+    return knorm(n, x) if x is y else math.sqrt(kdotr(n, x, y))
+
+
+def kscal_(n, s, x):
+    _ck(lib().khip_scal(x.ctx._h, n, s, _p(x)))
+    return x
+
+
+def kdiv_(n, x, s):
+    _ck(lib().khip_div(x.ctx._h, n, _p(x), s))
+    return x
+
+
+def kcopy_(n, y, x):
+    _ck(lib().khip_copy(y.ctx._h, n, _p(y), _p(x)))
+    return y
+
+
+def kscalcopy_(n, y, s, x):
+    _ck(lib().khip_scalcopy(y.ctx._h, n, _p(y), s, _p(x)))
+    return y
+
+
+def kdivcopy_(n, y, x, s):
+    _ck(lib().khip_divcopy(y.ctx._h, n, _p(y), _p(x), s))
+    return y
+
+
+def kaxpy_(n, s, x, y):
+    _ck(lib().khip_axpy(y.ctx._h, n, s, _p(x), _p(y)))
+    return y
+
+
+def kaxpby_(n, s, x, t, y):
+    _ck(lib().khip_axpby(y.ctx._h, n, s, _p(x), t, _p(y)))
+    return y
+
+
+def kfill_(x, val):
+    _ck(lib().khip_fill(x.ctx._h, x.n, _p(x), val))
+    return x
+
+
+def kref_(n, x, y, c, s):
+    _ck(lib().khip_ref(x.ctx._h, n, _p(x), _p(y), c, s))
+    return x, y
+
+
+def kmul_(y, A, x):
+    """kmul!(y, A, x) = mul!(y, A, x) (src/krylov_utils.jl:305); A: CsrMatrix, a callable operator, or None (= I,
+    the unguarded mul!(v, I, q) of src/bicgstab.jl:222)."""
+    if A is None:
+        return kcopy_(len(x), y, x)
+    if isinstance(A, CsrMatrix):
+        _ck(lib().khip_spmv(A.ctx._h, A._h, _p(x), _p(y)))
+        return y
+    A(x, y)
+    return y
+
+
+# fused accelerators
+def spmv_dot(A, x, y) -> float:
+    r = C.c_double()
+    _ck(lib().khip_spmv_dot(A.ctx._h, A._h, _p(x), _p(y), C.byref(r)))
+    return r.value
+
+
+def axpy2_dot(n, a, p, q, x, r) -> float:
+    out = C.c_double()
+    _ck(lib().khip_axpy2_dot(x.ctx._h, n, a, _p(p), _p(q), _p(x), _p(r), C.byref(out)))
+    return out.value
+
+
+def waxpy_(n, w, x, b, y):
+    _ck(lib().khip_waxpy(w.ctx._h, n, _p(w), _p(x), b, _p(y)))
+    return w
+
+
+def dot2(n, x, y):
+    out = (C.c_double * 2)()
+    _ck(lib().khip_dot2(x.ctx._h, n, _p(x), _p(y), out))
+    return out[0], out[1]
+
+
+def mgs_(n, V, q, accumulate_into=None, want_norm=True):
+    k = len(V)
+    ptrs = (C.c_void_p * max(k, 1))(*[_p(v) for v in V])
+    h = (C.c_double * max(k, 1))()
+    if accumulate_into is not None:
+        for i in range(k):
+            h[i] = accumulate_into[i]
+    nrm = C.c_double()
+    _ck(lib().khip_mgs(q.ctx._h, n, k, ptrs, _p(q), h, C.byref(nrm) if want_norm else None,
+                       1 if accumulate_into is not None else 0))
+    return [h[i] for i in range(k)], (nrm.value if want_norm else None)
+
+
+def multi_axpy_(n, y, V, x):
+    k = len(V)
+    ptrs = (C.c_void_p * max(k, 1))(*[_p(v) for v in V])
+    coef = (C.c_double * max(k, 1))(*[float(c) for c in y])
+    _ck(lib().khip_multi_axpy(x.ctx._h, n, k, coef, ptrs, _p(x)))
+    return x
+
+
+# --------------------------------------------------------------------------- CSR operator
+
+class CsrMatrix:
+    """CSR operator resident in HBM; `size`, `eltype`, `kmul_` = the operator contract
+    (docs/src/matrix_free.md:32-34)."""
+
+    eltype = np.float64
+
+    def __init__(self, ctx: Context, handle, keep=None):
+        self.ctx, self._h, self._keep = ctx, handle, keep
+        m, n, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        _ck(lib().khip_csr_shape(handle, C.byref(m), C.byref(n), C.byref(nnz)))
+        self.m, self.n, self.nnz = m.value, n.value, nnz.value
+
+    @property
+    def shape(self):
+        return (self.m, self.n)
+
+    @property
+    def spmv_bytes(self) -> int:
+        b = C.c_int64()
+        _ck(lib().khip_spmv_bytes(self._h, C.byref(b)))
+        return b.value
+
+    @classmethod
+    def from_host(cls, ctx, rowptr, col, val, shape, index_base=0, dist_rows=None, n_global=None):
+        rowptr = np.ascontiguousarray(rowptr)
+        bits = 64 if rowptr.dtype == np.int64 else 32
+        if bits == 32:
+            rowptr = rowptr.astype(np.int32, copy=False)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        h = C.c_void_p()
+        if dist_rows is None:
+            _ck(lib().khip_csr_create(ctx._h, shape[0], shape[1], val.size, rowptr.ctypes.data, bits, col.ctypes.data,
+                                      val.ctypes.data, index_base, 0, C.byref(h)))
+        else:
+            _ck(lib().khip_csr_create_dist(ctx._h, n_global, dist_rows[0], dist_rows[1] - dist_rows[0], val.size,
+                                           rowptr.ctypes.data, bits, col.ctypes.data, val.ctypes.data, index_base, 0,
+                                           C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_scipy(cls, ctx, S):
+        S = S.tocsr()
+        S.sort_indices()
+        return cls.from_host(ctx, S.indptr, S.indices, S.data, S.shape)
+
+    @classmethod
+    def stencil(cls, ctx, kind: str, n1, n2=None, n3=None, rows=None, distributed=False):
+        """Device-side generator of the benchmark operators: 'poisson' = get_div_grad(n1,n2,n3)
+        (test/get_div_grad.jl:8-25), 'kron_unsymmetric' (test/test_utils.jl:160-169), 'stencil27' (cfg 5)."""
+        kinds = {"poisson": 0, "kron_unsymmetric": 1, "stencil27": 2}
+        n2 = n2 or n1
+        n3 = n3 or n1
+        n = n1 * n2 * n3
+        r0, r1 = rows if rows is not None else (0, n)
+        rp, cl, vl, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        _ck(lib().khip_gen_stencil(ctx._h, kinds[kind], n1, n2, n3, r0, r1 - r0, C.byref(rp), C.byref(cl),
+                                   C.byref(vl), C.byref(nnz)))
+        h = C.c_void_p()
+        try:
+            if distributed:
+                _ck(lib().khip_csr_create_dist(ctx._h, n, r0, r1 - r0, nnz.value, rp, 32, cl, vl, 0, 1, C.byref(h)))
+            else:
+                if (r0, r1) != (0, n):
+                    raise ValueError("a row slice needs distributed=True")
+                _ck(lib().khip_csr_create(ctx._h, n, n, nnz.value, rp, 32, cl, vl, 0, 1, C.byref(h)))
+        finally:
+            for p in (rp, cl, vl):
+                lib().khip_free(ctx._h, p)
+        return cls(ctx, h)
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib().khip_csr_destroy(self._h)
+        except Exception:
+            pass
+
+    def matvec(self, x: DeviceVector, y: DeviceVector | None = None) -> DeviceVector:
+        y = y if y is not None else DeviceVector(self.ctx, self.m)
+        return kmul_(y, self, x)
+
+
+def gen_stencil_arrays(ctx, kind, n1, n2=None, n3=None, rows=None):
+    """Raw (rowptr, col, val) of the device generator copied to host -- used by the parity tests."""
+    kinds = {"poisson": 0, "kron_unsymmetric": 1, "stencil27": 2}
+    n2 = n2 or n1
+    n3 = n3 or n1
+    n = n1 * n2 * n3
+    r0, r1 = rows if rows is not None else (0, n)
+    rp, cl, vl, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+    _ck(lib().khip_gen_stencil(ctx._h, kinds[kind], n1, n2, n3, r0, r1 - r0, C.byref(rp), C.byref(cl), C.byref(vl),
+                               C.byref(nnz)))
+    m = r1 - r0
+    rowptr = np.empty(m + 1, dtype=np.int32)
+    col = np.empty(nnz.value, dtype=np.int32)
+    val = np.empty(nnz.value, dtype=np.float64)
+    _ck(lib().khip_memcpy_d2h(ctx._h, rowptr.ctypes.data, rp, 4 * (m + 1)))
+    if nnz.value:
+        _ck(lib().khip_memcpy_d2h(ctx._h, col.ctypes.data, cl, 4 * nnz.value))
+        _ck(lib().khip_memcpy_d2h(ctx._h, val.ctypes.data, vl, 8 * nnz.value))
+    for p in (rp, cl, vl):
+        lib().khip_free(ctx._h, p)
+    return rowptr, col, val
+
+
+# --------------------------------------------------------------------------- solvers
+
+class SimpleStats:
+    """SimpleStats (src/krylov_stats.jl:24-44)."""
+
+    def __init__(self, st: CStats):
+        self.niter = st.niter
+        self.solved = bool(st.solved)
+        self.inconsistent = bool(st.inconsistent)
+        self.indefinite = bool(st.indefinite)
+        self.npcCount = st.npcCount
+        self.timer = st.timer
+        self.status = st.status.decode("utf-8")
+        self.residuals = np.array([st.residuals[i] for i in range(st.nres)]) if st.nres else np.zeros(0)
+        self.error = st.error.decode("utf-8")
+
+    def __repr__(self):
+        return f"SimpleStats(niter={self.niter}, solved={self.solved}, status={self.status!r})"
+
+
+def _make_operator(ctx, op, n, keep):
+    """CsrMatrix | callable(x: DeviceVector, y: DeviceVector) | None -> POINTER(COperator) or None."""
+    if op is None:
+        return None
+    co = COperator()
+    if isinstance(op, CsrMatrix):
+        co.csr = op._h
+        co.apply = C.cast(None, APPLY_FN)
+    else:
+        def thunk(_self, xp, yp):
+            try:
+                op(DeviceVector(ctx, n, ptr=xp), DeviceVector(ctx, n, ptr=yp))
+                return 0
+            except Exception as e:  # never propagate across the C boundary
+                sys.stderr.write(f"operator callback failed: {e}\n")
+                return 1
+        fn = APPLY_FN(thunk)
+        keep.append(fn)
+        co.csr = None
+        co.apply = fn
+    keep.append(co)
+    return C.byref(co)
+
+
+def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, radius=0.0, linesearch=False,
+                  restart=False, reorthogonalization=False, fused=True, callback=None, keep=None, ws=None):
+    o = lib().khip_default_options()
+    if atol is not None:
+        o.atol = atol
+    if rtol is not None:
+        o.rtol = rtol
+    o.itmax = int(itmax)
+    if timemax is not None:
+        o.timemax = timemax
+    o.history = int(history)
+    o.radius = radius
+    o.linesearch = int(linesearch)
+    o.restart = int(restart)
+    o.reorthogonalization = int(reorthogonalization)
+    o.fused = int(fused)
+    if callback is not None:
+        def cb(_ws, _ud):
+            try:
+                return 1 if callback(ws) else 0
+            except Exception as e:
+                sys.stderr.write(f"callback failed: {e}\n")
+                return 1
+        fn = CALLBACK_FN(cb)
+        keep.append(fn)
+        o.callback = fn
+    return o
+
+
+class _Workspace:
+    _prefix = ""
+
+    def _fn(self, name):
+        return getattr(lib(), f"khip_{self._prefix}_{name}")
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                self._fn("workspace_destroy")(self._h)
+        except Exception:
+            pass
+
+    @property
+    def x(self) -> DeviceVector:
+        """solution(workspace) === workspace.x (src/workspace_accessors.jl:151, test/test_interface.jl:260)."""
+        return DeviceVector(self.ctx, self.n, ptr=self._fn("solution")(self._h), owner=self)
+
+    @property
+    def stats(self) -> SimpleStats:
+        return SimpleStats(self._fn("stats")(self._h).contents)
+
+    def warm_start_(self, x0: DeviceVector):
+        """warm_start!(workspace, x0) (src/workspace_accessors.jl:193-200)."""
+        _ck(self._fn("warm_start")(self._h, _p(x0)))
+        return self
+
+    @property
+    def nbytes(self) -> int:
+        return self._fn("workspace_bytes")(self._h)
+
+
+class CgWorkspace(_Workspace):
+    """CgWorkspace(m, n, S) (src/krylov_workspaces.jl:236-291)."""
+    _prefix = "cg"
+
+    def __init__(self, ctx: Context, m: int, n: int):
+        self.ctx, self.m, self.n = ctx, m, n
+        self._h = C.c_void_p()
+        _ck(lib().khip_cg_workspace_create(ctx._h, m, n, C.byref(self._h)))
+
+    def vector(self, name: str):
+        p = lib().khip_cg_vector(self._h, name.encode())
+        return DeviceVector(self.ctx, self.n, ptr=p, owner=self) if p else None
+
+
+class GmresWorkspace(_Workspace):
+    """GmresWorkspace(m, n, S; memory = 20) (src/krylov_workspaces.jl:2857-2924)."""
+    _prefix = "gmres"
+
+    def __init__(self, ctx: Context, m: int, n: int, memory: int = 20):
+        self.ctx, self.m, self.n, self.memory = ctx, m, n, memory
+        self._h = C.c_void_p()
+        _ck(lib().khip_gmres_workspace_create(ctx._h, m, n, memory, C.byref(self._h)))
+
+
+class BicgstabWorkspace(_Workspace):
+    """BicgstabWorkspace(m, n, S) (src/krylov_workspaces.jl:1568-1629)."""
+    _prefix = "bicgstab"
+
+    def __init__(self, ctx: Context, m: int, n: int):
+        self.ctx, self.m, self.n = ctx, m, n
+        self._h = C.c_void_p()
+        _ck(lib().khip_bicgstab_workspace_create(ctx._h, m, n, C.byref(self._h)))
+
+
+def _finish(ws, rc):
+    if rc != 0:
+        st = ws.stats
+        raise KhipError(rc, st.error or lib().khip_last_error().decode("utf-8", "replace"))
+    return ws
+
+
+def cg_(ws: CgWorkspace, A, b: DeviceVector, M=None, **kw):
+    """cg!(workspace, A, b; M, radius, linesearch, atol, rtol, itmax, timemax, history, callback)
+    (src/cg.jl:120-291).  Returns the workspace."""
+    keep = []
+    opts = _make_options(keep=keep, ws=ws, **kw)
+    rc = lib().khip_cg_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep), _make_operator(ws.ctx, M, ws.n, keep),
+                             _p(b), C.byref(opts))
+    return _finish(ws, rc)
+
+
+def gmres_(ws: GmresWorkspace, A, b: DeviceVector, M=None, N=None, **kw):
+    """gmres!(workspace, A, b; M, N, restart, reorthogonalization, ...) (src/gmres.jl:121-384)."""
+    keep = []
+    opts = _make_options(keep=keep, ws=ws, **kw)
+    rc = lib().khip_gmres_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep), _make_operator(ws.ctx, M, ws.n, keep),
+                                _make_operator(ws.ctx, N, ws.n, keep), _p(b), C.byref(opts))
+    return _finish(ws, rc)
+
+
+def bicgstab_(ws: BicgstabWorkspace, A, b: DeviceVector, c: DeviceVector | None = None, M=None, N=None, **kw):
+    """bicgstab!(workspace, A, b; c, M, N, ...) (src/bicgstab.jl:125-277)."""
+    keep = []
+    opts = _make_options(keep=keep, ws=ws, **kw)
+    rc = lib().khip_bicgstab_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep),
+                                   _make_operator(ws.ctx, M, ws.n, keep), _make_operator(ws.ctx, N, ws.n, keep),
+                                   _p(b), _p(c), C.byref(opts))
+    return _finish(ws, rc)
+
+
+def _local_rows(A):
+    return A.m if isinstance(A, CsrMatrix) else None
+
+
+def cg(A, b: DeviceVector, x0=None, **kw):
+    """Out-of-place cg(A, b; kwargs...) -> (x, stats) (src/interface.jl:146-154)."""
+    ws = CgWorkspace(b.ctx, len(b), len(b))
+    if x0 is not None:
+        ws.warm_start_(x0)
+    cg_(ws, A, b, **kw)
+    return ws.x, ws.stats, ws
+
+
+def gmres(A, b: DeviceVector, x0=None, memory=20, **kw):
+    ws = GmresWorkspace(b.ctx, len(b), len(b), memory=memory)
+    if x0 is not None:
+        ws.warm_start_(x0)
+    gmres_(ws, A, b, **kw)
+    return ws.x, ws.stats, ws
+
+
+def bicgstab(A, b: DeviceVector, x0=None, **kw):
+    ws = BicgstabWorkspace(b.ctx, len(b), len(b))
+    if x0 is not None:
+        ws.warm_start_(x0)
+    bicgstab_(ws, A, b, **kw)
+    return ws.x, ws.stats, ws
+
+
+# --------------------------------------------------------------------------- host-only partition helpers
+
+def row_partition(n: int, nranks: int):
+    """Contiguous 1-D row partition: rank g owns rows [g*n//G, (g+1)*n//G)."""
+    return [(g * n) // nranks for g in range(nranks + 1)]
+
+
+def ghost_columns_host(rowptr, col, row0):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    m = rowptr.size - 1
+    cnt = C.c_int64()
+    out = np.empty(max(col.size, 1), dtype=np.int32)
+    _ck(lib().khip_ghost_columns_host(rowptr.ctypes.data, col.ctypes.data, m, row0, out.ctypes.data, out.size,
+                                      C.byref(cnt)))
+    return out[: cnt.value].copy()
+
+
+def halo_plan_host(rank, nranks, row_starts, ghost_lists):
+    row_starts = np.ascontiguousarray(row_starts, dtype=np.int64)
+    off = np.zeros(nranks + 1, dtype=np.int64)
+    for r in range(nranks):
+        off[r + 1] = off[r] + len(ghost_lists[r])
+    allg = np.ascontiguousarray(np.concatenate([np.asarray(g, dtype=np.int32) for g in ghost_lists])
+                                if off[-1] else np.zeros(1, dtype=np.int32), dtype=np.int32)
+    recv_off = np.zeros(nranks + 1, dtype=np.int64)
+    send_off = np.zeros(nranks + 1, dtype=np.int64)
+    cap = int(off[-1]) + 1
+    send_idx = np.zeros(cap, dtype=np.int32)
+    _ck(lib().khip_halo_plan_host(rank, nranks, row_starts.ctypes.data, allg.ctypes.data, off.ctypes.data,
+                                  recv_off.ctypes.data, send_off.ctypes.data, send_idx.ctypes.data, cap))
+    return recv_off, send_off, send_idx[: send_off[-1]].copy()

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds libkrylov_hip.so for gfx950 (cross-compiles without a GPU).  -ffp-contract=off: every FMA
+# in the kernels is explicit (compensated reductions and bit-exact SpMV depend on it).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+SRC="$HERE/csrc"
+OUT="$HERE/libkrylov_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I/opt/rocm/include"
+mkdir -p "$HERE/build"
+objs=""
+for f in blas1.hip spmv.hip panel.hip comm.cpp api.cpp solvers.cpp block.cpp; do
+  [ -f "$SRC/$f" ] || continue
+  o="$HERE/build/${f%.*}.o"
+  if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h*' -newer "$o" | head -1)" ]; then
+    echo "hipcc $f"
+    $HIPCC $FLAGS -x hip -c "$SRC/$f" -o "$o" &
+  fi
+  objs="$objs $o"
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs -ldl
+echo "built $OUT"

@@ -1,0 +1,448 @@
+// api.cpp -- extern "C" entry points: context, device buffers, CSR handles, the k* primitives.
+#include <cmath>
+
+#include "khip_internal.hpp"
+
+using namespace khip;
+
+extern "C" int khip_comm_destroy_internal(khip_ctx *ctx);
+
+namespace khip {
+enum MapOpHost { H_COPY = 0, H_FILL, H_SCAL, H_SCALCOPY, H_DIVCOPY, H_AXPY, H_AXPBY, H_REF, H_WAXPY };
+constexpr int kPadHost = 8;
+}  // namespace khip
+
+extern "C" {
+
+void khip_version(int *major, int *minor) {
+  if (major) *major = KHIP_VERSION_MAJOR;
+  if (minor) *minor = KHIP_VERSION_MINOR;
+}
+
+// ------------------------------------------------------------------ context ----
+int khip_ctx_create(int device, void *stream, khip_ctx **out) {
+  KHIP_REQUIRE(out, "ctx_create: null output");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("no HIP device visible (%s): libkrylov_hip has no CPU fallback", hipGetErrorString(e));
+    return KHIP_ERR_HIP;
+  }
+  KHIP_REQUIRE(device >= 0 && device < ndev, "ctx_create: device %d out of range (0..%d)", device, ndev - 1);
+  KHIP_CHECK_HIP(hipSetDevice(device));
+  khip_ctx *ctx = new khip_ctx();
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
+  KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+  hipDeviceProp_t prop;
+  KHIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  KHIP_CHECK_HIP(hipMalloc(&ctx->partials, sizeof(dd) * (size_t)kMaxRedOut * kMaxRedBlocks));
+  KHIP_CHECK_HIP(hipMalloc(&ctx->tickets, sizeof(unsigned) * 16));
+  KHIP_CHECK_HIP(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 16));
+  KHIP_CHECK_HIP(hipMalloc(&ctx->results, sizeof(double) * kResultSlots));
+  KHIP_CHECK_HIP(hipMalloc(&ctx->results_dd, sizeof(dd) * kResultSlots));
+  KHIP_CHECK_HIP(hipMemset(ctx->results, 0, sizeof(double) * kResultSlots));
+  KHIP_CHECK_HIP(hipMemset(ctx->results_dd, 0, sizeof(dd) * kResultSlots));
+  KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->results_pinned), sizeof(double) * kResultSlots * 2,
+                               hipHostMallocDefault));
+  *out = ctx;
+  return KHIP_OK;
+}
+
+int khip_ctx_destroy(khip_ctx *ctx) {
+  if (!ctx) return KHIP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  khip_comm_destroy_internal(ctx);
+  for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+  (void)hipFree(ctx->partials);
+  (void)hipFree(ctx->tickets);
+  (void)hipFree(ctx->results);
+  (void)hipFree(ctx->results_dd);
+  (void)hipHostFree(ctx->results_pinned);
+  (void)hipEventDestroy(ctx->ev_a);
+  (void)hipEventDestroy(ctx->ev_b);
+  (void)hipStreamDestroy(ctx->comm_stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return KHIP_OK;
+}
+
+int khip_ctx_sync(khip_ctx *ctx) {
+  KHIP_REQUIRE(ctx, "ctx_sync: null context");
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return KHIP_OK;
+}
+
+void *khip_ctx_stream(khip_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+static int *tuning_field(khip_ctx *ctx, const char *key) {
+  Tuning &t = ctx->tune;
+  struct { const char *k; int *p; } tab[] = {
+      {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
+      {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
+      {"compensated", &t.compensated}, {"blas1_blocks", &t.blas1_blocks}, {"overlap_halo", &t.overlap_halo},
+      {"profile_spmv", &t.profile_spmv}};
+  for (auto &e : tab)
+    if (strcmp(e.k, key) == 0) return e.p;
+  return nullptr;
+}
+
+int khip_ctx_set_option(khip_ctx *ctx, const char *key, int value) {
+  KHIP_REQUIRE(ctx && key, "set_option: null argument");
+  int *p = tuning_field(ctx, key);
+  KHIP_REQUIRE(p, "set_option: unknown key '%s'", key);
+  if (strcmp(key, "blas1_blocks") == 0) KHIP_REQUIRE(value >= 1 && value <= kMaxRedBlocks, "blas1_blocks out of range");
+  *p = value;
+  return KHIP_OK;
+}
+
+int khip_ctx_get_option(khip_ctx *ctx, const char *key, int *value) {
+  KHIP_REQUIRE(ctx && key && value, "get_option: null argument");
+  int *p = tuning_field(ctx, key);
+  KHIP_REQUIRE(p, "get_option: unknown key '%s'", key);
+  *value = *p;
+  return KHIP_OK;
+}
+
+// ------------------------------------------------------------------ buffers ----
+int khip_malloc(khip_ctx *ctx, size_t bytes, void **dptr) {
+  KHIP_REQUIRE(ctx && dptr, "malloc: null argument");
+  KHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  *dptr = nullptr;
+  if (bytes == 0) return KHIP_OK;   // S(undef, 0): the lazily-allocated vectors of the workspaces
+  KHIP_CHECK_HIP(hipMalloc(dptr, bytes));
+  return KHIP_OK;
+}
+
+int khip_free(khip_ctx *ctx, void *dptr) {
+  KHIP_REQUIRE(ctx, "free: null context");
+  if (!dptr) return KHIP_OK;
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  KHIP_CHECK_HIP(hipFree(dptr));
+  return KHIP_OK;
+}
+
+int khip_memcpy_h2d(khip_ctx *ctx, void *dst, const void *src_host, size_t bytes) {
+  KHIP_REQUIRE(ctx && (bytes == 0 || (dst && src_host)), "memcpy_h2d: null argument");
+  if (!bytes) return KHIP_OK;
+  KHIP_CHECK_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return KHIP_OK;
+}
+
+int khip_memcpy_d2h(khip_ctx *ctx, void *dst_host, const void *src, size_t bytes) {
+  KHIP_REQUIRE(ctx && (bytes == 0 || (dst_host && src)), "memcpy_d2h: null argument");
+  if (!bytes) return KHIP_OK;
+  KHIP_CHECK_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return KHIP_OK;
+}
+
+int khip_memcpy_d2d(khip_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  KHIP_REQUIRE(ctx && (bytes == 0 || (dst && src)), "memcpy_d2d: null argument");
+  if (!bytes) return KHIP_OK;
+  KHIP_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return KHIP_OK;
+}
+
+int khip_mem_info(khip_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+  KHIP_REQUIRE(ctx, "mem_info: null context");
+  size_t f = 0, t = 0;
+  KHIP_CHECK_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return KHIP_OK;
+}
+
+// ------------------------------------------------------------------ CSR --------
+static int csr_upload(khip_ctx *ctx, khip_csr *A, const void *rowptr, int rowptr_bits, const int32_t *col,
+                      const double *val, int index_base, int on_device) {
+  const int64_t m = A->m, nnz = A->nnz;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  KHIP_CHECK_HIP(hipMalloc(&A->rowptr, sizeof(int32_t) * (size_t)(m + 1)));
+  KHIP_CHECK_HIP(hipMalloc(&A->col, sizeof(int32_t) * (size_t)(nnz + kPadHost)));
+  KHIP_CHECK_HIP(hipMalloc(&A->val, sizeof(double) * (size_t)(nnz + kPadHost)));
+  KHIP_CHECK_HIP(hipMemsetAsync(A->col + nnz, 0, sizeof(int32_t) * kPadHost, ctx->stream));
+  KHIP_CHECK_HIP(hipMemsetAsync(A->val + nnz, 0, sizeof(double) * kPadHost, ctx->stream));
+  if (nnz) {
+    KHIP_CHECK_HIP(hipMemcpyAsync(A->col, col, sizeof(int32_t) * (size_t)nnz, kind, ctx->stream));
+    KHIP_CHECK_HIP(hipMemcpyAsync(A->val, val, sizeof(double) * (size_t)nnz, kind, ctx->stream));
+  }
+  if (rowptr_bits == 32) {
+    KHIP_CHECK_HIP(hipMemcpyAsync(A->rowptr, rowptr, sizeof(int32_t) * (size_t)(m + 1), kind, ctx->stream));
+  } else {
+    // 64-bit row pointers are narrowed on the host (a shard's nnz fits int32 by contract)
+    std::vector<int64_t> tmp64((size_t)(m + 1));
+    if (on_device) KHIP_CHECK_HIP(hipMemcpy(tmp64.data(), rowptr, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToHost));
+    else memcpy(tmp64.data(), rowptr, sizeof(int64_t) * (size_t)(m + 1));
+    std::vector<int32_t> tmp32((size_t)(m + 1));
+    for (int64_t i = 0; i <= m; ++i) tmp32[(size_t)i] = (int32_t)tmp64[(size_t)i];
+    KHIP_CHECK_HIP(hipMemcpy(A->rowptr, tmp32.data(), sizeof(int32_t) * (size_t)(m + 1), hipMemcpyHostToDevice));
+  }
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return KHIP_OK;
+}
+
+}  // extern "C"
+
+namespace khip {
+int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);   // spmv.hip
+int comm_nranks(const khip_ctx *ctx);                                              // comm.cpp
+}
+
+extern "C" {
+
+static int csr_create_common(khip_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const void *rowptr, int rowptr_bits,
+                             const int32_t *col, const double *val, int index_base, int on_device, khip_csr **out) {
+  KHIP_REQUIRE(ctx && out && rowptr, "csr_create: null argument");
+  KHIP_REQUIRE(m >= 0 && n >= 0 && nnz >= 0, "csr_create: negative size");
+  KHIP_REQUIRE(nnz == 0 || (col && val), "csr_create: null col/val");
+  KHIP_REQUIRE(rowptr_bits == 32 || rowptr_bits == 64, "csr_create: rowptr_bits must be 32 or 64");
+  KHIP_REQUIRE(index_base == 0 || index_base == 1, "csr_create: index_base must be 0 or 1");
+  KHIP_REQUIRE(nnz < (1ll << 31) - 64 && n < (1ll << 31) && m < (1ll << 31),
+               "csr_create: shard exceeds int32 indexing (nnz=%lld)", (long long)nnz);
+  KHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  khip_csr *A = new khip_csr();
+  A->ctx = ctx; A->m = m; A->n = n; A->nnz = nnz;
+  int rc = csr_upload(ctx, A, rowptr, rowptr_bits, col, val, index_base, on_device);
+  if (rc == KHIP_OK && index_base != 0) {
+    rc = launch_index_shift(ctx, A->rowptr, m + 1, -index_base);
+    if (rc == KHIP_OK) rc = launch_index_shift(ctx, A->col, nnz, -index_base);
+  }
+  if (rc == KHIP_OK) rc = csr_finalize(ctx, A);
+  if (rc != KHIP_OK) { khip_csr_destroy(A); return rc; }
+  *out = A;
+  return KHIP_OK;
+}
+
+int khip_csr_create(khip_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const void *rowptr, int rowptr_bits,
+                    const int32_t *col, const double *val, int index_base, int on_device, khip_csr **out) {
+  return csr_create_common(ctx, m, n, nnz, rowptr, rowptr_bits, col, val, index_base, on_device, out);
+}
+
+int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t m, int64_t nnz, const void *rowptr,
+                         int rowptr_bits, const int32_t *col, const double *val, int index_base, int on_device,
+                         khip_csr **out) {
+  KHIP_REQUIRE(ctx && ctx->comm, "csr_create_dist: call khip_comm_init first");
+  KHIP_REQUIRE(row0 >= 0 && row0 + m <= n_global, "csr_create_dist: row range outside the operator");
+  khip_csr *A = nullptr;
+  KHIP_TRY(csr_create_common(ctx, m, n_global, nnz, rowptr, rowptr_bits, col, val, index_base, on_device, &A));
+  A->dist = true;
+  A->n_global = n_global;
+  A->row0 = row0;
+  int rc = comm_build_plan(ctx, A);
+  if (rc != KHIP_OK) { khip_csr_destroy(A); return rc; }
+  *out = A;
+  return KHIP_OK;
+}
+
+int khip_csr_destroy(khip_csr *A) {
+  if (!A) return KHIP_OK;
+  if (A->ctx) (void)hipStreamSynchronize(A->ctx->stream);
+  (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val);
+  (void)hipFree(A->ghost); (void)hipFree(A->sendbuf); (void)hipFree(A->send_idx);
+  delete A;
+  return KHIP_OK;
+}
+
+int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz) {
+  KHIP_REQUIRE(A, "csr_shape: null handle");
+  if (m) *m = A->m;
+  if (n) *n = A->n;
+  if (nnz) *nnz = A->nnz;
+  return KHIP_OK;
+}
+
+int khip_spmv_bytes(const khip_csr *A, int64_t *bytes) {
+  KHIP_REQUIRE(A && bytes, "spmv_bytes: null argument");
+  const int64_t ncols_read = A->dist ? A->m + A->n_ghost : A->n;
+  *bytes = 12 * A->nnz + 4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
+  return KHIP_OK;
+}
+
+// y <- A x, handling the halo exchange + interior/boundary split for distributed handles.
+static int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, int *nslots) {
+  if (nslots) *nslots = 1;
+  if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m);
+  KHIP_TRY(comm_halo_exchange_begin(ctx, A, x));
+  const bool split = ctx->tune.overlap_halo && A->interior_hi > A->interior_lo;
+  if (!split) {
+    KHIP_TRY(comm_halo_exchange_end(ctx, A));
+    return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m);
+  }
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_lo, A->interior_hi));
+  KHIP_TRY(comm_halo_exchange_end(ctx, A));
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot >= 0 ? dot_slot + 1 : -1, 0, A->interior_lo));
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot >= 0 ? dot_slot + 2 : -1, A->interior_hi, A->m));
+  if (nslots) *nslots = 3;
+  return KHIP_OK;
+}
+
+int khip_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y) {
+  KHIP_REQUIRE(ctx && A && x && y, "spmv: null argument");
+  KHIP_REQUIRE(x != y, "spmv: x and y must not alias");
+  return spmv_any(ctx, A, x, y, -1, nullptr);
+}
+
+int khip_spmv_dot(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, double *result_host) {
+  KHIP_REQUIRE(ctx && A && x && y && result_host, "spmv_dot: null argument");
+  KHIP_REQUIRE(x != y, "spmv_dot: x and y must not alias");
+  KHIP_REQUIRE(A->m == (A->dist ? A->m : A->n), "spmv_dot: operator must be square");
+  const int slot = take_slots(ctx, 3);
+  int ns = 1;
+  KHIP_TRY(spmv_any(ctx, A, x, y, slot, &ns));
+  double r[3] = {0, 0, 0};
+  KHIP_TRY(fetch_results(ctx, slot, ns, r));
+  *result_host = ns == 1 ? r[0] : (r[0] + r[1]) + r[2];
+  return KHIP_OK;
+}
+
+int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms) {
+  KHIP_REQUIRE(ctx && launches && total_ms, "profile_spmv: null argument");
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double tot = 0;
+  for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+    float ms = 0;
+    KHIP_CHECK_HIP(hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
+    tot += ms;
+  }
+  *launches = (int64_t)(ctx->prof_used / 2);
+  *total_ms = tot;
+  ctx->prof_used = 0;
+  return KHIP_OK;
+}
+
+int khip_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {
+  KHIP_REQUIRE(ctx && A && X && Y, "spmm: null argument");
+  return launch_spmm(ctx, A, X, Y, p);
+}
+
+// ------------------------------------------------------------------ BLAS-1 -----
+int khip_dot(khip_ctx *ctx, int64_t n, const double *x, const double *y, double *result_host) {
+  KHIP_REQUIRE(ctx && result_host && (n == 0 || (x && y)), "dot: null argument");
+  const int slot = take_slots(ctx, 1);
+  KHIP_TRY(launch_dot(ctx, n, x, y, slot));
+  return fetch_results(ctx, slot, 1, result_host);
+}
+
+int khip_nrm2(khip_ctx *ctx, int64_t n, const double *x, double *result_host) {
+  KHIP_REQUIRE(ctx && result_host && (n == 0 || x), "nrm2: null argument");
+  const int slot = take_slots(ctx, 1);
+  KHIP_TRY(launch_nrm2sq(ctx, n, x, slot));
+  double sq = 0;
+  KHIP_TRY(fetch_results(ctx, slot, 1, &sq));
+  *result_host = std::sqrt(sq);
+  return KHIP_OK;
+}
+
+int khip_dot2(khip_ctx *ctx, int64_t n, const double *x, const double *y, double *result_host) {
+  KHIP_REQUIRE(ctx && result_host && (n == 0 || (x && y)), "dot2: null argument");
+  const int slot = take_slots(ctx, 2);
+  KHIP_TRY(launch_dot2(ctx, n, x, y, slot));
+  return fetch_results(ctx, slot, 2, result_host);
+}
+
+#define KHIP_VEC_ARGS(name, cond) KHIP_REQUIRE(ctx && (n == 0 || (cond)), name ": null argument")
+
+int khip_scal(khip_ctx *ctx, int64_t n, double s, double *x) {
+  KHIP_VEC_ARGS("scal", x);
+  return launch_map(ctx, H_SCAL, n, s, 0, nullptr, x, nullptr);
+}
+int khip_div(khip_ctx *ctx, int64_t n, double *x, double s) {   // kdiv! = kscal!(1/s)  (src/krylov_utils.jl:325)
+  KHIP_VEC_ARGS("div", x);
+  return launch_map(ctx, H_SCAL, n, 1.0 / s, 0, nullptr, x, nullptr);
+}
+int khip_copy(khip_ctx *ctx, int64_t n, double *y, const double *x) {
+  KHIP_VEC_ARGS("copy", x && y);
+  if (x == y) return KHIP_OK;
+  return launch_map(ctx, H_COPY, n, 0, 0, x, y, nullptr);
+}
+int khip_scalcopy(khip_ctx *ctx, int64_t n, double *y, double s, const double *x) {
+  KHIP_VEC_ARGS("scalcopy", x && y);
+  return launch_map(ctx, H_SCALCOPY, n, s, 0, x, y, nullptr);
+}
+int khip_divcopy(khip_ctx *ctx, int64_t n, double *y, const double *x, double s) {
+  KHIP_VEC_ARGS("divcopy", x && y);
+  return launch_map(ctx, H_DIVCOPY, n, s, 0, x, y, nullptr);
+}
+int khip_axpy(khip_ctx *ctx, int64_t n, double s, const double *x, double *y) {
+  KHIP_VEC_ARGS("axpy", x && y);
+  return launch_map(ctx, H_AXPY, n, s, 0, x, y, nullptr);
+}
+int khip_axpby(khip_ctx *ctx, int64_t n, double s, const double *x, double t, double *y) {
+  KHIP_VEC_ARGS("axpby", x && y);
+  return launch_map(ctx, H_AXPBY, n, s, t, x, y, nullptr);
+}
+int khip_fill(khip_ctx *ctx, int64_t n, double *x, double val) {
+  KHIP_VEC_ARGS("fill", x);
+  return launch_map(ctx, H_FILL, n, val, 0, nullptr, x, nullptr);
+}
+int khip_ref(khip_ctx *ctx, int64_t n, double *x, double *y, double c, double s) {
+  KHIP_VEC_ARGS("ref", x && y);
+  KHIP_REQUIRE(x != y, "ref: x and y must be distinct");
+  return launch_map(ctx, H_REF, n, c, s, x, y, nullptr);
+}
+int khip_waxpy(khip_ctx *ctx, int64_t n, double *w, const double *x, double b, const double *y) {
+  KHIP_VEC_ARGS("waxpy", w && x && y);
+  // launch_map's WAXPY computes w = fma(b, Y, X) with X = x-argument, Y = y-argument
+  return launch_map(ctx, H_WAXPY, n, 0, b, x, const_cast<double *>(y), w);
+}
+
+int khip_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const double *q, double *x, double *r,
+                   double *result_host) {
+  KHIP_REQUIRE(ctx && result_host && (n == 0 || (p && q && x && r)), "axpy2_dot: null argument");
+  const int slot = take_slots(ctx, 1);
+  KHIP_TRY(launch_axpy2_dot(ctx, n, a, p, q, x, r, slot));
+  return fetch_results(ctx, slot, 1, result_host);
+}
+
+int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, double *q, double *h_host,
+             double *nrm_host, int accumulate) {
+  KHIP_REQUIRE(ctx && q && (k == 0 || (V_host && h_host)), "mgs: null argument");
+  KHIP_REQUIRE(k >= 0, "mgs: negative k");
+  if (comm_nranks(ctx) > 1 || k + 1 > kResultSlots) {
+    // distributed (every coefficient needs the all-reduced value before the next update) or a basis
+    // larger than the device scalar ring: the reference's own sequence, one sync per coefficient
+    for (int i = 0; i < k; ++i) {
+      double h;
+      KHIP_TRY(khip_dot(ctx, n, V_host[i], q, &h));
+      KHIP_TRY(khip_axpy(ctx, n, -h, V_host[i], q));
+      h_host[i] = accumulate ? h_host[i] + h : h;
+    }
+    if (nrm_host) KHIP_TRY(khip_nrm2(ctx, n, q, nrm_host));
+    return KHIP_OK;
+  }
+  // single GPU: chain through device-resident scalars, one sync at the end.
+  //   h_0 = V_0 . q ; then for i: q -= h_i V_i fused with h_{i+1} = V_{i+1} . q (or ||q||^2 at the end)
+  if (k == 0) {
+    if (nrm_host) return khip_nrm2(ctx, n, q, nrm_host);
+    return KHIP_OK;
+  }
+  const int slot = take_slots(ctx, k + 1);
+  KHIP_TRY(launch_dot(ctx, n, V_host[0], q, slot));
+  for (int i = 0; i < k; ++i) {
+    const double *znext = (i + 1 < k) ? V_host[i + 1] : q;   // last step: ||q||^2
+    KHIP_TRY(launch_axpy_dev_dot(ctx, n, ctx->results + slot + i, V_host[i], q, znext, slot + i + 1));
+  }
+  std::vector<double> tmp((size_t)k + 1);
+  KHIP_TRY(fetch_results(ctx, slot, k + 1, tmp.data()));
+  for (int i = 0; i < k; ++i) h_host[i] = accumulate ? h_host[i] + tmp[i] : tmp[i];
+  if (nrm_host) *nrm_host = std::sqrt(tmp[k]);
+  return KHIP_OK;
+}
+
+int khip_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *y_host, const double *const *V_host, double *x) {
+  KHIP_REQUIRE(ctx && (k == 0 || (y_host && V_host)) && (n == 0 || x), "multi_axpy: null argument");
+  return launch_multi_axpy(ctx, n, k, y_host, V_host, x);
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// khip_internal.hpp -- shared host-side declarations of libkrylov_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/krylov_hip.h"
+
+namespace khip {
+
+void set_error(const char *fmt, ...);
+
+#define KHIP_CHECK_HIP(expr)                                                              \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      ::khip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                        __LINE__);                                                        \
+      return KHIP_ERR_HIP;                                                                \
+    }                                                                                     \
+  } while (0)
+
+#define KHIP_REQUIRE(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::khip::set_error(__VA_ARGS__);    \
+      return KHIP_ERR_INVALID;           \
+    }                                    \
+  } while (0)
+
+#define KHIP_TRY(expr)                 \
+  do {                                 \
+    int rc__ = (expr);                 \
+    if (rc__ != KHIP_OK) return rc__;  \
+  } while (0)
+
+// double-double partial of a compensated reduction: value = hi + lo
+struct dd {
+  double hi, lo;
+};
+
+constexpr int kMaxRedBlocks = 2048;   // partials per reduction launch (256 CUs x 8)
+constexpr int kMaxRedOut = 64;        // independent results one launch may produce (dot2, mgs)
+constexpr int kResultSlots = 256;     // device-resident scalar ring (chained MGS coefficients)
+
+struct Comm;   // comm.cpp
+
+struct Tuning {
+  int spmv_kernel = 0;      // 0 = auto, 1 = stream (LDS-staged), 2 = vector (sub-wave per row)
+  int spmv_rows = 256;      // rows per workgroup of the stream kernel
+  int spmv_vec = 2;         // nnz per lane per load in the stream kernel (1, 2)
+  int spmv_nt = 1;          // non-temporal loads for the val/col streams
+  int spmv_xcd = 1;         // XCD-contiguous block remap
+  int spmv_lanes = 0;       // vector kernel lanes per row (0 = auto)
+  int compensated = 1;      // Dot2 (TwoSum/TwoProd) reductions
+  int blas1_blocks = 2048;  // max grid of BLAS-1 kernels
+  int overlap_halo = 1;     // overlap halo exchange with interior rows
+  int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
+};
+
+}  // namespace khip
+
+struct khip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  int num_cu = 256;
+  // reduction scratch
+  khip::dd *partials = nullptr;        // [kMaxRedOut][kMaxRedBlocks]
+  unsigned *tickets = nullptr;         // [kMaxRedOut]
+  double *results = nullptr;           // device scalar ring [kResultSlots]   (value)
+  khip::dd *results_dd = nullptr;      // device scalar ring [kResultSlots]   (hi, lo) for multi-GPU
+  double *results_pinned = nullptr;    // pinned host mirror [kResultSlots * 2]
+  int next_slot = 0;
+  // small device staging for pointer / coefficient arrays (mgs, multi_axpy)
+  void *stage_dev = nullptr;
+  void *stage_pinned = nullptr;
+  size_t stage_bytes = 0;
+  khip::Tuning tune;
+  khip::Comm *comm = nullptr;
+  // SpMV launch profiling (events recorded on `stream`, resolved lazily)
+  std::vector<hipEvent_t> prof_events;   // pairs: start, stop
+  size_t prof_used = 0;
+};
+
+struct khip_csr {
+  khip_ctx *ctx = nullptr;
+  int64_t m = 0, n = 0, nnz = 0;       // local rows, (global) cols, local nnz
+  int32_t *rowptr = nullptr;           // device, m+1, 0-based
+  int32_t *col = nullptr;              // device, nnz (+pad), 0-based; remapped when distributed
+  double *val = nullptr;               // device, nnz (+pad)
+  int64_t max_row_nnz = 0;
+  double mean_row_nnz = 0;
+  // distributed state (null / zero when single GPU)
+  bool dist = false;
+  int64_t n_global = 0, row0 = 0;
+  int64_t n_ghost = 0;
+  double *ghost = nullptr;             // device, n_ghost : received remote x entries
+  double *sendbuf = nullptr;           // device, n_send
+  int32_t *send_idx = nullptr;         // device, n_send : owned indices to pack
+  int64_t n_send = 0;
+  std::vector<int64_t> send_off, recv_off;   // per-peer offsets (size nranks+1)
+  int64_t interior_lo = 0, interior_hi = 0;  // rows [lo,hi) reference no ghost column
+};
+
+namespace khip {
+
+// ---- slot ring -------------------------------------------------------------
+inline int take_slots(khip_ctx *ctx, int count) {
+  if (ctx->next_slot + count > kResultSlots) ctx->next_slot = 0;
+  int s = ctx->next_slot;
+  ctx->next_slot += count;
+  return s;
+}
+
+// blas1.hip
+int launch_dot(khip_ctx *ctx, int64_t n, const double *x, const double *y, int slot);
+int launch_nrm2sq(khip_ctx *ctx, int64_t n, const double *x, int slot);
+int launch_dot2(khip_ctx *ctx, int64_t n, const double *x, const double *y, int slot);  // slot: x.y, slot+1: x.x
+int launch_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const double *q, double *x,
+                     double *r, int slot);
+// y <- y - (*coef_dev) x ; out[slot] = z . y (z == y -> ||y||^2), coef read from device memory
+int launch_axpy_dev_dot(khip_ctx *ctx, int64_t n, const double *coef_dev, const double *x, double *y,
+                        const double *z, int slot);
+int launch_map(khip_ctx *ctx, int op, int64_t n, double a, double b, const double *x, double *y,
+               double *w);
+int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host,
+                      const double *const *V_host, double *x);
+// fetch `count` results starting at slot into host memory (synchronises the stream; all-reduces
+// across ranks when a communicator is attached). sqrt_mask bit i -> take sqrt of result i.
+int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host);
+
+// spmv.hip
+int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot /* -1 = none */,
+                int64_t row_lo, int64_t row_hi);
+int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
+int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays are resident
+int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out);
+int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost);
+int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64_t row1, int32_t *out_dev,
+                           unsigned long long *count_dev, int64_t cap);
+int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host);
+
+int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
+
+// comm.cpp
+int comm_nranks(const khip_ctx *ctx);
+int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host);
+int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x);
+int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A);
+int comm_build_plan(khip_ctx *ctx, khip_csr *A);
+
+}  // namespace khip

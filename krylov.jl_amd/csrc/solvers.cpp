@@ -1,0 +1,884 @@
+// solvers.cpp -- host control flow of cg!, gmres!, bicgstab! above the device primitives.
+//
+// With Julia present the UNMODIFIED reference solvers (src/cg.jl, src/gmres.jl, src/bicgstab.jl)
+// drive the k* entry points through the glue of INTEGRATION.md.  Julia is absent in this build
+// environment, so the same control flow is restated here in C++ -- scalar recurrences, stopping
+// tests, status strings and workspace aliasing follow the cited lines -- and only ever touches
+// device memory through the khip_* primitives of include/krylov_hip.h.
+//
+// opts.fused = 0 issues exactly the primitive sequence of the reference (one launch per k* call,
+// one host sync per kdot/knorm).  opts.fused = 1 replaces legal groups by fused kernels
+// (SpMV+dot, axpy+axpy+dot, copy+axpy, MGS cascade with device-resident coefficients, multi-axpy);
+// elementwise results are bit-identical, reductions agree to one ulp.
+#include <chrono>
+#include <cmath>
+#include <limits>
+
+#include "khip_internal.hpp"
+
+using namespace khip;
+
+namespace {
+
+constexpr double kEps = std::numeric_limits<double>::epsilon();
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+double tol_or_default(double t) { return std::isnan(t) ? std::sqrt(kEps) : t; }
+double timemax_of(const khip_options &o) {
+  return (std::isnan(o.timemax) || o.timemax <= 0) ? std::numeric_limits<double>::infinity() : o.timemax;
+}
+
+struct StatsBox {
+  khip_stats st;
+  std::vector<double> residuals;
+  StatsBox() {
+    memset(&st, 0, sizeof(st));
+    snprintf(st.status, sizeof(st.status), "unknown");
+  }
+  void reset() {   // reset!(stats), src/krylov_stats.jl:38-44
+    residuals.clear();
+    st.residuals = nullptr;
+    st.nres = 0;
+    st.indefinite = 0;
+    st.npcCount = 0;
+    st.error[0] = 0;
+  }
+  void push(double v) { residuals.push_back(v); }
+  void publish() {
+    st.residuals = residuals.empty() ? nullptr : residuals.data();
+    st.nres = (int)residuals.size();
+  }
+  int fail(int code, const char *msg) {
+    snprintf(st.error, sizeof(st.error), "%s", msg);
+    set_error("%s", msg);
+    publish();
+    return code;
+  }
+  int fail_rc(int rc) {   // a primitive failed: message already in khip_last_error()
+    snprintf(st.error, sizeof(st.error), "%s", khip_last_error());
+    publish();
+    return rc;
+  }
+};
+
+int apply_op(khip_ctx *ctx, const khip_operator *op, const double *x, double *y) {
+  if (op->apply) {
+    int rc = op->apply(op->self, x, y);
+    if (rc != 0) { set_error("user operator returned %d", rc); return KHIP_ERR_INVALID; }
+    return KHIP_OK;
+  }
+  if (!op->csr) { set_error("operator has neither a CSR handle nor an apply callback"); return KHIP_ERR_INVALID; }
+  return khip_spmv(ctx, op->csr, x, y);
+}
+
+int64_t padded(int64_t n) { return (n + 31) & ~(int64_t)31; }   // 256-byte multiples keep every slice 16-B aligned
+
+int alloc_vec(khip_ctx *ctx, int64_t n, double **out) {
+  return khip_malloc(ctx, sizeof(double) * (size_t)padded(n > 0 ? n : 1), reinterpret_cast<void **>(out));
+}
+
+#define K(expr)                                   \
+  do {                                            \
+    int rc_k = (expr);                            \
+    if (rc_k != KHIP_OK) return ws->box.fail_rc(rc_k); \
+  } while (0)
+
+}  // namespace
+
+// ================================================================== CG ==========
+struct khip_cg_workspace {
+  khip_ctx *ctx;
+  int64_t m, n;
+  double *dx = nullptr, *x = nullptr, *r = nullptr, *npc_dir = nullptr, *p = nullptr, *Ap = nullptr, *z = nullptr;
+  bool warm_start = false;
+  StatsBox box;
+};
+
+extern "C" {
+
+khip_options khip_default_options(void) {
+  khip_options o;
+  memset(&o, 0, sizeof(o));
+  o.atol = NAN; o.rtol = NAN; o.timemax = NAN;
+  o.fused = 1;
+  return o;
+}
+
+int khip_cg_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_cg_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "cg_workspace_create: bad argument");
+  khip_cg_workspace *ws = new khip_cg_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n;
+  // x, r, p, Ap allocated; dx, npc_dir, z stay empty until needed (src/krylov_workspaces.jl:269-285)
+  int rc = alloc_vec(ctx, n, &ws->x);
+  if (!rc) rc = alloc_vec(ctx, n, &ws->r);
+  if (!rc) rc = alloc_vec(ctx, n, &ws->p);
+  if (!rc) rc = alloc_vec(ctx, n, &ws->Ap);
+  if (rc) { khip_cg_workspace_destroy(ws); return rc; }
+  *out = ws;
+  return KHIP_OK;
+}
+
+int khip_cg_workspace_destroy(khip_cg_workspace *ws) {
+  if (!ws) return KHIP_OK;
+  for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z}) khip_free(ws->ctx, v);
+  delete ws;
+  return KHIP_OK;
+}
+
+int khip_cg_warm_start(khip_cg_workspace *ws, const double *x0) {
+  KHIP_REQUIRE(ws && x0, "cg_warm_start: null argument");
+  if (!ws->dx) KHIP_TRY(alloc_vec(ws->ctx, ws->n, &ws->dx));
+  KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
+  ws->warm_start = true;
+  return KHIP_OK;
+}
+
+double *khip_cg_solution(khip_cg_workspace *ws) { return ws ? ws->x : nullptr; }
+const khip_stats *khip_cg_stats(khip_cg_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+double *khip_cg_vector(khip_cg_workspace *ws, const char *name) {
+  if (!ws || !name) return nullptr;
+  struct { const char *k; double *p; } tab[] = {{"x", ws->x}, {"r", ws->r}, {"p", ws->p}, {"Ap", ws->Ap},
+                                                {"z", ws->z}, {"dx", ws->dx}, {"npc_dir", ws->npc_dir}};
+  for (auto &e : tab) if (strcmp(e.k, name) == 0) return e.p;
+  return nullptr;
+}
+size_t khip_cg_workspace_bytes(khip_cg_workspace *ws) {
+  if (!ws) return 0;
+  size_t cnt = 0;
+  for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z}) cnt += v ? 1 : 0;
+  return cnt * sizeof(double) * (size_t)ws->n;
+}
+
+// to_boundary with M === I (src/krylov_utils.jl:375-402) + roots_quadratic (:110-152)
+static int roots_quadratic(double q2, double q1, double q0, double *r1, double *r2) {
+  const int nitref = 1;
+  double root1, root2;
+  if (q2 == 0.0) {
+    double root;
+    if (q1 == 0.0) {
+      if (q0 != 0.0) return -1;
+      root = 0.0;
+    } else {
+      root = -q0 / q1;
+    }
+    *r1 = root; *r2 = root;
+    return 0;
+  }
+  const double rhs = std::sqrt(kEps) * q1 * q1;
+  if (std::fabs(q0 * q2) > rhs) {
+    const double rho = q1 * q1 - 4 * q2 * q0;
+    if (rho < 0) return -1;
+    const double d = -(q1 + std::copysign(std::sqrt(rho), q1)) / 2;
+    root1 = d / q2;
+    root2 = q0 / d;
+  } else {
+    root1 = -q1 / q2;
+    root2 = 0.0;
+  }
+  for (int it = 0; it < nitref; ++it) {
+    const double q = (q2 * root1 + q1) * root1 + q0, dq = 2 * q2 * root1 + q1;
+    if (dq == 0.0) continue;
+    root1 = root1 - q / dq;
+  }
+  for (int it = 0; it < nitref; ++it) {
+    const double q = (q2 * root2 + q1) * root2 + q0, dq = 2 * q2 * root2 + q1;
+    if (dq == 0.0) continue;
+    root2 = root2 - q / dq;
+  }
+  *r1 = root1; *r2 = root2;
+  return 0;
+}
+
+int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_operator *M, const double *b,
+                  const khip_options *opts_in) {
+  KHIP_REQUIRE(ws && A && b, "cg_solve: null argument");
+  khip_ctx *ctx = ws->ctx;
+  khip_options o = opts_in ? *opts_in : khip_default_options();
+  const double t0 = now_s();
+  const double timemax = timemax_of(o);
+  const int64_t n = ws->n;
+  khip_stats *st = &ws->box.st;
+  const double atol = tol_or_default(o.atol), rtol = tol_or_default(o.rtol);
+  const double radius = o.radius;
+  const bool linesearch = o.linesearch != 0;
+  const bool fused = o.fused != 0;
+
+  if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (A->csr && !A->apply) {
+    int64_t am, an;
+    khip_csr_shape(A->csr, &am, &an, nullptr);
+    if (am != ws->m) return ws->box.fail(KHIP_ERR_INVALID, "(workspace.m, workspace.n) is inconsistent with size(A)");
+  }
+  if (linesearch && radius > 0)
+    return ws->box.fail(KHIP_ERR_INVALID, "`linesearch` set to `true` but trust-region radius > 0");
+  if (ws->warm_start && linesearch)
+    return ws->box.fail(KHIP_ERR_INVALID, "warm_start and linesearch cannot be used together");
+  const bool MisI = (M == nullptr);
+  if (!MisI && radius > 0)
+    return ws->box.fail(KHIP_ERR_UNSUPPORTED, "radius > 0 with a preconditioner needs ldiv!(M): not available through a callback");
+
+  if (!MisI && !ws->z) K(alloc_vec(ctx, n, &ws->z));                               // src/cg.jl:142
+  if ((linesearch || radius > 0) && !ws->npc_dir) K(alloc_vec(ctx, n, &ws->npc_dir));  // :143
+  double *dx = ws->dx, *x = ws->x, *r = ws->r, *p = ws->p, *Ap = ws->Ap;
+  const bool warm_start = ws->warm_start;
+  ws->box.reset();
+  double *z = MisI ? r : ws->z;
+  double *npc_dir = ws->npc_dir;
+
+  K(khip_fill(ctx, n, x, 0.0));                                                    // :153
+  if (warm_start) {
+    K(apply_op(ctx, A, dx, r));
+    K(khip_axpby(ctx, n, 1.0, b, -1.0, r));
+  } else {
+    K(khip_copy(ctx, n, r, b));
+  }
+  if (!MisI) K(apply_op(ctx, M, r, z));
+  K(khip_copy(ctx, n, p, z));
+  double gamma;
+  K(khip_dot(ctx, n, r, z, &gamma));                                               // :162
+  if (!(gamma >= 0))
+    return ws->box.fail(KHIP_ERR_NUMERIC,
+                        "The linear operator `A` or the preconditioner `M` is not symmetric positive definite.");
+  double rNorm = std::sqrt(gamma);
+  if (o.history) ws->box.push(rNorm);
+  if (gamma == 0) {                                                                // :166-174
+    st->niter = 0; st->solved = 1; st->inconsistent = 0;
+    st->timer = now_s() - t0;
+    snprintf(st->status, sizeof(st->status), "x is a zero-residual solution");
+    if (warm_start) K(khip_axpy(ctx, n, 1.0, dx, x));
+    ws->warm_start = false;
+    ws->box.publish();
+    return KHIP_OK;
+  }
+
+  int64_t iter = 0;
+  const int64_t itmax = o.itmax == 0 ? 2 * n : o.itmax;
+  double pAp = 0.0;
+  double pNorm2 = gamma;
+  const double eps_tol = atol + rtol * rNorm;
+
+  bool solved = rNorm <= eps_tol;
+  bool tired = iter >= itmax;
+  bool inconsistent = false, on_boundary = false, zero_curvature = false, user_requested_exit = false,
+       overtimed = false;
+  const char *status = "unknown";
+
+  while (!(solved || tired || zero_curvature || user_requested_exit || overtimed)) {
+    if (fused && !A->apply) {
+      K(khip_spmv_dot(ctx, A->csr, p, Ap, &pAp));                                  // :196-197 fused
+    } else {
+      K(apply_op(ctx, A, p, Ap));                                                  // :196
+      K(khip_dot(ctx, n, p, Ap, &pAp));                                            // :197
+    }
+    if ((pAp <= kEps * pNorm2) && (radius == 0)) {                                 // :198-211
+      if (std::fabs(pAp) <= kEps * pNorm2) {
+        zero_curvature = true;
+        inconsistent = !linesearch;
+      }
+      if (linesearch) {
+        if (iter == 0) K(khip_copy(ctx, n, x, p));
+        K(khip_copy(ctx, n, npc_dir, p));
+        st->npcCount = 1;
+        st->indefinite = 1;
+        solved = true;
+      }
+    }
+    if (zero_curvature || solved) continue;
+
+    double alpha = gamma / pAp;                                                    // :213
+    double sigma;
+    if (radius == 0) {
+      sigma = alpha;
+    } else {                                                                       // to_boundary(n, x, p, z, radius, dNorm2=pNorm²)
+      double rxd, xNorm2;
+      K(khip_dot(ctx, n, x, p, &rxd));
+      K(khip_dot(ctx, n, x, x, &xNorm2));
+      const double radius2 = radius * radius;
+      if (pNorm2 == 0.0) return ws->box.fail(KHIP_ERR_NUMERIC, "zero direction");
+      if (!(xNorm2 <= radius2)) return ws->box.fail(KHIP_ERR_NUMERIC, "outside of the trust region");
+      double s1, s2;
+      if (roots_quadratic(pNorm2, 2 * rxd, xNorm2 - radius2, &s1, &s2))
+        return ws->box.fail(KHIP_ERR_NUMERIC, "The quadratic `q` doesn't have real roots.");
+      sigma = s1 > s2 ? s1 : s2;
+    }
+    if ((radius > 0) && ((pAp <= 0) || (alpha > sigma))) {                         // :229-237
+      alpha = sigma;
+      if (pAp <= 0) {
+        K(khip_copy(ctx, n, npc_dir, p));
+        st->npcCount = 1;
+        st->indefinite = 1;
+      }
+      on_boundary = true;
+    }
+
+    double gamma_next;
+    if (fused && MisI) {
+      K(khip_axpy2_dot(ctx, n, alpha, p, Ap, x, r, &gamma_next));                  // :239-242 fused
+    } else {
+      K(khip_axpy(ctx, n, alpha, p, x));                                           // :239
+      K(khip_axpy(ctx, n, -alpha, Ap, r));                                         // :240
+      if (!MisI) K(apply_op(ctx, M, r, z));                                        // :241
+      K(khip_dot(ctx, n, r, z, &gamma_next));                                      // :242
+    }
+    if (!(gamma_next >= 0))
+      return ws->box.fail(KHIP_ERR_NUMERIC,
+                          "The linear operator `A` or the preconditioner `M` is not symmetric positive definite.");
+    rNorm = std::sqrt(gamma_next);
+    if (o.history) ws->box.push(rNorm);
+
+    const bool resid_decrease_mach = (rNorm + 1.0 <= 1.0);
+    const bool resid_decrease_lim = rNorm <= eps_tol;
+    const bool resid_decrease = resid_decrease_lim || resid_decrease_mach;
+    solved = resid_decrease || on_boundary;
+
+    if (!solved) {                                                                 // :255-260
+      const double beta = gamma_next / gamma;
+      pNorm2 = gamma_next + beta * beta * pNorm2;
+      gamma = gamma_next;
+      K(khip_axpby(ctx, n, 1.0, z, beta, p));
+    }
+
+    iter = iter + 1;
+    tired = iter >= itmax;
+    if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;    // :264
+    overtimed = (now_s() - t0) > timemax;
+  }
+
+  if (solved && on_boundary) status = "on trust-region boundary";
+  if (solved && st->indefinite) status = "nonpositive curvature";
+  if (solved && strcmp(status, "unknown") == 0) status = "solution good enough given atol and rtol";
+  if (zero_curvature) status = "zero curvature detected";
+  if (tired) status = "maximum number of iterations exceeded";
+  if (user_requested_exit) status = "user-requested exit";
+  if (overtimed) status = "time limit exceeded";
+
+  if (warm_start) K(khip_axpy(ctx, n, 1.0, dx, x));
+  ws->warm_start = false;
+  K(khip_ctx_sync(ctx));
+
+  st->niter = (int)iter;
+  st->solved = solved;
+  st->inconsistent = inconsistent;
+  st->timer = now_s() - t0;
+  snprintf(st->status, sizeof(st->status), "%s", status);
+  ws->box.publish();
+  return KHIP_OK;
+}
+
+}  // extern "C"
+
+// ================================================================== GMRES =======
+struct khip_gmres_workspace {
+  khip_ctx *ctx;
+  int64_t m, n, stride;
+  int mem;                       // length(c)
+  double *dx = nullptr, *x = nullptr, *w = nullptr, *p = nullptr, *q = nullptr;
+  std::vector<double *> V;       // V[i] -> slice of a slab
+  std::vector<double *> slabs;   // owned allocations backing V
+  std::vector<int> slab_count;
+  std::vector<double> c, s, z, R;
+  int inner_iter = 0;
+  bool warm_start = false;
+  StatsBox box;
+};
+
+static int gmres_grow_basis(khip_gmres_workspace *ws, int count) {   // push!(V, similar(x)) in slabs
+  double *slab = nullptr;
+  KHIP_TRY(khip_malloc(ws->ctx, sizeof(double) * (size_t)ws->stride * (size_t)count, reinterpret_cast<void **>(&slab)));
+  ws->slabs.push_back(slab);
+  ws->slab_count.push_back(count);
+  for (int i = 0; i < count; ++i) ws->V.push_back(slab + (size_t)i * ws->stride);
+  return KHIP_OK;
+}
+
+// sym_givens(a, b) for reals, src/krylov_utils.jl:21-51
+static void sym_givens(double a, double b, double &c, double &s, double &rho) {
+  auto sgn = [](double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); };
+  if (b == 0.0) {
+    c = sgn(a) + (a == 0.0 ? 1.0 : 0.0);
+    s = 0.0;
+    rho = std::fabs(a);
+  } else if (a == 0.0) {
+    c = 0.0;
+    s = sgn(b);
+    rho = std::fabs(b);
+  } else if (std::fabs(b) > std::fabs(a)) {
+    const double t = a / b;
+    s = sgn(b) / std::sqrt(1.0 + t * t);
+    c = s * t;
+    rho = b / s;
+  } else {
+    const double t = b / a;
+    c = sgn(a) / std::sqrt(1.0 + t * t);
+    s = c * t;
+    rho = a / c;
+  }
+}
+
+extern "C" {
+
+int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory, khip_gmres_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "gmres_workspace_create: bad argument");
+  if (memory <= 0) memory = 20;
+  if ((int64_t)memory > m) memory = (int)m;                          // memory = min(m, memory) :2900
+  khip_gmres_workspace *ws = new khip_gmres_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n; ws->mem = memory;
+  ws->stride = padded(n > 0 ? n : 1);
+  int rc = alloc_vec(ctx, n, &ws->x);
+  if (!rc) rc = alloc_vec(ctx, n, &ws->w);
+  if (!rc && memory > 0) rc = gmres_grow_basis(ws, memory);         // the basis is ONE slab: V[i] are consecutive slices
+  if (rc) { khip_gmres_workspace_destroy(ws); return rc; }
+  ws->c.assign(memory, 0.0); ws->s.assign(memory, 0.0); ws->z.assign(memory, 0.0);
+  ws->R.assign((size_t)memory * (memory + 1) / 2, 0.0);
+  *out = ws;
+  return KHIP_OK;
+}
+
+int khip_gmres_workspace_destroy(khip_gmres_workspace *ws) {
+  if (!ws) return KHIP_OK;
+  for (double *v : {ws->dx, ws->x, ws->w, ws->p, ws->q}) khip_free(ws->ctx, v);
+  for (double *s : ws->slabs) khip_free(ws->ctx, s);
+  delete ws;
+  return KHIP_OK;
+}
+
+int khip_gmres_warm_start(khip_gmres_workspace *ws, const double *x0) {
+  KHIP_REQUIRE(ws && x0, "gmres_warm_start: null argument");
+  if (!ws->dx) KHIP_TRY(alloc_vec(ws->ctx, ws->n, &ws->dx));
+  KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
+  ws->warm_start = true;
+  return KHIP_OK;
+}
+
+double *khip_gmres_solution(khip_gmres_workspace *ws) { return ws ? ws->x : nullptr; }
+const khip_stats *khip_gmres_stats(khip_gmres_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+size_t khip_gmres_workspace_bytes(khip_gmres_workspace *ws) {
+  if (!ws) return 0;
+  size_t cnt = ws->V.size();
+  for (double *v : {ws->dx, ws->x, ws->w, ws->p, ws->q}) cnt += v ? 1 : 0;
+  return cnt * sizeof(double) * (size_t)ws->n +
+         sizeof(double) * (ws->c.size() + ws->s.size() + ws->z.size() + ws->R.size());
+}
+
+int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                     const khip_operator *N, const double *b, const khip_options *opts_in) {
+  KHIP_REQUIRE(ws && A && b, "gmres_solve: null argument");
+  khip_ctx *ctx = ws->ctx;
+  khip_options o = opts_in ? *opts_in : khip_default_options();
+  const double t0 = now_s();
+  const double timemax = timemax_of(o);
+  const int64_t n = ws->n;
+  khip_stats *st = &ws->box.st;
+  const double atol = tol_or_default(o.atol), rtol = tol_or_default(o.rtol);
+  const bool restart = o.restart != 0, reorth = o.reorthogonalization != 0, fused = o.fused != 0;
+  if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+
+  const bool MisI = (M == nullptr), NisI = (N == nullptr);
+  if (!MisI && !ws->q) K(alloc_vec(ctx, n, &ws->q));                               // src/gmres.jl:142-144
+  if (!NisI && !ws->p) K(alloc_vec(ctx, n, &ws->p));
+  if (restart && !ws->dx) K(alloc_vec(ctx, n, &ws->dx));
+  double *dx = ws->dx, *x = ws->x, *w = ws->w;
+  std::vector<double *> &V = ws->V;
+  std::vector<double> &c = ws->c, &s = ws->s, &z = ws->z, &R = ws->R;
+  const bool warm_start = ws->warm_start;
+  ws->box.reset();
+  double *q = MisI ? w : ws->q;
+  double *r0 = MisI ? w : ws->q;
+  double *xr = restart ? dx : x;
+
+  K(khip_fill(ctx, n, x, 0.0));                                                    // :155
+  if (warm_start) {
+    K(apply_op(ctx, A, dx, w));
+    K(khip_axpby(ctx, n, 1.0, b, -1.0, w));
+    if (restart) K(khip_axpy(ctx, n, 1.0, dx, x));
+  } else {
+    K(khip_copy(ctx, n, w, b));
+  }
+  if (!MisI) K(apply_op(ctx, M, w, r0));
+  double beta;
+  K(khip_nrm2(ctx, n, r0, &beta));                                                 // :166
+  double rNorm = beta;
+  if (o.history) ws->box.push(beta);
+  const double eps_tol = atol + rtol * rNorm;
+
+  if (beta == 0) {
+    st->niter = 0; st->solved = 1; st->inconsistent = 0;
+    st->timer = now_s() - t0;
+    snprintf(st->status, sizeof(st->status), "x is a zero-residual solution");
+    if (warm_start) K(khip_axpy(ctx, n, 1.0, dx, x));
+    ws->warm_start = false;
+    ws->box.publish();
+    return KHIP_OK;
+  }
+
+  const int mem = (int)c.size();                                                   // :188
+  int npass = 0;
+  int64_t iter = 0;
+  int inner_iter = 0;
+  const int64_t itmax = o.itmax == 0 ? 2 * n : o.itmax;
+  int64_t inner_itmax = itmax;
+  const double btol = std::pow(kEps, 0.75);                                        // :195
+
+  bool breakdown = false, inconsistent = false;
+  bool solved = rNorm <= eps_tol;
+  bool tired = iter >= itmax;
+  bool inner_tired = inner_iter >= inner_itmax;
+  bool user_requested_exit = false, overtimed = false;
+  const char *status = "unknown";
+
+  while (!(solved || tired || breakdown || user_requested_exit || overtimed)) {
+    int nr = 0;
+    // kfill!(V[i], 0) for i = 1:mem (:211-213); the first slab holds at least `mem` consecutive slices
+    if (!ws->slabs.empty() && ws->slab_count[0] >= mem) {
+      K(khip_fill(ctx, (int64_t)ws->stride * mem, ws->slabs[0], 0.0));
+    } else {
+      for (int i = 0; i < mem; ++i) K(khip_fill(ctx, n, V[i], 0.0));
+    }
+    std::fill(s.begin(), s.end(), 0.0);
+    std::fill(c.begin(), c.end(), 0.0);
+    std::fill(R.begin(), R.end(), 0.0);
+    std::fill(z.begin(), z.end(), 0.0);
+
+    if (restart) {
+      K(khip_fill(ctx, n, xr, 0.0));
+      if (npass >= 1) {
+        K(apply_op(ctx, A, x, w));
+        K(khip_axpby(ctx, n, 1.0, b, -1.0, w));
+        if (!MisI) K(apply_op(ctx, M, w, r0));
+      }
+    }
+
+    K(khip_nrm2(ctx, n, r0, &beta));                                               // :229
+    z[0] = beta;
+    K(khip_divcopy(ctx, n, V[0], r0, rNorm));                                      // :231 divides by rNorm (estimate), not beta
+
+    npass = npass + 1;
+    ws->inner_iter = 0;
+    inner_tired = false;
+
+    while (!(solved || inner_tired || breakdown || user_requested_exit || overtimed)) {
+      ws->inner_iter = ws->inner_iter + 1;
+      inner_iter = ws->inner_iter;
+
+      if (!restart && (inner_iter > mem)) {                                        // :244-252
+        for (int i = 0; i < inner_iter; ++i) R.push_back(0.0);
+        s.push_back(0.0);
+        c.push_back(0.0);
+      }
+
+      double *Vk = V[inner_iter - 1];
+      double *pp = NisI ? Vk : ws->p;
+      if (!NisI) K(apply_op(ctx, N, Vk, pp));
+      K(apply_op(ctx, A, pp, w));                                                  // :257
+      if (!MisI) K(apply_op(ctx, M, w, q));
+
+      double Hbis;
+      if (fused) {
+        // MGS cascade with device-resident coefficients; ||q|| of :274 comes out of the last pass
+        K(khip_mgs(ctx, n, inner_iter, V.data(), q, &R[nr], reorth ? nullptr : &Hbis, 0));
+        if (reorth) K(khip_mgs(ctx, n, inner_iter, V.data(), q, &R[nr], &Hbis, 1));
+      } else {
+        for (int i = 0; i < inner_iter; ++i) {                                     // :259-262
+          K(khip_dot(ctx, n, V[i], q, &R[nr + i]));
+          K(khip_axpy(ctx, n, -R[nr + i], V[i], q));
+        }
+        if (reorth) {                                                              // :265-271
+          for (int i = 0; i < inner_iter; ++i) {
+            double Htmp;
+            K(khip_dot(ctx, n, V[i], q, &Htmp));
+            R[nr + i] += Htmp;
+            K(khip_axpy(ctx, n, -Htmp, V[i], q));
+          }
+        }
+        K(khip_nrm2(ctx, n, q, &Hbis));                                            // :274
+      }
+
+      for (int i = 0; i < inner_iter - 1; ++i) {                                   // :280-284
+        const double Rtmp = c[i] * R[nr + i] + s[i] * R[nr + i + 1];
+        R[nr + i + 1] = s[i] * R[nr + i] - c[i] * R[nr + i + 1];
+        R[nr + i] = Rtmp;
+      }
+      const int k = inner_iter - 1;
+      sym_givens(R[nr + k], Hbis, c[k], s[k], R[nr + k]);                          // :289
+
+      const double zeta_next = s[k] * z[k];                                        // :292-293
+      z[k] = c[k] * z[k];
+
+      rNorm = std::fabs(zeta_next);
+      if (o.history) ws->box.push(rNorm);
+      nr = nr + inner_iter;
+
+      const bool resid_decrease_mach = (rNorm + 1.0 <= 1.0);
+      if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+      const bool resid_decrease_lim = rNorm <= eps_tol;
+      breakdown = Hbis <= btol;
+      solved = resid_decrease_lim || resid_decrease_mach;
+      if (restart) {
+        const int64_t lim = (int64_t)mem < inner_itmax ? (int64_t)mem : inner_itmax;
+        inner_tired = inner_iter >= lim;
+      } else {
+        inner_tired = inner_iter >= inner_itmax;
+      }
+      overtimed = (now_s() - t0) > timemax;
+
+      if (!(solved || inner_tired || breakdown || user_requested_exit || overtimed)) {
+        if (!restart && (inner_iter >= mem)) {                                     // :319-324
+          if ((int)V.size() <= inner_iter) K(gmres_grow_basis(ws, mem > 4 ? mem : 4));
+          if ((int)z.size() <= inner_iter) z.resize(inner_iter + 1, 0.0);
+        }
+        K(khip_divcopy(ctx, n, V[inner_iter], q, Hbis));                           // :325
+        z[inner_iter] = zeta_next;
+      }
+    }
+
+    // back-substitution R y = z (:331-345), y aliases z
+    std::vector<double> &y = z;
+    for (int i = inner_iter; i >= 1; --i) {
+      int pos = nr + i - inner_iter;          // 1-based position of r_{i,k}
+      for (int j = inner_iter; j >= i + 1; --j) {
+        y[i - 1] = y[i - 1] - R[pos - 1] * y[j - 1];
+        pos = pos - j + 1;
+      }
+      if (std::fabs(R[pos - 1]) <= btol) {
+        y[i - 1] = 0.0;
+        inconsistent = true;
+      } else {
+        y[i - 1] = y[i - 1] / R[pos - 1];
+      }
+    }
+
+    if (fused) {
+      K(khip_multi_axpy(ctx, n, inner_iter, y.data(), V.data(), xr));              // :348-350 in one pass
+    } else {
+      for (int i = 0; i < inner_iter; ++i) K(khip_axpy(ctx, n, y[i], V[i], xr));
+    }
+    if (!NisI) {
+      K(khip_copy(ctx, n, ws->p, xr));
+      K(apply_op(ctx, N, ws->p, xr));
+    }
+    if (restart) K(khip_axpy(ctx, n, 1.0, xr, x));                                 // :355
+
+    inner_itmax = inner_itmax - inner_iter;
+    iter = iter + inner_iter;
+    tired = iter >= itmax;
+    overtimed = (now_s() - t0) > timemax;
+  }
+
+  if (tired) status = "maximum number of iterations exceeded";
+  if (solved) status = "solution good enough given atol and rtol";
+  if (inconsistent) status = "found approximate least-squares solution";
+  if (user_requested_exit) status = "user-requested exit";
+  if (overtimed) status = "time limit exceeded";
+
+  if (warm_start && !restart) K(khip_axpy(ctx, n, 1.0, dx, x));
+  ws->warm_start = false;
+  K(khip_ctx_sync(ctx));
+
+  st->niter = (int)iter;
+  st->solved = solved;
+  st->inconsistent = inconsistent;
+  st->timer = now_s() - t0;
+  snprintf(st->status, sizeof(st->status), "%s", status);
+  ws->box.publish();
+  return KHIP_OK;
+}
+
+}  // extern "C"
+
+// ================================================================== BiCGSTAB ====
+struct khip_bicgstab_workspace {
+  khip_ctx *ctx;
+  int64_t m, n;
+  double *dx = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *qd = nullptr,
+         *yz = nullptr, *t = nullptr;
+  bool warm_start = false;
+  StatsBox box;
+};
+
+extern "C" {
+
+int khip_bicgstab_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_bicgstab_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "bicgstab_workspace_create: bad argument");
+  khip_bicgstab_workspace *ws = new khip_bicgstab_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n;
+  int rc = 0;                                                        // x, r, p, v, s, qd (src/krylov_workspaces.jl:1605-1623)
+  for (double **v : {&ws->x, &ws->r, &ws->p, &ws->v, &ws->s, &ws->qd})
+    if (!rc) rc = alloc_vec(ctx, n, v);
+  if (rc) { khip_bicgstab_workspace_destroy(ws); return rc; }
+  *out = ws;
+  return KHIP_OK;
+}
+
+int khip_bicgstab_workspace_destroy(khip_bicgstab_workspace *ws) {
+  if (!ws) return KHIP_OK;
+  for (double *v : {ws->dx, ws->x, ws->r, ws->p, ws->v, ws->s, ws->qd, ws->yz, ws->t}) khip_free(ws->ctx, v);
+  delete ws;
+  return KHIP_OK;
+}
+
+int khip_bicgstab_warm_start(khip_bicgstab_workspace *ws, const double *x0) {
+  KHIP_REQUIRE(ws && x0, "bicgstab_warm_start: null argument");
+  if (!ws->dx) KHIP_TRY(alloc_vec(ws->ctx, ws->n, &ws->dx));
+  KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
+  ws->warm_start = true;
+  return KHIP_OK;
+}
+
+double *khip_bicgstab_solution(khip_bicgstab_workspace *ws) { return ws ? ws->x : nullptr; }
+const khip_stats *khip_bicgstab_stats(khip_bicgstab_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+size_t khip_bicgstab_workspace_bytes(khip_bicgstab_workspace *ws) {
+  if (!ws) return 0;
+  size_t cnt = 0;
+  for (double *v : {ws->dx, ws->x, ws->r, ws->p, ws->v, ws->s, ws->qd, ws->yz, ws->t}) cnt += v ? 1 : 0;
+  return cnt * sizeof(double) * (size_t)ws->n;
+}
+
+int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, const khip_operator *M,
+                        const khip_operator *N, const double *b, const double *c, const khip_options *opts_in) {
+  KHIP_REQUIRE(ws && A && b, "bicgstab_solve: null argument");
+  khip_ctx *ctx = ws->ctx;
+  khip_options o = opts_in ? *opts_in : khip_default_options();
+  const double t0 = now_s();
+  const double timemax = timemax_of(o);
+  const int64_t n = ws->n;
+  khip_stats *st = &ws->box.st;
+  const double atol = tol_or_default(o.atol), rtol = tol_or_default(o.rtol);
+  const bool fused = o.fused != 0;
+  if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (!c) c = b;                                                                   // src/bicgstab.jl:105
+
+  const bool MisI = (M == nullptr), NisI = (N == nullptr);
+  if (!MisI && !ws->t) K(alloc_vec(ctx, n, &ws->t));
+  if (!NisI && !ws->yz) K(alloc_vec(ctx, n, &ws->yz));
+  double *dx = ws->dx, *x = ws->x, *r = ws->r, *p = ws->p, *v = ws->v, *s = ws->s;
+  const bool warm_start = ws->warm_start;
+  ws->box.reset();
+  double *q = ws->qd, *d = ws->qd;                                                 // aliasing :153-157
+  double *t = MisI ? d : ws->t;
+  double *y = NisI ? p : ws->yz;
+  double *z = NisI ? s : ws->yz;
+  double *r0 = MisI ? r : ws->qd;
+
+  if (warm_start) {
+    K(apply_op(ctx, A, dx, r0));
+    K(khip_axpby(ctx, n, 1.0, b, -1.0, r0));
+  } else {
+    K(khip_copy(ctx, n, r0, b));
+  }
+  K(khip_fill(ctx, n, x, 0.0));
+  K(khip_fill(ctx, n, s, 0.0));
+  K(khip_fill(ctx, n, v, 0.0));
+  if (!MisI) K(apply_op(ctx, M, r0, r));
+  K(khip_copy(ctx, n, p, r));
+
+  double alpha = 1.0, omega = 1.0, rho = 1.0;
+  double rNorm;
+  K(khip_nrm2(ctx, n, r, &rNorm));                                                 // :177
+  if (o.history) ws->box.push(rNorm);
+  if (rNorm == 0) {
+    st->niter = 0; st->solved = 1; st->inconsistent = 0;
+    st->timer = now_s() - t0;
+    snprintf(st->status, sizeof(st->status), "x is a zero-residual solution");
+    if (warm_start) K(khip_axpy(ctx, n, 1.0, dx, x));
+    ws->warm_start = false;
+    ws->box.publish();
+    return KHIP_OK;
+  }
+
+  int64_t iter = 0;
+  const int64_t itmax = o.itmax == 0 ? 2 * n : o.itmax;
+  const double eps_tol = atol + rtol * rNorm;
+
+  double next_rho;
+  K(khip_dot(ctx, n, c, r, &next_rho));                                            // :196
+  if (next_rho == 0) {
+    st->niter = 0; st->solved = 0; st->inconsistent = 0;
+    st->timer = now_s() - t0;
+    snprintf(st->status, sizeof(st->status), "Breakdown b\xe1\xb4\xb4""c = 0");
+    if (warm_start) K(khip_axpy(ctx, n, 1.0, dx, x));
+    ws->warm_start = false;
+    ws->box.publish();
+    return KHIP_OK;
+  }
+
+  bool solved = rNorm <= eps_tol;
+  bool tired = iter >= itmax;
+  bool breakdown = false, user_requested_exit = false, overtimed = false;
+  const char *status = "unknown";
+
+  while (!(solved || tired || breakdown || user_requested_exit || overtimed)) {
+    iter = iter + 1;
+    rho = next_rho;
+
+    if (!NisI) K(apply_op(ctx, N, p, y));
+    K(apply_op(ctx, A, y, q));                                                     // :221
+    if (MisI) K(khip_copy(ctx, n, v, q)); else K(apply_op(ctx, M, q, v));          // :222 (unguarded mul!(v, I, q))
+    double cv;
+    K(khip_dot(ctx, n, c, v, &cv));
+    alpha = rho / cv;                                                              // :223
+    if (fused) {
+      K(khip_waxpy(ctx, n, s, r, -alpha, v));                                      // :224-225  s = r - alpha v
+    } else {
+      K(khip_copy(ctx, n, s, r));                                                  // :224
+      K(khip_axpy(ctx, n, -alpha, v, s));                                          // :225
+    }
+    K(khip_axpy(ctx, n, alpha, y, x));                                             // :226
+    if (!NisI) K(apply_op(ctx, N, s, z));
+    K(apply_op(ctx, A, z, d));                                                     // :228
+    if (!MisI) K(apply_op(ctx, M, d, t));
+    if (fused) {
+      double two[2];
+      K(khip_dot2(ctx, n, t, s, two));                                             // :230 both dots in one pass
+      omega = two[0] / two[1];
+    } else {
+      double ts, tt;
+      K(khip_dot(ctx, n, t, s, &ts));
+      K(khip_dot(ctx, n, t, t, &tt));
+      omega = ts / tt;                                                             // :230
+    }
+    K(khip_axpy(ctx, n, omega, z, x));                                             // :231
+    if (fused) {
+      K(khip_waxpy(ctx, n, r, s, -omega, t));                                      // :232-233  r = s - omega t
+    } else {
+      K(khip_copy(ctx, n, r, s));                                                  // :232
+      K(khip_axpy(ctx, n, -omega, t, r));                                          // :233
+    }
+    K(khip_dot(ctx, n, c, r, &next_rho));                                          // :234
+    const double beta = (next_rho / rho) * (alpha / omega);                        // :235
+    K(khip_axpy(ctx, n, -omega, v, p));                                            // :236
+    K(khip_axpby(ctx, n, 1.0, r, beta, p));                                        // :237
+
+    K(khip_nrm2(ctx, n, r, &rNorm));                                               // :240
+    if (o.history) ws->box.push(rNorm);
+
+    const bool resid_decrease_mach = (rNorm + 1.0 <= 1.0);
+    if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+    const bool resid_decrease_lim = rNorm <= eps_tol;
+    solved = resid_decrease_lim || resid_decrease_mach;
+    tired = iter >= itmax;
+    breakdown = (alpha == 0 || std::isnan(alpha));
+    overtimed = (now_s() - t0) > timemax;
+  }
+
+  if (tired) status = "maximum number of iterations exceeded";
+  if (breakdown) status = "breakdown \xce\xb1\xe2\x82\x96 == 0";
+  if (solved) status = "solution good enough given atol and rtol";
+  if (user_requested_exit) status = "user-requested exit";
+  if (overtimed) status = "time limit exceeded";
+
+  if (warm_start) K(khip_axpy(ctx, n, 1.0, dx, x));
+  ws->warm_start = false;
+  K(khip_ctx_sync(ctx));
+
+  st->niter = (int)iter;
+  st->solved = solved;
+  st->inconsistent = 0;
+  st->timer = now_s() - t0;
+  snprintf(st->status, sizeof(st->status), "%s", status);
+  ws->box.publish();
+  return KHIP_OK;
+}
+
+}  // extern "C"

@@ -72,39 +72,51 @@ typedef double (*stencil_fn)(int d1, int d2, int d3);
 
 static int csr_stencil3d(int n1, int n2, int n3, int reach, stencil_fn coef, ko_csr *A) {
   int64_t n = (int64_t)n1 * n2 * n3;
-  int64_t nnz = 0;
-  /* count */
+  /* nonzero offsets in ascending column order (d3 slowest) */
+  int od1[125], od2[125], od3[125], noff = 0;
+  double ov[125];
   for (int d3 = -reach; d3 <= reach; d3++)
     for (int d2 = -reach; d2 <= reach; d2++)
       for (int d1 = -reach; d1 <= reach; d1++) {
-        if (coef(d1, d2, d3) == 0.0) continue;
-        int64_t c1 = n1 - abs(d1), c2 = n2 - abs(d2), c3 = n3 - abs(d3);
-        if (c1 > 0 && c2 > 0 && c3 > 0) nnz += c1 * c2 * c3;
+        double v = coef(d1, d2, d3);
+        if (v == 0.0) continue;
+        od1[noff] = d1; od2[noff] = d2; od3[noff] = d3; ov[noff] = v; noff++;
       }
-  if (csr_alloc(A, n, nnz)) return -1;
-  int64_t k = 0;
-  for (int i3 = 0; i3 < n3; i3++)
-    for (int i2 = 0; i2 < n2; i2++)
-      for (int i1 = 0; i1 < n1; i1++) {
-        int64_t row = (int64_t)i1 + (int64_t)n1 * i2 + (int64_t)n1 * n2 * i3;
-        A->rowptr[row] = k;
-        for (int d3 = -reach; d3 <= reach; d3++) {
-          int j3 = i3 + d3; if (j3 < 0 || j3 >= n3) continue;
-          for (int d2 = -reach; d2 <= reach; d2++) {
-            int j2 = i2 + d2; if (j2 < 0 || j2 >= n2) continue;
-            for (int d1 = -reach; d1 <= reach; d1++) {
-              int j1 = i1 + d1; if (j1 < 0 || j1 >= n1) continue;
-              double v = coef(d1, d2, d3);
-              if (v == 0.0) continue;
-              A->col[k] = (int32_t)((int64_t)j1 + (int64_t)n1 * j2 + (int64_t)n1 * n2 * j3);
-              A->val[k] = v;
-              k++;
-            }
-          }
-        }
-      }
-  A->rowptr[n] = k;
-  return k == nnz ? 0 : -2;
+  A->n = n; A->nnz = 0; A->col = NULL; A->val = NULL;
+  A->rowptr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+  if (!A->rowptr) return -1;
+  /* pass 1: entries per row (parallel), then a serial prefix sum */
+#pragma omp parallel for schedule(static)
+  for (int64_t row = 0; row < n; row++) {
+    int i1 = (int)(row % n1), i2 = (int)((row / n1) % n2), i3 = (int)(row / ((int64_t)n1 * n2));
+    int cnt = 0;
+    for (int o = 0; o < noff; o++) {
+      int j1 = i1 + od1[o], j2 = i2 + od2[o], j3 = i3 + od3[o];
+      cnt += (j1 >= 0 && j1 < n1 && j2 >= 0 && j2 < n2 && j3 >= 0 && j3 < n3);
+    }
+    A->rowptr[row + 1] = cnt;
+  }
+  A->rowptr[0] = 0;
+  for (int64_t row = 0; row < n; row++) A->rowptr[row + 1] += A->rowptr[row];
+  int64_t nnz = A->rowptr[n];
+  A->nnz = nnz;
+  A->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+  A->val = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+  if (!A->col || !A->val) { ko_csr_free(A); return -1; }
+  /* pass 2: fill (parallel => first touch spreads the pages over the NUMA nodes) */
+#pragma omp parallel for schedule(static)
+  for (int64_t row = 0; row < n; row++) {
+    int i1 = (int)(row % n1), i2 = (int)((row / n1) % n2), i3 = (int)(row / ((int64_t)n1 * n2));
+    int64_t k = A->rowptr[row];
+    for (int o = 0; o < noff; o++) {
+      int j1 = i1 + od1[o], j2 = i2 + od2[o], j3 = i3 + od3[o];
+      if (j1 < 0 || j1 >= n1 || j2 < 0 || j2 >= n2 || j3 < 0 || j3 >= n3) continue;
+      A->col[k] = (int32_t)((int64_t)j1 + (int64_t)n1 * j2 + (int64_t)n1 * n2 * j3);
+      A->val[k] = ov[o];
+      k++;
+    }
+  }
+  return 0;
 }
 
 /* get_div_grad(n1,n2,n3) = Div*Div' with ddx(n)*ddx(n)' = tridiag(-1,2,-1)
@@ -1352,4 +1364,41 @@ int ko_block_gmres(ko_block_gmres_workspace *ws, ko_block_matvec A, ko_block_mat
   st->timer = now_s() - t0;
   snprintf(st->status, sizeof(st->status), "%s", status);
   return 0;
+}
+
+/* ===================================================================== *
+ *  CPU baseline loop (bench.py cpu_baseline leg): `iters` iterations of the CG recurrence of
+ *  src/cg.jl:195-268 (M = I, no stopping test) with the OpenMP kernels; threads = 1 is the
+ *  faithful single-thread mode (SparseArrays.mul! is not threaded, docs/src/tips.md:38),
+ *  threads = nproc the all-core mode (threaded_mul! recipe + OPENBLAS_NUM_THREADS, tips.md:8-55).
+ *  Returns seconds per iteration (setup and allocation excluded, like stats.timer vs
+ *  stats.allocation_timer); *rnorm_out = final ||r||.
+ * ===================================================================== */
+double ko_cg_bench(const ko_csr *A, int iters, int threads, double *rnorm_out) {
+  int64_t n = A->n;
+  ko_set_threads(threads);
+  double *x = (double *)malloc(sizeof(double) * (size_t)n), *r = (double *)malloc(sizeof(double) * (size_t)n);
+  double *p = (double *)malloc(sizeof(double) * (size_t)n), *Ap = (double *)malloc(sizeof(double) * (size_t)n);
+  if (!x || !r || !p || !Ap) { free(x); free(r); free(p); free(Ap); return -1.0; }
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) { x[i] = 0.0; r[i] = 1.0; p[i] = 1.0; Ap[i] = 0.0; }   /* b = ones */
+  double gamma = ko_dot_omp(n, r, r);
+  /* one untimed warm-up product */
+  ko_spmv_omp(A, p, Ap);
+  double t0 = now_s();
+  for (int it = 0; it < iters; it++) {
+    ko_spmv_omp(A, p, Ap);
+    double pAp = ko_dot_omp(n, p, Ap);
+    double alpha = gamma / pAp;
+    ko_axpy_omp(n, alpha, p, x);
+    ko_axpy_omp(n, -alpha, Ap, r);
+    double gamma_next = ko_dot_omp(n, r, r);
+    double beta = gamma_next / gamma;
+    gamma = gamma_next;
+    ko_axpby_omp(n, 1.0, r, beta, p);
+  }
+  double dt = now_s() - t0;
+  if (rnorm_out) *rnorm_out = sqrt(gamma);
+  free(x); free(r); free(p); free(Ap);
+  return dt / (iters > 0 ? iters : 1);
 }

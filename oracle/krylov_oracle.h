@@ -184,6 +184,9 @@ int ko_bicgstab(ko_bicgstab_workspace *ws, ko_matvec A, ko_matvec M, ko_matvec N
 int ko_block_gmres(ko_block_gmres_workspace *ws, ko_block_matvec A, ko_block_matvec M,
                    ko_block_matvec N, void *ud, const double *B, const ko_options *opts);
 
+/* CPU-baseline loop for bench.py: seconds per CG iteration with `threads` OpenMP threads */
+double ko_cg_bench(const ko_csr *A, int iters, int threads, double *rnorm_out);
+
 /* ---- dense helpers restating LAPACK (src/block_krylov_utils.jl:192-301) --- */
 void ko_geqrf(int m, int n, double *A, int lda, double *tau);               /* DGEQR2 */
 void ko_orgqr(int m, int n, int k, double *A, int lda, const double *tau);  /* DORG2R */

@@ -137,6 +137,7 @@ def lib():
                                   C.POINTER(Options)]),
         "ko_block_gmres": (C.c_int, [C.POINTER(BlockGmresWs), BLOCK_MATVEC, BLOCK_MATVEC, BLOCK_MATVEC,
                                      C.c_void_p, dp, C.POINTER(Options)]),
+        "ko_cg_bench": (C.c_double, [C.POINTER(Csr), C.c_int, C.c_int, dp]),
         "ko_geqrf": (None, [C.c_int, C.c_int, dp, C.c_int, dp]),
         "ko_orgqr": (None, [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]),
         "ko_ormqr_LT": (None, [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, dp, C.c_int]),

@@ -1,3 +1,4 @@
+import json
 import os
 import sys
 
@@ -13,16 +14,38 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
-def has_gpu() -> bool:
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as ok  # oracle/oracle.py -- the checker, never the product
+    ok.lib()
+    return ok
 
 
 @pytest.fixture(scope="session")
-def oracle():
-    import oracle as ok  # oracle/oracle.py
-    ok.lib()
-    return ok
+def K():
+    import krylov_jl_amd as K
+    K.lib()
+    return K
+
+
+@pytest.fixture(scope="session")
+def ctx(K):
+    if not K.gpu_available():
+        pytest.fail("GPU test selected but /dev/kfd is absent: the HIP path has no CPU fallback")
+    c = K.Context(0)
+    yield c
+    c.close()
+
+
+_PARITY_LOG = os.path.join(ROOT, "gpurun_out", "parity_log.jsonl")
+
+
+@pytest.fixture(scope="session")
+def parity_log():
+    """Append measured GPU-vs-oracle deviations to gpurun_out/parity_log.jsonl (evidence for DESIGN.md)."""
+    os.makedirs(os.path.dirname(_PARITY_LOG), exist_ok=True)
+
+    def log(**kw):
+        with open(_PARITY_LOG, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    return log

@@ -1,0 +1,128 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/krylov_hip.h declares, fails loudly without a GPU, and the host-only partition / halo-plan
+helpers are correct.  No kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def K():
+    import krylov_jl_amd as K
+    if not os.path.exists(K.LIB_PATH):
+        K.build()
+    K.lib()
+    return K
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "krylov_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(khip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(K):
+    import ctypes
+    L = ctypes.CDLL(K.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) > 60
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    # typedef'd callback names are not functions
+    fn_types = {"khip_apply_fn", "khip_callback_fn"}
+    bound = set(K.SIGNATURES)
+    assert (set(declared) - fn_types) <= bound | fn_types, sorted(set(declared) - bound - fn_types)
+
+
+def test_no_cpu_fallback(K):
+    if K.gpu_available():
+        pytest.skip("GPU present")
+    with pytest.raises(K.KhipError) as e:
+        K.Context()
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "krylov.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".sh")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "krylov_oracle" not in txt and "import oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_row_partition(K):
+    assert K.row_partition(10, 3) == [0, 3, 6, 10]
+    p = K.row_partition(512 ** 3, 8)
+    assert p[0] == 0 and p[-1] == 512 ** 3 and all(b - a == 512 ** 3 // 8 for a, b in zip(p, p[1:]))
+
+
+def test_halo_plan_poisson_slabs(K, oracle):
+    """Slab partition of the 7-point grid: each rank needs exactly the neighbouring planes
+    (SURVEY.md section 8e), and the send lists mirror the peers' receive lists."""
+    n1, G = 8, 4
+    A = oracle.poisson3d(n1)
+    n = A.n
+    starts = K.row_partition(n, G)
+    ghosts = []
+    for g in range(G):
+        sl = A.row_slice(starts[g], starts[g + 1])
+        ghosts.append(K.ghost_columns_host(sl.rowptr, sl.col, starts[g]))
+    plane = n1 * n1
+    for g in range(G):
+        exp = []
+        if g > 0:
+            exp += list(range(starts[g] - plane, starts[g]))
+        if g < G - 1:
+            exp += list(range(starts[g + 1], starts[g + 1] + plane))
+        assert ghosts[g].tolist() == exp
+    plans = [K.halo_plan_host(g, G, starts, ghosts) for g in range(G)]
+    for g in range(G):
+        recv_off, send_off, send_idx = plans[g]
+        assert recv_off[-1] == len(ghosts[g])
+        for r in range(G):
+            # what g sends to r == what r expects from g, as global indices
+            sent = send_idx[send_off[r]:send_off[r + 1]] + starts[g]
+            r_recv_off = plans[r][0]
+            expected = ghosts[r][r_recv_off[g]:r_recv_off[g + 1]]
+            assert sent.tolist() == expected.tolist()
+
+
+def test_halo_plan_random_matrix(K):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n, G = 97, 3
+    S = (sp.random(n, n, density=0.08, random_state=3, format="csr") + sp.identity(n)).tocsr()
+    S.sort_indices()
+    starts = K.row_partition(n, G)
+    ghosts = []
+    for g in range(G):
+        blk = S[starts[g]:starts[g + 1]]
+        ghosts.append(K.ghost_columns_host(blk.indptr.astype(np.int64), blk.indices.astype(np.int32), starts[g]))
+        ref = np.unique(blk.indices[(blk.indices < starts[g]) | (blk.indices >= starts[g + 1])])
+        assert ghosts[g].tolist() == ref.tolist()
+    x = rng.standard_normal(n)
+    y = np.zeros(n)
+    plans = [K.halo_plan_host(g, G, starts, ghosts) for g in range(G)]
+    # emulate the exchange + local product with [owned | ghost] column numbering
+    for g in range(G):
+        recv_off, _, _ = plans[g]
+        ghost_vals = np.zeros(len(ghosts[g]))
+        for r in range(G):
+            _, so, si = plans[r]
+            seg = x[starts[r]:starts[r + 1]][si[so[g]:so[g + 1]]]
+            ghost_vals[recv_off[r]:recv_off[r + 1]] = seg
+        blk = S[starts[g]:starts[g + 1]].tocsr()
+        m = starts[g + 1] - starts[g]
+        xe = np.concatenate([x[starts[g]:starts[g + 1]], ghost_vals])
+        cols = blk.indices.copy()
+        own = (cols >= starts[g]) & (cols < starts[g + 1])
+        loc = np.where(own, cols - starts[g], m + np.searchsorted(ghosts[g], cols))
+        yl = np.zeros(m)
+        np.add.at(yl, np.repeat(np.arange(m), np.diff(blk.indptr)), blk.data * xe[loc])
+        y[starts[g]:starts[g + 1]] = yl
+    assert np.allclose(y, S @ x, atol=1e-13)

@@ -1,0 +1,345 @@
+"""GPU parity of the k* primitives and the CSR SpMV against the CPU oracle, through the C ABI.
+Bit-exact where the arithmetic is order-independent (elementwise ops, stream SpMV, generators);
+reductions: the compensated device result must agree with the oracle's extended-precision
+result to 2 ulp of the result + 1e-16 * sum|x_i y_i| (tolerance stated per test)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 63, 64, 65, 255, 257, 1000, 4099, 100003, (1 << 20) + 1]
+EPS = np.finfo(float).eps
+
+
+def _vec(rng, n):
+    return rng.standard_normal(n) * np.exp(rng.uniform(-3, 3, n))
+
+
+def _dev(K, ctx, a, misalign=False):
+    """misalign=True puts the vector at an odd element offset (8-byte aligned only)."""
+    if not misalign:
+        return ctx.array(a)
+    base = ctx.zeros(a.size + 1)
+    v = base.slice(1, a.size + 1)
+    v.copy_from_host(a)
+    v._base = base
+    return v
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("mis", [False, True])
+def test_elementwise_ops_bit_exact(K, ctx, oracle, n, mis):
+    rng = np.random.default_rng(n)
+    x, y = _vec(rng, n), _vec(rng, n)
+    L = oracle.lib()
+
+    def run(gpu_fn, cpu_fn, nout=1):
+        dx, dy = _dev(K, ctx, x, mis), _dev(K, ctx, y, mis)
+        gpu_fn(dx, dy)
+        hx, hy = x.copy(), y.copy()
+        cpu_fn(hx, hy)
+        assert np.array_equal(dy.to_host(), hy)
+        assert np.array_equal(dx.to_host(), hx)
+
+    dp = oracle._dp
+    run(lambda a, b: K.kaxpy_(n, 0.37, a, b), lambda a, b: L.ko_axpy(n, 0.37, dp(a), dp(b)))
+    run(lambda a, b: K.kaxpby_(n, -1.25, a, 0.7, b), lambda a, b: L.ko_axpby(n, -1.25, dp(a), 0.7, dp(b)))
+    run(lambda a, b: K.kcopy_(n, b, a), lambda a, b: L.ko_copy(n, dp(b), dp(a)))
+    run(lambda a, b: K.kscal_(n, 3.3, b), lambda a, b: L.ko_scal(n, 3.3, dp(b)))
+    run(lambda a, b: K.kdiv_(n, b, 3.3), lambda a, b: L.ko_div(n, dp(b), 3.3))
+    run(lambda a, b: K.kscalcopy_(n, b, -0.1, a), lambda a, b: L.ko_scalcopy(n, dp(b), -0.1, dp(a)))
+    run(lambda a, b: K.kdivcopy_(n, b, a, 7.7), lambda a, b: L.ko_divcopy(n, dp(b), dp(a), 7.7))
+    run(lambda a, b: K.kfill_(b, 2.5), lambda a, b: L.ko_fill(n, dp(b), 2.5))
+    run(lambda a, b: K.kref_(n, a, b, 0.6, 0.8), lambda a, b: L.ko_ref(n, dp(a), dp(b), 0.6, 0.8))
+    # fused copy+axpy == kcopy! then kaxpy!
+    dw, dx, dy = ctx.zeros(n), _dev(K, ctx, x, mis), _dev(K, ctx, y, mis)
+    K.waxpy_(n, dw, dx, -0.45, dy)
+    ref = x.copy()
+    L.ko_axpy(n, -0.45, dp(y), dp(ref))
+    assert np.array_equal(dw.to_host(), ref)
+    # exact aliasing (BLAS semantics): y += s*y, w aliasing x
+    dy = _dev(K, ctx, y, mis)
+    K.kaxpy_(n, 0.5, dy, dy)
+    ref = y.copy()
+    L.ko_axpy(n, 0.5, dp(y.copy()), dp(ref))
+    assert np.array_equal(dy.to_host(), ref)
+
+
+@pytest.mark.parametrize("n", SIZES + [5_000_003])
+@pytest.mark.parametrize("mis", [False, True])
+def test_reductions_match_oracle(K, ctx, oracle, parity_log, n, mis):
+    rng = np.random.default_rng(n + 17)
+    x, y = _vec(rng, n), _vec(rng, n)
+    dx, dy = _dev(K, ctx, x, mis), _dev(K, ctx, y, mis)
+    absum = float(np.abs(x * y).sum())
+    d_gpu, d_cpu = K.kdot(n, dx, dy), oracle.dot(x, y)
+    tol = 2 * EPS * abs(d_cpu) + 1e-16 * absum
+    assert abs(d_gpu - d_cpu) <= tol, (d_gpu, d_cpu)
+    n_gpu, n_cpu = K.knorm(n, dx), oracle.nrm2(x)
+    assert abs(n_gpu - n_cpu) <= 2 * EPS * n_cpu
+    # aliased dot (src/cg.jl:242 with z === r) equals norm^2
+    assert abs(K.kdot(n, dx, dx) - oracle.dot(x, x)) <= 2 * EPS * oracle.dot(x, x)
+    a, b = K.dot2(n, dx, dy)
+    assert a == d_gpu or abs(a - d_gpu) <= tol
+    assert abs(b - oracle.dot(x, x)) <= 2 * EPS * b
+    parity_log(test="dot", n=n, misaligned=mis, rel=abs(d_gpu - d_cpu) / max(abs(d_cpu), 1e-300),
+               rel_to_abs=abs(d_gpu - d_cpu) / absum)
+    # run-to-run determinism
+    assert K.kdot(n, dx, dy) == d_gpu
+
+
+def test_reduction_uncompensated_mode(K, ctx, oracle):
+    n = 1_000_003
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy = ctx.array(x), ctx.array(y)
+    ctx.set_option("compensated", 0)
+    try:
+        d = K.kdot(n, dx, dy)
+    finally:
+        ctx.set_option("compensated", 1)
+    assert abs(d - oracle.dot(x, y)) <= 1e-12 * float(np.abs(x * y).sum())
+
+
+def test_empty_vectors(K, ctx):
+    v = ctx.empty(4)
+    assert K.kdot(0, v, v) == 0.0 and K.knorm(0, v) == 0.0
+    K.kaxpy_(0, 1.0, v, v)
+
+
+@pytest.mark.parametrize("n", [2, 1001, 300007])
+def test_fused_axpy2_dot(K, ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    p, q, x, r = (_vec(rng, n) for _ in range(4))
+    dp_, dq, dx, dr = (ctx.array(v) for v in (p, q, x, r))
+    g = K.axpy2_dot(n, 0.3, dp_, dq, dx, dr)
+    # unfused sequence on the device
+    ux, ur = ctx.array(x), ctx.array(r)
+    K.kaxpy_(n, 0.3, dp_, ux)
+    K.kaxpy_(n, -0.3, dq, ur)
+    g2 = K.kdot(n, ur, ur)
+    assert np.array_equal(dx.to_host(), ux.to_host()) and np.array_equal(dr.to_host(), ur.to_host())
+    assert abs(g - g2) <= 2 * EPS * abs(g2)
+    # and against the oracle
+    hx, hr = x.copy(), r.copy()
+    oracle.axpy(0.3, p, hx)
+    oracle.axpy(-0.3, q, hr)
+    assert np.array_equal(dx.to_host(), hx) and np.array_equal(dr.to_host(), hr)
+    assert abs(g - oracle.dot(hr, hr)) <= 2 * EPS * g
+
+
+@pytest.mark.parametrize("n,k", [(1000, 1), (4097, 5), (200001, 30)])
+def test_mgs_and_multi_axpy(K, ctx, oracle, n, k):
+    rng = np.random.default_rng(k)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    V = [np.ascontiguousarray(Q[:, i]) for i in range(k)]
+    q = rng.standard_normal(n)
+    dV = [ctx.array(v) for v in V]
+    dq = ctx.array(q)
+    h, nrm = K.mgs_(n, dV, dq)
+    # oracle: the reference's loop, src/gmres.jl:259-262,274
+    hq = q.copy()
+    href = []
+    for i in range(k):
+        hi = oracle.dot(V[i], hq)
+        href.append(hi)
+        oracle.axpy(-hi, V[i], hq)
+    scale = np.linalg.norm(q)
+    assert np.allclose(h, href, rtol=0, atol=4 * EPS * scale)
+    assert np.allclose(dq.to_host(), hq, rtol=0, atol=8 * EPS * scale)
+    assert abs(nrm - oracle.nrm2(hq)) <= 1e-14 * scale
+    # unfused device sequence: same coefficients to 1 ulp-ish, same vector
+    dq2 = ctx.array(q)
+    for i in range(k):
+        hi = K.kdot(n, dV[i], dq2)
+        K.kaxpy_(n, -hi, dV[i], dq2)
+    assert np.allclose(dq.to_host(), dq2.to_host(), rtol=0, atol=8 * EPS * scale)
+    # accumulate pass (reorthogonalisation, src/gmres.jl:265-271)
+    h2, _ = K.mgs_(n, dV, dq, accumulate_into=h)
+    assert np.allclose(h2, h, rtol=0, atol=1e-12 * scale)
+    # multi-axpy == k kaxpy! calls, bit for bit
+    y = rng.standard_normal(k)
+    x0 = rng.standard_normal(n)
+    dx1, dx2 = ctx.array(x0), ctx.array(x0)
+    K.multi_axpy_(n, y, dV, dx1)
+    for i in range(k):
+        K.kaxpy_(n, float(y[i]), dV[i], dx2)
+    assert np.array_equal(dx1.to_host(), dx2.to_host())
+    hx = x0.copy()
+    for i in range(k):
+        oracle.axpy(float(y[i]), V[i], hx)
+    assert np.array_equal(dx1.to_host(), hx)
+
+
+# ------------------------------------------------------------------------------ CSR
+
+def _upload(K, ctx, A):
+    return K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (A.n, A.n))
+
+
+@pytest.mark.parametrize("kind,dims", [("poisson", (16, 16, 16)), ("poisson", (33, 17, 9)), ("poisson", (1, 1, 1)),
+                                       ("poisson", (2, 3, 1)), ("kron_unsymmetric", (12,)), ("stencil27", (11,))])
+def test_device_generators_bit_exact(K, ctx, oracle, kind, dims):
+    gen = {"poisson": oracle.poisson3d, "kron_unsymmetric": oracle.kron_unsymmetric, "stencil27": oracle.stencil27_unsym}
+    A = gen[kind](*dims)
+    rowptr, col, val = K.gen_stencil_arrays(ctx, kind, *dims)
+    assert np.array_equal(rowptr, A.rowptr) and np.array_equal(col, A.col) and np.array_equal(val, A.val)
+    # a row slab with global columns (distributed layout)
+    r0, r1 = A.n // 3, (2 * A.n) // 3 + 1
+    rp2, col2, val2 = K.gen_stencil_arrays(ctx, kind, *dims, rows=(r0, r1))
+    sl = A.row_slice(r0, r1)
+    assert np.array_equal(rp2, sl.rowptr) and np.array_equal(col2, sl.col) and np.array_equal(val2, sl.val)
+
+
+@pytest.mark.parametrize("dims", [(16, 16, 16), (33, 17, 9), (64, 64, 64), (5, 1, 1)])
+def test_spmv_stream_bit_exact_vs_oracle(K, ctx, oracle, parity_log, dims):
+    A = oracle.poisson3d(*dims)
+    rng = np.random.default_rng(11)
+    x = _vec(rng, A.n)
+    dA = _upload(K, ctx, A)
+    y_ref = A.matvec(x)
+    dx = ctx.array(x)
+    for rows in (256, 128, 64, 32):
+        for vec in (1, 2):
+            for nt in (0, 1):
+                for xcd in (0, 1):
+                    ctx.set_option("spmv_kernel", 1)
+                    ctx.set_option("spmv_rows", rows); ctx.set_option("spmv_vec", vec)
+                    ctx.set_option("spmv_nt", nt); ctx.set_option("spmv_xcd", xcd)
+                    dy = ctx.zeros(A.n)
+                    dA.matvec(dx, dy)
+                    assert np.array_equal(dy.to_host(), y_ref), (rows, vec, nt, xcd)
+    ctx.set_option("spmv_kernel", 0); ctx.set_option("spmv_rows", 256); ctx.set_option("spmv_vec", 2)
+    ctx.set_option("spmv_nt", 1); ctx.set_option("spmv_xcd", 1)
+    # device-generated operator gives the same product
+    dB = K.CsrMatrix.stencil(ctx, "poisson", *dims)
+    assert dB.nnz == A.nnz
+    assert np.array_equal(dB.matvec(dx).to_host(), y_ref)
+    assert dB.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+    parity_log(test="spmv_stream", dims=dims, bit_exact=True)
+
+
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
+def test_spmv_vector_kernel(K, ctx, oracle, lanes):
+    A = oracle.stencil27_unsym(13)
+    rng = np.random.default_rng(2)
+    x = _vec(rng, A.n)
+    dA = _upload(K, ctx, A)
+    ctx.set_option("spmv_kernel", 2); ctx.set_option("spmv_lanes", lanes)
+    try:
+        y = dA.matvec(ctx.array(x)).to_host()
+    finally:
+        ctx.set_option("spmv_kernel", 0); ctx.set_option("spmv_lanes", 0)
+    y_ref = A.matvec(x)
+    S = A.to_scipy()
+    bound = 40 * EPS * (abs(S) @ np.abs(x))          # FMA + tree order: a few ulps of sum |a_ij x_j|
+    assert np.all(np.abs(y - y_ref) <= bound)
+
+
+def test_spmv_general_matrix_and_long_rows(K, ctx):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(9)
+    n = 3001
+    S = sp.random(n, n, density=0.01, random_state=4, format="lil")
+    S[7, :] = rng.standard_normal(n)           # one dense row (3001 entries > one LDS pass)
+    S[n - 1, : n // 2] = 1.0
+    S = S.tocsr()
+    S.sort_indices()
+    x = rng.standard_normal(n)
+    dA = K.CsrMatrix.from_scipy(ctx, S)
+    ref = S @ x
+    bound = 64 * EPS * (abs(S) @ np.abs(x)) + 1e-300
+    for kernel in (0, 1, 2):
+        ctx.set_option("spmv_kernel", kernel)
+        try:
+            y = dA.matvec(ctx.array(x)).to_host()
+        finally:
+            ctx.set_option("spmv_kernel", 0)
+        assert np.all(np.abs(y - ref) <= bound), kernel
+    # 1-based input arrays (Julia convention)
+    dB = K.CsrMatrix.from_host(ctx, S.indptr + 1, S.indices + 1, S.data, S.shape, index_base=1)
+    assert np.all(np.abs(dB.matvec(ctx.array(x)).to_host() - ref) <= bound)
+    # 64-bit row pointers
+    dC = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices, S.data, S.shape)
+    assert np.all(np.abs(dC.matvec(ctx.array(x)).to_host() - ref) <= bound)
+    # empty operator
+    E = sp.csr_matrix((5, 5))
+    dE = K.CsrMatrix.from_scipy(ctx, E)
+    assert np.array_equal(dE.matvec(ctx.array(np.ones(5))).to_host(), np.zeros(5))
+
+
+@pytest.mark.parametrize("dims", [(16, 16, 16), (40, 40, 40)])
+def test_spmv_dot_fused_equals_unfused(K, ctx, oracle, dims):
+    A = oracle.poisson3d(*dims)
+    rng = np.random.default_rng(21)
+    x = _vec(rng, A.n)
+    dA = _upload(K, ctx, A)
+    dx = ctx.array(x)
+    dy = ctx.zeros(A.n)
+    d = K.spmv_dot(dA, dx, dy)
+    y_ref = A.matvec(x)
+    assert np.array_equal(dy.to_host(), y_ref)
+    d_unfused = K.kdot(A.n, dx, dy)
+    d_cpu = oracle.dot(x, y_ref)
+    tol = 2 * EPS * abs(d_cpu) + 1e-16 * float(np.abs(x * y_ref).sum())
+    assert abs(d - d_unfused) <= tol and abs(d - d_cpu) <= tol
+
+
+def test_spmm_rowmajor_panel(K, ctx, oracle):
+    A = oracle.stencil27_unsym(9)
+    rng = np.random.default_rng(31)
+    for p in (1, 3, 16):
+        X = rng.standard_normal((A.n, p))
+        dA = _upload(K, ctx, A)
+        dX = ctx.array(X.ravel())          # row-major n x p
+        dY = ctx.zeros(A.n * p)
+        K._ck(K.lib().khip_spmm(ctx._h, dA._h, dX.ptr, dY.ptr, p))
+        Y = dY.to_host().reshape(A.n, p)
+        ref = np.stack([A.matvec(np.ascontiguousarray(X[:, j])) for j in range(p)], axis=1)
+        assert np.array_equal(Y, ref)
+
+
+# ------------------------------------------------------------------ full-size properties (cfg 2)
+
+def test_full_size_spmv_properties_512(K, ctx, parity_log):
+    """BASELINE cfg 2 (512^3, n = 134,217,728, nnz = 937,951,232): properties that need no oracle run.
+    (1) A*ones = number of missing neighbours per row (exact small integers), (2) linearity
+    A(ax + by) = a Ax + b Ay to rounding, (3) symmetry <Ax, y> = <x, Ay> to reduction accuracy."""
+    n1 = 512
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "poisson", n1)
+    assert A.nnz == 7 * n - 6 * n1 * n1 == 937_951_232
+    ones = ctx.empty(n)
+    K.kfill_(ones, 1.0)
+    y = ctx.empty(n)
+    A.matvec(ones, y)
+    s1 = K.kdot(n, ones, y)            # sum of row sums = 6 n - (nnz - n) = 6 * n1^2 * ... exact integer
+    assert s1 == float(6 * n - (A.nnz - n))
+    sq = K.kdot(n, y, y)               # sum of (missing neighbours)^2, exact integer
+    faces = 6 * (n1 - 2) ** 2
+    edges = 12 * (n1 - 2)
+    corners = 8
+    assert sq == float(faces * 1 + edges * 4 + corners * 9)
+    # non-trivial vectors built on the device: x = 0.5 + 0.25 * (A ones), z = 2 * ones - 3 * x
+    x = ctx.empty(n)
+    K.kfill_(x, 0.5)
+    K.kaxpy_(n, 0.25, y, x)
+    Ax = ctx.empty(n)
+    A.matvec(x, Ax)
+    z = ctx.empty(n)
+    K.kcopy_(n, z, x)
+    K.kaxpby_(n, 2.0, ones, -3.0, z)
+    Az = ctx.empty(n)
+    A.matvec(z, Az)
+    # symmetry: <A x, z> == <x, A z>
+    lhs, rhs = K.kdot(n, Ax, z), K.kdot(n, x, Az)
+    sym = abs(lhs - rhs) / abs(lhs)
+    assert sym <= 1e-13
+    # linearity: A z == 2 * (A ones) - 3 * (A x)
+    K.kaxpby_(n, 2.0, y, -3.0, Ax)
+    K.kaxpy_(n, -1.0, Az, Ax)
+    lin = K.knorm(n, Ax) / K.knorm(n, Az)
+    assert lin <= 1e-14
+    parity_log(test="spmv_512_properties", linearity_rel=lin, symmetry_rel=sym)
