@@ -150,7 +150,7 @@ def main():
             "hbm_gbps_iteration": its * iter_bytes_local * world / 1e9,
             "hbm_gbps_iteration_reference_sequence": its * iter_bytes_unfused_local * world / 1e9,
             "final_residual_norm": float(st.residuals[-1]),
-            "roofline": {"bound": "hbm", "kernel": "spmv_stream_kernel (CSR SpMV fused with p.Ap)",
+            "roofline": {"bound": "hbm", "kernel": "spmv_stage_kernel (CSR SpMV fused with p.Ap)",
                          "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": None,
                          "bytes_per_launch": spmv_bytes_local, "avg_ms": avg_spmv_ms,

@@ -44,9 +44,7 @@ int khip_ctx_create(int device, void *stream, khip_ctx **out) {
   hipDeviceProp_t prop;
   KHIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  KHIP_CHECK_HIP(hipMalloc(&ctx->partials, sizeof(dd) * (size_t)kMaxRedOut * kMaxRedBlocks));
-  KHIP_CHECK_HIP(hipMalloc(&ctx->tickets, sizeof(unsigned) * 16));
-  KHIP_CHECK_HIP(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 16));
+  KHIP_TRY(ensure_reduction_scratch(ctx, 1 << 18, 1));
   KHIP_CHECK_HIP(hipMalloc(&ctx->results, sizeof(double) * kResultSlots));
   KHIP_CHECK_HIP(hipMalloc(&ctx->results_dd, sizeof(dd) * kResultSlots));
   KHIP_CHECK_HIP(hipMemset(ctx->results, 0, sizeof(double) * kResultSlots));
@@ -64,6 +62,7 @@ int khip_ctx_destroy(khip_ctx *ctx) {
   khip_comm_destroy_internal(ctx);
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
   (void)hipFree(ctx->partials);
+  (void)hipFree(ctx->partials2);
   (void)hipFree(ctx->tickets);
   (void)hipFree(ctx->results);
   (void)hipFree(ctx->results_dd);
@@ -89,8 +88,8 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
   struct { const char *k; int *p; } tab[] = {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
-      {"compensated", &t.compensated}, {"blas1_blocks", &t.blas1_blocks}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}};
+      {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
+      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;
@@ -100,7 +99,6 @@ int khip_ctx_set_option(khip_ctx *ctx, const char *key, int value) {
   KHIP_REQUIRE(ctx && key, "set_option: null argument");
   int *p = tuning_field(ctx, key);
   KHIP_REQUIRE(p, "set_option: unknown key '%s'", key);
-  if (strcmp(key, "blas1_blocks") == 0) KHIP_REQUIRE(value >= 1 && value <= kMaxRedBlocks, "blas1_blocks out of range");
   *p = value;
   return KHIP_OK;
 }
@@ -248,7 +246,7 @@ int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t 
 int khip_csr_destroy(khip_csr *A) {
   if (!A) return KHIP_OK;
   if (A->ctx) (void)hipStreamSynchronize(A->ctx->stream);
-  (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val);
+  (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val); (void)hipFree(A->blockptr);
   (void)hipFree(A->ghost); (void)hipFree(A->sendbuf); (void)hipFree(A->send_idx);
   delete A;
   return KHIP_OK;

@@ -1,13 +1,18 @@
 // blas1.hip -- the BLAS-1 shim of Krylov.jl (src/krylov_utils.jl:309-349) as gfx950 kernels.
 //
-// Every kernel here is HBM-bound.  Layout: plain contiguous f64 vectors.  Each lane moves
-// 16 B per access (double2, the coalescing sweet spot on CDNA4), four independent accesses
-// in flight per array per lane, grid capped at 8 workgroups per CU with a grid-stride loop.
+// Every kernel here is HBM-bound.  Layout: plain contiguous f64 vectors.  Launch shape (measured,
+// profiles/r01_membench*.log): LOOP-FREE -- a workgroup of 256 lanes owns one contiguous tile of
+// 256*U 16-byte vectors (U = 1 for the streaming maps, U = 4 for the reductions), every lane issues
+// its U independent 16-byte accesses up front; vectors beyond `nt_min_elems` use non-temporal
+// loads/stores (they cannot stay in the 256 MiB Infinity Cache anyway).  On MI355X this reaches
+// copy 6.7, axpy 6.5, dot 7.1 TB/s versus 4.2-4.5 TB/s for 2048-workgroup grid-stride loops.
 // Algorithmic bytes per element: dot 16 (8 if x === y), nrm2 8, axpy/axpby 24, copy/divcopy/
 // scalcopy 16, fill 8, scal 16, reflect 32; fused: axpy2_dot 48, axpy_dev_dot 24(+8), waxpy 24.
 #include "device_reduce.hpp"
 
 namespace khip {
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 enum MapOp {
   OP_COPY = 0,      // y = x
@@ -23,12 +28,21 @@ enum MapOp {
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using type = double; };
-template <> struct VecT<2> { using type = double2; };
+template <> struct VecT<2> { using type = dbl2; };
 
 __device__ __forceinline__ double vget(const double &v, int) { return v; }
-__device__ __forceinline__ double vget(const double2 &v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ double vget(const dbl2 &v, int i) { return i == 0 ? v.x : v.y; }
 __device__ __forceinline__ void vset(double &v, int, double s) { v = s; }
-__device__ __forceinline__ void vset(double2 &v, int i, double s) { if (i == 0) v.x = s; else v.y = s; }
+__device__ __forceinline__ void vset(dbl2 &v, int i, double s) { if (i == 0) v.x = s; else v.y = s; }
+
+template <bool NT, typename T> __device__ __forceinline__ T ldg(const T *p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+template <bool NT, typename T> __device__ __forceinline__ void stg(T v, T *p) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 template <int OP> __host__ __device__ constexpr bool reads_x() {
   return OP == OP_COPY || OP == OP_SCALCOPY || OP == OP_DIVCOPY || OP == OP_AXPY || OP == OP_AXPBY ||
@@ -53,27 +67,29 @@ __device__ __forceinline__ void map_scalar(double a, double b, double xv, double
 }
 
 // x, y, w deliberately NOT __restrict__: exact aliasing is legal (BLAS semantics, src/bicgstab.jl:153-157).
-template <int OP, int VEC>
+template <int OP, int VEC, bool NT, int U>
 __global__ __launch_bounds__(kBlock) void map_kernel(int64_t n, double a, double b, const double *x, double *y,
                                                      double *w) {
   using T = typename VecT<VEC>::type;
-  constexpr int U = 4;
   const int64_t nvec = n / VEC;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
   const T *X = reinterpret_cast<const T *>(x);
   T *Y = reinterpret_cast<T *>(y);
   T *W = reinterpret_cast<T *>(OP == OP_WAXPY ? w : y);
   T *XO = reinterpret_cast<T *>(const_cast<double *>(x));
-  for (; i + (U - 1) * stride < nvec; i += U * stride) {
-    T xv[U] = {}, yv[U] = {};
+  T xv[U] = {}, yv[U] = {};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (reads_x<OP>()) xv[u] = X[i + u * stride];
-      if (reads_y<OP>()) yv[u] = Y[i + u * stride];
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + u * kBlock;
+    if (i < nvec) {
+      if (reads_x<OP>()) xv[u] = ldg<NT>(X + i);
+      if (reads_y<OP>()) yv[u] = ldg<NT>(Y + i);
     }
+  }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + u * kBlock;
+    if (i < nvec) {
       T ox, oy;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -82,23 +98,9 @@ __global__ __launch_bounds__(kBlock) void map_kernel(int64_t n, double a, double
         vset(ox, e, sx);
         vset(oy, e, sy);
       }
-      W[i + u * stride] = oy;
-      if (OP == OP_REF) XO[i + u * stride] = ox;
+      stg<NT>(oy, W + i);
+      if (OP == OP_REF) stg<NT>(ox, XO + i);
     }
-  }
-  for (; i < nvec; i += stride) {
-    T xv = {}, yv = {}, ox, oy;
-    if (reads_x<OP>()) xv = X[i];
-    if (reads_y<OP>()) yv = Y[i];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      double sx, sy;
-      map_scalar<OP>(a, b, reads_x<OP>() ? vget(xv, e) : 0.0, reads_y<OP>() ? vget(yv, e) : 0.0, sx, sy);
-      vset(ox, e, sx);
-      vset(oy, e, sy);
-    }
-    W[i] = oy;
-    if (OP == OP_REF) XO[i] = ox;
   }
   if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd tail element
     const int64_t t = n - 1;
@@ -111,25 +113,26 @@ __global__ __launch_bounds__(kBlock) void map_kernel(int64_t n, double a, double
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-static inline int grid_for(khip_ctx *ctx, int64_t nvec, int unroll) {
-  int64_t want = (nvec + (int64_t)kBlock * unroll - 1) / ((int64_t)kBlock * unroll);
-  int64_t cap = ctx->tune.blas1_blocks;
-  if (cap > kMaxRedBlocks) cap = kMaxRedBlocks;
-  if (want < 1) want = 1;
-  return (int)(want < cap ? want : cap);
+static inline bool use_nt(khip_ctx *ctx, int64_t n) { return n >= (int64_t)ctx->tune.nt_min_elems; }
+
+static inline int64_t tiles_for(int64_t nvec, int u) {
+  int64_t t = (nvec + (int64_t)kBlock * u - 1) / ((int64_t)kBlock * u);
+  return t < 1 ? 1 : t;
 }
 
 template <int OP>
 static int launch_map_op(khip_ctx *ctx, int64_t n, double a, double b, const double *x, double *y, double *w) {
   if (n <= 0) return KHIP_OK;
-  bool v2 = (!reads_x<OP>() || aligned16(x)) && aligned16(y) && (OP != OP_WAXPY || aligned16(w)) && n >= 2;
-  if (v2) {
-    int g = grid_for(ctx, n / 2, 4);
-    hipLaunchKernelGGL((map_kernel<OP, 2>), dim3(g), dim3(kBlock), 0, ctx->stream, n, a, b, x, y, w);
-  } else {
-    int g = grid_for(ctx, n, 4);
-    hipLaunchKernelGGL((map_kernel<OP, 1>), dim3(g), dim3(kBlock), 0, ctx->stream, n, a, b, x, y, w);
-  }
+  const bool v2 = (!reads_x<OP>() || aligned16(x)) && aligned16(y) && (OP != OP_WAXPY || aligned16(w)) && n >= 2;
+  const bool nt = use_nt(ctx, n);
+  const int64_t nvec = v2 ? n / 2 : n;
+  const int64_t g = tiles_for(nvec, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_MAP(VEC, NT) \
+  hipLaunchKernelGGL((map_kernel<OP, VEC, NT, 1>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, a, b, x, y, w)
+  if (v2) { if (nt) KHIP_MAP(2, true); else KHIP_MAP(2, false); }
+  else    { if (nt) KHIP_MAP(1, true); else KHIP_MAP(1, false); }
+#undef KHIP_MAP
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }
@@ -169,17 +172,15 @@ struct RedPtrs {
   double a;             // AXPY2
 };
 
-template <int ROP, bool COMP, int VEC>
+template <int ROP, bool COMP, int VEC, bool NT, int U>
 __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, RedArgs ra) {
   using T = typename VecT<VEC>::type;
   constexpr int NOUT = RedOut<ROP>::n;
-  constexpr int U = 4;
   dd acc[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) acc[o] = dd{0.0, 0.0};
   const int64_t nvec = n / VEC;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
   const T *X = reinterpret_cast<const T *>(p.x);
   const T *Y = reinterpret_cast<const T *>(p.y);
   T *Uv = reinterpret_cast<T *>(p.u);
@@ -187,64 +188,58 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
   double a = p.a;
   if (ROP == RED_AXPYDEV) a = -(*p.coef);
   const bool z_is_y = (ROP == RED_AXPYDEV) && (p.y == p.u);
-
-  auto body = [&](T xv, T yv, T uv, T vv, int64_t idx) {
-    if (ROP == RED_AXPY2) {
-      T un, vn;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        vset(un, e, fma(a, vget(xv, e), vget(uv, e)));
-        double rn = fma(-a, vget(yv, e), vget(vv, e));
-        vset(vn, e, rn);
-        acc_prod<COMP>(acc[0], rn, rn);
-      }
-      Uv[idx] = un;
-      Vv[idx] = vn;
-    } else if (ROP == RED_AXPYDEV) {
-      T un;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        double yn = fma(a, vget(xv, e), vget(uv, e));
-        vset(un, e, yn);
-        acc_prod<COMP>(acc[0], z_is_y ? yn : vget(yv, e), yn);
-      }
-      Uv[idx] = un;
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        double xe = vget(xv, e);
-        if (ROP == RED_DOT) acc_prod<COMP>(acc[0], xe, vget(yv, e));
-        if (ROP == RED_SQ) acc_prod<COMP>(acc[0], xe, xe);
-        if (ROP == RED_DOT2) {
-          acc_prod<COMP>(acc[0], xe, vget(yv, e));
-          acc_prod<COMP>(acc[NOUT - 1], xe, xe);
-        }
-      }
-    }
-  };
   constexpr bool rd_y = (ROP == RED_DOT || ROP == RED_DOT2 || ROP == RED_AXPY2 || ROP == RED_AXPYDEV);
   constexpr bool rd_u = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV);
   constexpr bool rd_v = (ROP == RED_AXPY2);
 
-  for (; i + (U - 1) * stride < nvec; i += U * stride) {
-    T xv[U] = {}, yv[U] = {}, uv[U] = {}, vv[U] = {};
+  T xv[U] = {}, yv[U] = {}, uv[U] = {}, vv[U] = {};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t j = i + u * stride;
-      xv[u] = X[j];
-      if (rd_y && !(ROP == RED_AXPYDEV && z_is_y)) yv[u] = Y[j];
-      if (rd_u) uv[u] = Uv[j];
-      if (rd_v) vv[u] = Vv[j];
+  for (int u = 0; u < U; ++u) {
+    const int64_t j = base + u * kBlock;
+    if (j < nvec) {
+      xv[u] = ldg<NT>(X + j);
+      if (rd_y && !(ROP == RED_AXPYDEV && z_is_y)) yv[u] = ldg<NT>(Y + j);
+      if (rd_u) uv[u] = ldg<NT>(Uv + j);
+      if (rd_v) vv[u] = ldg<NT>(Vv + j);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) body(xv[u], yv[u], uv[u], vv[u], i + u * stride);
   }
-  for (; i < nvec; i += stride) {
-    T xv = X[i], yv = {}, uv = {}, vv = {};
-    if (rd_y && !(ROP == RED_AXPYDEV && z_is_y)) yv = Y[i];
-    if (rd_u) uv = Uv[i];
-    if (rd_v) vv = Vv[i];
-    body(xv, yv, uv, vv, i);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t j = base + u * kBlock;
+    if (j < nvec) {
+      if (ROP == RED_AXPY2) {
+        T un, vn;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          vset(un, e, fma(a, vget(xv[u], e), vget(uv[u], e)));
+          double rn = fma(-a, vget(yv[u], e), vget(vv[u], e));
+          vset(vn, e, rn);
+          acc_prod<COMP>(acc[0], rn, rn);
+        }
+        stg<NT>(un, Uv + j);
+        stg<NT>(vn, Vv + j);
+      } else if (ROP == RED_AXPYDEV) {
+        T un;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          double yn = fma(a, vget(xv[u], e), vget(uv[u], e));
+          vset(un, e, yn);
+          acc_prod<COMP>(acc[0], z_is_y ? yn : vget(yv[u], e), yn);
+        }
+        stg<NT>(un, Uv + j);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          double xe = vget(xv[u], e);
+          if (ROP == RED_DOT) acc_prod<COMP>(acc[0], xe, vget(yv[u], e));
+          if (ROP == RED_SQ) acc_prod<COMP>(acc[0], xe, xe);
+          if (ROP == RED_DOT2) {
+            acc_prod<COMP>(acc[0], xe, vget(yv[u], e));
+            acc_prod<COMP>(acc[NOUT - 1], xe, xe);
+          }
+        }
+      }
+    }
   }
   if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd tail element, scalar
     const int64_t t = n - 1;
@@ -265,24 +260,33 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
       acc_prod<COMP>(acc[0], ze, yn);
     }
   }
-  grid_finish<NOUT>(acc, ra);
+  wave_publish<NOUT>(acc, ra);
 }
 
 template <int ROP>
 static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   if (n < 0) { set_error("negative length"); return KHIP_ERR_INVALID; }
-  bool v2 = n >= 2 && aligned16(p.x) && (p.y == nullptr || aligned16(p.y)) && (p.u == nullptr || aligned16(p.u)) &&
-            (p.v == nullptr || aligned16(p.v));
-  RedArgs ra = make_red_args(ctx, slot);
+  const bool v2 = n >= 2 && aligned16(p.x) && (p.y == nullptr || aligned16(p.y)) && (p.u == nullptr || aligned16(p.u)) &&
+                  (p.v == nullptr || aligned16(p.v));
   const bool comp = ctx->tune.compensated != 0;
-  int g = grid_for(ctx, v2 ? n / 2 : n, 4);
-#define KHIP_LAUNCH_RED(COMP, VEC) \
-  hipLaunchKernelGGL((reduce_kernel<ROP, COMP, VEC>), dim3(g), dim3(kBlock), 0, ctx->stream, n, p, ra)
-  if (comp) { if (v2) KHIP_LAUNCH_RED(true, 2); else KHIP_LAUNCH_RED(true, 1); }
-  else      { if (v2) KHIP_LAUNCH_RED(false, 2); else KHIP_LAUNCH_RED(false, 1); }
-#undef KHIP_LAUNCH_RED
+  const bool nt = use_nt(ctx, n);
+  const int64_t nvec = v2 ? n / 2 : n;
+  const bool u4 = nvec >= (int64_t)kBlock * 4 * 1024;          // big vectors: 4 independent accesses per lane
+  const int64_t g = tiles_for(nvec, u4 ? 4 : 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+  KHIP_TRY(ensure_reduction_scratch(ctx, g * kWavesPerBlock, RedOut<ROP>::n));
+  RedArgs ra = make_red_args(ctx, slot);
+#define KHIP_RED(COMP, VEC, NT, U) \
+  hipLaunchKernelGGL((reduce_kernel<ROP, COMP, VEC, NT, U>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra)
+#define KHIP_RED_U(COMP, VEC, NT) do { if (u4) KHIP_RED(COMP, VEC, NT, 4); else KHIP_RED(COMP, VEC, NT, 1); } while (0)
+#define KHIP_RED_NT(COMP, VEC) do { if (nt) KHIP_RED_U(COMP, VEC, true); else KHIP_RED_U(COMP, VEC, false); } while (0)
+  if (comp) { if (v2) KHIP_RED_NT(true, 2); else KHIP_RED_NT(true, 1); }
+  else      { if (v2) KHIP_RED_NT(false, 2); else KHIP_RED_NT(false, 1); }
+#undef KHIP_RED_NT
+#undef KHIP_RED_U
+#undef KHIP_RED
   KHIP_CHECK_HIP(hipGetLastError());
-  return KHIP_OK;
+  return launch_finish(ctx, g * kWavesPerBlock, RedOut<ROP>::n, slot);
 }
 
 int launch_dot(khip_ctx *ctx, int64_t n, const double *x, const double *y, int slot) {
@@ -316,20 +320,20 @@ struct MultiArgs {
   double c[kMultiMax];
 };
 
-template <int VEC>
+template <int VEC, bool NT>
 __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, int k, MultiArgs ma, double *x) {
   using T = typename VecT<VEC>::type;
   const int64_t nvec = n / VEC;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
   T *X = reinterpret_cast<T *>(x);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-    T xv = X[i];
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    T xv = ldg<NT>(X + i);
     int j = 0;
     for (; j + 4 <= k; j += 4) {
-      T v0 = reinterpret_cast<const T *>(ma.v[j])[i];
-      T v1 = reinterpret_cast<const T *>(ma.v[j + 1])[i];
-      T v2 = reinterpret_cast<const T *>(ma.v[j + 2])[i];
-      T v3 = reinterpret_cast<const T *>(ma.v[j + 3])[i];
+      T v0 = ldg<NT>(reinterpret_cast<const T *>(ma.v[j]) + i);
+      T v1 = ldg<NT>(reinterpret_cast<const T *>(ma.v[j + 1]) + i);
+      T v2 = ldg<NT>(reinterpret_cast<const T *>(ma.v[j + 2]) + i);
+      T v3 = ldg<NT>(reinterpret_cast<const T *>(ma.v[j + 3]) + i);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         double s = vget(xv, e);
@@ -341,11 +345,11 @@ __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, int k, Mu
       }
     }
     for (; j < k; ++j) {
-      T v0 = reinterpret_cast<const T *>(ma.v[j])[i];
+      T v0 = ldg<NT>(reinterpret_cast<const T *>(ma.v[j]) + i);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) vset(xv, e, fma(ma.c[j], vget(v0, e), vget(xv, e)));
     }
-    X[i] = xv;
+    stg<NT>(xv, X + i);
   }
   if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t t = n - 1;
@@ -358,8 +362,9 @@ __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, int k, Mu
 int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host, const double *const *V_host,
                       double *x) {
   if (n <= 0 || k <= 0) return KHIP_OK;
+  const bool nt = use_nt(ctx, n);
   for (int base = 0; base < k; base += kMultiMax) {
-    int kk = k - base < kMultiMax ? k - base : kMultiMax;
+    const int kk = k - base < kMultiMax ? k - base : kMultiMax;
     MultiArgs ma;
     bool v2 = n >= 2 && aligned16(x);
     for (int j = 0; j < kMultiMax; ++j) {
@@ -367,15 +372,48 @@ int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host, 
       ma.c[j] = j < kk ? coef_host[base + j] : 0.0;
       if (j < kk && !aligned16(ma.v[j])) v2 = false;
     }
+    const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
     if (v2) {
-      int g = grid_for(ctx, n / 2, 1);
-      hipLaunchKernelGGL((multi_axpy_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, n, kk, ma, x);
+      if (nt) hipLaunchKernelGGL((multi_axpy_kernel<2, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, ma, x);
+      else hipLaunchKernelGGL((multi_axpy_kernel<2, false>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, ma, x);
     } else {
-      int g = grid_for(ctx, n, 1);
-      hipLaunchKernelGGL((multi_axpy_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, n, kk, ma, x);
+      if (nt) hipLaunchKernelGGL((multi_axpy_kernel<1, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, ma, x);
+      else hipLaunchKernelGGL((multi_axpy_kernel<1, false>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, ma, x);
     }
     KHIP_CHECK_HIP(hipGetLastError());
   }
+  return KHIP_OK;
+}
+
+// ------------------------------------------------------------ scratch / results ---
+int ensure_reduction_scratch(khip_ctx *ctx, int64_t nwaves, int nout) {
+  if (nout > kMaxNout) { set_error("too many reduction outputs"); return KHIP_ERR_INVALID; }
+  if (nwaves <= ctx->red_cap1) return KHIP_OK;
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t cap1 = 1 << 18;
+  while (cap1 < nwaves) cap1 <<= 1;
+  if (ctx->partials) KHIP_CHECK_HIP(hipFree(ctx->partials));
+  if (ctx->partials2) KHIP_CHECK_HIP(hipFree(ctx->partials2));
+  if (ctx->tickets) KHIP_CHECK_HIP(hipFree(ctx->tickets));
+  ctx->partials = nullptr; ctx->partials2 = nullptr; ctx->tickets = nullptr; ctx->red_cap1 = 0;
+  KHIP_CHECK_HIP(hipMalloc(&ctx->partials, sizeof(dd) * (size_t)kMaxNout * (size_t)cap1));
+  KHIP_CHECK_HIP(hipMalloc(&ctx->partials2, sizeof(dd) * (size_t)kMaxNout * kFinishMaxBlocks));
+  KHIP_CHECK_HIP(hipMalloc(&ctx->tickets, sizeof(unsigned) * 32));
+  KHIP_CHECK_HIP(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 32));
+  ctx->red_cap1 = cap1;
+  ctx->scratch_word = reinterpret_cast<int *>(ctx->tickets + 16);
+  return KHIP_OK;
+}
+
+// fold `nwaves` per-wave partials of the kernel just launched on ctx->stream into results[slot..]
+int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot) {
+  RedArgs ra = make_red_args(ctx, slot);
+  int64_t want = (nwaves + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+  const unsigned g = (unsigned)(want < 1 ? 1 : (want > kFinishMaxBlocks ? kFinishMaxBlocks : want));
+  if (nout == 1) hipLaunchKernelGGL((reduce_finish_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);
+  else if (nout == 2) hipLaunchKernelGGL((reduce_finish_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);
+  else { set_error("launch_finish: unsupported output count %d", nout); return KHIP_ERR_INVALID; }
+  KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }
 

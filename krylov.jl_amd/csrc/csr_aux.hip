@@ -1,0 +1,373 @@
+// csr_aux.hip -- SpMM for row-major panels, CSR set-up helpers (row statistics, index shift, halo
+// gather / remap kernels) and the device-side generators of the benchmark operators.
+#include "spmv_common.hpp"
+
+namespace khip {
+
+// ---------------------------------------------------------------- SpMM ----------
+// Y(m x p, row-major) = A * X(n x p, row-major).  P lanes cooperate on one row: lane c owns
+// column c, val/col loads are wave-broadcast, the X gather is one contiguous 8p-byte line.
+template <int P>
+__global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
+  constexpr int RPB = kBlock / P;
+  const int sub = threadIdx.x / P, c = threadIdx.x % P;
+  for (int64_t row = a.row_lo + (int64_t)blockIdx.x * RPB + sub; row < a.row_hi; row += (int64_t)gridDim.x * RPB) {
+    const int64_t s = a.rowptr[row], e = a.rowptr[row + 1];
+    double acc = 0.0;
+    if (c < p) {
+      for (int64_t j = s; j < e; ++j) {
+        double prod = a.val[j] * a.x[(int64_t)a.col[j] * p + c];
+        acc = acc + prod;
+      }
+      a.y[row * p + c] = acc;
+    }
+  }
+}
+
+int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {
+  if (A->dist) { set_error("spmm: distributed operator not supported"); return KHIP_ERR_UNSUPPORTED; }
+  if (p < 1 || p > 64) { set_error("spmm: 1 <= p <= 64 required (got %d)", p); return KHIP_ERR_INVALID; }
+  SpmvArgs a;
+  a.rowptr = A->rowptr; a.blockptr = nullptr; a.col = A->col; a.val = A->val; a.x = X; a.ghost = nullptr; a.y = Y;
+  a.n_owned = A->n; a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.fake_gather = 0; a.tiles_per_block = 1; a.nnz_bound = A->nnz + kPad;
+  int P = 4;
+  while (P < p) P <<= 1;
+  const int rpb = kBlock / P;
+  int64_t want = (A->m + rpb - 1) / rpb;
+  int grid = (int)(want < ctx->num_cu * 16 ? want : ctx->num_cu * 16);
+  if (grid < 1) grid = 1;
+  switch (P) {
+    case 4: hipLaunchKernelGGL((spmm_kernel<4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
+    case 8: hipLaunchKernelGGL((spmm_kernel<8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
+    case 16: hipLaunchKernelGGL((spmm_kernel<16>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
+    case 32: hipLaunchKernelGGL((spmm_kernel<32>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
+    default: hipLaunchKernelGGL((spmm_kernel<64>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
+  }
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+// ---------------------------------------------------------------- row statistics -
+__global__ __launch_bounds__(kBlock) void row_stats_kernel(const int32_t *rowptr, int64_t m, int *max_out) {
+  int mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    int len = rowptr[i + 1] - rowptr[i];
+    mx = len > mx ? len : mx;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(max_out, mx);
+}
+
+__global__ __launch_bounds__(kBlock) void blockptr_kernel(const int32_t *rowptr, int64_t m, int64_t nb, int32_t *bp) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= nb; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i * 256 < m ? i * 256 : m;
+    bp[i] = rowptr[r];
+  }
+}
+
+int csr_finalize(khip_ctx *ctx, khip_csr *A) {
+  A->mean_row_nnz = A->m > 0 ? (double)A->nnz / (double)A->m : 0.0;
+  A->max_row_nnz = 0;
+  if (A->m == 0) return KHIP_OK;
+  {
+    const int64_t nb = (A->m + 255) / 256;
+    KHIP_CHECK_HIP(hipMalloc(&A->blockptr, sizeof(int32_t) * (size_t)(nb + 1)));
+    int64_t want = (nb + 1 + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(blockptr_kernel, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(kBlock), 0, ctx->stream, A->rowptr,
+                       A->m, nb, A->blockptr);
+    KHIP_CHECK_HIP(hipGetLastError());
+  }
+  int *d = ctx->scratch_word;
+  KHIP_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
+  int64_t want = (A->m + kBlock - 1) / kBlock;
+  int grid = (int)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->rowptr, A->m, d);
+  KHIP_CHECK_HIP(hipGetLastError());
+  int h = 0;
+  KHIP_CHECK_HIP(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  A->max_row_nnz = h;
+  return KHIP_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void index_shift_kernel(int32_t *data, int64_t n, int32_t delta) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) data[i] += delta;
+}
+int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta) {
+  if (n <= 0 || delta == 0) return KHIP_OK;
+  int64_t want = (n + kBlock - 1) / kBlock;
+  int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(index_shift_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, data, n, delta);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+// ---------------------------------------------------------------- halo helpers ---
+__global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t *idx, const double *x, double *out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = x[idx[i]];
+}
+
+int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out) {
+  if (n <= 0) return KHIP_OK;
+  int64_t want = (n + kBlock - 1) / kBlock;
+  int grid = (int)(want < 1024 ? want : 1024);
+  hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, n, idx, x, out);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void collect_offrank_kernel(const int32_t *col, int64_t nnz, int64_t row0,
+                                                                  int64_t row1, int32_t *out,
+                                                                  unsigned long long *count, int64_t cap) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * kBlock) {
+    const int64_t c = col[j];
+    if (c < row0 || c >= row1) {
+      unsigned long long k = atomicAdd(count, 1ull);
+      if ((int64_t)k < cap) out[k] = (int32_t)c;
+    }
+  }
+}
+
+int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64_t row1, int32_t *out_dev,
+                           unsigned long long *count_dev, int64_t cap) {
+  if (A->nnz == 0) return KHIP_OK;
+  int64_t want = (A->nnz + kBlock - 1) / kBlock;
+  int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(collect_offrank_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->col, A->nnz, row0, row1,
+                     out_dev, count_dev, cap);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void col_remap_kernel(int32_t *col, int64_t nnz, int64_t row0, int64_t m,
+                                                            const int32_t *ghost_sorted, int64_t n_ghost) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * kBlock) {
+    const int64_t c = col[j];
+    if (c >= row0 && c < row0 + m) {
+      col[j] = (int32_t)(c - row0);
+    } else {
+      int64_t lo = 0, hi = n_ghost;   // lower_bound
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (ghost_sorted[mid] < c) lo = mid + 1; else hi = mid;
+      }
+      col[j] = (int32_t)(m + lo);
+    }
+  }
+}
+
+int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost) {
+  if (A->nnz == 0) return KHIP_OK;
+  int64_t want = (A->nnz + kBlock - 1) / kBlock;
+  int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(col_remap_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->col, A->nnz, A->row0, A->m,
+                     ghost_sorted_dev, n_ghost);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+// rows whose (remapped) columns reach into the ghost region: largest such row in the lower half,
+// smallest in the upper half -> [lo, hi) is guaranteed interior.
+__global__ __launch_bounds__(kBlock) void ghost_range_kernel(const int32_t *rowptr, const int32_t *col, int64_t m,
+                                                              unsigned long long *lo_hi) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    bool b = false;
+    for (int64_t j = rowptr[i]; j < rowptr[i + 1]; ++j) b |= (col[j] >= m);
+    if (b) {
+      if (i < m / 2) atomicMax(&lo_hi[0], (unsigned long long)(i + 1));
+      else atomicMin(&lo_hi[1], (unsigned long long)i);
+    }
+  }
+}
+
+int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host) {
+  unsigned long long *d = nullptr;
+  KHIP_CHECK_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
+  unsigned long long init[2] = {0ull, (unsigned long long)A->m};
+  KHIP_CHECK_HIP(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+  if (A->m > 0) {
+    int64_t want = (A->m + kBlock - 1) / kBlock;
+    int grid = (int)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(ghost_range_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, A->m, d);
+    KHIP_CHECK_HIP(hipGetLastError());
+  }
+  unsigned long long out[2];
+  KHIP_CHECK_HIP(hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  KHIP_CHECK_HIP(hipFree(d));
+  lo_hi_host[0] = (int64_t)out[0];
+  lo_hi_host[1] = (int64_t)out[1];
+  if (lo_hi_host[1] < lo_hi_host[0]) lo_hi_host[1] = lo_hi_host[0];
+  return KHIP_OK;
+}
+
+// ---------------------------------------------------------------- generators -----
+// Device restatement of the benchmark operators (test/get_div_grad.jl:8-25, test/test_utils.jl:160-169
+// and the cfg-5 27-point operator documented in DESIGN.md); parity-tested bit-exact against the oracle.
+__device__ __forceinline__ double stencil_coef(int kind, int d1, int d2, int d3) {
+  const int ab = abs(d1) + abs(d2) + abs(d3);
+  if (kind == 0) return ab == 0 ? 6.0 : (ab == 1 ? -1.0 : 0.0);
+  if (kind == 1) {
+    if (ab == 0) return 12.0;
+    if (ab != 1) return 0.0;
+    if (d1 == -1) return -1.0;
+    if (d1 == 1) return -2.0;
+    if (d2 == -1) return -2.0;
+    if (d2 == 1) return -4.0;
+    if (d3 == -1) return -1.0;
+    return -2.0;
+  }
+  if (ab == 0) return 16.0;
+  const double w = (ab == 1) ? 1.0 : (ab == 2 ? 0.5 : 0.25);
+  const int lead = d3 != 0 ? d3 : (d2 != 0 ? d2 : d1);
+  return -w * (lead > 0 ? 1.25 : 0.75);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void stencil_kernel(int kind, int n1, int n2, int n3, int64_t row0, int64_t m,
+                                                          int32_t *rowptr, int32_t *col, double *val) {
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = row0 + r;
+    const int i1 = (int)(row % n1), i2 = (int)((row / n1) % n2), i3 = (int)(row / ((int64_t)n1 * n2));
+    int64_t k = FILL ? rowptr[r] : 0;
+    int cnt = 0;
+    for (int d3 = -1; d3 <= 1; ++d3) {
+      const int j3 = i3 + d3;
+      if (j3 < 0 || j3 >= n3) continue;
+      for (int d2 = -1; d2 <= 1; ++d2) {
+        const int j2 = i2 + d2;
+        if (j2 < 0 || j2 >= n2) continue;
+        for (int d1 = -1; d1 <= 1; ++d1) {
+          const int j1 = i1 + d1;
+          if (j1 < 0 || j1 >= n1) continue;
+          const double v = stencil_coef(kind, d1, d2, d3);
+          if (v == 0.0) continue;
+          if (FILL) {
+            col[k] = (int32_t)((int64_t)j1 + (int64_t)n1 * j2 + (int64_t)n1 * n2 * j3);
+            val[k] = v;
+            ++k;
+          }
+          ++cnt;
+        }
+      }
+    }
+    if (!FILL) rowptr[r] = cnt;   // counts; scanned afterwards
+  }
+}
+
+// exclusive scan of int32 counts (3 phases: per-tile sums, scan of tile sums, add back)
+constexpr int kScanTile = 2048;   // elements per workgroup (8 per lane)
+__global__ __launch_bounds__(kBlock) void scan_tile_sums(const int32_t *in, int64_t n, long long *tile_sums) {
+  __shared__ long long s_w[kWavesPerBlock];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  long long s = 0;
+  for (int k = 0; k < kScanTile / kBlock; ++k) {
+    int64_t i = base + (int64_t)threadIdx.x * (kScanTile / kBlock) + k;
+    if (i < n) s += in[i];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += s_w[w];
+    tile_sums[blockIdx.x] = t;
+  }
+}
+__global__ void scan_tiles_serial(long long *tile_sums, int64_t ntiles, long long *total) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    long long run = 0;
+    for (int64_t t = 0; t < ntiles; ++t) {
+      long long v = tile_sums[t];
+      tile_sums[t] = run;
+      run += v;
+    }
+    *total = run;
+  }
+}
+__global__ __launch_bounds__(kBlock) void scan_apply(int32_t *data, int64_t n, const long long *tile_offs) {
+  __shared__ long long s_t[kBlock];
+  constexpr int PER = kScanTile / kBlock;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * PER;
+  int v[PER];
+  long long s = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    v[k] = (base + k < n) ? data[base + k] : 0;
+    s += v[k];
+  }
+  s_t[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // serial scan of 256 lane totals: one-time setup kernel
+    long long run = tile_offs[blockIdx.x];
+    for (int t = 0; t < kBlock; ++t) {
+      long long x = s_t[t];
+      s_t[t] = run;
+      run += x;
+    }
+  }
+  __syncthreads();
+  long long run = s_t[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (base + k < n) data[base + k] = (int32_t)run;
+    run += v[k];
+  }
+}
+
+}  // namespace khip
+
+using namespace khip;
+
+extern "C" int khip_gen_stencil(khip_ctx *ctx, int kind, int n1, int n2, int n3, int64_t row0, int64_t m,
+                                int32_t **rowptr_dev, int32_t **col_dev, double **val_dev, int64_t *nnz_out) {
+  KHIP_REQUIRE(ctx && rowptr_dev && col_dev && val_dev && nnz_out, "gen_stencil: null argument");
+  KHIP_REQUIRE(kind >= 0 && kind <= 2 && n1 > 0 && n2 > 0 && n3 > 0, "gen_stencil: bad kind/dims");
+  const int64_t n = (int64_t)n1 * n2 * n3;
+  KHIP_REQUIRE(n < (1ll << 31), "gen_stencil: column index would overflow int32");
+  KHIP_REQUIRE(row0 >= 0 && m >= 0 && row0 + m <= n, "gen_stencil: bad row range");
+  KHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  int32_t *rp = nullptr, *cl = nullptr;
+  double *vl = nullptr;
+  KHIP_CHECK_HIP(hipMalloc(&rp, sizeof(int32_t) * (size_t)(m + 1)));
+  const int64_t want = (m + kBlock - 1) / kBlock;
+  const int grid = (int)(want < 8192 ? (want > 0 ? want : 1) : 8192);
+  hipLaunchKernelGGL((stencil_kernel<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, kind, n1, n2, n3, row0, m, rp,
+                     (int32_t *)nullptr, (double *)nullptr);
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipMemsetAsync(rp + m, 0, sizeof(int32_t), ctx->stream));
+  // exclusive scan over m+1 entries (last input is 0 -> rowptr[m] = total)
+  const int64_t cnt = m + 1;
+  const int64_t ntiles = (cnt + kScanTile - 1) / kScanTile;
+  long long *tiles = nullptr;
+  KHIP_CHECK_HIP(hipMalloc(&tiles, sizeof(long long) * (size_t)(ntiles + 1)));
+  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)ntiles), dim3(kBlock), 0, ctx->stream, rp, cnt, tiles);
+  hipLaunchKernelGGL(scan_tiles_serial, dim3(1), dim3(64), 0, ctx->stream, tiles, ntiles, tiles + ntiles);
+  hipLaunchKernelGGL(scan_apply, dim3((unsigned)ntiles), dim3(kBlock), 0, ctx->stream, rp, cnt, tiles);
+  KHIP_CHECK_HIP(hipGetLastError());
+  long long total = 0;
+  KHIP_CHECK_HIP(hipMemcpyAsync(&total, tiles + ntiles, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  KHIP_CHECK_HIP(hipFree(tiles));
+  if (total >= (1ll << 31) - 64) {
+    (void)hipFree(rp);
+    set_error("gen_stencil: shard nnz %lld does not fit int32 row pointers", total);
+    return KHIP_ERR_INVALID;
+  }
+  KHIP_CHECK_HIP(hipMalloc(&cl, sizeof(int32_t) * (size_t)(total + kPad)));
+  KHIP_CHECK_HIP(hipMalloc(&vl, sizeof(double) * (size_t)(total + kPad)));
+  KHIP_CHECK_HIP(hipMemsetAsync(cl + total, 0, sizeof(int32_t) * kPad, ctx->stream));
+  KHIP_CHECK_HIP(hipMemsetAsync(vl + total, 0, sizeof(double) * kPad, ctx->stream));
+  hipLaunchKernelGGL((stencil_kernel<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, kind, n1, n2, n3, row0, m, rp,
+                     cl, vl);
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  *rowptr_dev = rp; *col_dev = cl; *val_dev = vl; *nnz_out = total;
+  return KHIP_OK;
+}

@@ -7,6 +7,15 @@
 // reduction tree -- different grids, fused vs. unfused kernels and 1 vs. 8 GPUs agree.
 // The kernels are HBM-bound (<= 0.125 flop/B); the ~10 extra fp64 VALU ops per element are free.
 //
+// Structure (measured on MI355X, profiles/r01*): streaming kernels want LOOP-FREE launches with
+// short-lived workgroups (10^5..10^6 of them), and any in-kernel publish/ticket protocol per
+// workgroup costs more than the streaming itself (dot 4.3 TB/s with it, 7.1 TB/s without).  So the
+// streaming kernel only does a wave64 shuffle reduction and ONE plain 16-byte store per wave
+// (`wave_publish`), then exits; a tiny second kernel (`reduce_finish_kernel`, <= 256 workgroups)
+// folds the per-wave partials in a FIXED order -- chunk per workgroup, strided within the chunk,
+// shuffle tree, then a ticketed last-arriver fold of the <= 256 workgroup partials with agent-scope
+// release/acquire (cdna_hip_programming.md Guideline 16).  Deterministic run to run.
+//
 // Compiled with -ffp-contract=off: every fma() below is explicit, nothing else is fused.
 #pragma once
 
@@ -18,6 +27,7 @@ namespace khip {
 
 constexpr int kBlock = 256;            // 4 waves of 64
 constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kFinishMaxBlocks = 256;
 
 __device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
   s = a + b;
@@ -59,6 +69,27 @@ __device__ __forceinline__ dd wave_reduce(dd v) {
   return v;   // valid in lane 0
 }
 
+struct RedArgs {
+  dd *wave_partials;   // [NOUT][cap]  one per wave of the streaming kernel
+  dd *blk_partials;    // [NOUT][kFinishMaxBlocks]
+  unsigned *ticket;    // one word, zero between launches
+  double *results;     // ring base
+  dd *results_dd;      // ring base
+  int64_t cap;
+  int slot;
+};
+
+// Streaming-kernel side: every wave folds its lanes and stores one partial per output.
+template <int NOUT>
+__device__ __forceinline__ void wave_publish(dd (&acc)[NOUT], const RedArgs &ra) {
+  const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    dd r = wave_reduce(acc[o]);
+    if ((threadIdx.x & 63) == 0) ra.wave_partials[(size_t)o * ra.cap + wid] = r;
+  }
+}
+
 // Workgroup reduction of NOUT partials; result valid in thread 0.
 template <int NOUT>
 __device__ __forceinline__ void block_reduce(dd (&acc)[NOUT], dd (*s_w)[kWavesPerBlock]) {
@@ -80,25 +111,24 @@ __device__ __forceinline__ void block_reduce(dd (&acc)[NOUT], dd (*s_w)[kWavesPe
   }
 }
 
-struct RedArgs {
-  dd *partials;        // [NOUT][kMaxRedBlocks]
-  unsigned *ticket;    // one word, zero between launches
-  double *results;     // ring base
-  dd *results_dd;      // ring base
-  int slot;
-};
-
-// Grid-level finish: every workgroup publishes its partial with write-through (sc1) agent-scope
-// stores, drains them, then takes a ticket; the last arriver re-reads all partials with agent-scope
-// loads (L1-bypassing) in a FIXED order and writes the result.  Follows the publish/consume rules of
-// cdna_hip_programming.md Guideline 16 ("8-B agent atomics both sides", drain before the flag).
+// Second kernel: P per-wave partials -> results[slot .. slot+NOUT).
 template <int NOUT>
-__device__ __forceinline__ void grid_finish(dd (&acc)[NOUT], const RedArgs &ra) {
+__global__ __launch_bounds__(kBlock) void reduce_finish_kernel(RedArgs ra, int64_t P) {
   __shared__ dd s_w[NOUT][kWavesPerBlock];
   __shared__ int s_last;
-  const int nblocks = gridDim.x;
+  const int G = gridDim.x;
+  const int64_t chunk = (P + G - 1) / G;
+  const int64_t lo = chunk * blockIdx.x;
+  const int64_t hi = (lo + chunk < P) ? lo + chunk : P;
+  dd acc[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    dd a = {0.0, 0.0};
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) a = dd_merge(a, ra.wave_partials[(size_t)o * ra.cap + i]);
+    acc[o] = a;
+  }
   block_reduce<NOUT>(acc, s_w);
-  if (nblocks == 1) {
+  if (G == 1) {
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
@@ -110,31 +140,28 @@ __device__ __forceinline__ void grid_finish(dd (&acc)[NOUT], const RedArgs &ra) 
   }
   if (threadIdx.x == 0) {
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      dd *p = ra.partials + (size_t)o * kMaxRedBlocks + blockIdx.x;
+    for (int o = 0; o < NOUT; ++o) {   // write-through (sc1) agent-scope stores
+      dd *p = ra.blk_partials + (size_t)o * kFinishMaxBlocks + blockIdx.x;
       __hip_atomic_store(&p->hi, acc[o].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&p->lo, acc[o].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain before the ticket (Guideline 16 compiler hazard)
     unsigned t = __hip_atomic_fetch_add(ra.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (unsigned)(nblocks - 1));
+    s_last = (t == (unsigned)(G - 1));
   }
   __syncthreads();
   if (!s_last) return;
   dd fin[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
-    dd a = {0.0, 0.0};
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
-      const dd *p = ra.partials + (size_t)o * kMaxRedBlocks + b;
-      dd v;
-      v.hi = __hip_atomic_load(&p->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v.lo = __hip_atomic_load(&p->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a = dd_merge(a, v);
+    fin[o] = dd{0.0, 0.0};
+    if ((int)threadIdx.x < G) {                        // L1-bypassing agent-scope loads
+      const dd *p = ra.blk_partials + (size_t)o * kFinishMaxBlocks + threadIdx.x;
+      fin[o].hi = __hip_atomic_load(&p->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fin[o].lo = __hip_atomic_load(&p->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    fin[o] = a;
   }
-  __syncthreads();   // s_w reuse
+  __syncthreads();
   block_reduce<NOUT>(fin, s_w);
   if (threadIdx.x == 0) {
 #pragma unroll
@@ -146,12 +173,18 @@ __device__ __forceinline__ void grid_finish(dd (&acc)[NOUT], const RedArgs &ra) 
   }
 }
 
+// host side (blas1.hip)
+int ensure_reduction_scratch(khip_ctx *ctx, int64_t nwaves, int nout);
+int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot);
+
 inline RedArgs make_red_args(khip_ctx *ctx, int slot) {
   RedArgs ra;
-  ra.partials = ctx->partials;
+  ra.wave_partials = ctx->partials;
+  ra.blk_partials = ctx->partials2;
   ra.ticket = ctx->tickets;
   ra.results = ctx->results;
   ra.results_dd = ctx->results_dd;
+  ra.cap = ctx->red_cap1;
   ra.slot = slot;
   return ra;
 }

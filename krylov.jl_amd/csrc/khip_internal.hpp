@@ -44,21 +44,26 @@ struct dd {
   double hi, lo;
 };
 
-constexpr int kMaxRedBlocks = 2048;   // partials per reduction launch (256 CUs x 8)
-constexpr int kMaxRedOut = 64;        // independent results one launch may produce (dot2, mgs)
+constexpr int kMaxNout = 4;           // outputs one reduction launch may produce (dot2 = 2)
+constexpr int kMaxRedOut = 64;        // scalars one all-reduce call may carry (multi-GPU)
 constexpr int kResultSlots = 256;     // device-resident scalar ring (chained MGS coefficients)
 
 struct Comm;   // comm.cpp
 
 struct Tuning {
-  int spmv_kernel = 0;      // 0 = auto, 1 = stream (LDS-staged), 2 = vector (sub-wave per row)
+  int spmv_kernel = 0;      // 0 = auto, 1 = stream (LDS-staged), 2 = vector (sub-wave per row), 3 = ordered sub-wave
   int spmv_rows = 256;      // rows per workgroup of the stream kernel
-  int spmv_vec = 2;         // nnz per lane per load in the stream kernel (1, 2)
-  int spmv_nt = 1;          // non-temporal loads for the val/col streams
-  int spmv_xcd = 1;         // XCD-contiguous block remap
+  int spmv_vec = 1;         // nnz per lane per load in the stream kernel (1, 2)
+  int spmv_nt = 0;          // non-temporal loads for the val/col streams (measured slower on MI355X)
+  int spmv_xcd = 0;         // XCD-aware tile remap: R > 0 runs of R tiles per XCD, -1 contiguous eighths, 0 off
+  int spmv_nty = 0;         // non-temporal store of y
+  int spmv_fake_gather = 0; // tuning experiment (wrong results): coalesced x reads
+  int spmv_tiles = 1;       // staged kernel: consecutive row blocks per workgroup
+  int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
   int spmv_lanes = 0;       // vector kernel lanes per row (0 = auto)
+  int spmv_persist = 0;     // 1 = persistent grid (<= 8 workgroups per CU) instead of one row block per workgroup
   int compensated = 1;      // Dot2 (TwoSum/TwoProd) reductions
-  int blas1_blocks = 2048;  // max grid of BLAS-1 kernels
+  int nt_min_elems = 1 << 22;  // BLAS-1 vectors at least this long use non-temporal accesses (32 MiB)
   int overlap_halo = 1;     // overlap halo exchange with interior rows
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
@@ -72,17 +77,16 @@ struct khip_ctx {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   int num_cu = 256;
-  // reduction scratch
-  khip::dd *partials = nullptr;        // [kMaxRedOut][kMaxRedBlocks]
-  unsigned *tickets = nullptr;         // [kMaxRedOut]
+  // reduction scratch (grown on demand by ensure_reduction_scratch)
+  khip::dd *partials = nullptr;        // [kMaxNout][red_cap1]  one per wave of the streaming kernel
+  khip::dd *partials2 = nullptr;       // [kMaxNout][256]       one per workgroup of the finish kernel
+  unsigned *tickets = nullptr;         // ticket word (+ spare words)
+  int64_t red_cap1 = 0;
+  int *scratch_word = nullptr;         // spare device word (row statistics)
   double *results = nullptr;           // device scalar ring [kResultSlots]   (value)
   khip::dd *results_dd = nullptr;      // device scalar ring [kResultSlots]   (hi, lo) for multi-GPU
   double *results_pinned = nullptr;    // pinned host mirror [kResultSlots * 2]
   int next_slot = 0;
-  // small device staging for pointer / coefficient arrays (mgs, multi_axpy)
-  void *stage_dev = nullptr;
-  void *stage_pinned = nullptr;
-  size_t stage_bytes = 0;
   khip::Tuning tune;
   khip::Comm *comm = nullptr;
   // SpMV launch profiling (events recorded on `stream`, resolved lazily)
@@ -94,6 +98,7 @@ struct khip_csr {
   khip_ctx *ctx = nullptr;
   int64_t m = 0, n = 0, nnz = 0;       // local rows, (global) cols, local nnz
   int32_t *rowptr = nullptr;           // device, m+1, 0-based
+  int32_t *blockptr = nullptr;         // device, ceil(m/256)+1 : rowptr[min(256 i, m)]
   int32_t *col = nullptr;              // device, nnz (+pad), 0-based; remapped when distributed
   double *val = nullptr;               // device, nnz (+pad)
   int64_t max_row_nnz = 0;
@@ -121,6 +126,8 @@ inline int take_slots(khip_ctx *ctx, int count) {
 }
 
 // blas1.hip
+int ensure_reduction_scratch(khip_ctx *ctx, int64_t nwaves, int nout);
+int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot);
 int launch_dot(khip_ctx *ctx, int64_t n, const double *x, const double *y, int slot);
 int launch_nrm2sq(khip_ctx *ctx, int64_t n, const double *x, int slot);
 int launch_dot2(khip_ctx *ctx, int64_t n, const double *x, const double *y, int slot);  // slot: x.y, slot+1: x.x
@@ -134,7 +141,7 @@ int launch_map(khip_ctx *ctx, int op, int64_t n, double a, double b, const doubl
 int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host,
                       const double *const *V_host, double *x);
 // fetch `count` results starting at slot into host memory (synchronises the stream; all-reduces
-// across ranks when a communicator is attached). sqrt_mask bit i -> take sqrt of result i.
+// across ranks when a communicator is attached).
 int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host);
 
 // spmv.hip
@@ -147,7 +154,6 @@ int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev
 int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64_t row1, int32_t *out_dev,
                            unsigned long long *count_dev, int64_t cap);
 int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host);
-
 int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
 
 // comm.cpp

@@ -1,4 +1,4 @@
-// spmv.hip -- CSR SpMV / SpMM for gfx950 and the device-side operator generators.
+// spmv.hip -- CSR SpMV for gfx950.
 //
 // Replaces kmul!(y, A, x) = mul!(y, A, x) (src/krylov_utils.jl:305).  HBM-bound: algorithmic
 // bytes = 12 nnz + 4 (m+1) + 8 n + 8 m, AI = 0.135 flop/B on the 7-point
@@ -7,67 +7,50 @@
 // Data layout in HBM: val f64[nnz], col i32[nnz], rowptr i32[m+1] (0-based), x f64[n], y f64[m];
 // val/col are padded by 8 zeroed entries so that 16-byte lane loads may overrun the last row.
 //
-// Kernels
-//  * spmv_stream: for short rows (stencils).  A workgroup owns a CONTIGUOUS range of row blocks
-//    (persistent grid: <= 8 workgroups per CU), so the x entries touched by consecutive rows are
-//    re-used from the same CU's L1 / the XCD's L2.  Per row block: the val/col streams are read
-//    fully coalesced (16 B per lane for val), each product val*x[col] is staged in LDS, then one
-//    lane per row sums its segment of LDS in stored order -- one rounded multiply and one
-//    rounded add per entry, the same arithmetic as the serial CPU loop, so y is BIT-IDENTICAL to
-//    the oracle's.  LDS: 256 rows * 7 nnz * 8 B = 14 KB + 1 KB row pointers per workgroup.
-//  * spmv_vector: rows with many entries: L = 4..64 lanes stride over one row (coalesced), then a
-//    wave64 __shfl_down tree; FMA accumulation (not bit-identical to the serial loop).
-//  * optional fused dot (x . y) for CG's pAp (src/cg.jl:196-197): each row's y value is multiplied
-//    by x[row] on the fly and reduced with the grid-level compensated reduction.
-//  * XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order); the logical chunk
-//    id is remapped so every XCD sweeps one contiguous eighth of the rows and the three plane
-//    neighbours of a stencil row land in the same 4 MiB L2.
-#include "device_reduce.hpp"
+// Launch shape: LOOP-FREE by default -- one tile of rows per workgroup, ~10^5..10^6 workgroups --
+// because on MI355X streaming kernels with short-lived workgroups sustain 30-50 % more HBM bandwidth
+// than persistent grid-stride loops (profiles/r01_membench*.log).  `spmv_persist` restores the
+// persistent form (contiguous row ranges per workgroup, optional XCD-contiguous remap) for A/B runs.
+//
+// Kernels (all produce y BIT-IDENTICAL to the serial CPU loop except spmv_vector):
+//  * spmv_ordered<L>: L = 4..64 lanes cooperate on a row.  Lane k loads entry k of the row (the
+//    val/col streams of consecutive rows are contiguous, so a wave reads one contiguous span),
+//    multiplies by the gathered x, and the L products are folded IN STORED ORDER with L broadcast
+//    shuffles: one rounded multiply and one rounded add per entry, exactly the arithmetic of
+//    SparseArrays.mul! / the oracle.  No LDS, no barrier, ~30 VGPRs -> 8 waves per SIMD.  Several
+//    rows per lane group are in flight at once (independent loads issued up front).
+//  * spmv_stream: the LDS-staged form of the north star: a workgroup reads the val/col streams of
+//    256 rows fully coalesced, stages val*x[col] in LDS (14 KB), then one lane per row sums its
+//    segment in stored order.  Row pointers live in registers (no LDS, no extra barrier).
+//  * spmv_vector<L>: L lanes stride over a long row with FMA accumulation + shuffle tree (rows with
+//    hundreds of entries); not bit-identical to the serial loop.
+//  * optional fused dot (x . y) for CG's pAp (src/cg.jl:196-197): the lane that owns a row multiplies
+//    its y value by x[row]; one partial per wave + the tiny finish kernel (device_reduce.hpp).
+#include "spmv_common.hpp"
 
 namespace khip {
 
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-typedef int int2v __attribute__((ext_vector_type(2)));
-
-constexpr int kPad = 8;
-
-struct SpmvArgs {
-  const int32_t *rowptr;
-  const int32_t *col;
-  const double *val;
-  const double *x;
-  const double *ghost;   // remote x entries (distributed), indexed col - n_owned
-  double *y;
-  int64_t n_owned;       // columns < n_owned read x, others read ghost
-  int64_t row_lo, row_hi;
-  int xcd_remap;
-};
-
-template <bool NT, typename T>
-__device__ __forceinline__ T ld(const T *p) {
-  if (NT) return __builtin_nontemporal_load(p);
-  return *p;
-}
-
-template <bool DIST>
-__device__ __forceinline__ double gather_x(const SpmvArgs &a, int32_t c) {
-  if (DIST) {
-    const double *src = (c < a.n_owned) ? a.x : (a.ghost - a.n_owned);
-    return src[c];
+// Logical tile id of workgroup b (of G).  The dispatcher places workgroup b on XCD b % 8 (observed,
+// MI355X_MICROARCH.md), each XCD has its own 4 MiB L2.  xcd_run = R > 0 hands every XCD runs of R
+// CONSECUTIVE tiles inside each window of 8R workgroups, so the x entries shared by neighbouring rows
+// (a stencil's +-n1 couplings) are fetched into ONE L2 instead of three, while the chip-wide access
+// front stays compact (window = 8R tiles).  xcd_run = -1: one contiguous eighth per XCD.
+__device__ __forceinline__ int chunk_id(int b, int G, int xcd_run) {
+  if (xcd_run > 0) {
+    const int win = 8 * xcd_run;
+    const int full = (G / win) * win;
+    if (b < full) return (b / win) * win + (b & 7) * xcd_run + ((b % win) >> 3);
+    return b;
   }
-  return a.x[c];
-}
-
-// logical chunk id for workgroup b of G: XCD-contiguous when requested and G % 8 == 0
-__device__ __forceinline__ int chunk_id(int b, int G, int xcd_remap) {
-  if (xcd_remap && (G & 7) == 0) return (b & 7) * (G >> 3) + (b >> 3);
+  if (xcd_run < 0 && (G & 7) == 0) return (b & 7) * (G >> 3) + (b >> 3);
   return b;
 }
 
+// ---------------------------------------------------------------- stream (LDS-staged) ----
 template <int ROWS, int VEC, bool NT, bool DOT, bool COMP, bool DIST>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs ra) {
+  static_assert(ROWS <= kBlock, "one lane per row");
   constexpr int CAP = 2048;   // products staged per pass (16 KB)
-  __shared__ int32_t s_ptr[ROWS + 1];
   __shared__ double s_prod[CAP + 4];
   const int tid = threadIdx.x;
   const int G = gridDim.x;
@@ -82,30 +65,59 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
   for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
     const int64_t r0 = a.row_lo + rb * ROWS;
     const int nr = (int)((a.row_hi - r0) < ROWS ? (a.row_hi - r0) : ROWS);
-    for (int i = tid; i <= nr; i += kBlock) s_ptr[i] = a.rowptr[r0 + i];
-    __syncthreads();
-    const int64_t s = s_ptr[0], e = s_ptr[nr];
-    const int my_a = (tid < nr) ? s_ptr[tid] : 0;
-    const int my_b = (tid < nr) ? s_ptr[tid + 1] : 0;
+    // block-uniform range (scalar loads) + this lane's row, all issued before anything waits
+    // With a block-pointer table (every 256th row pointer, 2 MB at 512^3 => L2-resident) the first,
+    // chain-starting lookup is an L2 hit instead of an HBM miss on a fresh rowptr line.
+    int64_t s, e;
+    if (ROWS == 256 && a.blockptr != nullptr) {
+      const int64_t bi = (r0 >> 8);
+      s = a.blockptr[bi];
+      e = a.blockptr[bi + 1];
+    } else {
+      s = a.rowptr[r0];
+      e = a.rowptr[r0 + nr];
+    }
+    const int my_a = (tid < nr) ? a.rowptr[r0 + tid] : 0;
+    const int my_b = (tid < nr) ? a.rowptr[r0 + tid + 1] : 0;
     double acc = 0.0;
     for (int64_t c0 = s & ~(int64_t)(VEC - 1); c0 < e; c0 += CAP) {
-      // wave-uniform bases + 32-bit lane offsets: keeps the address math in SGPRs
       const double *vbase = a.val + c0;
       const int32_t *cbase = a.col + c0;
       const int len = (int)((e - c0) < CAP ? (e - c0) : CAP);
+      if (VEC == 1) {
+        // CAP = 8 * kBlock: all (<= 8) val/col loads of this lane are issued first, then all x
+        // gathers, then the LDS writes -- two memory latencies per row block instead of four
+        constexpr int IT = CAP / kBlock;
+        double v[IT];
+        int32_t c[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int o = tid + it * kBlock;
+          const bool ok = o < len;
+          v[it] = ld<NT>(vbase + (ok ? o : 0));
+          c[it] = ld<NT>(cbase + (ok ? o : 0));
+        }
+        double xg[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          // a.fake_gather (tuning experiment only): replace the scattered gather by a coalesced read
+          const int32_t ci = a.fake_gather ? (int32_t)((tid + it * kBlock) & 2047) + (c[it] & 0) : c[it];
+          xg[it] = gather_x<DIST>(a, ci);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int o = tid + it * kBlock;
+          if (o < len) s_prod[o] = v[it] * xg[it];
+        }
+      } else {
 #pragma unroll 4
-      for (int o = VEC * tid; o < len; o += VEC * kBlock) {
-        if (VEC == 2) {
+        for (int o = VEC * tid; o < len; o += VEC * kBlock) {
           dbl2 v = ld<NT>(reinterpret_cast<const dbl2 *>(vbase + o));
           int2v c = ld<NT>(reinterpret_cast<const int2v *>(cbase + o));
           double p0 = v.x * gather_x<DIST>(a, c.x);
           double p1 = v.y * gather_x<DIST>(a, c.y);
           s_prod[o] = p0;
           s_prod[o + 1] = p1;
-        } else {
-          double v = ld<NT>(vbase + o);
-          int32_t c = ld<NT>(cbase + o);
-          s_prod[o] = v * gather_x<DIST>(a, c);
         }
       }
       __syncthreads();
@@ -117,15 +129,181 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
       }
       __syncthreads();
     }
-    if (e <= s) __syncthreads();   // empty row block: keep s_ptr reuse ordered
     if (tid < nr) {
-      a.y[r0 + tid] = acc;
+      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
       if (DOT) acc_prod<COMP>(dacc[0], a.x[r0 + tid], acc);
     }
   }
-  if (DOT) grid_finish<1>(dacc, ra);
+  if (DOT) wave_publish<1>(dacc, ra);
 }
 
+// ---------------------------------------------------------------- staged rows ------------
+// The scattered x gather is what limits the kernels above: with val*x[col] formed in nnz order a
+// wave's 64 gather addresses fall in ~14 different cache lines, and the texture-address path, not
+// HBM, sets the pace (measured: replacing the gather by a coalesced L1-resident read takes the
+// stream kernel from 2.79 ms to 1.96 ms at 512^3, profiles/r01_sweep2d.log).  This kernel keeps the
+// val/col streams fully coalesced (HBM -> registers -> LDS, 24 KB per 256 rows) and then lets ONE
+// LANE PER ROW walk its row out of LDS: at step k the 64 lanes of a wave gather x[col(row, k)] for 64
+// CONSECUTIVE rows -- for banded / stencil operators those are consecutive addresses, i.e. the
+// gather becomes a coalesced load.  Each lane accumulates its row in stored order with a rounded
+// multiply and a rounded add per entry: bit-identical to the serial CPU loop for any matrix.
+// LDS reads are conflict-free for odd row lengths (stride 7 doubles -> distinct bank pairs).
+template <int ROWS, bool NT, bool DOT, bool COMP, bool DIST>
+__global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs ra) {
+  static_assert(ROWS <= kBlock, "one lane per row");
+  constexpr int CAP = 2048;                  // window of staged entries: 8 per lane, moved as 16-byte vectors
+  constexpr int UK = 8;                      // row entries whose gathers are in flight together
+  __shared__ __attribute__((aligned(16))) double s_val[CAP];
+  __shared__ __attribute__((aligned(16))) int32_t s_col[CAP];
+  const int tid = threadIdx.x;
+  const int64_t nrows = a.row_hi - a.row_lo;
+  const int64_t nrb = (nrows + ROWS - 1) / ROWS;
+  const int tpb = a.tiles_per_block > 0 ? a.tiles_per_block : 1;
+  const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap);
+  const int64_t rb_begin = (int64_t)cid * tpb;
+  const int64_t rb_end = (rb_begin + tpb < nrb) ? rb_begin + tpb : nrb;
+  dd dacc[1];
+  dacc[0] = dd{0.0, 0.0};
+
+  for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
+    const int64_t r0 = a.row_lo + rb * ROWS;
+    const int nr = (int)((a.row_hi - r0) < ROWS ? (a.row_hi - r0) : ROWS);
+    const int64_t s = a.rowptr[r0], e = a.rowptr[r0 + nr];
+    const int my_a = (tid < nr) ? a.rowptr[r0 + tid] : 0;
+    const int my_b = (tid < nr) ? a.rowptr[r0 + tid + 1] : 0;
+    double acc = 0.0;
+    // windows start on a multiple of 4 entries so that every lane moves aligned 16-byte vectors:
+    // 4 val loads (2 entries each) + 2 col loads (4 entries each) per lane and window -- the
+    // vector-memory instruction count, not HBM, is what bounds this kernel
+    for (int64_t c0 = s & ~(int64_t)3; c0 < e; c0 += CAP) {
+      dbl2 v[4];
+      int4v c[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int o = q * (CAP / 2) + 4 * tid;
+        const int64_t j = (c0 + o + 4 <= a.nnz_bound) ? c0 + o : 0;
+        v[2 * q] = ld<NT>(reinterpret_cast<const dbl2 *>(a.val + j));
+        v[2 * q + 1] = ld<NT>(reinterpret_cast<const dbl2 *>(a.val + j + 2));
+        c[q] = ld<NT>(reinterpret_cast<const int4v *>(a.col + j));
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int o = q * (CAP / 2) + 4 * tid;
+        *reinterpret_cast<dbl2 *>(s_val + o) = v[2 * q];
+        *reinterpret_cast<dbl2 *>(s_val + o + 2) = v[2 * q + 1];
+        *reinterpret_cast<int4v *>(s_col + o) = c[q];
+      }
+      __syncthreads();
+      if (tid < nr) {
+        const int64_t wend = (e - c0) < CAP ? (e - c0) : CAP;
+        const int rel_a = (int)(my_a - c0), rel_b = (int)(my_b - c0);
+        const int lo = rel_a > 0 ? rel_a : 0;
+        const int hi = rel_b < (int)wend ? rel_b : (int)wend;
+        for (int k0 = lo; k0 < hi; k0 += UK) {
+          int32_t cc[UK];
+          double vv[UK], xx[UK];
+#pragma unroll
+          for (int u = 0; u < UK; ++u) {
+            const int j = (k0 + u < hi) ? k0 + u : k0;
+            cc[u] = s_col[j];
+            vv[u] = s_val[j];
+          }
+#pragma unroll
+          for (int u = 0; u < UK; ++u) {
+            xx[u] = 0.0;
+            if (k0 + u < hi) xx[u] = gather_x<DIST>(a, cc[u]);      // skipped when no lane of the wave needs it
+          }
+#pragma unroll
+          for (int u = 0; u < UK; ++u) {
+            if (k0 + u < hi) {
+              const double prod = vv[u] * xx[u];
+              acc = acc + prod;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (tid < nr) {
+      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+      if (DOT) acc_prod<COMP>(dacc[0], a.x[r0 + tid], acc);
+    }
+  }
+  if (DOT) wave_publish<1>(dacc, ra);
+}
+
+// ---------------------------------------------------------------- ordered sub-wave -------
+// L lanes per row, RPG rows per lane group in flight.  Wave layout: NG = 64 / L groups; step u of a
+// wave covers rows wave_row0 + u * NG + g (g = group index) so that each load instruction of the
+// wave touches one contiguous span of the val / col streams.
+template <int L, int RPG, bool NT, bool DOT, bool COMP, bool DIST>
+__global__ __launch_bounds__(kBlock) void spmv_ordered_kernel(SpmvArgs a, RedArgs ra) {
+  constexpr int NG = 64 / L;                       // lane groups per wave
+  constexpr int ROWS_PER_WAVE = NG * RPG;
+  constexpr int ROWS_PER_BLOCK = ROWS_PER_WAVE * kWavesPerBlock;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane / L, k = lane % L;
+  dd dacc[1];
+  dacc[0] = dd{0.0, 0.0};
+  const int64_t nrows = a.row_hi - a.row_lo;
+  const int64_t ntiles = (nrows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t wrow0 = a.row_lo + tile * ROWS_PER_BLOCK + (int64_t)wave * ROWS_PER_WAVE;
+    int32_t rs[RPG], re[RPG];
+    double prod[RPG];
+#pragma unroll
+    for (int u = 0; u < RPG; ++u) {
+      const int64_t row = wrow0 + u * NG + g;
+      const bool ok = row < a.row_hi;
+      rs[u] = ok ? a.rowptr[row] : 0;
+      re[u] = ok ? a.rowptr[row + 1] : 0;
+    }
+    double v[RPG];
+    int32_t c[RPG];
+#pragma unroll
+    for (int u = 0; u < RPG; ++u) {
+      const bool valid = rs[u] + k < re[u];
+      const int64_t j = valid ? (int64_t)rs[u] + k : 0;
+      v[u] = ld<NT>(a.val + j);
+      c[u] = ld<NT>(a.col + j);
+      if (!valid) { v[u] = 0.0; c[u] = 0; }
+    }
+#pragma unroll
+    for (int u = 0; u < RPG; ++u) {
+      const double xv = gather_x<DIST>(a, c[u]);
+      prod[u] = (rs[u] + k < re[u]) ? v[u] * xv : 0.0;
+    }
+    double mine = 0.0;        // result of the row this lane will store (row u == k for k < RPG)
+#pragma unroll
+    for (int u = 0; u < RPG; ++u) {
+      // in-order fold of the first L entries: acc = (((0 + p0) + p1) + ...) ; padding adds +0.0
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < L; ++t) acc = acc + __shfl(prod[u], t, L);
+      // rows longer than L (group-uniform loop): further chunks of L entries, still in order
+      for (int32_t base = rs[u] + L; base < re[u]; base += L) {
+        const bool valid = base + k < re[u];
+        const int64_t j = valid ? (int64_t)base + k : 0;
+        const double vv = a.val[j];
+        const int32_t cc = a.col[j];
+        const double p = valid ? vv * gather_x<DIST>(a, cc) : 0.0;
+#pragma unroll
+        for (int t = 0; t < L; ++t) acc = acc + __shfl(p, t, L);
+      }
+      if (k == u) mine = acc;
+    }
+    if (k < RPG) {
+      const int64_t row = wrow0 + k * NG + g;
+      if (row < a.row_hi) {
+        a.y[row] = mine;
+        if (DOT) acc_prod<COMP>(dacc[0], a.x[row], mine);
+      }
+    }
+  }
+  if (DOT) wave_publish<1>(dacc, ra);
+}
+
+// ---------------------------------------------------------------- vector (long rows) -----
 template <int LPR, bool DOT, bool COMP, bool DIST>
 __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a, RedArgs ra) {
   constexpr int RPB = kBlock / LPR;   // rows per workgroup per sweep
@@ -144,37 +322,66 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a, RedArgs
       if (DOT) acc_prod<COMP>(dacc[0], a.x[row], acc);
     }
   }
-  if (DOT) grid_finish<1>(dacc, ra);
+  if (DOT) wave_publish<1>(dacc, ra);
 }
 
 // ---------------------------------------------------------------- dispatch ------
+#define KHIP_DISPATCH_DCD(LAUNCH)                                                        \
+  do {                                                                                   \
+    if (dot) {                                                                           \
+      if (comp) { if (dist) LAUNCH(true, true, true); else LAUNCH(true, true, false); }  \
+      else      { if (dist) LAUNCH(true, false, true); else LAUNCH(true, false, false); } \
+    } else {                                                                             \
+      if (dist) LAUNCH(false, false, true); else LAUNCH(false, false, false);            \
+    }                                                                                    \
+  } while (0)
+
 template <int ROWS, int VEC, bool NT>
-static void launch_stream_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, int grid, bool dot, bool comp,
+static void launch_stream_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                               bool dist) {
-#define KHIP_SPMV_LAUNCH(DOT, COMP, DIST)                                                                         \
-  hipLaunchKernelGGL((spmv_stream_kernel<ROWS, VEC, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, \
-                     ra)
-  if (dot) {
-    if (comp) { if (dist) KHIP_SPMV_LAUNCH(true, true, true); else KHIP_SPMV_LAUNCH(true, true, false); }
-    else      { if (dist) KHIP_SPMV_LAUNCH(true, false, true); else KHIP_SPMV_LAUNCH(true, false, false); }
-  } else {
-    if (dist) KHIP_SPMV_LAUNCH(false, false, true); else KHIP_SPMV_LAUNCH(false, false, false);
-  }
-#undef KHIP_SPMV_LAUNCH
+#define KHIP_L(DOT, COMP, DIST) \
+  hipLaunchKernelGGL((spmv_stream_kernel<ROWS, VEC, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, ra)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
+template <int ROWS, bool NT>
+static void launch_stage_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
+                             bool dist) {
+#define KHIP_L(DOT, COMP, DIST) \
+  hipLaunchKernelGGL((spmv_stage_kernel<ROWS, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, ra)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
+template <int L, int RPG, bool NT>
+static void launch_ordered_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
+                               bool dist) {
+#define KHIP_L(DOT, COMP, DIST) \
+  hipLaunchKernelGGL((spmv_ordered_kernel<L, RPG, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, ra)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
 }
 
 template <int LPR>
-static void launch_vector_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, int grid, bool dot, bool comp,
+static void launch_vector_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                               bool dist) {
-#define KHIP_SPMV_LAUNCH(DOT, COMP, DIST) \
+#define KHIP_L(DOT, COMP, DIST) \
   hipLaunchKernelGGL((spmv_vector_kernel<LPR, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, ra)
-  if (dot) {
-    if (comp) { if (dist) KHIP_SPMV_LAUNCH(true, true, true); else KHIP_SPMV_LAUNCH(true, true, false); }
-    else      { if (dist) KHIP_SPMV_LAUNCH(true, false, true); else KHIP_SPMV_LAUNCH(true, false, false); }
-  } else {
-    if (dist) KHIP_SPMV_LAUNCH(false, false, true); else KHIP_SPMV_LAUNCH(false, false, false);
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
+static inline unsigned pick_grid(khip_ctx *ctx, int64_t tiles, bool persist) {
+  if (tiles < 1) tiles = 1;
+  if (persist) {
+    int64_t cap = (int64_t)ctx->num_cu * 8;
+    int64_t g = tiles < cap ? tiles : cap;
+    if (g >= 8) g &= ~(int64_t)7;      // XCD remap needs a multiple of 8
+    return (unsigned)g;
   }
-#undef KHIP_SPMV_LAUNCH
+  const int64_t cap = 1 << 22;         // 4M workgroups: beyond that tiles are looped over
+  return (unsigned)(tiles < cap ? tiles : cap);
 }
 
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, int64_t row_lo,
@@ -189,10 +396,15 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.n_owned = A->dist ? A->m : A->n;
   a.row_lo = row_lo; a.row_hi = row_hi;
   a.xcd_remap = ctx->tune.spmv_xcd;
-  RedArgs ra = make_red_args(ctx, dot_slot >= 0 ? dot_slot : 0);
+  a.nt_y = ctx->tune.spmv_nty;
+  a.tiles_per_block = 1;
+  a.nnz_bound = A->nnz + kPad;
+  a.fake_gather = ctx->tune.spmv_fake_gather;
+  a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;
   const bool dot = dot_slot >= 0, comp = ctx->tune.compensated != 0, dist = A->dist;
+  const bool persist = ctx->tune.spmv_persist != 0;
+  const bool nt = ctx->tune.spmv_nt != 0;
   const int64_t nrows = row_hi - row_lo;
-  const int maxgrid = ctx->num_cu * 8 < kMaxRedBlocks ? ctx->num_cu * 8 : kMaxRedBlocks;
 
   hipEvent_t ev_stop = nullptr;
   if (ctx->tune.profile_spmv) {
@@ -209,7 +421,11 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   }
 
   int kernel = ctx->tune.spmv_kernel;
-  if (kernel == 0) kernel = (A->mean_row_nnz <= 48.0 && A->max_row_nnz <= 2048) ? 1 : 2;
+  // short rows (stencils, <= 8 entries on average): staged-rows kernel; mid-size rows: ordered
+  // sub-wave kernel; very long rows: strided vector kernel
+  if (kernel == 0) kernel = (A->mean_row_nnz <= 8.0 && A->max_row_nnz <= 64) ? 4 : (A->mean_row_nnz <= 96.0 ? 3 : 2);
+  unsigned grid = 1;
+  RedArgs ra;
   if (kernel == 1) {
     int rows = ctx->tune.spmv_rows;
     if (rows * A->mean_row_nnz > 2048.0) {           // keep one LDS pass per row block
@@ -217,11 +433,10 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       while (rows > 32 && rows * A->mean_row_nnz > 2048.0) rows >>= 1;
     }
     if (rows != 256 && rows != 128 && rows != 64 && rows != 32) rows = 256;
-    const int64_t nrb = (nrows + rows - 1) / rows;
-    int grid = (int)(nrb < maxgrid ? nrb : maxgrid);
-    if (grid >= 8) grid &= ~7;                          // XCD remap needs a multiple of 8
-    const int vec = ctx->tune.spmv_vec == 1 ? 1 : 2;
-    const bool nt = ctx->tune.spmv_nt != 0;
+    grid = pick_grid(ctx, (nrows + rows - 1) / rows, persist);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));
+    ra = make_red_args(ctx, dot ? dot_slot : 0);
+    const int vec = ctx->tune.spmv_vec == 2 ? 2 : 1;
 #define KHIP_ROWS(R)                                                                              \
   do {                                                                                            \
     if (vec == 2) { if (nt) launch_stream_cfg<R, 2, true>(ctx, a, ra, grid, dot, comp, dist);     \
@@ -236,6 +451,49 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       default: KHIP_ROWS(32); break;
     }
 #undef KHIP_ROWS
+  } else if (kernel == 4) {
+    int rows = ctx->tune.spmv_rows;
+    if (rows != 256 && rows != 128 && rows != 64 && rows != 32) rows = 256;
+    while (rows > 32 && rows * A->mean_row_nnz > 2048.0) rows >>= 1;
+    a.tiles_per_block = ctx->tune.spmv_tiles > 0 ? ctx->tune.spmv_tiles : 1;
+    const int64_t nrb4 = (nrows + rows - 1) / rows;
+    grid = pick_grid(ctx, (nrb4 + a.tiles_per_block - 1) / a.tiles_per_block, false);
+    if ((int64_t)grid * a.tiles_per_block < nrb4) a.tiles_per_block = (int)((nrb4 + grid - 1) / grid);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));
+    ra = make_red_args(ctx, dot ? dot_slot : 0);
+#define KHIP_STG(R) do { if (nt) launch_stage_cfg<R, true>(ctx, a, ra, grid, dot, comp, dist); \
+                         else launch_stage_cfg<R, false>(ctx, a, ra, grid, dot, comp, dist); } while (0)
+    switch (rows) {
+      case 256: KHIP_STG(256); break;
+      case 128: KHIP_STG(128); break;
+      case 64: KHIP_STG(64); break;
+      default: KHIP_STG(32); break;
+    }
+#undef KHIP_STG
+  } else if (kernel == 3) {
+    int L = ctx->tune.spmv_lanes;
+    if (L == 0) {                                    // smallest power of two covering a typical row
+      L = 4;
+      const double target = A->max_row_nnz <= 64 ? (double)A->max_row_nnz : A->mean_row_nnz;
+      while (L < 64 && L < target) L <<= 1;
+    }
+#define KHIP_ORD(LL, RPG)                                                                     \
+  do {                                                                                        \
+    constexpr int rpb = (64 / LL) * RPG * kWavesPerBlock;                                     \
+    grid = pick_grid(ctx, (nrows + rpb - 1) / rpb, persist);                                  \
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));                                \
+    ra = make_red_args(ctx, dot ? dot_slot : 0);                                              \
+    if (nt) launch_ordered_cfg<LL, RPG, true>(ctx, a, ra, grid, dot, comp, dist);             \
+    else launch_ordered_cfg<LL, RPG, false>(ctx, a, ra, grid, dot, comp, dist);               \
+  } while (0)
+    switch (L) {
+      case 4: KHIP_ORD(4, 4); break;
+      case 8: KHIP_ORD(8, 4); break;
+      case 16: KHIP_ORD(16, 4); break;
+      case 32: KHIP_ORD(32, 2); break;
+      default: KHIP_ORD(64, 1); break;
+    }
+#undef KHIP_ORD
   } else {
     int lpr = ctx->tune.spmv_lanes;
     if (lpr == 0) {
@@ -243,8 +501,9 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       while (lpr < 64 && lpr * 2 <= A->mean_row_nnz) lpr <<= 1;
     }
     const int rpb = kBlock / lpr;
-    const int64_t want = (nrows + rpb - 1) / rpb;
-    const int grid = (int)(want < maxgrid ? want : maxgrid);
+    grid = pick_grid(ctx, (nrows + rpb - 1) / rpb, persist);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));
+    ra = make_red_args(ctx, dot ? dot_slot : 0);
     switch (lpr) {
       case 4: launch_vector_cfg<4>(ctx, a, ra, grid, dot, comp, dist); break;
       case 8: launch_vector_cfg<8>(ctx, a, ra, grid, dot, comp, dist); break;
@@ -254,359 +513,9 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
   }
   KHIP_CHECK_HIP(hipGetLastError());
+  if (dot) KHIP_TRY(launch_finish(ctx, (int64_t)grid * kWavesPerBlock, 1, dot_slot));
   if (ev_stop) KHIP_CHECK_HIP(hipEventRecord(ev_stop, ctx->stream));
   return KHIP_OK;
 }
 
-// ---------------------------------------------------------------- SpMM ----------
-// Y(m x p, row-major) = A * X(n x p, row-major).  P lanes cooperate on one row: lane c owns
-// column c, val/col loads are wave-broadcast, the X gather is one contiguous 8p-byte line.
-template <int P>
-__global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
-  constexpr int RPB = kBlock / P;
-  const int sub = threadIdx.x / P, c = threadIdx.x % P;
-  for (int64_t row = a.row_lo + (int64_t)blockIdx.x * RPB + sub; row < a.row_hi; row += (int64_t)gridDim.x * RPB) {
-    const int64_t s = a.rowptr[row], e = a.rowptr[row + 1];
-    double acc = 0.0;
-    if (c < p) {
-      for (int64_t j = s; j < e; ++j) {
-        double prod = a.val[j] * a.x[(int64_t)a.col[j] * p + c];
-        acc = acc + prod;
-      }
-      a.y[row * p + c] = acc;
-    }
-  }
-}
-
-int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {
-  if (A->dist) { set_error("spmm: distributed operator not supported"); return KHIP_ERR_UNSUPPORTED; }
-  if (p < 1 || p > 64) { set_error("spmm: 1 <= p <= 64 required (got %d)", p); return KHIP_ERR_INVALID; }
-  SpmvArgs a;
-  a.rowptr = A->rowptr; a.col = A->col; a.val = A->val; a.x = X; a.ghost = nullptr; a.y = Y;
-  a.n_owned = A->n; a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0;
-  int P = 4;
-  while (P < p) P <<= 1;
-  const int rpb = kBlock / P;
-  int64_t want = (A->m + rpb - 1) / rpb;
-  int grid = (int)(want < ctx->num_cu * 16 ? want : ctx->num_cu * 16);
-  if (grid < 1) grid = 1;
-  switch (P) {
-    case 4: hipLaunchKernelGGL((spmm_kernel<4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
-    case 8: hipLaunchKernelGGL((spmm_kernel<8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
-    case 16: hipLaunchKernelGGL((spmm_kernel<16>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
-    case 32: hipLaunchKernelGGL((spmm_kernel<32>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
-    default: hipLaunchKernelGGL((spmm_kernel<64>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
-  }
-  KHIP_CHECK_HIP(hipGetLastError());
-  return KHIP_OK;
-}
-
-// ---------------------------------------------------------------- row statistics -
-__global__ __launch_bounds__(kBlock) void row_stats_kernel(const int32_t *rowptr, int64_t m, int *max_out) {
-  int mx = 0;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-    int len = rowptr[i + 1] - rowptr[i];
-    mx = len > mx ? len : mx;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    int o = __shfl_down(mx, off, 64);
-    mx = o > mx ? o : mx;
-  }
-  if ((threadIdx.x & 63) == 0) atomicMax(max_out, mx);
-}
-
-int csr_finalize(khip_ctx *ctx, khip_csr *A) {
-  A->mean_row_nnz = A->m > 0 ? (double)A->nnz / (double)A->m : 0.0;
-  A->max_row_nnz = 0;
-  if (A->m == 0) return KHIP_OK;
-  int *d = reinterpret_cast<int *>(ctx->tickets + 8);   // scratch word (tickets buffer has spare words)
-  KHIP_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
-  int64_t want = (A->m + kBlock - 1) / kBlock;
-  int grid = (int)(want < 2048 ? want : 2048);
-  hipLaunchKernelGGL(row_stats_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->rowptr, A->m, d);
-  KHIP_CHECK_HIP(hipGetLastError());
-  int h = 0;
-  KHIP_CHECK_HIP(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  A->max_row_nnz = h;
-  return KHIP_OK;
-}
-
-__global__ __launch_bounds__(kBlock) void index_shift_kernel(int32_t *data, int64_t n, int32_t delta) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) data[i] += delta;
-}
-int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta) {
-  if (n <= 0 || delta == 0) return KHIP_OK;
-  int64_t want = (n + kBlock - 1) / kBlock;
-  int grid = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(index_shift_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, data, n, delta);
-  KHIP_CHECK_HIP(hipGetLastError());
-  return KHIP_OK;
-}
-
-// ---------------------------------------------------------------- halo helpers ---
-__global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t *idx, const double *x, double *out) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    out[i] = x[idx[i]];
-}
-
-int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out) {
-  if (n <= 0) return KHIP_OK;
-  int64_t want = (n + kBlock - 1) / kBlock;
-  int grid = (int)(want < 1024 ? want : 1024);
-  hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, n, idx, x, out);
-  KHIP_CHECK_HIP(hipGetLastError());
-  return KHIP_OK;
-}
-
-__global__ __launch_bounds__(kBlock) void collect_offrank_kernel(const int32_t *col, int64_t nnz, int64_t row0,
-                                                                  int64_t row1, int32_t *out,
-                                                                  unsigned long long *count, int64_t cap) {
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * kBlock) {
-    const int64_t c = col[j];
-    if (c < row0 || c >= row1) {
-      unsigned long long k = atomicAdd(count, 1ull);
-      if ((int64_t)k < cap) out[k] = (int32_t)c;
-    }
-  }
-}
-
-int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64_t row1, int32_t *out_dev,
-                           unsigned long long *count_dev, int64_t cap) {
-  if (A->nnz == 0) return KHIP_OK;
-  int64_t want = (A->nnz + kBlock - 1) / kBlock;
-  int grid = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(collect_offrank_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->col, A->nnz, row0, row1,
-                     out_dev, count_dev, cap);
-  KHIP_CHECK_HIP(hipGetLastError());
-  return KHIP_OK;
-}
-
-__global__ __launch_bounds__(kBlock) void col_remap_kernel(int32_t *col, int64_t nnz, int64_t row0, int64_t m,
-                                                            const int32_t *ghost_sorted, int64_t n_ghost) {
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * kBlock) {
-    const int64_t c = col[j];
-    if (c >= row0 && c < row0 + m) {
-      col[j] = (int32_t)(c - row0);
-    } else {
-      int64_t lo = 0, hi = n_ghost;   // lower_bound
-      while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (ghost_sorted[mid] < c) lo = mid + 1; else hi = mid;
-      }
-      col[j] = (int32_t)(m + lo);
-    }
-  }
-}
-
-int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost) {
-  if (A->nnz == 0) return KHIP_OK;
-  int64_t want = (A->nnz + kBlock - 1) / kBlock;
-  int grid = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(col_remap_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->col, A->nnz, A->row0, A->m,
-                     ghost_sorted_dev, n_ghost);
-  KHIP_CHECK_HIP(hipGetLastError());
-  return KHIP_OK;
-}
-
-// rows whose (remapped) columns reach into the ghost region: largest such row in the lower half,
-// smallest in the upper half -> [lo, hi) is guaranteed interior.
-__global__ __launch_bounds__(kBlock) void ghost_range_kernel(const int32_t *rowptr, const int32_t *col, int64_t m,
-                                                              unsigned long long *lo_hi) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-    bool b = false;
-    for (int64_t j = rowptr[i]; j < rowptr[i + 1]; ++j) b |= (col[j] >= m);
-    if (b) {
-      if (i < m / 2) atomicMax(&lo_hi[0], (unsigned long long)(i + 1));
-      else atomicMin(&lo_hi[1], (unsigned long long)i);
-    }
-  }
-}
-
-int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host) {
-  unsigned long long *d = nullptr;
-  KHIP_CHECK_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
-  unsigned long long init[2] = {0ull, (unsigned long long)A->m};
-  KHIP_CHECK_HIP(hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-  if (A->m > 0) {
-    int64_t want = (A->m + kBlock - 1) / kBlock;
-    int grid = (int)(want < 4096 ? want : 4096);
-    hipLaunchKernelGGL(ghost_range_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, A->m, d);
-    KHIP_CHECK_HIP(hipGetLastError());
-  }
-  unsigned long long out[2];
-  KHIP_CHECK_HIP(hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
-  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  KHIP_CHECK_HIP(hipFree(d));
-  lo_hi_host[0] = (int64_t)out[0];
-  lo_hi_host[1] = (int64_t)out[1];
-  if (lo_hi_host[1] < lo_hi_host[0]) lo_hi_host[1] = lo_hi_host[0];
-  return KHIP_OK;
-}
-
-// ---------------------------------------------------------------- generators -----
-// Device restatement of the benchmark operators (test/get_div_grad.jl:8-25, test/test_utils.jl:160-169
-// and the cfg-5 27-point operator documented in DESIGN.md); parity-tested bit-exact against the oracle.
-__device__ __forceinline__ double stencil_coef(int kind, int d1, int d2, int d3) {
-  const int ab = abs(d1) + abs(d2) + abs(d3);
-  if (kind == 0) return ab == 0 ? 6.0 : (ab == 1 ? -1.0 : 0.0);
-  if (kind == 1) {
-    if (ab == 0) return 12.0;
-    if (ab != 1) return 0.0;
-    if (d1 == -1) return -1.0;
-    if (d1 == 1) return -2.0;
-    if (d2 == -1) return -2.0;
-    if (d2 == 1) return -4.0;
-    if (d3 == -1) return -1.0;
-    return -2.0;
-  }
-  if (ab == 0) return 16.0;
-  const double w = (ab == 1) ? 1.0 : (ab == 2 ? 0.5 : 0.25);
-  const int lead = d3 != 0 ? d3 : (d2 != 0 ? d2 : d1);
-  return -w * (lead > 0 ? 1.25 : 0.75);
-}
-
-template <bool FILL>
-__global__ __launch_bounds__(kBlock) void stencil_kernel(int kind, int n1, int n2, int n3, int64_t row0, int64_t m,
-                                                          int32_t *rowptr, int32_t *col, double *val) {
-  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (int64_t)gridDim.x * kBlock) {
-    const int64_t row = row0 + r;
-    const int i1 = (int)(row % n1), i2 = (int)((row / n1) % n2), i3 = (int)(row / ((int64_t)n1 * n2));
-    int64_t k = FILL ? rowptr[r] : 0;
-    int cnt = 0;
-    for (int d3 = -1; d3 <= 1; ++d3) {
-      const int j3 = i3 + d3;
-      if (j3 < 0 || j3 >= n3) continue;
-      for (int d2 = -1; d2 <= 1; ++d2) {
-        const int j2 = i2 + d2;
-        if (j2 < 0 || j2 >= n2) continue;
-        for (int d1 = -1; d1 <= 1; ++d1) {
-          const int j1 = i1 + d1;
-          if (j1 < 0 || j1 >= n1) continue;
-          const double v = stencil_coef(kind, d1, d2, d3);
-          if (v == 0.0) continue;
-          if (FILL) {
-            col[k] = (int32_t)((int64_t)j1 + (int64_t)n1 * j2 + (int64_t)n1 * n2 * j3);
-            val[k] = v;
-            ++k;
-          }
-          ++cnt;
-        }
-      }
-    }
-    if (!FILL) rowptr[r] = cnt;   // counts; scanned afterwards
-  }
-}
-
-// exclusive scan of int32 counts (3 phases: per-tile sums, scan of tile sums, add back)
-constexpr int kScanTile = 2048;   // elements per workgroup (8 per lane)
-__global__ __launch_bounds__(kBlock) void scan_tile_sums(const int32_t *in, int64_t n, long long *tile_sums) {
-  __shared__ long long s_w[kWavesPerBlock];
-  const int64_t base = (int64_t)blockIdx.x * kScanTile;
-  long long s = 0;
-  for (int k = 0; k < kScanTile / kBlock; ++k) {
-    int64_t i = base + (int64_t)threadIdx.x * (kScanTile / kBlock) + k;
-    if (i < n) s += in[i];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long t = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) t += s_w[w];
-    tile_sums[blockIdx.x] = t;
-  }
-}
-__global__ void scan_tiles_serial(long long *tile_sums, int64_t ntiles, long long *total) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    long long run = 0;
-    for (int64_t t = 0; t < ntiles; ++t) {
-      long long v = tile_sums[t];
-      tile_sums[t] = run;
-      run += v;
-    }
-    *total = run;
-  }
-}
-__global__ __launch_bounds__(kBlock) void scan_apply(int32_t *data, int64_t n, const long long *tile_offs) {
-  __shared__ long long s_t[kBlock];
-  constexpr int PER = kScanTile / kBlock;
-  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * PER;
-  int v[PER];
-  long long s = 0;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    v[k] = (base + k < n) ? data[base + k] : 0;
-    s += v[k];
-  }
-  s_t[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {   // serial scan of 256 lane totals: one-time setup kernel
-    long long run = tile_offs[blockIdx.x];
-    for (int t = 0; t < kBlock; ++t) {
-      long long x = s_t[t];
-      s_t[t] = run;
-      run += x;
-    }
-  }
-  __syncthreads();
-  long long run = s_t[threadIdx.x];
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    if (base + k < n) data[base + k] = (int32_t)run;
-    run += v[k];
-  }
-}
-
 }  // namespace khip
-
-using namespace khip;
-
-extern "C" int khip_gen_stencil(khip_ctx *ctx, int kind, int n1, int n2, int n3, int64_t row0, int64_t m,
-                                int32_t **rowptr_dev, int32_t **col_dev, double **val_dev, int64_t *nnz_out) {
-  KHIP_REQUIRE(ctx && rowptr_dev && col_dev && val_dev && nnz_out, "gen_stencil: null argument");
-  KHIP_REQUIRE(kind >= 0 && kind <= 2 && n1 > 0 && n2 > 0 && n3 > 0, "gen_stencil: bad kind/dims");
-  const int64_t n = (int64_t)n1 * n2 * n3;
-  KHIP_REQUIRE(n < (1ll << 31), "gen_stencil: column index would overflow int32");
-  KHIP_REQUIRE(row0 >= 0 && m >= 0 && row0 + m <= n, "gen_stencil: bad row range");
-  KHIP_CHECK_HIP(hipSetDevice(ctx->device));
-  int32_t *rp = nullptr, *cl = nullptr;
-  double *vl = nullptr;
-  KHIP_CHECK_HIP(hipMalloc(&rp, sizeof(int32_t) * (size_t)(m + 1)));
-  const int64_t want = (m + kBlock - 1) / kBlock;
-  const int grid = (int)(want < 8192 ? (want > 0 ? want : 1) : 8192);
-  hipLaunchKernelGGL((stencil_kernel<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, kind, n1, n2, n3, row0, m, rp,
-                     (int32_t *)nullptr, (double *)nullptr);
-  KHIP_CHECK_HIP(hipGetLastError());
-  KHIP_CHECK_HIP(hipMemsetAsync(rp + m, 0, sizeof(int32_t), ctx->stream));
-  // exclusive scan over m+1 entries (last input is 0 -> rowptr[m] = total)
-  const int64_t cnt = m + 1;
-  const int64_t ntiles = (cnt + kScanTile - 1) / kScanTile;
-  long long *tiles = nullptr;
-  KHIP_CHECK_HIP(hipMalloc(&tiles, sizeof(long long) * (size_t)(ntiles + 1)));
-  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)ntiles), dim3(kBlock), 0, ctx->stream, rp, cnt, tiles);
-  hipLaunchKernelGGL(scan_tiles_serial, dim3(1), dim3(64), 0, ctx->stream, tiles, ntiles, tiles + ntiles);
-  hipLaunchKernelGGL(scan_apply, dim3((unsigned)ntiles), dim3(kBlock), 0, ctx->stream, rp, cnt, tiles);
-  KHIP_CHECK_HIP(hipGetLastError());
-  long long total = 0;
-  KHIP_CHECK_HIP(hipMemcpyAsync(&total, tiles + ntiles, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  KHIP_CHECK_HIP(hipFree(tiles));
-  if (total >= (1ll << 31) - 64) {
-    (void)hipFree(rp);
-    set_error("gen_stencil: shard nnz %lld does not fit int32 row pointers", total);
-    return KHIP_ERR_INVALID;
-  }
-  KHIP_CHECK_HIP(hipMalloc(&cl, sizeof(int32_t) * (size_t)(total + kPad)));
-  KHIP_CHECK_HIP(hipMalloc(&vl, sizeof(double) * (size_t)(total + kPad)));
-  KHIP_CHECK_HIP(hipMemsetAsync(cl + total, 0, sizeof(int32_t) * kPad, ctx->stream));
-  KHIP_CHECK_HIP(hipMemsetAsync(vl + total, 0, sizeof(double) * kPad, ctx->stream));
-  hipLaunchKernelGGL((stencil_kernel<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, kind, n1, n2, n3, row0, m, rp,
-                     cl, vl);
-  KHIP_CHECK_HIP(hipGetLastError());
-  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  *rowptr_dev = rp; *col_dev = cl; *val_dev = vl; *nnz_out = total;
-  return KHIP_OK;
-}

@@ -1,0 +1,46 @@
+// spmv_common.hpp -- argument block and load helpers shared by the CSR kernels.
+#pragma once
+
+#include "device_reduce.hpp"
+
+namespace khip {
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef int int2v __attribute__((ext_vector_type(2)));
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+constexpr int kPad = 8;   // val/col are over-allocated by this many zeroed entries
+
+struct SpmvArgs {
+  const int32_t *rowptr;
+  const int32_t *blockptr;   // rowptr[256 * i] (i = 0..ceil(m/256)), or null
+  const int32_t *col;
+  const double *val;
+  const double *x;
+  const double *ghost;   // remote x entries (distributed), indexed col - n_owned
+  double *y;
+  int64_t n_owned;       // columns < n_owned read x, others read ghost
+  int64_t row_lo, row_hi;
+  int xcd_remap;         // see chunk_id() in spmv.hip
+  int nt_y;              // non-temporal store of y
+  int tiles_per_block;   // staged kernel: consecutive row blocks per workgroup (software pipeline depth)
+  int64_t nnz_bound;     // nnz + pad: prefetches beyond it are clamped
+  int fake_gather;       // experiment: coalesced x reads instead of x[col] (WRONG results)
+};
+
+template <bool NT, typename T>
+__device__ __forceinline__ T ld(const T *p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+template <bool DIST>
+__device__ __forceinline__ double gather_x(const SpmvArgs &a, int32_t c) {
+  if (DIST) {
+    const double *src = (c < a.n_owned) ? a.x : (a.ghost - a.n_owned);
+    return src[c];
+  }
+  return a.x[c];
+}
+
+}  // namespace khip

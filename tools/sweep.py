@@ -63,32 +63,42 @@ for name, (bpe, fn) in ops.items():
         t = timeit(fn, args.reps)
         emit(kernel=name, n=n, compensated=comp, ms=t * 1e3, gbps=bpe * n / t / GB)
 ctx.set_option("compensated", 1)
-for blocks in (512, 1024, 2048):
-    ctx.set_option("blas1_blocks", blocks)
+for nt_min in (1 << 30, 1 << 22):
+    ctx.set_option("nt_min_elems", nt_min)
     t = timeit(lambda: K.kaxpy_(n, 1e-9, x, y), args.reps)
-    emit(kernel="axpy(24n)", blas1_blocks=blocks, ms=t * 1e3, gbps=24 * n / t / GB)
+    emit(kernel="axpy(24n)", nt=(nt_min <= n), ms=t * 1e3, gbps=24 * n / t / GB)
     t = timeit(lambda: K.kdot(n, x, y), args.reps)
-    emit(kernel="dot(16n)", blas1_blocks=blocks, ms=t * 1e3, gbps=16 * n / t / GB)
-ctx.set_option("blas1_blocks", 2048)
+    emit(kernel="dot(16n)", nt=(nt_min <= n), ms=t * 1e3, gbps=16 * n / t / GB)
 
 # ---- SpMV variants ----
 sb = A.spmv_bytes
-grid = [(256, 2, 1, 1), (256, 2, 0, 1), (256, 2, 1, 0), (256, 2, 0, 0), (256, 1, 1, 1), (128, 2, 1, 1), (64, 2, 1, 1)]
-if not args.quick:
-    grid += [(128, 1, 1, 1), (128, 2, 0, 0), (64, 1, 1, 1)]
-for rows, vec, nt, xcd in grid:
-    ctx.set_option("spmv_kernel", 1); ctx.set_option("spmv_rows", rows); ctx.set_option("spmv_vec", vec)
-    ctx.set_option("spmv_nt", nt); ctx.set_option("spmv_xcd", xcd)
+
+
+def spmv_case(label, **opts):
+    for k, v in opts.items():
+        ctx.set_option(k, v)
     t = timeit(lambda: A.matvec(x, y), args.reps)
-    emit(kernel="spmv_stream", rows=rows, vec=vec, nt=nt, xcd=xcd, ms=t * 1e3, gbps=sb / t / GB, frac_of_8TBs=sb / t / 8e12)
+    emit(kernel="spmv", label=label, **opts, ms=t * 1e3, gbps=sb / t / GB, frac_of_8TBs=sb / t / 8e12)
     t = timeit(lambda: K.spmv_dot(A, x, y), args.reps)
-    emit(kernel="spmv_stream+dot", rows=rows, vec=vec, nt=nt, xcd=xcd, ms=t * 1e3, gbps=sb / t / GB)
-ctx.set_option("spmv_rows", 256); ctx.set_option("spmv_vec", 2); ctx.set_option("spmv_nt", 1); ctx.set_option("spmv_xcd", 1)
+    emit(kernel="spmv+dot", label=label, **opts, ms=t * 1e3, gbps=sb / t / GB)
+
+
+for lanes in (8, 4):
+    for nt in (1, 0):
+        spmv_case("ordered flat", spmv_kernel=3, spmv_lanes=lanes, spmv_nt=nt, spmv_persist=0)
+spmv_case("ordered persistent", spmv_kernel=3, spmv_lanes=8, spmv_nt=1, spmv_persist=1)
+for vec in (1, 2):
+    for nt in (1, 0):
+        spmv_case("stream flat", spmv_kernel=1, spmv_rows=256, spmv_vec=vec, spmv_nt=nt, spmv_persist=0)
+spmv_case("stream flat xcd", spmv_kernel=1, spmv_rows=256, spmv_vec=1, spmv_nt=0, spmv_persist=0, spmv_xcd=1)
+ctx.set_option("spmv_xcd", 0)
+spmv_case("stream persistent", spmv_kernel=1, spmv_rows=256, spmv_vec=1, spmv_nt=1, spmv_persist=1)
+spmv_case("stream persistent xcd", spmv_kernel=1, spmv_rows=256, spmv_vec=1, spmv_nt=1, spmv_persist=1, spmv_xcd=1)
+ctx.set_option("spmv_xcd", 0)
 for lanes in (4, 8):
-    ctx.set_option("spmv_kernel", 2); ctx.set_option("spmv_lanes", lanes)
-    t = timeit(lambda: A.matvec(x, y), args.reps)
-    emit(kernel="spmv_vector", lanes=lanes, ms=t * 1e3, gbps=sb / t / GB)
-ctx.set_option("spmv_kernel", 0); ctx.set_option("spmv_lanes", 0)
+    spmv_case("vector flat", spmv_kernel=2, spmv_lanes=lanes, spmv_persist=0)
+for k, v in dict(spmv_kernel=0, spmv_lanes=0, spmv_rows=256, spmv_vec=1, spmv_nt=0, spmv_persist=0).items():
+    ctx.set_option(k, v)
 
 # ---- CG iteration, fused vs unfused ----
 b = ctx.empty(n)
