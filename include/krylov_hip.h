@@ -149,6 +149,8 @@ int khip_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *y_host,
 /* Panels are n-by-p ROW-MAJOR in HBM (p contiguous; DESIGN.md "panel layout").
  * ref: mul!(R, V', Q) / mul!(Q, V, R, -1, 1) src/block_gmres.jl:244-247, householder!
  * src/block_krylov_utils.jl:201-208, X += V*Y src/block_gmres.jl:324-326. */
+/* a panel holds n_pad = n rounded up to 16 rows; the padding rows must be (and stay) zero */
+int khip_panel_rows(int64_t n, int64_t *n_pad);
 int khip_panel_from_colmajor(khip_ctx *ctx, int64_t n, int p, const double *X_colmajor, double *P);
 int khip_panel_to_colmajor(khip_ctx *ctx, int64_t n, int p, const double *P, double *X_colmajor);
 /* Psi_host (p-by-p, column-major, HOST) <- V^T Q */
@@ -259,6 +261,7 @@ size_t            khip_bicgstab_workspace_bytes(khip_bicgstab_workspace *ws);
 int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p, int memory,
                                       khip_block_gmres_workspace **out);
 int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws);
+int khip_block_gmres_warm_start(khip_block_gmres_workspace *ws, const double *X0_colmajor);
 /* block_gmres!(ws, A, B; restart, reorthogonalization, ...) src/block_gmres.jl:110-358.
  * B and the solution are n-by-p COLUMN-MAJOR device arrays (the reference layout); the
  * workspace converts to row-major panels internally. */

@@ -102,6 +102,7 @@ SIGNATURES = {
     "khip_dot2": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
     "khip_mgs": (_int, [_vp, _i64, _int, c_void_pp, _vp, c_double_p, c_double_p, _int]),
     "khip_multi_axpy": (_int, [_vp, _i64, _int, c_double_p, c_void_pp, _vp]),
+    "khip_panel_rows": (_int, [_i64, C.POINTER(_i64)]),
     "khip_panel_from_colmajor": (_int, [_vp, _i64, _int, _vp, _vp]),
     "khip_panel_to_colmajor": (_int, [_vp, _i64, _int, _vp, _vp]),
     "khip_panel_gemm_tn": (_int, [_vp, _i64, _int, _vp, _vp, c_double_p]),
@@ -139,6 +140,7 @@ SIGNATURES = {
     "khip_bicgstab_workspace_bytes": (_sz, [_vp]),
     "khip_block_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, _int, c_void_pp]),
     "khip_block_gmres_workspace_destroy": (_int, [_vp]),
+    "khip_block_gmres_warm_start": (_int, [_vp, _vp]),
     "khip_block_gmres_solve": (_int, [_vp, C.POINTER(COperator), _vp, C.POINTER(COptions)]),
     "khip_block_gmres_get_X": (_int, [_vp, _vp]),
     "khip_block_gmres_stats": (C.POINTER(CStats), [_vp]),
@@ -793,3 +795,115 @@ def halo_plan_host(rank, nranks, row_starts, ghost_lists):
     _ck(lib().khip_halo_plan_host(rank, nranks, row_starts.ctypes.data, allg.ctypes.data, off.ctypes.data,
                                   recv_off.ctypes.data, send_off.ctypes.data, send_idx.ctypes.data, cap))
     return recv_off, send_off, send_idx[: send_off[-1]].copy()
+
+
+# --------------------------------------------------------------------------- block-GMRES (panels)
+
+def panel_rows(n: int) -> int:
+    out = C.c_int64()
+    _ck(lib().khip_panel_rows(n, C.byref(out)))
+    return out.value
+
+
+class Panel:
+    """n x p block in HBM, ROW-MAJOR with the row count padded to 16 (csrc/panel.hip).  The reference's
+    `SM(undef, n, p)` storage (src/block_krylov_workspaces.jl:137-163) in the layout the MFMA kernels want."""
+
+    def __init__(self, ctx: Context, n: int, p: int):
+        self.ctx, self.n, self.p = ctx, n, p
+        self.n_pad = panel_rows(n)
+        self.buf = ctx.zeros(self.n_pad * p)
+
+    @classmethod
+    def from_host(cls, ctx, M):
+        M = np.asarray(M, dtype=np.float64)
+        P = cls(ctx, M.shape[0], M.shape[1])
+        col = ctx.array(np.asfortranarray(M).ravel(order="F"))
+        _ck(lib().khip_panel_from_colmajor(ctx._h, P.n, P.p, col.ptr, P.buf.ptr))
+        ctx.sync()
+        return P
+
+    def to_host(self) -> np.ndarray:
+        col = self.ctx.empty(self.n * self.p)
+        _ck(lib().khip_panel_to_colmajor(self.ctx._h, self.n, self.p, self.buf.ptr, col.ptr))
+        return col.to_host().reshape(self.p, self.n).T.copy()
+
+
+def panel_gemm_tn(V: Panel, Q: Panel) -> np.ndarray:
+    """Psi = V' * Q  (mul!(R, V', Q), src/block_gmres.jl:245)."""
+    out = np.zeros((V.p, V.p), order="F")
+    _ck(lib().khip_panel_gemm_tn(V.ctx._h, V.n, V.p, V.buf.ptr, Q.buf.ptr, out.ctypes.data_as(c_double_p)))
+    return out
+
+
+def panel_gemm_nn_(alpha, V: Panel, Psi, beta, Q: Panel) -> Panel:
+    """Q = beta Q + alpha V Psi  (mul!(Q, V, Psi, alpha, beta), src/block_gmres.jl:246)."""
+    Pf = np.asfortranarray(Psi, dtype=np.float64)
+    _ck(lib().khip_panel_gemm_nn(V.ctx._h, V.n, V.p, alpha, V.buf.ptr, Pf.ctypes.data_as(c_double_p), beta, Q.buf.ptr))
+    return Q
+
+
+def panel_qr_(Q: Panel) -> np.ndarray:
+    """Reduced QR in place (householder!(Q, R, tau), src/block_krylov_utils.jl:201-208); returns R."""
+    R = np.zeros((Q.p, Q.p), order="F")
+    _ck(lib().khip_panel_qr(Q.ctx._h, Q.n, Q.p, Q.buf.ptr, R.ctypes.data_as(c_double_p)))
+    return R
+
+
+def panel_norm(Q: Panel) -> float:
+    r = C.c_double()
+    _ck(lib().khip_panel_norm(Q.ctx._h, Q.n, Q.p, Q.buf.ptr, C.byref(r)))
+    return r.value
+
+
+def spmm_(A: CsrMatrix, X: Panel, Y: Panel) -> Panel:
+    _ck(lib().khip_spmm(A.ctx._h, A._h, X.buf.ptr, Y.buf.ptr, X.p))
+    return Y
+
+
+class BlockGmresWorkspace(_Workspace):
+    """BlockGmresWorkspace(m, n, p, SV, SM; memory = 5) (src/block_krylov_workspaces.jl:115-171)."""
+    _prefix = "block_gmres"
+
+    def __init__(self, ctx: Context, m: int, n: int, p: int, memory: int = 5):
+        self.ctx, self.m, self.n, self.p, self.memory = ctx, m, n, p, memory
+        self._h = C.c_void_p()
+        _ck(lib().khip_block_gmres_workspace_create(ctx._h, m, n, p, memory, C.byref(self._h)))
+
+    @property
+    def X(self) -> np.ndarray:
+        col = self.ctx.empty(self.n * self.p)
+        _ck(lib().khip_block_gmres_get_X(self._h, col.ptr))
+        return col.to_host().reshape(self.p, self.n).T.copy()
+
+    x = X
+
+    def warm_start_(self, X0):
+        col = self.ctx.array(np.asfortranarray(np.asarray(X0, dtype=np.float64)).ravel(order="F"))
+        _ck(lib().khip_block_gmres_warm_start(self._h, col.ptr))
+        return self
+
+    @property
+    def nbytes(self):
+        raise NotImplementedError
+
+
+def block_gmres_(ws: BlockGmresWorkspace, A: CsrMatrix, B_colmajor: DeviceVector, **kw):
+    """block_gmres!(workspace, A, B; restart, reorthogonalization, atol, rtol, itmax, history, ...)
+    (src/block_gmres.jl:110-358); B is an n x p column-major device array."""
+    keep = []
+    opts = _make_options(keep=keep, ws=ws, **kw)
+    rc = lib().khip_block_gmres_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep), _p(B_colmajor), C.byref(opts))
+    return _finish(ws, rc)
+
+
+def block_gmres(A: CsrMatrix, B, X0=None, memory=5, **kw):
+    """Out-of-place block_gmres(A, B) for a host n x p array B -> (X, stats, workspace)."""
+    B = np.asarray(B, dtype=np.float64)
+    n, p = B.shape
+    ws = BlockGmresWorkspace(A.ctx, n, n, p, memory=memory)
+    if X0 is not None:
+        ws.warm_start_(X0)
+    Bd = A.ctx.array(np.asfortranarray(B).ravel(order="F"))
+    block_gmres_(ws, A, Bd, **kw)
+    return ws.X, ws.stats, ws

@@ -1,24 +1,475 @@
-// block.cpp -- block-GMRES entry points (panel kernels live in panel.hip).
+// block.cpp -- block_gmres! (src/block_gmres.jl:110-358) above the panel kernels of panel.hip.
+//
+// Device side: the n x p blocks X, W, V[1..mem] live in HBM as row-major panels (panel.hip); SpMM,
+// V^T Q, Q -= V Psi, X += V Y and the panel QR run there.  Host side: the p x p / 2p x p algebra of
+// the block Hessenberg QR (LAPACK-style Householder on 2p x p blocks, block back-substitution) --
+// a few kflop per iteration, exactly as the reference keeps it in small dense matrices.
+//
+// Panel QR: the reference calls householder!(Q, C, tau) = geqrf + orgqr on the n x p block
+// (src/block_krylov_utils.jl:201-208): p BLAS-2 passes over the panel.  Here: CholeskyQR2 --
+// G = Q^T Q (one MFMA pass), R = chol(G), Q <- Q R^-1 (one pass), repeated once -- 4 passes, all
+// at HBM speed.  Q spans the same space and R = R2 R1 has a positive diagonal (LAPACK's has
+// Householder signs): block-GMRES residual norms ||C||_F and the iterates X are invariant under
+// that column-sign change, so parity with the reference holds on residual norms / solutions, not on
+// the individual Psi blocks (SURVEY.md section 7 "hard parts").  If the Cholesky factorisation
+// breaks down (numerically rank-deficient block, which the reference does not support either:
+// docs/src/interfaces/reference.md:236) the panel is factored with host Householder instead.
+#include <chrono>
+#include <cmath>
+#include <limits>
+
 #include "khip_internal.hpp"
 
 using namespace khip;
 
+extern "C" int khip_panel_rows(int64_t n, int64_t *n_pad);
+
+namespace {
+
+constexpr double kEps = std::numeric_limits<double>::epsilon();
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- small dense helpers, column-major (LAPACK DGEQR2 / DORG2R / DORM2R semantics) ----------
+double nrm2_h(int n, const double *x) {
+  long double s = 0;
+  for (int i = 0; i < n; ++i) s += (long double)x[i] * x[i];
+  return (double)std::sqrt((double)s);
+}
+void larfg(int n, double &alpha, double *x, double &tau) {
+  if (n <= 1) { tau = 0; return; }
+  const double xnorm = nrm2_h(n - 1, x);
+  if (xnorm == 0) { tau = 0; return; }
+  const double beta = -std::copysign(std::hypot(alpha, xnorm), alpha);
+  tau = (beta - alpha) / beta;
+  const double sc = 1.0 / (alpha - beta);
+  for (int i = 0; i < n - 1; ++i) x[i] *= sc;
+  alpha = beta;
+}
+void larf_left(int m, int n, const double *v, double tau, double *C, int ldc) {   // v[0] = 1 implicit
+  if (tau == 0) return;
+  for (int j = 0; j < n; ++j) {
+    double *c = C + (size_t)j * ldc;
+    double w = c[0];
+    for (int i = 1; i < m; ++i) w += v[i] * c[i];
+    const double tw = tau * w;
+    c[0] -= tw;
+    for (int i = 1; i < m; ++i) c[i] -= v[i] * tw;
+  }
+}
+void geqr2(int m, int n, double *A, int lda, double *tau) {
+  const int k = m < n ? m : n;
+  for (int i = 0; i < k; ++i) {
+    double *aii = A + (size_t)i * lda + i;
+    larfg(m - i, aii[0], aii + (m - i > 1 ? 1 : 0), tau[i]);
+    if (i < n - 1) larf_left(m - i, n - i - 1, aii, tau[i], A + (size_t)(i + 1) * lda + i, lda);
+  }
+}
+void org2r(int m, int n, int k, double *A, int lda, const double *tau) {
+  for (int j = k; j < n; ++j) {
+    for (int l = 0; l < m; ++l) A[(size_t)j * lda + l] = 0;
+    A[(size_t)j * lda + j] = 1;
+  }
+  for (int i = k - 1; i >= 0; --i) {
+    double *aii = A + (size_t)i * lda + i;
+    if (i < n - 1) larf_left(m - i, n - i - 1, aii, tau[i], A + (size_t)(i + 1) * lda + i, lda);
+    for (int l = 1; l < m - i; ++l) aii[l] *= -tau[i];
+    aii[0] = 1.0 - tau[i];
+    for (int l = 0; l < i; ++l) A[(size_t)i * lda + l] = 0;
+  }
+}
+void orm2r_LT(int m, int n, int k, const double *A, int lda, const double *tau, double *C, int ldc) {
+  for (int i = 0; i < k; ++i) larf_left(m - i, n, A + (size_t)i * lda + i, tau[i], C + i, ldc);
+}
+// upper Cholesky G = R^T R (column-major p x p); false on breakdown
+bool chol_upper(int p, const double *G, double *R) {
+  for (int j = 0; j < p; ++j) {
+    for (int i = 0; i <= j; ++i) {
+      double s = G[(size_t)j * p + i];
+      for (int l = 0; l < i; ++l) s -= R[(size_t)i * p + l] * R[(size_t)j * p + l];
+      if (i == j) {
+        if (!(s > 0) || !std::isfinite(s)) return false;
+        R[(size_t)j * p + j] = std::sqrt(s);
+      } else {
+        R[(size_t)j * p + i] = s / R[(size_t)i * p + i];
+      }
+    }
+    for (int i = j + 1; i < p; ++i) R[(size_t)j * p + i] = 0;
+  }
+  return true;
+}
+void inv_upper(int p, const double *R, double *Ri) {   // Ri = R^-1, both upper, column-major
+  for (int j = 0; j < p; ++j) {
+    for (int i = 0; i < p; ++i) Ri[(size_t)j * p + i] = 0;
+    Ri[(size_t)j * p + j] = 1.0 / R[(size_t)j * p + j];
+    for (int i = j - 1; i >= 0; --i) {
+      double s = 0;
+      for (int l = i + 1; l <= j; ++l) s += R[(size_t)l * p + i] * Ri[(size_t)j * p + l];
+      Ri[(size_t)j * p + i] = -s / R[(size_t)i * p + i];
+    }
+  }
+}
+void matmul_pp(int p, const double *A, const double *B, double *C) {   // C = A B
+  for (int j = 0; j < p; ++j)
+    for (int i = 0; i < p; ++i) {
+      double s = 0;
+      for (int l = 0; l < p; ++l) s += A[(size_t)l * p + i] * B[(size_t)j * p + l];
+      C[(size_t)j * p + i] = s;
+    }
+}
+
+struct StatsBoxB {
+  khip_stats st;
+  std::vector<double> residuals;
+  StatsBoxB() { memset(&st, 0, sizeof(st)); snprintf(st.status, sizeof(st.status), "unknown"); }
+  void reset() { residuals.clear(); st.residuals = nullptr; st.nres = 0; st.indefinite = 0; st.npcCount = 0; st.error[0] = 0; }
+  void publish() { st.residuals = residuals.empty() ? nullptr : residuals.data(); st.nres = (int)residuals.size(); }
+  int fail(int code, const char *msg) { snprintf(st.error, sizeof(st.error), "%s", msg); set_error("%s", msg); publish(); return code; }
+  int fail_rc(int rc) { snprintf(st.error, sizeof(st.error), "%s", khip_last_error()); publish(); return rc; }
+};
+
+}  // namespace
+
+extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host) {
+  KHIP_REQUIRE(ctx && Q && R_host && p >= 1 && p <= 32, "panel_qr: bad argument (1 <= p <= 32)");
+  const size_t pp = (size_t)p * p;
+  std::vector<double> G(pp), R1(pp), R2(pp), Ri(pp);
+  bool ok = true, pass0_applied = false;
+  for (int pass = 0; pass < 2 && ok; ++pass) {
+    KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, Q, Q, G.data()));
+    std::vector<double> &R = pass == 0 ? R1 : R2;
+    // guard against a numerically rank-deficient block: the diagonal of chol must stay well above eps * ||G||
+    ok = chol_upper(p, G.data(), R.data());
+    if (ok) {
+      double dmax = 0, dmin = std::numeric_limits<double>::infinity();
+      for (int i = 0; i < p; ++i) { dmax = std::fmax(dmax, R[(size_t)i * p + i]); dmin = std::fmin(dmin, R[(size_t)i * p + i]); }
+      if (pass == 0 && !(dmin > 1e-7 * dmax)) ok = false;      // cond(Q)^2 would exceed 1/eps: CholQR is not safe
+    }
+    if (ok) {
+      inv_upper(p, R.data(), Ri.data());
+      KHIP_TRY(khip_panel_gemm_nn(ctx, n, p, 1.0, Q, Ri.data(), 0.0, Q));   // in place: Q <- Q R^-1
+      if (pass == 0) pass0_applied = true;
+    }
+  }
+  if (ok) {
+    matmul_pp(p, R2.data(), R1.data(), R_host);
+    for (int j = 0; j < p; ++j)
+      for (int i = j + 1; i < p; ++i) R_host[(size_t)j * p + i] = 0;
+    return KHIP_OK;
+  }
+  // Householder fallback on the host (rare path): same convention as the reference's householder!
+  int64_t np = 0;
+  khip_panel_rows(n, &np);
+  std::vector<double> rowm((size_t)np * p), colm((size_t)n * p), tau(p), Rh(pp, 0.0);
+  KHIP_TRY(khip_memcpy_d2h(ctx, rowm.data(), Q, sizeof(double) * rowm.size()));
+  for (int64_t r = 0; r < n; ++r)
+    for (int c = 0; c < p; ++c) colm[(size_t)c * n + r] = rowm[(size_t)r * p + c];
+  geqr2((int)n, p, colm.data(), (int)n, tau.data());
+  for (int j = 0; j < p; ++j)
+    for (int i = 0; i <= j && i < n; ++i) Rh[(size_t)j * p + i] = colm[(size_t)j * n + i];
+  org2r((int)n, p, p, colm.data(), (int)n, tau.data());
+  for (int64_t r = 0; r < n; ++r)
+    for (int c = 0; c < p; ++c) rowm[(size_t)r * p + c] = colm[(size_t)c * n + r];
+  KHIP_TRY(khip_memcpy_h2d(ctx, Q, rowm.data(), sizeof(double) * rowm.size()));
+  // if pass 0 had been applied before the breakdown the panel was already multiplied by R1^-1
+  if (pass0_applied) matmul_pp(p, Rh.data(), R1.data(), R_host);
+  else memcpy(R_host, Rh.data(), sizeof(double) * pp);
+  return KHIP_OK;
+}
+
+// ================================================================== block-GMRES =====
+struct khip_block_gmres_workspace {
+  khip_ctx *ctx;
+  int64_t m, n, np;
+  int p, mem;
+  double *dX = nullptr, *X = nullptr, *W = nullptr;            // panels (row-major, np x p)
+  double *Bp = nullptr;                                        // panel copy of B
+  std::vector<double *> V;
+  std::vector<std::vector<double>> Z, R, H, tau;               // host p x p, p x p, 2p x p, p
+  bool warm_start = false;
+  StatsBoxB box;
+};
+
+#define KB(expr)                                        \
+  do {                                                  \
+    int rc_k = (expr);                                  \
+    if (rc_k != KHIP_OK) return ws->box.fail_rc(rc_k);  \
+  } while (0)
+
+static int alloc_panel(khip_ctx *ctx, int64_t np, int p, double **out) {
+  KHIP_TRY(khip_malloc(ctx, sizeof(double) * (size_t)np * p, reinterpret_cast<void **>(out)));
+  return khip_fill(ctx, np * p, *out, 0.0);
+}
+
 extern "C" {
 
-#define KHIP_TODO(name) \
-  set_error(name ": not implemented yet in this build"); \
-  return KHIP_ERR_UNSUPPORTED
+int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p, int memory,
+                                      khip_block_gmres_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0 && p >= 1 && p <= 32, "block_gmres_workspace_create: bad argument (1 <= p <= 32)");
+  if (memory <= 0) memory = 5;
+  if ((int64_t)memory > n / p) memory = (int)(n / p);              // memory = min(div(n,p), memory)
+  if (memory < 1) memory = 1;
+  khip_block_gmres_workspace *ws = new khip_block_gmres_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n; ws->p = p; ws->mem = memory;
+  khip_panel_rows(n, &ws->np);
+  int rc = alloc_panel(ctx, ws->np, p, &ws->X);
+  if (!rc) rc = alloc_panel(ctx, ws->np, p, &ws->W);
+  if (!rc) rc = alloc_panel(ctx, ws->np, p, &ws->Bp);
+  for (int i = 0; i < memory && !rc; ++i) {
+    double *v = nullptr;
+    rc = alloc_panel(ctx, ws->np, p, &v);
+    if (!rc) ws->V.push_back(v);
+  }
+  if (rc) { khip_block_gmres_workspace_destroy(ws); return rc; }
+  const size_t pp = (size_t)p * p;
+  ws->Z.assign(memory, std::vector<double>(pp, 0.0));
+  ws->R.assign((size_t)memory * (memory + 1) / 2, std::vector<double>(pp, 0.0));
+  ws->H.assign(memory, std::vector<double>(2 * pp, 0.0));
+  ws->tau.assign(memory, std::vector<double>(p, 0.0));
+  *out = ws;
+  return KHIP_OK;
+}
 
-int khip_panel_from_colmajor(khip_ctx *, int64_t, int, const double *, double *) { KHIP_TODO("panel_from_colmajor"); }
-int khip_panel_to_colmajor(khip_ctx *, int64_t, int, const double *, double *) { KHIP_TODO("panel_to_colmajor"); }
-int khip_panel_gemm_tn(khip_ctx *, int64_t, int, const double *, const double *, double *) { KHIP_TODO("panel_gemm_tn"); }
-int khip_panel_gemm_nn(khip_ctx *, int64_t, int, double, const double *, const double *, double, double *) { KHIP_TODO("panel_gemm_nn"); }
-int khip_panel_qr(khip_ctx *, int64_t, int, double *, double *) { KHIP_TODO("panel_qr"); }
-int khip_panel_norm(khip_ctx *, int64_t, int, const double *, double *) { KHIP_TODO("panel_norm"); }
-int khip_block_gmres_workspace_create(khip_ctx *, int64_t, int64_t, int, int, khip_block_gmres_workspace **) { KHIP_TODO("block_gmres_workspace_create"); }
-int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *) { return KHIP_OK; }
-int khip_block_gmres_solve(khip_block_gmres_workspace *, const khip_operator *, const double *, const khip_options *) { KHIP_TODO("block_gmres_solve"); }
-int khip_block_gmres_get_X(khip_block_gmres_workspace *, double *) { KHIP_TODO("block_gmres_get_X"); }
-const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *) { return nullptr; }
+int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws) {
+  if (!ws) return KHIP_OK;
+  for (double *v : {ws->dX, ws->X, ws->W, ws->Bp}) khip_free(ws->ctx, v);
+  for (double *v : ws->V) khip_free(ws->ctx, v);
+  delete ws;
+  return KHIP_OK;
+}
+
+const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+
+int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor) {
+  KHIP_REQUIRE(ws && X_colmajor, "block_gmres_get_X: null argument");
+  return khip_panel_to_colmajor(ws->ctx, ws->n, ws->p, ws->X, X_colmajor);
+}
+
+int khip_block_gmres_warm_start(khip_block_gmres_workspace *ws, const double *X0_colmajor) {
+  KHIP_REQUIRE(ws && X0_colmajor, "block_gmres_warm_start: null argument");
+  if (!ws->dX) KHIP_TRY(alloc_panel(ws->ctx, ws->np, ws->p, &ws->dX));
+  KHIP_TRY(khip_panel_from_colmajor(ws->ctx, ws->n, ws->p, X0_colmajor, ws->dX));
+  ws->warm_start = true;
+  return KHIP_OK;
+}
+
+int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A, const double *B_colmajor,
+                           const khip_options *opts_in) {
+  KHIP_REQUIRE(ws && A && B_colmajor, "block_gmres_solve: null argument");
+  KHIP_REQUIRE(A->csr && !A->apply, "block_gmres_solve: the operator must be a CSR handle (SpMM)");
+  khip_ctx *ctx = ws->ctx;
+  khip_options o = opts_in ? *opts_in : khip_default_options();
+  const double t0 = now_s();
+  const double timemax = (std::isnan(o.timemax) || o.timemax <= 0) ? std::numeric_limits<double>::infinity() : o.timemax;
+  const int64_t n = ws->n, np = ws->np;
+  const int p = ws->p;
+  const int64_t len = np * p;                       // panel length in doubles (padding rows stay zero)
+  const size_t pp = (size_t)p * p;
+  khip_stats *st = &ws->box.st;
+  const double atol = std::isnan(o.atol) ? std::sqrt(kEps) : o.atol, rtol = std::isnan(o.rtol) ? std::sqrt(kEps) : o.rtol;
+  const bool restart = o.restart != 0, reorth = o.reorthogonalization != 0;
+  if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+
+  if (restart && !ws->dX) KB(alloc_panel(ctx, np, p, &ws->dX));
+  double *dX = ws->dX, *X = ws->X, *W = ws->W, *Bp = ws->Bp;
+  std::vector<double *> &V = ws->V;
+  auto &Z = ws->Z; auto &R = ws->R; auto &H = ws->H; auto &tau = ws->tau;
+  std::vector<double> C(pp), D(2 * pp), Psi(pp);
+  const bool warm_start = ws->warm_start;
+  ws->box.reset();
+  double *Q = W, *R0 = W;                            // M = I
+  double *Xr = restart ? dX : X;
+
+  KB(khip_panel_from_colmajor(ctx, n, p, B_colmajor, Bp));
+  KB(khip_fill(ctx, len, X, 0.0));                                                 // src/block_gmres.jl:155
+  if (warm_start) {
+    KB(khip_spmm(ctx, A->csr, dX, W, p));
+    KB(khip_axpby(ctx, len, 1.0, Bp, -1.0, W));                                    // W .= B .- W
+    if (restart) KB(khip_axpy(ctx, len, 1.0, dX, X));
+  } else {
+    KB(khip_copy(ctx, len, W, Bp));
+  }
+  double RNorm;
+  KB(khip_panel_norm(ctx, n, p, R0, &RNorm));                                      // :166
+  if (o.history) ws->box.residuals.push_back(RNorm);
+  const double eps_tol = atol + rtol * RNorm;
+
+  const int mem = (int)V.size();
+  int npass = 0;
+  int64_t iter = 0;
+  int inner_iter = 0;
+  const int64_t itmax = o.itmax == 0 ? 2 * (n / p) : o.itmax;
+  int64_t inner_itmax = itmax;
+
+  bool solved = RNorm <= eps_tol;
+  bool tired = iter >= itmax;
+  bool inner_tired = inner_iter >= inner_itmax;
+  bool user_requested_exit = false, overtimed = false;
+  const char *status = "unknown";
+
+  while (!(solved || tired || user_requested_exit || overtimed)) {
+    int nr = 0;
+    for (int i = 0; i < mem; ++i) KB(khip_fill(ctx, len, V[i], 0.0));              // :195-197
+    for (auto &blk : R) std::fill(blk.begin(), blk.end(), 0.0);
+    for (auto &blk : Z) std::fill(blk.begin(), blk.end(), 0.0);
+
+    if (restart) {
+      KB(khip_fill(ctx, len, Xr, 0.0));
+      if (npass >= 1) {
+        KB(khip_spmm(ctx, A->csr, X, W, p));
+        KB(khip_axpby(ctx, len, 1.0, Bp, -1.0, W));
+      }
+    }
+
+    KB(khip_copy(ctx, len, V[0], R0));                                             // :211
+    KB(khip_panel_qr(ctx, n, p, V[0], Z[0].data()));                               // :212 householder!(V[1], Z[1], ..)
+
+    npass = npass + 1;
+    inner_iter = 0;
+    inner_tired = false;
+
+    while (!(solved || inner_tired || user_requested_exit || overtimed)) {
+      inner_iter = inner_iter + 1;
+
+      if (!restart && (inner_iter > mem)) {                                        // :224-232
+        for (int i = 0; i < inner_iter; ++i) R.emplace_back(pp, 0.0);
+        H.emplace_back(2 * pp, 0.0);
+        tau.emplace_back(p, 0.0);
+      }
+
+      KB(khip_spmm(ctx, A->csr, V[inner_iter - 1], W, p));                         // :242  W <- A V_k
+      for (int i = 0; i < inner_iter; ++i) {                                       // :244-247
+        KB(khip_panel_gemm_tn(ctx, n, p, V[i], Q, R[nr + i].data()));              // Psi = V_i^T Q
+        KB(khip_panel_gemm_nn(ctx, n, p, -1.0, V[i], R[nr + i].data(), 1.0, Q));   // Q -= V_i Psi
+      }
+      if (reorth) {                                                                // :250-256
+        for (int i = 0; i < inner_iter; ++i) {
+          KB(khip_panel_gemm_tn(ctx, n, p, V[i], Q, Psi.data()));
+          KB(khip_panel_gemm_nn(ctx, n, p, -1.0, V[i], Psi.data(), 1.0, Q));
+          for (size_t l = 0; l < pp; ++l) R[nr + i][l] += Psi[l];
+        }
+      }
+
+      KB(khip_panel_qr(ctx, n, p, Q, C.data()));                                   // :259 householder!(Q, C, ..)
+
+      for (int i = 0; i < inner_iter - 1; ++i) {                                   // :263-269
+        for (int j = 0; j < p; ++j)
+          for (int l = 0; l < p; ++l) {
+            D[(size_t)j * 2 * p + l] = R[nr + i][(size_t)j * p + l];
+            D[(size_t)j * 2 * p + p + l] = R[nr + i + 1][(size_t)j * p + l];
+          }
+        orm2r_LT(2 * p, p, p, H[i].data(), 2 * p, tau[i].data(), D.data(), 2 * p);
+        for (int j = 0; j < p; ++j)
+          for (int l = 0; l < p; ++l) {
+            R[nr + i][(size_t)j * p + l] = D[(size_t)j * 2 * p + l];
+            R[nr + i + 1][(size_t)j * p + l] = D[(size_t)j * 2 * p + p + l];
+          }
+      }
+
+      std::vector<double> &Hk = H[inner_iter - 1];                                 // :272-274
+      std::vector<double> &tauk = tau[inner_iter - 1];
+      for (int j = 0; j < p; ++j)
+        for (int l = 0; l < p; ++l) {
+          Hk[(size_t)j * 2 * p + l] = R[nr + inner_iter - 1][(size_t)j * p + l];
+          Hk[(size_t)j * 2 * p + p + l] = C[(size_t)j * p + l];
+        }
+      geqr2(2 * p, p, Hk.data(), 2 * p, tauk.data());                              // householder!(H_k, R, tau, compact=true)
+      std::vector<double> &Rkk = R[nr + inner_iter - 1];
+      std::fill(Rkk.begin(), Rkk.end(), 0.0);
+      for (int j = 0; j < p; ++j)
+        for (int i = 0; i <= j; ++i) Rkk[(size_t)j * p + i] = Hk[(size_t)j * 2 * p + i];
+
+      std::vector<double> &Zk = Z[inner_iter - 1];                                 // :277-280
+      for (int j = 0; j < p; ++j)
+        for (int l = 0; l < p; ++l) {
+          D[(size_t)j * 2 * p + l] = Zk[(size_t)j * p + l];
+          D[(size_t)j * 2 * p + p + l] = 0.0;
+        }
+      orm2r_LT(2 * p, p, p, Hk.data(), 2 * p, tauk.data(), D.data(), 2 * p);
+      for (int j = 0; j < p; ++j)
+        for (int l = 0; l < p; ++l) {
+          Zk[(size_t)j * p + l] = D[(size_t)j * 2 * p + l];
+          C[(size_t)j * p + l] = D[(size_t)j * 2 * p + p + l];                      // C .= D2 (:284)
+        }
+      RNorm = nrm2_h((int)pp, C.data());                                           // :285
+      if (o.history) ws->box.residuals.push_back(RNorm);
+      nr = nr + inner_iter;
+
+      if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+      solved = RNorm <= eps_tol;
+      if (restart) {
+        const int64_t lim = (int64_t)mem < inner_itmax ? (int64_t)mem : inner_itmax;
+        inner_tired = inner_iter >= lim;
+      } else {
+        inner_tired = inner_iter >= inner_itmax;
+      }
+      overtimed = (now_s() - t0) > timemax;
+
+      if (!(solved || inner_tired || user_requested_exit || overtimed)) {
+        if (!restart && (inner_iter >= mem)) {                                     // :300-305
+          while ((int)V.size() <= inner_iter) {
+            double *v = nullptr;
+            KB(alloc_panel(ctx, np, p, &v));
+            V.push_back(v);
+          }
+          while ((int)Z.size() <= inner_iter) Z.emplace_back(pp, 0.0);
+        }
+        KB(khip_copy(ctx, len, V[inner_iter], Q));                                 // :307
+        for (int j = 0; j < p; ++j)
+          for (int l = 0; l < p; ++l) Z[inner_iter][(size_t)j * p + l] = D[(size_t)j * 2 * p + p + l];
+      }
+    }
+
+    // block back-substitution (:313-321), Y aliases Z
+    auto &Y = Z;
+    std::vector<double> tmp(pp);
+    for (int i = inner_iter; i >= 1; --i) {
+      int pos = nr + i - inner_iter;
+      for (int j = inner_iter; j >= i + 1; --j) {
+        const std::vector<double> &Rm = R[pos - 1];
+        for (int cc = 0; cc < p; ++cc)
+          for (int rr = 0; rr < p; ++rr) {
+            double acc = 0.0;
+            for (int l = 0; l < p; ++l) acc += Rm[(size_t)l * p + rr] * Y[j - 1][(size_t)cc * p + l];
+            tmp[(size_t)cc * p + rr] = acc;
+          }
+        for (size_t l = 0; l < pp; ++l) Y[i - 1][l] -= tmp[l];
+        pos = pos - j + 1;
+      }
+      const std::vector<double> &U = R[pos - 1];
+      for (int cc = 0; cc < p; ++cc) {
+        double *ycol = Y[i - 1].data() + (size_t)cc * p;
+        for (int rr = p - 1; rr >= 0; --rr) {
+          double acc = ycol[rr];
+          for (int l = rr + 1; l < p; ++l) acc -= U[(size_t)l * p + rr] * ycol[l];
+          ycol[rr] = acc / U[(size_t)rr * p + rr];
+        }
+      }
+    }
+
+    for (int i = 0; i < inner_iter; ++i) KB(khip_panel_gemm_nn(ctx, n, p, 1.0, V[i], Y[i].data(), 1.0, Xr));   // :324-326
+    if (restart) KB(khip_axpy(ctx, len, 1.0, Xr, X));
+
+    inner_itmax = inner_itmax - inner_iter;
+    iter = iter + inner_iter;
+    tired = iter >= itmax;
+    overtimed = (now_s() - t0) > timemax;
+  }
+
+  if (tired) status = "maximum number of iterations exceeded";
+  if (solved) status = "solution good enough given atol and rtol";
+  if (overtimed) status = "time limit exceeded";
+  if (user_requested_exit) status = "user-requested exit";
+
+  if (warm_start && !restart) KB(khip_axpy(ctx, len, 1.0, dX, X));
+  ws->warm_start = false;
+  KB(khip_ctx_sync(ctx));
+
+  st->niter = (int)iter;
+  st->solved = solved;
+  st->timer = now_s() - t0;
+  snprintf(st->status, sizeof(st->status), "%s", status);
+  ws->box.publish();
+  return KHIP_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,309 @@
+// panel.hip -- tall-skinny panel kernels of block_gmres! (src/block_gmres.jl:244-247,259,324-326) on
+// the FP64 matrix cores of gfx950.
+//
+// Panel layout in HBM: n_pad x p ROW-MAJOR (p contiguous doubles per row, n_pad = n rounded up to 16,
+// padding rows are zero).  With p = 16 a panel row is one 128-byte line: the SpMM gather of a row of
+// X is a single line and four consecutive rows are exactly one v_mfma_f64_16x16x4_f64 operand (64
+// lanes x 8 B, fully coalesced).  The reference keeps n x p column-major Matrix{Float64}; conversion
+// happens once at the boundary (khip_panel_from/to_colmajor).
+//
+// All three panel products are HBM-bound (AI = p/8 = 2 flop/B at p = 16): V^T Q reads two panels,
+// Q - V Psi reads two and writes one.  The MFMA only keeps the FP64 pipe from co-limiting:
+//   Psi = V^T Q : D(16x16) += A(16x4) B(4x16) with A[i][k] = V[r0+k][i], B[k][j] = Q[r0+k][j]
+//                 => lane l feeds V[r0*p + l] and Q[r0*p + l] (p = 16): one MFMA per 4 rows.
+//   Q += a V Psi: D(16 rows x 16 cols) += A(16 rows x 4) B(4 x 16): A[i][k] = V[r0+i][4kk+k],
+//                 B[k][j] = Psi[4kk+k][j] held in registers; C/D lane layout of the f64 MFMA:
+//                 col = lane & 15, row = (lane >> 4) + 4 * reg  (cdna_hip_programming.md section 3).
+// p up to 32 is handled with 2 x 2 tiles of 16 columns; p that is not a multiple of 16 zero-fills.
+#include "device_reduce.hpp"
+
+namespace khip {
+
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRowsPerWaveTN = 256;   // rows folded by one wave of the V^T Q kernel (64 MFMAs per tile pair)
+
+// ---------------------------------------------------------------- layout conversion ------
+// in: column-major n x p (ld = n); out: row-major n_pad x p (ld = p).  256 rows per workgroup via LDS.
+__global__ __launch_bounds__(kBlock) void panel_from_colmajor_kernel(int64_t n, int p, const double *in, double *out) {
+  extern __shared__ double s_tile[];                 // [256][p + 1]
+  const int64_t r0 = (int64_t)blockIdx.x * kBlock;
+  const int tid = threadIdx.x;
+  for (int c = 0; c < p; ++c) {
+    const int64_t r = r0 + tid;
+    s_tile[tid * (p + 1) + c] = (r < n) ? in[(int64_t)c * n + r] : 0.0;
+  }
+  __syncthreads();
+  const int64_t base = r0 * p;
+  for (int i = tid; i < kBlock * p; i += kBlock) {
+    const int rl = i / p, c = i % p;
+    if (r0 + rl < n) out[base + i] = s_tile[rl * (p + 1) + c];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void panel_to_colmajor_kernel(int64_t n, int p, const double *in, double *out) {
+  extern __shared__ double s_tile[];
+  const int64_t r0 = (int64_t)blockIdx.x * kBlock;
+  const int tid = threadIdx.x;
+  const int64_t base = r0 * p;
+  for (int i = tid; i < kBlock * p; i += kBlock) {
+    const int rl = i / p, c = i % p;
+    s_tile[rl * (p + 1) + c] = (r0 + rl < n) ? in[base + i] : 0.0;
+  }
+  __syncthreads();
+  for (int c = 0; c < p; ++c) {
+    const int64_t r = r0 + tid;
+    if (r < n) out[(int64_t)c * n + r] = s_tile[tid * (p + 1) + c];
+  }
+}
+
+// ---------------------------------------------------------------- Psi = V^T Q -------------
+// Each wave folds kRowsPerWaveTN consecutive rows into NT x NT accumulator tiles and writes them to
+// partials[wave][NT*NT][256]; panel_tn_finish_kernel sums the per-wave tiles in wave order.
+template <int NT>
+__global__ __launch_bounds__(kBlock) void panel_gemm_tn_kernel(int64_t n_pad, int p, const double *V, const double *Q,
+                                                               double *partials) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t row_begin = wid * kRowsPerWaveTN;
+  const int i = lane & 15, k = lane >> 4;
+  dbl4 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = dbl4{0.0, 0.0, 0.0, 0.0};
+  if (row_begin < n_pad) {
+    const int64_t row_end = (row_begin + kRowsPerWaveTN < n_pad) ? row_begin + kRowsPerWaveTN : n_pad;
+    constexpr int UN = 8;                            // MFMA steps whose loads are issued together
+    for (int64_t r = row_begin; r < row_end; r += 4 * UN) {
+      double va[UN][NT], qb[UN][NT];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int64_t row = r + 4 * u + k;
+        const bool rok = row < row_end;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int col = 16 * t + i;
+          const bool ok = rok && col < p;
+          va[u][t] = ok ? V[row * p + col] : 0.0;
+          qb[u][t] = ok ? Q[row * p + col] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b < NT; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u][a], qb[u][b], acc[a][b], 0, 0, 0);
+    }
+  }
+  // tile (a, b), register g of lane l holds Psi[16a + (l >> 4) + 4g][16b + (l & 15)]
+  double *out = partials + (size_t)wid * (NT * NT * 256);
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) out[(a * NT + b) * 256 + g * 64 + lane] = acc[a][b][g];
+}
+
+// Fixed-order tree over the per-wave tiles: each workgroup (x = group, y = tile pair) sums up to
+// kTnFan consecutive tiles; repeated until one is left, which is scattered into Psi_dev
+// (p x p column-major).  The order depends only on the wave count: deterministic.
+constexpr int kTnFan = 64;
+template <int NT>
+__global__ __launch_bounds__(kBlock) void panel_tn_reduce_kernel(int64_t count, int p, const double *in, double *out,
+                                                                 double *Psi_dev) {
+  const int tile = blockIdx.y;                      // a * NT + b
+  const int t = threadIdx.x;                        // = g * 64 + lane
+  const int64_t w0 = (int64_t)blockIdx.x * kTnFan;
+  const int64_t w1 = (w0 + kTnFan < count) ? w0 + kTnFan : count;
+  double s = 0.0;
+  for (int64_t w = w0; w < w1; ++w) s += in[(size_t)w * (NT * NT * 256) + tile * 256 + t];
+  if (Psi_dev == nullptr) {
+    out[(size_t)blockIdx.x * (NT * NT * 256) + tile * 256 + t] = s;
+  } else {                                           // last level (gridDim.x == 1)
+    const int a = tile / NT, b = tile % NT;
+    const int g = t >> 6, lane = t & 63;
+    const int row = 16 * a + (lane >> 4) + 4 * g, col = 16 * b + (lane & 15);
+    if (row < p && col < p) Psi_dev[(size_t)col * p + row] = s;
+  }
+}
+
+// ---------------------------------------------------------------- Q = beta Q + alpha V Psi --
+// One wave per 16-row tile of the panel; V may alias Q (in-place Q <- Q * Psi when beta == 0):
+// every A fragment of the tile is loaded before the first store.
+template <int NT>
+__global__ __launch_bounds__(kBlock) void panel_gemm_nn_kernel(int64_t n_pad, int p, double alpha, const double *V,
+                                                               const double *Psi_dev, double beta, double *Q) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t r0 = tile * 16;
+  if (r0 >= n_pad) return;
+  const int i = lane & 15, k = lane >> 4;
+  constexpr int KK = NT * 4;                         // k-steps of 4 covering up to 16 * NT columns of V
+  // B fragments: Psi[4kk + k][16b + i]  (column-major p x p)
+  double bf[KK][NT];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int prow = 4 * kk + k, pcol = 16 * b + i;
+      bf[kk][b] = (prow < p && pcol < p) ? Psi_dev[(size_t)pcol * p + prow] : 0.0;
+    }
+  // A fragments: V[r0 + i][4kk + k]
+  double af[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int vcol = 4 * kk + k;
+    af[kk] = (vcol < p) ? V[(r0 + i) * p + vcol] : 0.0;
+  }
+  dbl4 cin[NT], acc[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    acc[b] = dbl4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 16 * b + i;
+      const int64_t row = r0 + k + 4 * g;
+      cin[b][g] = (beta != 0.0 && col < p) ? Q[row * p + col] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk][b], acc[b], 0, 0, 0);
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 16 * b + i;
+      const int64_t row = r0 + k + 4 * g;
+      if (col < p) Q[row * p + col] = fma(alpha, acc[b][g], beta * cin[b][g]);
+    }
+}
+
+}  // namespace khip
+
+using namespace khip;
+
+namespace {
+int64_t pad16(int64_t n) { return (n + 15) & ~(int64_t)15; }
+
+constexpr int kPsiSlots = 64;    // staging ring for the p x p factors of Q += V Psi
+struct PanelScratch {            // scratch for the V^T Q partial tiles and the Psi staging
+  double *partials = nullptr;    // two ping-pong regions
+  size_t partial_elems = 0;
+  double *psi_dev = nullptr;     // kPsiSlots x 32 x 32
+  double *psi_pinned = nullptr;
+  int next_slot = 0;
+};
+PanelScratch g_ps;               // one context per process in practice; keyed lazily
+
+int ensure_panel_scratch(khip_ctx *ctx, size_t elems) {
+  if (!g_ps.psi_dev) {
+    KHIP_CHECK_HIP(hipMalloc(&g_ps.psi_dev, sizeof(double) * 32 * 32 * kPsiSlots));
+    KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_ps.psi_pinned), sizeof(double) * 32 * 32 * kPsiSlots,
+                                 hipHostMallocDefault));
+  }
+  if (elems > g_ps.partial_elems) {
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (g_ps.partials) KHIP_CHECK_HIP(hipFree(g_ps.partials));
+    KHIP_CHECK_HIP(hipMalloc(&g_ps.partials, sizeof(double) * elems));
+    g_ps.partial_elems = elems;
+  }
+  return KHIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int khip_panel_rows(int64_t n, int64_t *n_pad) {
+  KHIP_REQUIRE(n_pad, "panel_rows: null argument");
+  *n_pad = pad16(n);
+  return KHIP_OK;
+}
+
+int khip_panel_from_colmajor(khip_ctx *ctx, int64_t n, int p, const double *X_colmajor, double *P) {
+  KHIP_REQUIRE(ctx && X_colmajor && P && p >= 1 && p <= 32, "panel_from_colmajor: bad argument (1 <= p <= 32)");
+  const int64_t np = pad16(n);
+  if (np > n) KHIP_CHECK_HIP(hipMemsetAsync(P + n * p, 0, sizeof(double) * (size_t)(np - n) * p, ctx->stream));
+  if (n == 0) return KHIP_OK;
+  const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(panel_from_colmajor_kernel, dim3(g), dim3(kBlock), sizeof(double) * kBlock * (p + 1), ctx->stream, n, p,
+                     X_colmajor, P);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+int khip_panel_to_colmajor(khip_ctx *ctx, int64_t n, int p, const double *P, double *X_colmajor) {
+  KHIP_REQUIRE(ctx && X_colmajor && P && p >= 1 && p <= 32, "panel_to_colmajor: bad argument (1 <= p <= 32)");
+  if (n == 0) return KHIP_OK;
+  const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(panel_to_colmajor_kernel, dim3(g), dim3(kBlock), sizeof(double) * kBlock * (p + 1), ctx->stream, n, p, P,
+                     X_colmajor);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const double *Q, double *Psi_host) {
+  KHIP_REQUIRE(ctx && V && Q && Psi_host && p >= 1 && p <= 32, "panel_gemm_tn: bad argument (1 <= p <= 32)");
+  const int64_t np = pad16(n);
+  const int NT = p <= 16 ? 1 : 2;
+  const int64_t nwaves_used = (np + kRowsPerWaveTN - 1) / kRowsPerWaveTN;
+  const int64_t nblocks = (nwaves_used + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t nwaves = (nblocks > 0 ? nblocks : 1) * kWavesPerBlock;
+  const size_t tile_elems = (size_t)NT * NT * 256;
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)nwaves * tile_elems));
+  const unsigned g = (unsigned)(nblocks > 0 ? nblocks : 1);
+  double *ping = g_ps.partials, *pong = g_ps.partials + (size_t)nwaves * tile_elems;
+  if (NT == 1) hipLaunchKernelGGL((panel_gemm_tn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, V, Q, ping);
+  else hipLaunchKernelGGL((panel_gemm_tn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, V, Q, ping);
+  int64_t count = nwaves;
+  while (true) {
+    const int64_t groups = (count + kTnFan - 1) / kTnFan;
+    double *psi_out = groups == 1 ? g_ps.psi_dev : nullptr;
+    if (NT == 1) hipLaunchKernelGGL((panel_tn_reduce_kernel<1>), dim3((unsigned)groups, 1), dim3(kBlock), 0, ctx->stream, count, p, ping, pong, psi_out);
+    else hipLaunchKernelGGL((panel_tn_reduce_kernel<2>), dim3((unsigned)groups, 4), dim3(kBlock), 0, ctx->stream, count, p, ping, pong, psi_out);
+    if (groups == 1) break;
+    count = groups;
+    double *t = ping; ping = pong; pong = t;
+  }
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned, g_ps.psi_dev, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(Psi_host, g_ps.psi_pinned, sizeof(double) * (size_t)p * p);
+  return KHIP_OK;
+}
+
+int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const double *V, const double *Psi_host, double beta,
+                       double *Q) {
+  KHIP_REQUIRE(ctx && V && Q && Psi_host && p >= 1 && p <= 32, "panel_gemm_nn: bad argument (1 <= p <= 32)");
+  const int64_t np = pad16(n);
+  KHIP_TRY(ensure_panel_scratch(ctx, 1));
+  // Psi is uploaded through a ring of staging slots (the ring is drained before it wraps)
+  if (g_ps.next_slot == kPsiSlots) {
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    g_ps.next_slot = 1;                      // slot 0 is the result slot of khip_panel_gemm_tn
+  }
+  if (g_ps.next_slot == 0) g_ps.next_slot = 1;
+  const int slot = g_ps.next_slot++;
+  double *psi_h = g_ps.psi_pinned + (size_t)slot * 1024, *psi_d = g_ps.psi_dev + (size_t)slot * 1024;
+  memcpy(psi_h, Psi_host, sizeof(double) * (size_t)p * p);
+  KHIP_CHECK_HIP(hipMemcpyAsync(psi_d, psi_h, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, ctx->stream));
+  const int64_t tiles = np / 16;
+  if (tiles == 0) return KHIP_OK;
+  const unsigned g = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (p <= 16) hipLaunchKernelGGL((panel_gemm_nn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, psi_d, beta, Q);
+  else hipLaunchKernelGGL((panel_gemm_nn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, psi_d, beta, Q);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+int khip_panel_norm(khip_ctx *ctx, int64_t n, int p, const double *Q, double *result_host) {
+  KHIP_REQUIRE(ctx && Q && result_host && p >= 1, "panel_norm: bad argument");
+  return khip_nrm2(ctx, pad16(n) * p, Q, result_host);     // padding rows are zero
+}
+
+}  // extern "C"
