@@ -26,12 +26,33 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(n1):
+    """HBM-side bytes per launch of the fused SpMV kernel from the committed rocprofv3 PMC passes
+    (tools/gpu_prof.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/spmv_only.py at 512^3).
+    Correction per MI355X_MICROARCH.md: counters are in KiB and FETCH_SIZE tallies 128-B line fetches
+    as 64 B, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  None when no matching profile exists."""
+    path = os.path.join(ROOT, "profiles", "r01f_spmv_pmc.json")
+    if n1 != 512 or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+        for k, v in d.items():
+            if "spmv_stage_kernel" in k and "true, true" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                return (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(n1, budget_s=30.0):
     """Oracle CG loop (the reference's cg! recurrence, src/cg.jl:195-268) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctypes as C
     import oracle as ok
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        ncores = os.cpu_count() or 1
     try:
         avail_gb = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) / 1e6
     except Exception:
@@ -75,7 +96,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_comm = os.environ.get("KHIP_FORCE_COMM") == "1"      # exercise the distributed path with one rank
+    if world > 1 or "RANK" in os.environ:
         import torch                      # torch FIRST: one shared HIP runtime in the process
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -87,9 +109,11 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    if world > 1:
+    use_comm = world > 1 or force_comm
+    if use_comm:
         uid = [K.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(rank, world, uid[0])
 
     n1 = args.n1
@@ -98,7 +122,7 @@ def main():
     r0, r1 = starts[rank], starts[rank + 1]
     nloc = r1 - r0
     t_setup = time.time()
-    A = K.CsrMatrix.stencil(ctx, "poisson", n1, rows=(r0, r1), distributed=(world > 1))
+    A = K.CsrMatrix.stencil(ctx, "poisson", n1, rows=(r0, r1), distributed=use_comm)
     b = ctx.empty(nloc)
     K.kfill_(b, 1.0)
     ws = K.CgWorkspace(ctx, nloc, nloc)
@@ -152,7 +176,8 @@ def main():
             "final_residual_norm": float(st.residuals[-1]),
             "roofline": {"bound": "hbm", "kernel": "spmv_stage_kernel (CSR SpMV fused with p.Ap)",
                          "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic(n1) if world == 1 else None,
+                         "traffic_note": "L2-miss-side bytes per launch from separate rocprofv3 --pmc passes (profiles/r01f_spmv_pmc.json); includes Infinity-Cache hits",
                          "bytes_per_launch": spmv_bytes_local, "avg_ms": avg_spmv_ms,
                          "launches_per_iteration": spmv_per_iter},
         }

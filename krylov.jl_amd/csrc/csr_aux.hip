@@ -5,8 +5,11 @@
 namespace khip {
 
 // ---------------------------------------------------------------- SpMM ----------
-// Y(m x p, row-major) = A * X(n x p, row-major).  P lanes cooperate on one row: lane c owns
-// column c, val/col loads are wave-broadcast, the X gather is one contiguous 8p-byte line.
+// Y(m x p, row-major) = A * X(n x p, row-major); P = lanes per row (>= p, power of two).  The P lanes
+// first fetch P consecutive (val, col) entries of the row in one coalesced access each, then every
+// entry is broadcast with a shuffle and all P gathers of X rows (one contiguous 8p-byte line each)
+// are issued before the first use; accumulation in stored order with a rounded multiply and a rounded
+// add => column j of Y is bit-identical to the SpMV of column j.
 template <int P>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
   constexpr int RPB = kBlock / P;
@@ -14,13 +17,27 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
   for (int64_t row = a.row_lo + (int64_t)blockIdx.x * RPB + sub; row < a.row_hi; row += (int64_t)gridDim.x * RPB) {
     const int64_t s = a.rowptr[row], e = a.rowptr[row + 1];
     double acc = 0.0;
-    if (c < p) {
-      for (int64_t j = s; j < e; ++j) {
-        double prod = a.val[j] * a.x[(int64_t)a.col[j] * p + c];
-        acc = acc + prod;
+    for (int64_t base = s; base < e; base += P) {
+      const int cnt = (int)((e - base) < P ? (e - base) : P);
+      const bool mine = c < cnt;
+      const double myv = mine ? a.val[base + c] : 0.0;
+      const int32_t myc = mine ? a.col[base + c] : 0;
+      double xs[P];
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const int32_t cc = __shfl(myc, t, P);
+        xs[t] = (t < cnt && c < p) ? a.x[(int64_t)cc * p + c] : 0.0;
       }
-      a.y[row * p + c] = acc;
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const double vv = __shfl(myv, t, P);
+        if (t < cnt) {
+          const double prod = vv * xs[t];
+          acc = acc + prod;
+        }
+      }
     }
+    if (c < p) a.y[row * p + c] = acc;
   }
 }
 
@@ -34,7 +51,8 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
   while (P < p) P <<= 1;
   const int rpb = kBlock / P;
   int64_t want = (A->m + rpb - 1) / rpb;
-  int grid = (int)(want < ctx->num_cu * 16 ? want : ctx->num_cu * 16);
+  int64_t gcap = 1 << 22;
+  int grid = (int)(want < gcap ? want : gcap);     // loop-free: one row group per workgroup slot
   if (grid < 1) grid = 1;
   switch (P) {
     case 4: hipLaunchKernelGGL((spmm_kernel<4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;

@@ -349,7 +349,7 @@ template <int ROWS, bool NT>
 static void launch_stage_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                              bool dist) {
 #define KHIP_L(DOT, COMP, DIST) \
-  hipLaunchKernelGGL((spmv_stage_kernel<ROWS, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, ra)
+  hipLaunchKernelGGL((spmv_stage_kernel<ROWS, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), (size_t)ctx->tune.spmv_lds_pad, ctx->stream, a, ra)
   KHIP_DISPATCH_DCD(KHIP_L);
 #undef KHIP_L
 }

@@ -18,8 +18,7 @@ def case(**o):
     for k, v in o.items(): ctx.set_option(k, v)
     t = timeit(lambda: A.matvec(x, y)); t2 = timeit(lambda: K.spmv_dot(A, x, y))
     print(json.dumps(dict(o, ms=round(t * 1e3, 4), gbps=round(sb / t / 1e9), frac=round(sb / t / 8e12, 4), ms_dot=round(t2 * 1e3, 4))), flush=True)
-base = dict(spmv_vec=1, spmv_nt=0, spmv_persist=0, spmv_xcd=0, spmv_nty=0, spmv_fake_gather=0, spmv_tiles=1)
-for rows in (256, 128, 64):
-    case(**base, spmv_kernel=4, spmv_rows=rows)
-case(**base, spmv_kernel=4, spmv_rows=256)
+base = dict(spmv_vec=1, spmv_nt=0, spmv_persist=0, spmv_nty=0, spmv_fake_gather=0, spmv_tiles=1, spmv_rows=256, spmv_kernel=4, spmv_xcd=0)
+for pad in (0, 8192, 16384, 32768, 57344, 0):      # 6, 4, 3, 2, 1(+) workgroups per CU
+    case(**base, spmv_lds_pad=pad)
 ctx.close()
