@@ -264,9 +264,11 @@ int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws);
 int khip_block_gmres_warm_start(khip_block_gmres_workspace *ws, const double *X0_colmajor);
 /* block_gmres!(ws, A, B; restart, reorthogonalization, ...) src/block_gmres.jl:110-358.
  * B and the solution are n-by-p COLUMN-MAJOR device arrays (the reference layout); the
- * workspace converts to row-major panels internally. */
-int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A,
-                           const double *B_colmajor, const khip_options *opts);
+ * workspace converts to row-major panels internally.  A: CSR handle (SpMM kernel) or an apply
+ * callback; M / N: NULL (= I) or apply callbacks.  Callbacks of the block solver receive ROW-MAJOR
+ * device panels of khip_panel_rows(n) x p doubles (padding rows zero, and they must stay zero). */
+int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                           const khip_operator *N, const double *B_colmajor, const khip_options *opts);
 int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor);
 const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws);
 

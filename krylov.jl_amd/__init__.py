@@ -141,7 +141,8 @@ SIGNATURES = {
     "khip_block_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, _int, c_void_pp]),
     "khip_block_gmres_workspace_destroy": (_int, [_vp]),
     "khip_block_gmres_warm_start": (_int, [_vp, _vp]),
-    "khip_block_gmres_solve": (_int, [_vp, C.POINTER(COperator), _vp, C.POINTER(COptions)]),
+    "khip_block_gmres_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), C.POINTER(COperator), _vp,
+                               C.POINTER(COptions)]),
     "khip_block_gmres_get_X": (_int, [_vp, _vp]),
     "khip_block_gmres_stats": (C.POINTER(CStats), [_vp]),
     # host-only helpers (partition / halo plan logic, testable without a GPU)
@@ -888,22 +889,48 @@ class BlockGmresWorkspace(_Workspace):
         raise NotImplementedError
 
 
-def block_gmres_(ws: BlockGmresWorkspace, A: CsrMatrix, B_colmajor: DeviceVector, **kw):
+def _make_block_operator(ctx, op, n, p, keep):
+    """CsrMatrix | callable(X: Panel, Y: Panel) | None for the block solver (callbacks see row-major panels)."""
+    if op is None or isinstance(op, CsrMatrix):
+        return _make_operator(ctx, op, n, keep)
+
+    def thunk(_self, xp, yp):
+        try:
+            X, Y = Panel.__new__(Panel), Panel.__new__(Panel)
+            for P_, ptr in ((X, xp), (Y, yp)):
+                P_.ctx, P_.n, P_.p, P_.n_pad = ctx, n, p, panel_rows(n)
+                P_.buf = DeviceVector(ctx, P_.n_pad * p, ptr=ptr)
+            op(X, Y)
+            return 0
+        except Exception as e:
+            sys.stderr.write(f"block operator callback failed: {e}\n")
+            return 1
+    fn = APPLY_FN(thunk)
+    co = COperator()
+    co.csr, co.apply = None, fn
+    keep.extend([fn, co])
+    return C.byref(co)
+
+
+def block_gmres_(ws: BlockGmresWorkspace, A, B_colmajor: DeviceVector, M=None, N=None, **kw):
     """block_gmres!(workspace, A, B; restart, reorthogonalization, atol, rtol, itmax, history, ...)
     (src/block_gmres.jl:110-358); B is an n x p column-major device array."""
     keep = []
     opts = _make_options(keep=keep, ws=ws, **kw)
-    rc = lib().khip_block_gmres_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep), _p(B_colmajor), C.byref(opts))
+    rc = lib().khip_block_gmres_solve(ws._h, _make_block_operator(ws.ctx, A, ws.n, ws.p, keep),
+                                      _make_block_operator(ws.ctx, M, ws.n, ws.p, keep),
+                                      _make_block_operator(ws.ctx, N, ws.n, ws.p, keep), _p(B_colmajor), C.byref(opts))
     return _finish(ws, rc)
 
 
-def block_gmres(A: CsrMatrix, B, X0=None, memory=5, **kw):
+def block_gmres(A, B, X0=None, memory=5, ctx=None, **kw):
     """Out-of-place block_gmres(A, B) for a host n x p array B -> (X, stats, workspace)."""
     B = np.asarray(B, dtype=np.float64)
     n, p = B.shape
-    ws = BlockGmresWorkspace(A.ctx, n, n, p, memory=memory)
+    ctx = ctx or A.ctx
+    ws = BlockGmresWorkspace(ctx, n, n, p, memory=memory)
     if X0 is not None:
         ws.warm_start_(X0)
-    Bd = A.ctx.array(np.asfortranarray(B).ravel(order="F"))
+    Bd = ctx.array(np.asfortranarray(B).ravel(order="F"))
     block_gmres_(ws, A, Bd, **kw)
     return ws.X, ws.stats, ws

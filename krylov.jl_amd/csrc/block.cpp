@@ -182,6 +182,7 @@ struct khip_block_gmres_workspace {
   int64_t m, n, np;
   int p, mem;
   double *dX = nullptr, *X = nullptr, *W = nullptr;            // panels (row-major, np x p)
+  double *Pn = nullptr, *Qm = nullptr;                         // only with N / M preconditioners (src/block_gmres.jl:146-147)
   double *Bp = nullptr;                                        // panel copy of B
   std::vector<double *> V;
   std::vector<std::vector<double>> Z, R, H, tau;               // host p x p, p x p, 2p x p, p
@@ -231,7 +232,7 @@ int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p
 
 int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws) {
   if (!ws) return KHIP_OK;
-  for (double *v : {ws->dX, ws->X, ws->W, ws->Bp}) khip_free(ws->ctx, v);
+  for (double *v : {ws->dX, ws->X, ws->W, ws->Bp, ws->Pn, ws->Qm}) khip_free(ws->ctx, v);
   for (double *v : ws->V) khip_free(ws->ctx, v);
   delete ws;
   return KHIP_OK;
@@ -252,10 +253,20 @@ int khip_block_gmres_warm_start(khip_block_gmres_workspace *ws, const double *X0
   return KHIP_OK;
 }
 
-int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A, const double *B_colmajor,
-                           const khip_options *opts_in) {
+// Y <- Op X for row-major panels: CSR handle -> SpMM kernel; callback -> user code on the device panels
+static int apply_block_op(khip_ctx *ctx, const khip_operator *op, const double *X, double *Y, int p) {
+  if (op->apply) {
+    const int rc = op->apply(op->self, X, Y);
+    if (rc != 0) { set_error("user block operator returned %d", rc); return KHIP_ERR_INVALID; }
+    return KHIP_OK;
+  }
+  if (!op->csr) { set_error("block operator has neither a CSR handle nor an apply callback"); return KHIP_ERR_INVALID; }
+  return khip_spmm(ctx, op->csr, X, Y, p);
+}
+
+int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                           const khip_operator *N, const double *B_colmajor, const khip_options *opts_in) {
   KHIP_REQUIRE(ws && A && B_colmajor, "block_gmres_solve: null argument");
-  KHIP_REQUIRE(A->csr && !A->apply, "block_gmres_solve: the operator must be a CSR handle (SpMM)");
   khip_ctx *ctx = ws->ctx;
   khip_options o = opts_in ? *opts_in : khip_default_options();
   const double t0 = now_s();
@@ -276,18 +287,22 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   std::vector<double> C(pp), D(2 * pp), Psi(pp);
   const bool warm_start = ws->warm_start;
   ws->box.reset();
-  double *Q = W, *R0 = W;                            // M = I
+  const bool MisI = (M == nullptr), NisI = (N == nullptr);
+  if (!MisI && !ws->Qm) KB(alloc_panel(ctx, np, p, &ws->Qm));                      // :146
+  if (!NisI && !ws->Pn) KB(alloc_panel(ctx, np, p, &ws->Pn));                      // :147
+  double *Q = MisI ? W : ws->Qm, *R0 = MisI ? W : ws->Qm;
   double *Xr = restart ? dX : X;
 
   KB(khip_panel_from_colmajor(ctx, n, p, B_colmajor, Bp));
   KB(khip_fill(ctx, len, X, 0.0));                                                 // src/block_gmres.jl:155
   if (warm_start) {
-    KB(khip_spmm(ctx, A->csr, dX, W, p));
+    KB(apply_block_op(ctx, A, dX, W, p));
     KB(khip_axpby(ctx, len, 1.0, Bp, -1.0, W));                                    // W .= B .- W
     if (restart) KB(khip_axpy(ctx, len, 1.0, dX, X));
   } else {
     KB(khip_copy(ctx, len, W, Bp));
   }
+  if (!MisI) KB(apply_block_op(ctx, M, W, R0, p));                                 // R0 = M (B - A X0)  :165
   double RNorm;
   KB(khip_panel_norm(ctx, n, p, R0, &RNorm));                                      // :166
   if (o.history) ws->box.residuals.push_back(RNorm);
@@ -315,8 +330,9 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
     if (restart) {
       KB(khip_fill(ctx, len, Xr, 0.0));
       if (npass >= 1) {
-        KB(khip_spmm(ctx, A->csr, X, W, p));
+        KB(apply_block_op(ctx, A, X, W, p));
         KB(khip_axpby(ctx, len, 1.0, Bp, -1.0, W));
+        if (!MisI) KB(apply_block_op(ctx, M, W, R0, p));
       }
     }
 
@@ -336,7 +352,10 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
         tau.emplace_back(p, 0.0);
       }
 
-      KB(khip_spmm(ctx, A->csr, V[inner_iter - 1], W, p));                         // :242  W <- A V_k
+      double *Pk = NisI ? V[inner_iter - 1] : ws->Pn;
+      if (!NisI) KB(apply_block_op(ctx, N, V[inner_iter - 1], Pk, p));             // :241  P <- N V_k
+      KB(apply_block_op(ctx, A, Pk, W, p));                                        // :242  W <- A N V_k
+      if (!MisI) KB(apply_block_op(ctx, M, W, Q, p));                              // :243  Q <- M A N V_k
       for (int i = 0; i < inner_iter; ++i) {                                       // :244-247
         KB(khip_panel_gemm_tn(ctx, n, p, V[i], Q, R[nr + i].data()));              // Psi = V_i^T Q
         KB(khip_panel_gemm_nn(ctx, n, p, -1.0, V[i], R[nr + i].data(), 1.0, Q));   // Q -= V_i Psi
@@ -447,6 +466,10 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
     }
 
     for (int i = 0; i < inner_iter; ++i) KB(khip_panel_gemm_nn(ctx, n, p, 1.0, V[i], Y[i].data(), 1.0, Xr));   // :324-326
+    if (!NisI) {                                                                   // :327-330
+      KB(khip_copy(ctx, len, ws->Pn, Xr));
+      KB(apply_block_op(ctx, N, ws->Pn, Xr, p));
+    }
     if (restart) KB(khip_axpy(ctx, len, 1.0, Xr, X));
 
     inner_itmax = inner_itmax - inner_iter;

@@ -345,25 +345,32 @@ def bicgstab(A, b, c=None, M=None, N=None, x0=None, **kw):
     return res
 
 
-def block_gmres(A, B, X0=None, memory=5, **kw):
-    """block_gmres!(ws, A, B; restart, reorthogonalization, ...) -- src/block_gmres.jl:110-358.
-    B is n-by-p (any layout; converted to column-major)."""
+def block_gmres(A, B, X0=None, memory=5, M=None, N=None, **kw):
+    """block_gmres!(ws, A, B; M, N, restart, reorthogonalization, ...) -- src/block_gmres.jl:110-358.
+    B is n-by-p (any layout; converted to column-major); M / N are python callables on n-by-p arrays."""
     L = lib()
     Bf = np.asfortranarray(B, dtype=np.float64)
     n, p = Bf.shape
-    if isinstance(A, CsrMatrix):
-        fa, ud, keep = L.csr_block_matvec, A.ptr(), A
-    else:
+
+    def mk(f):
+        if f is None:
+            return NULL_BLOCK_MATVEC
+
         def cb(Xp, Yp, pp, _ud):
             X = np.ctypeslib.as_array(Xp, shape=(pp, n)).T
             Y = np.ctypeslib.as_array(Yp, shape=(pp, n)).T
-            Y[:, :] = A(X)
-        fa, ud, keep = BLOCK_MATVEC(cb), None, cb
+            Y[:, :] = f(X)
+        return BLOCK_MATVEC(cb)
+    if isinstance(A, CsrMatrix):
+        fa, ud = L.csr_block_matvec, A.ptr()
+    else:
+        fa, ud = mk(A), None
+    fm, fn = mk(M), mk(N)
     ws = L.ko_block_gmres_workspace_create(n, n, p, memory)
     if X0 is not None:
         L.ko_block_gmres_warm_start(ws, _dp(np.asfortranarray(X0, dtype=np.float64)))
     o = make_options(**kw)
-    rc = L.ko_block_gmres(ws, fa, NULL_BLOCK_MATVEC, NULL_BLOCK_MATVEC, ud, _dp(Bf), C.byref(o))
+    rc = L.ko_block_gmres(ws, fa, fm, fn, ud, _dp(Bf), C.byref(o))
     X = np.ctypeslib.as_array(ws.contents.X, shape=(p, n)).T.copy()
     res = Result(X, ws.contents.stats, rc)
     L.ko_block_gmres_workspace_free(ws)

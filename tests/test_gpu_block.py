@@ -119,3 +119,24 @@ def test_block_gmres_warm_start_and_itmax(K, ctx, oracle):
     ref = oracle.block_gmres(A, B, X0=X0, memory=8)
     X, st, _ = K.block_gmres(dA, B, X0=X0, memory=8)
     assert st.solved and st.niter == ref.niter and np.abs(X - ref.x).max() <= 1e-8
+
+
+def test_block_gmres_preconditioners(K, ctx, oracle):
+    """Left / right Jacobi as device callbacks on row-major panels (interfaces/test/C/test_block.c Jacobi cases);
+    kron_unsymmetric has the constant diagonal 12."""
+    A = oracle.kron_unsymmetric(7)
+    S = A.to_scipy()
+    B, Xt = _rhs(S, A.n, 4)
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (A.n, A.n))
+
+    def jac(X, Y):
+        K.kdivcopy_(len(X.buf), Y.buf, X.buf, 12.0)
+    for side in ("M", "N"):
+        ref = oracle.block_gmres(A, B, memory=8, history=True, **{side: (lambda X: X / 12.0)})
+        X, st, _ = K.block_gmres(dA, B, memory=8, history=True, **{side: jac})
+        assert st.solved and st.niter == ref.niter
+        assert np.max(np.abs(st.residuals - ref.residuals) / (1e-8 * ref.residuals + 100 * EPS * ref.residuals[0])) <= 1.0
+        assert np.abs(X - Xt).max() <= 1e-5
+    # operator given as a callback instead of a CSR handle
+    X, st, _ = K.block_gmres(lambda Xp, Yp: K.spmm_(dA, Xp, Yp), B, memory=8, ctx=ctx)
+    assert st.solved and np.abs(X - Xt).max() <= 1e-5

@@ -1,0 +1,60 @@
+"""The reference's OWN C clients (interfaces/test/C/*.c, interfaces/examples/C/*.c -- compiled from where they
+lie by `make -C oracle refhip`, only possible where /root/reference exists) driving the HIP path through
+oracle/ref_capi_hip_shim.cpp.  The prebuilt binaries travel to the GPU box inside oracle/_ref/."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref")
+OUT_OF_SCOPE = ("MINRES", "Float32", "DQGMRES", "block_minres")
+
+
+def _run(name):
+    path = os.path.join(BIN, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not built (needs /root/reference at build time: make -C oracle refhip)")
+    return subprocess.run([path], capture_output=True, text=True, timeout=300)
+
+
+def test_hip_basic_cg_example():
+    out = _run("hip_basic_cg")                 # interfaces/examples/C/basic_cg.c:13-15: niter 3, x = ones
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Solved: yes" in out.stdout and "niter: 3" in out.stdout
+    assert "x = [ 1.00 1.00 1.00 1.00 1.00 ]" in out.stdout
+
+
+def test_hip_test_api_client():
+    out = _run("hip_test_api")
+    fails = [l for l in out.stdout.splitlines() if "FAIL" in l]
+    bad = [l for l in fails if not any(k in l for k in OUT_OF_SCOPE)]
+    assert not bad, (bad, out.stderr[-500:])
+    assert len(fails) == 5 and "36 checks passed" in out.stdout        # same outcome as against the CPU oracle
+
+
+def test_hip_test_all_solvers_client():
+    out = _run("hip_test_all_solvers")
+    lines = {l.split()[0]: l for l in out.stdout.splitlines() if "..." in l}
+    for s in ("cg", "gmres", "bicgstab"):
+        assert "PASS" in lines[s], (lines[s], out.stderr[-500:])
+
+
+def test_hip_test_block_client():
+    out = _run("hip_test_block")
+    sections, cur = {}, None
+    for l in out.stdout.splitlines():
+        if l.endswith("..."):
+            cur = l
+            sections[cur] = []
+        elif "FAIL" in l and cur:
+            sections[cur].append(l)
+    assert sections, out.stdout + out.stderr
+    for name, fails in sections.items():
+        if "block_minres" in name:
+            continue
+        assert not fails, (name, fails)
+    ex = _run("hip_block_gmres_example")
+    assert "Block solved: yes" in ex.stdout
