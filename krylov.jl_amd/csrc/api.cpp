@@ -60,6 +60,7 @@ int khip_ctx_destroy(khip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   khip_comm_destroy_internal(ctx);
+  panel_scratch_destroy(ctx);
   for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
   (void)hipFree(ctx->partials);
   (void)hipFree(ctx->partials2);

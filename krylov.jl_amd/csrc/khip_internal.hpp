@@ -90,6 +90,7 @@ struct khip_ctx {
   int next_slot = 0;
   khip::Tuning tune;
   khip::Comm *comm = nullptr;
+  void *panel_scratch = nullptr;       // panel.hip: V^T Q partial tiles + Psi staging ring
   // SpMV launch profiling (events recorded on `stream`, resolved lazily)
   std::vector<hipEvent_t> prof_events;   // pairs: start, stop
   size_t prof_used = 0;
@@ -156,6 +157,9 @@ int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64
                            unsigned long long *count_dev, int64_t cap);
 int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host);
 int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
+
+// panel.hip
+void panel_scratch_destroy(khip_ctx *ctx);
 
 // comm.cpp
 int comm_nranks(const khip_ctx *ctx);

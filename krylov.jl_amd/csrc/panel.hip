@@ -199,9 +199,11 @@ struct PanelScratch {            // scratch for the V^T Q partial tiles and the 
   double *psi_pinned = nullptr;
   int next_slot = 0;
 };
-PanelScratch g_ps;               // one context per process in practice; keyed lazily
+// scratch is owned by the context (khip_ctx::panel_scratch, freed by khip_ctx_destroy)
+#define g_ps (*static_cast<PanelScratch *>(ctx->panel_scratch))
 
 int ensure_panel_scratch(khip_ctx *ctx, size_t elems) {
+  if (!ctx->panel_scratch) ctx->panel_scratch = new PanelScratch();
   if (!g_ps.psi_dev) {
     KHIP_CHECK_HIP(hipMalloc(&g_ps.psi_dev, sizeof(double) * 32 * 32 * kPsiSlots));
     KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&g_ps.psi_pinned), sizeof(double) * 32 * 32 * kPsiSlots,
@@ -216,6 +218,18 @@ int ensure_panel_scratch(khip_ctx *ctx, size_t elems) {
   return KHIP_OK;
 }
 }  // namespace
+
+namespace khip {
+void panel_scratch_destroy(khip_ctx *ctx) {
+  if (!ctx->panel_scratch) return;
+  PanelScratch *ps = static_cast<PanelScratch *>(ctx->panel_scratch);
+  if (ps->partials) (void)hipFree(ps->partials);
+  if (ps->psi_dev) (void)hipFree(ps->psi_dev);
+  if (ps->psi_pinned) (void)hipHostFree(ps->psi_pinned);
+  delete ps;
+  ctx->panel_scratch = nullptr;
+}
+}  // namespace khip
 
 extern "C" {
 

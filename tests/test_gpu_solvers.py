@@ -70,19 +70,25 @@ def test_cg_poisson_matches_oracle(K, ctx, oracle, parity_log, n1, fused):
     assert ws.nbytes == 4 * 8 * A.n                                      # storage: CG = 4n (test_allocations.jl:41-57)
 
 
-def test_cg_benchmark_settings_and_golden(K, ctx, oracle, parity_log):
-    """benchmark/benchmarks.jl:14-21 (atol=0, rtol=1e-8, itmax=n) + the committed golden histories."""
+def test_golden_histories_all_solvers(K, ctx, oracle, parity_log):
+    """The committed golden vectors (tests/golden/oracle_histories.json): CG with the package defaults and with the
+    benchmark settings of benchmark/benchmarks.jl:14-21 (atol=0, rtol=1e-8, itmax=n), restarted GMRES with and
+    without reorthogonalisation, BiCGSTAB."""
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_histories.json")))
+    run = {"cg": K.cg, "gmres": K.gmres, "bicgstab": K.bicgstab}
     for case in gold["cases"]:
-        if case["solver"] != "cg":
-            continue
         A = getattr(oracle, case["matrix"])(case["n1"])
         b = np.ones(A.n) if case["rhs"] == "ones" else A.matvec(np.ones(A.n))
-        x, st, _ = K.cg(_upload(K, ctx, A), ctx.array(b), history=True, **case["kwargs"])
+        x, st, _ = run[case["solver"]](_upload(K, ctx, A), ctx.array(b), history=True, **case["kwargs"])
         assert st.niter == case["niter"] and st.status == case["status"], case["name"]
-        dev = _hist_dev(st.residuals, np.array(case["residuals"]))
-        parity_log(test="cg_golden", name=case["name"], hist_max_rel=dev)
-        assert dev <= 1.0, case["name"]
+        ref_hist = np.array(case["residuals"])
+        dev = _hist_dev(st.residuals, ref_hist)
+        rel = _hist_rel(st.residuals, ref_hist)
+        parity_log(test="golden", name=case["name"], hist_tol_units=dev, hist_max_rel=rel)
+        if case["solver"] == "bicgstab":
+            assert rel <= HIST_RTOL_BICGSTAB, case["name"]
+        else:
+            assert dev <= 1.0, case["name"]
 
 
 def test_cg_device_generated_operator_64(K, ctx, oracle):
