@@ -168,6 +168,10 @@ int khip_panel_norm(khip_ctx *ctx, int64_t n, int p, const double *Q, double *re
  * khip_comm_unique_id on rank 0 and broadcast by the launcher (torch.distributed / MPI). */
 int khip_comm_unique_id(void *id128_host);
 int khip_comm_init(khip_ctx *ctx, int rank, int nranks, const void *id128_host);
+/* In-process backend: all `nranks` ranks are contexts of THIS process (one host thread each; any mix of
+ * devices, including several ranks on one GPU), exchanging by device-to-device copies.  Same semantics as
+ * the RCCL backend for everything built on top; used to test the distributed path on a single GPU. */
+int khip_comm_init_local(khip_ctx *ctx, int rank, int nranks, int hub_id);
 int khip_comm_rank(khip_ctx *ctx, int *rank, int *nranks);
 int khip_comm_barrier(khip_ctx *ctx);
 

@@ -111,6 +111,7 @@ SIGNATURES = {
     "khip_panel_norm": (_int, [_vp, _i64, _int, _vp, c_double_p]),
     "khip_comm_unique_id": (_int, [_vp]),
     "khip_comm_init": (_int, [_vp, _int, _int, _vp]),
+    "khip_comm_init_local": (_int, [_vp, _int, _int, _int]),
     "khip_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "khip_comm_barrier": (_int, [_vp]),
     "khip_default_options": (COptions, []),
@@ -249,6 +250,11 @@ class Context:
         assert len(unique_id) == 128
         buf = C.create_string_buffer(unique_id, 128)
         _ck(lib().khip_comm_init(self._h, rank, nranks, buf))
+        self.rank, self.nranks = rank, nranks
+
+    def comm_init_local(self, rank: int, nranks: int, hub_id: int = 0):
+        """In-process communicator: the ranks are contexts of this process, one host thread each."""
+        _ck(lib().khip_comm_init_local(self._h, rank, nranks, hub_id))
         self.rank, self.nranks = rank, nranks
 
     def barrier(self):

@@ -295,13 +295,20 @@ int khip_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y) {
 int khip_spmv_dot(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, double *result_host) {
   KHIP_REQUIRE(ctx && A && x && y && result_host, "spmv_dot: null argument");
   KHIP_REQUIRE(x != y, "spmv_dot: x and y must not alias");
-  KHIP_REQUIRE(A->m == (A->dist ? A->m : A->n), "spmv_dot: operator must be square");
   const int slot = take_slots(ctx, 3);
   int ns = 1;
   KHIP_TRY(spmv_any(ctx, A, x, y, slot, &ns));
+  // A distributed operator may be split into interior + two boundary launches on SOME ranks only (a rank
+  // whose rows all touch ghosts is not split): every rank must contribute the same number of partials to
+  // the all-reduce, so unsplit ranks pad with zeros.
+  const int nfetch = (A->dist && ctx->comm) ? 3 : 1;
+  if (nfetch == 3 && ns == 1) {
+    KHIP_CHECK_HIP(hipMemsetAsync(ctx->results + slot + 1, 0, sizeof(double) * 2, ctx->stream));
+    KHIP_CHECK_HIP(hipMemsetAsync(ctx->results_dd + slot + 1, 0, sizeof(dd) * 2, ctx->stream));
+  }
   double r[3] = {0, 0, 0};
-  KHIP_TRY(fetch_results(ctx, slot, ns, r));
-  *result_host = ns == 1 ? r[0] : (r[0] + r[1]) + r[2];
+  KHIP_TRY(fetch_results(ctx, slot, nfetch, r));
+  *result_host = nfetch == 1 ? r[0] : (r[0] + r[1]) + r[2];
   return KHIP_OK;
 }
 

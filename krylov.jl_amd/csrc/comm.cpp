@@ -16,7 +16,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdarg>
+#include <map>
+#include <mutex>
 
 #include "khip_internal.hpp"
 
@@ -84,9 +87,41 @@ static int load_rccl() {
     }                                                                                          \
   } while (0)
 
+// In-process communicator ("local" backend): all ranks are contexts of ONE process, each driven by its
+// own host thread, and exchange through device-to-device copies plus a host barrier.  It exists so that
+// the whole distributed path (plan construction on the device, [owned | ghost] kernels, interior /
+// boundary split, all-reduced dots) can be tested on a single GPU, where RCCL refuses two ranks on one
+// device; it is also usable for one-process multi-GPU runs.  Only the three transport calls differ from
+// the RCCL backend.
+struct LocalHub {
+  int nranks = 0;
+  int joined = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int waiting = 0;
+  long generation = 0;
+  std::vector<std::vector<char>> stage;          // per-rank host staging for the small all-gathers
+  std::vector<const double *> sendbuf;           // per-rank device send buffers of the current exchange
+  std::vector<std::vector<int64_t>> send_off;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++waiting == nranks) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+static std::mutex g_hub_mu;
+static std::map<int, LocalHub *> g_hubs;
+
 struct Comm {
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  LocalHub *hub = nullptr;         // non-null => local backend
   dd *gather_dev = nullptr;       // [nranks][kMaxRedOut]
   dd *gather_pinned = nullptr;
   void *scratch_dev = nullptr;    // setup-time allgather staging
@@ -135,6 +170,14 @@ int build_halo_plan_host(int rank, int nranks, const int64_t *row_starts, const 
 // --------------------------------------------------------------------------- setup-time allgather
 static int allgather_host(khip_ctx *ctx, const void *in, void *out, size_t bytes_per_rank) {
   Comm *c = ctx->comm;
+  if (c->hub) {
+    LocalHub *h = c->hub;
+    h->stage[c->rank].assign(static_cast<const char *>(in), static_cast<const char *>(in) + bytes_per_rank);
+    h->barrier();
+    for (int r = 0; r < c->nranks; ++r) memcpy(static_cast<char *>(out) + (size_t)r * bytes_per_rank, h->stage[r].data(), bytes_per_rank);
+    h->barrier();
+    return KHIP_OK;
+  }
   const size_t need = bytes_per_rank * (size_t)(c->nranks + 1);
   if (need > c->scratch_bytes) {
     if (c->scratch_dev) KHIP_CHECK_HIP(hipFree(c->scratch_dev));
@@ -243,6 +286,21 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x) 
   Comm *c = ctx->comm;
   if (!c || c->nranks == 1 || (A->n_send == 0 && A->n_ghost == 0)) return KHIP_OK;
   KHIP_TRY(launch_gather(ctx, A->n_send, A->send_idx, x, A->sendbuf));
+  if (c->hub) {
+    LocalHub *h = c->hub;
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));          // my send buffer is packed
+    h->sendbuf[c->rank] = A->sendbuf;
+    h->send_off[c->rank] = A->send_off;
+    h->barrier();                                                // everybody's buffers are packed and published
+    for (int r = 0; r < c->nranks; ++r) {
+      if (r == c->rank) continue;
+      const int64_t nr = A->recv_off[r + 1] - A->recv_off[r];
+      if (nr > 0)
+        KHIP_CHECK_HIP(hipMemcpyAsync(A->ghost + A->recv_off[r], h->sendbuf[r] + h->send_off[r][c->rank], sizeof(double) * (size_t)nr,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return KHIP_OK;
+  }
   hipStream_t cs = ctx->tune.overlap_halo ? ctx->comm_stream : ctx->stream;
   if (cs != ctx->stream) {
     KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a, ctx->stream));
@@ -264,6 +322,11 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x) 
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A) {
   Comm *c = ctx->comm;
   if (!c || c->nranks == 1 || (A->n_send == 0 && A->n_ghost == 0)) return KHIP_OK;
+  if (c->hub) {
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));          // my copies out of the peers' buffers are done
+    c->hub->barrier();                                          // ... and so are theirs out of mine
+    return KHIP_OK;
+  }
   if (ctx->tune.overlap_halo) KHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_b, 0));
   return KHIP_OK;
 }
@@ -279,10 +342,17 @@ int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host) 
   Comm *c = ctx->comm;
   if (count > kMaxRedOut) { set_error("allreduce: too many scalars"); return KHIP_ERR_INVALID; }
   const int G = c->nranks;
-  KHIP_CHECK_NCCL(g_rccl.AllGather(vals_dev, c->gather_dev, (size_t)count * 2, ncclFloat64, c->comm, ctx->stream));
-  KHIP_CHECK_HIP(hipMemcpyAsync(c->gather_pinned, c->gather_dev, sizeof(dd) * (size_t)count * G, hipMemcpyDeviceToHost,
-                                ctx->stream));
-  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (c->hub) {
+    std::vector<dd> mine((size_t)count);
+    KHIP_CHECK_HIP(hipMemcpyAsync(mine.data(), vals_dev, sizeof(dd) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    KHIP_TRY(allgather_host(ctx, mine.data(), c->gather_pinned, sizeof(dd) * (size_t)count));
+  } else {
+    KHIP_CHECK_NCCL(g_rccl.AllGather(vals_dev, c->gather_dev, (size_t)count * 2, ncclFloat64, c->comm, ctx->stream));
+    KHIP_CHECK_HIP(hipMemcpyAsync(c->gather_pinned, c->gather_dev, sizeof(dd) * (size_t)count * G, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
   for (int i = 0; i < count; ++i) {
     double hi = 0.0, lo = 0.0;
     for (int r = 0; r < G; ++r) {   // fixed rank order -> identical on every rank
@@ -337,6 +407,37 @@ int khip_comm_init(khip_ctx *ctx, int rank, int nranks, const void *id128_host) 
   return KHIP_OK;
 }
 
+int khip_comm_init_local(khip_ctx *ctx, int rank, int nranks, int hub_id) {
+  KHIP_REQUIRE(ctx && nranks >= 1 && rank >= 0 && rank < nranks, "comm_init_local: bad arguments");
+  KHIP_REQUIRE(!ctx->comm, "comm_init_local: context already has a communicator");
+  KHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  LocalHub *h = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_hub_mu);
+    auto it = g_hubs.find(hub_id);
+    if (it == g_hubs.end()) {
+      h = new LocalHub();
+      h->nranks = nranks;
+      h->stage.resize(nranks);
+      h->sendbuf.assign(nranks, nullptr);
+      h->send_off.resize(nranks);
+      g_hubs[hub_id] = h;
+    } else {
+      h = it->second;
+    }
+    KHIP_REQUIRE(h->nranks == nranks, "comm_init_local: hub %d was created for %d ranks", hub_id, h->nranks);
+    h->joined++;
+  }
+  Comm *c = new Comm();
+  c->rank = rank;
+  c->nranks = nranks;
+  c->hub = h;
+  KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->gather_pinned), sizeof(dd) * (size_t)kMaxRedOut * nranks,
+                               hipHostMallocDefault));
+  ctx->comm = c;
+  return KHIP_OK;
+}
+
 int khip_comm_rank(khip_ctx *ctx, int *rank, int *nranks) {
   KHIP_REQUIRE(ctx, "comm_rank: null context");
   if (rank) *rank = ctx->comm ? ctx->comm->rank : 0;
@@ -356,7 +457,7 @@ int khip_comm_barrier(khip_ctx *ctx) {
 int khip_comm_destroy_internal(khip_ctx *ctx) {
   Comm *c = ctx->comm;
   if (!c) return KHIP_OK;
-  if (c->comm) g_rccl.CommDestroy(c->comm);
+  if (c->comm && !c->hub) g_rccl.CommDestroy(c->comm);
   if (c->gather_dev) (void)hipFree(c->gather_dev);
   if (c->gather_pinned) (void)hipHostFree(c->gather_pinned);
   if (c->scratch_dev) (void)hipFree(c->scratch_dev);

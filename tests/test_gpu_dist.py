@@ -47,3 +47,100 @@ def test_row_slab_with_ghost_columns_single_process(K, dctx, oracle):
     n = n1 ** 3
     with pytest.raises(K.KhipError):
         K.CsrMatrix.stencil(dctx, "poisson", n1, rows=(n // 4, n // 2), distributed=True)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Several ranks on ONE GPU through the in-process communicator (khip_comm_init_local): every rank is a
+# context driven by its own host thread.  Exercises the device-side halo-plan construction with real
+# ghost columns, the [owned | ghost] kernels, the interior/boundary split with fused dots and the
+# all-reduced reductions; only the three RCCL transport calls are replaced by device-to-device copies.
+import threading
+
+
+def _run_ranks(K, world, hub_id, body):
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            c = K.Context(0)
+            c.comm_init_local(rank, world, hub_id)
+            results[rank] = body(c, rank)
+            c.barrier()
+            c.close()
+        except Exception as e:  # pragma: no cover
+            import traceback
+            errors.append(f"rank {rank}: {e}\n{traceback.format_exc()}")
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in ts), "a rank is stuck (collective mismatch)"
+    return results
+
+
+@pytest.mark.parametrize("world,n1", [(2, 16), (4, 16), (3, 15), (8, 16)])
+def test_distributed_spmv_and_cg_local_ranks(K, oracle, world, n1):
+    A_cpu = oracle.poisson3d(n1)
+    n = A_cpu.n
+    x = np.linspace(-1, 1, n) ** 3 + 0.25
+    y_ref = A_cpu.matvec(x)
+    ref = oracle.cg(A_cpu, np.ones(n), history=True)
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = K.CsrMatrix.stencil(c, "poisson", n1, rows=(r0, r1), distributed=True)
+        out = {}
+        for overlap in (1, 0):
+            c.set_option("overlap_halo", overlap)
+            y = A.matvec(c.array(x[r0:r1])).to_host()
+            out[f"y{overlap}"] = y
+            yv = c.empty(r1 - r0)
+            out[f"d{overlap}"] = K.spmv_dot(A, c.array(x[r0:r1]), yv)
+        c.set_option("overlap_halo", 1)
+        b = c.empty(r1 - r0)
+        K.kfill_(b, 1.0)
+        for fused in (True, False):
+            xs, st, _ = K.cg(A, b, history=True, fused=fused)
+            out[f"cg{int(fused)}"] = (st.niter, st.residuals, xs.to_host(), st.status)
+        return out
+
+    res = _run_ranks(K, world, 100 + world * 10 + n1, body)
+    d_ref = oracle.dot(x, y_ref)
+    for rank, out in enumerate(res):
+        r0, r1 = starts[rank], starts[rank + 1]
+        for overlap in (1, 0):
+            assert np.array_equal(out[f"y{overlap}"], y_ref[r0:r1]), (rank, overlap)        # bit-identical to the oracle
+            assert abs(out[f"d{overlap}"] - d_ref) <= 4 * np.finfo(float).eps * abs(d_ref) + 1e-16 * np.abs(x * y_ref).sum()
+        for fused in (1, 0):
+            niter, hist, xs, status = out[f"cg{fused}"]
+            assert niter == ref.niter and status == ref.status
+            assert np.max(np.abs(hist - ref.residuals) / ref.residuals) <= 1e-10
+            assert np.allclose(xs, ref.x[r0:r1], atol=1e-10)
+        # every rank computed the bit-identical scalars
+        assert np.array_equal(out["cg1"][1], res[0]["cg1"][1])
+
+
+def test_distributed_gmres_bicgstab_local_ranks(K, oracle):
+    world, n1 = 2, 10
+    A_cpu = oracle.kron_unsymmetric(n1)
+    n = A_cpu.n
+    bh = A_cpu.matvec(np.ones(n))
+    ref_g = oracle.gmres(A_cpu, bh, memory=10, restart=True, history=True)
+    ref_b = oracle.bicgstab(A_cpu, bh, history=True)
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+        b = c.array(bh[r0:r1])
+        _, stg, _ = K.gmres(A, b, memory=10, restart=True, history=True)
+        _, stb, _ = K.bicgstab(A, b, history=True)
+        return stg.niter, stg.residuals, stb.niter, stb.residuals
+
+    for rank, (gi, gh, bi, bhist) in enumerate(_run_ranks(K, world, 777, body)):
+        assert gi == ref_g.niter and bi == ref_b.niter
+        assert np.max(np.abs(gh - ref_g.residuals) / (1e-10 * ref_g.residuals + 100 * np.finfo(float).eps * ref_g.residuals[0])) <= 1.0
+        assert np.max(np.abs(bhist - ref_b.residuals) / ref_b.residuals) <= 1e-7
