@@ -268,9 +268,10 @@ int khip_spmv_bytes(const khip_csr *A, int64_t *bytes) {
   return KHIP_OK;
 }
 
-// y <- A x, handling the halo exchange + interior/boundary split for distributed handles.
-static int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, int *nslots) {
-  if (nslots) *nslots = 1;
+// y <- A x (optionally fused with x . y into results[dot_slot]), handling the halo exchange and the
+// interior / boundary split of distributed handles.  The up to three launches of a split product feed a
+// single finish kernel, so every rank contributes exactly one partial to the all-reduce.
+static int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot) {
   if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m);
   KHIP_TRY(comm_halo_exchange_begin(ctx, A, x));
   const bool split = ctx->tune.overlap_halo && A->interior_hi > A->interior_lo;
@@ -278,38 +279,26 @@ static int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y
     KHIP_TRY(comm_halo_exchange_end(ctx, A));
     return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m);
   }
-  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_lo, A->interior_hi));
+  int64_t cursor = 0;
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_lo, A->interior_hi, &cursor, false));
   KHIP_TRY(comm_halo_exchange_end(ctx, A));
-  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot >= 0 ? dot_slot + 1 : -1, 0, A->interior_lo));
-  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot >= 0 ? dot_slot + 2 : -1, A->interior_hi, A->m));
-  if (nslots) *nslots = 3;
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, 0, A->interior_lo, &cursor, false));
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_hi, A->m, &cursor, true));
   return KHIP_OK;
 }
 
 int khip_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y) {
   KHIP_REQUIRE(ctx && A && x && y, "spmv: null argument");
   KHIP_REQUIRE(x != y, "spmv: x and y must not alias");
-  return spmv_any(ctx, A, x, y, -1, nullptr);
+  return spmv_any(ctx, A, x, y, -1);
 }
 
 int khip_spmv_dot(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, double *result_host) {
   KHIP_REQUIRE(ctx && A && x && y && result_host, "spmv_dot: null argument");
   KHIP_REQUIRE(x != y, "spmv_dot: x and y must not alias");
-  const int slot = take_slots(ctx, 3);
-  int ns = 1;
-  KHIP_TRY(spmv_any(ctx, A, x, y, slot, &ns));
-  // A distributed operator may be split into interior + two boundary launches on SOME ranks only (a rank
-  // whose rows all touch ghosts is not split): every rank must contribute the same number of partials to
-  // the all-reduce, so unsplit ranks pad with zeros.
-  const int nfetch = (A->dist && ctx->comm) ? 3 : 1;
-  if (nfetch == 3 && ns == 1) {
-    KHIP_CHECK_HIP(hipMemsetAsync(ctx->results + slot + 1, 0, sizeof(double) * 2, ctx->stream));
-    KHIP_CHECK_HIP(hipMemsetAsync(ctx->results_dd + slot + 1, 0, sizeof(dd) * 2, ctx->stream));
-  }
-  double r[3] = {0, 0, 0};
-  KHIP_TRY(fetch_results(ctx, slot, nfetch, r));
-  *result_host = nfetch == 1 ? r[0] : (r[0] + r[1]) + r[2];
-  return KHIP_OK;
+  const int slot = take_slots(ctx, 1);
+  KHIP_TRY(spmv_any(ctx, A, x, y, slot));
+  return fetch_results(ctx, slot, 1, result_host);
 }
 
 int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms) {

@@ -388,20 +388,28 @@ int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host, 
 // ------------------------------------------------------------ scratch / results ---
 int ensure_reduction_scratch(khip_ctx *ctx, int64_t nwaves, int nout) {
   if (nout > kMaxNout) { set_error("too many reduction outputs"); return KHIP_ERR_INVALID; }
+  if (!ctx->partials2) {                                   // fixed-size parts, allocated once
+    KHIP_CHECK_HIP(hipMalloc(&ctx->partials2, sizeof(dd) * (size_t)kMaxNout * kFinishMaxBlocks));
+    KHIP_CHECK_HIP(hipMalloc(&ctx->tickets, sizeof(unsigned) * 32));
+    KHIP_CHECK_HIP(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 32));
+    ctx->scratch_word = reinterpret_cast<int *>(ctx->tickets + 16);
+  }
   if (nwaves <= ctx->red_cap1) return KHIP_OK;
-  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   int64_t cap1 = 1 << 18;
   while (cap1 < nwaves) cap1 <<= 1;
-  if (ctx->partials) KHIP_CHECK_HIP(hipFree(ctx->partials));
-  if (ctx->partials2) KHIP_CHECK_HIP(hipFree(ctx->partials2));
-  if (ctx->tickets) KHIP_CHECK_HIP(hipFree(ctx->tickets));
-  ctx->partials = nullptr; ctx->partials2 = nullptr; ctx->tickets = nullptr; ctx->red_cap1 = 0;
-  KHIP_CHECK_HIP(hipMalloc(&ctx->partials, sizeof(dd) * (size_t)kMaxNout * (size_t)cap1));
-  KHIP_CHECK_HIP(hipMalloc(&ctx->partials2, sizeof(dd) * (size_t)kMaxNout * kFinishMaxBlocks));
-  KHIP_CHECK_HIP(hipMalloc(&ctx->tickets, sizeof(unsigned) * 32));
-  KHIP_CHECK_HIP(hipMemset(ctx->tickets, 0, sizeof(unsigned) * 32));
+  dd *fresh = nullptr;
+  KHIP_CHECK_HIP(hipMalloc(&fresh, sizeof(dd) * (size_t)kMaxNout * (size_t)cap1));
+  if (ctx->partials) {
+    // growth in the middle of a multi-launch reduction (split distributed SpMV): keep what the earlier
+    // launches have published -- stream-ordered copy, then retire the old buffer
+    for (int o = 0; o < kMaxNout; ++o)
+      KHIP_CHECK_HIP(hipMemcpyAsync(fresh + (size_t)o * cap1, ctx->partials + (size_t)o * ctx->red_cap1,
+                                    sizeof(dd) * (size_t)ctx->red_cap1, hipMemcpyDeviceToDevice, ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    KHIP_CHECK_HIP(hipFree(ctx->partials));
+  }
+  ctx->partials = fresh;
   ctx->red_cap1 = cap1;
-  ctx->scratch_word = reinterpret_cast<int *>(ctx->tickets + 16);
   return KHIP_OK;
 }
 

@@ -76,13 +76,14 @@ struct RedArgs {
   double *results;     // ring base
   dd *results_dd;      // ring base
   int64_t cap;
+  int64_t wave_offset;  // first partial index of this launch (several launches may feed one finish)
   int slot;
 };
 
 // Streaming-kernel side: every wave folds its lanes and stores one partial per output.
 template <int NOUT>
 __device__ __forceinline__ void wave_publish(dd (&acc)[NOUT], const RedArgs &ra) {
-  const int64_t wid = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t wid = ra.wave_offset + (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     dd r = wave_reduce(acc[o]);
@@ -185,6 +186,7 @@ inline RedArgs make_red_args(khip_ctx *ctx, int slot) {
   ra.results = ctx->results;
   ra.results_dd = ctx->results_dd;
   ra.cap = ctx->red_cap1;
+  ra.wave_offset = 0;
   ra.slot = slot;
   return ra;
 }

@@ -148,7 +148,7 @@ int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host);
 
 // spmv.hip
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot /* -1 = none */,
-                int64_t row_lo, int64_t row_hi);
+                int64_t row_lo, int64_t row_hi, int64_t *wave_cursor = nullptr, bool finish = true);
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
 int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays are resident
 int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out);

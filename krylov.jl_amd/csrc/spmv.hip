@@ -384,10 +384,18 @@ static inline unsigned pick_grid(khip_ctx *ctx, int64_t tiles, bool persist) {
   return (unsigned)(tiles < cap ? tiles : cap);
 }
 
+// dot_slot >= 0 fuses x . y.  Several launches (interior + boundary ranges of a distributed operator) can
+// feed ONE reduction: each passes the running partial count in *wave_cursor (updated here) and only the
+// last one sets `finish`, which folds all partials written so far into results[dot_slot].
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, int64_t row_lo,
-                int64_t row_hi) {
+                int64_t row_hi, int64_t *wave_cursor, bool finish) {
+  int64_t local_cursor = 0;
+  if (!wave_cursor) wave_cursor = &local_cursor;
   if (row_hi <= row_lo) {
-    if (dot_slot >= 0) return launch_nrm2sq(ctx, 0, x, dot_slot);   // writes 0
+    if (dot_slot >= 0 && finish) {
+      if (*wave_cursor == 0) return launch_nrm2sq(ctx, 0, x, dot_slot);   // nothing at all: writes 0
+      return launch_finish(ctx, *wave_cursor, 1, dot_slot);
+    }
     return KHIP_OK;
   }
   SpmvArgs a;
@@ -434,8 +442,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
     if (rows != 256 && rows != 128 && rows != 64 && rows != 32) rows = 256;
     grid = pick_grid(ctx, (nrows + rows - 1) / rows, persist);
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));
-    ra = make_red_args(ctx, dot ? dot_slot : 0);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));
+    ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
     const int vec = ctx->tune.spmv_vec == 2 ? 2 : 1;
 #define KHIP_ROWS(R)                                                                              \
   do {                                                                                            \
@@ -459,8 +467,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     const int64_t nrb4 = (nrows + rows - 1) / rows;
     grid = pick_grid(ctx, (nrb4 + a.tiles_per_block - 1) / a.tiles_per_block, false);
     if ((int64_t)grid * a.tiles_per_block < nrb4) a.tiles_per_block = (int)((nrb4 + grid - 1) / grid);
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));
-    ra = make_red_args(ctx, dot ? dot_slot : 0);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));
+    ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
 #define KHIP_STG(R) do { if (nt) launch_stage_cfg<R, true>(ctx, a, ra, grid, dot, comp, dist); \
                          else launch_stage_cfg<R, false>(ctx, a, ra, grid, dot, comp, dist); } while (0)
     switch (rows) {
@@ -481,8 +489,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   do {                                                                                        \
     constexpr int rpb = (64 / LL) * RPG * kWavesPerBlock;                                     \
     grid = pick_grid(ctx, (nrows + rpb - 1) / rpb, persist);                                  \
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));                                \
-    ra = make_red_args(ctx, dot ? dot_slot : 0);                                              \
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));                                \
+    ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;                                              \
     if (nt) launch_ordered_cfg<LL, RPG, true>(ctx, a, ra, grid, dot, comp, dist);             \
     else launch_ordered_cfg<LL, RPG, false>(ctx, a, ra, grid, dot, comp, dist);               \
   } while (0)
@@ -502,8 +510,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
     const int rpb = kBlock / lpr;
     grid = pick_grid(ctx, (nrows + rpb - 1) / rpb, persist);
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, (int64_t)grid * kWavesPerBlock, 1));
-    ra = make_red_args(ctx, dot ? dot_slot : 0);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));
+    ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
     switch (lpr) {
       case 4: launch_vector_cfg<4>(ctx, a, ra, grid, dot, comp, dist); break;
       case 8: launch_vector_cfg<8>(ctx, a, ra, grid, dot, comp, dist); break;
@@ -513,7 +521,10 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
   }
   KHIP_CHECK_HIP(hipGetLastError());
-  if (dot) KHIP_TRY(launch_finish(ctx, (int64_t)grid * kWavesPerBlock, 1, dot_slot));
+  if (dot) {
+    *wave_cursor += (int64_t)grid * kWavesPerBlock;
+    if (finish) KHIP_TRY(launch_finish(ctx, *wave_cursor, 1, dot_slot));
+  }
   if (ev_stop) KHIP_CHECK_HIP(hipEventRecord(ev_stop, ctx->stream));
   return KHIP_OK;
 }
