@@ -105,7 +105,10 @@ def main():
     import numpy as np
     import krylov_jl_amd as K
 
-    ctx = K.Context(local_rank)
+    try:
+        ctx = K.Context(local_rank)
+    except K.KhipError:
+        ctx = K.Context(0)          # the launcher restricted this rank to one visible device
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))

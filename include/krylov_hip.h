@@ -121,6 +121,12 @@ int khip_axpby(khip_ctx *ctx, int64_t n, double s, const double *x, double t, do
 int khip_fill(khip_ctx *ctx, int64_t n, double *x, double val);                                     /* kfill!  :347 */
 int khip_ref(khip_ctx *ctx, int64_t n, double *x, double *y, double c, double s);                   /* kref!   :349 */
 
+/* elementwise products for diagonal operators / Jacobi preconditioning (SURVEY.md section 8f N1;
+ * ref: M = Diagonal(1 ./ diag(A)) applied through mulorldiv!, src/cg.jl:160,241, test/test_gmres.jl:105-128) */
+int khip_vmul(khip_ctx *ctx, int64_t n, double *w, const double *x, const double *y);   /* w = x .* y */
+int khip_vdiv(khip_ctx *ctx, int64_t n, double *w, const double *x, const double *y);   /* w = x ./ y */
+int khip_csr_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);                  /* diag[i] = A[i,i] */
+
 /* ------------------------------------------------ fused accelerators --------- */
 /* Each equals its unfused sequence on the device up to the last bit of the reduction
  * (elementwise results are bit-identical; reductions agree to <= 1 ulp). */
@@ -198,6 +204,10 @@ typedef struct {
   khip_apply_fn   apply;     /* user operator on device pointers */
   void           *self;
 } khip_operator;
+
+/* built-in Jacobi preconditioner z <- r ./ diag(A) as an operator for the M / N arguments of the solvers */
+int khip_jacobi_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out);
+int khip_jacobi_destroy(khip_operator *op);
 
 typedef int (*khip_callback_fn)(void *workspace, void *userdata);       /* callback(workspace)::Bool */
 

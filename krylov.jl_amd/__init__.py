@@ -96,6 +96,11 @@ SIGNATURES = {
     "khip_axpby": (_int, [_vp, _i64, _dbl, _vp, _dbl, _vp]),
     "khip_fill": (_int, [_vp, _i64, _vp, _dbl]),
     "khip_ref": (_int, [_vp, _i64, _vp, _vp, _dbl, _dbl]),
+    "khip_vmul": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "khip_vdiv": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "khip_csr_diagonal": (_int, [_vp, _vp, _vp]),
+    "khip_jacobi_create": (_int, [_vp, _vp, C.POINTER(COperator)]),
+    "khip_jacobi_destroy": (_int, [C.POINTER(COperator)]),
     "khip_spmv_dot": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
     "khip_axpy2_dot": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
@@ -413,6 +418,44 @@ def kmul_(y, A, x):
     return y
 
 
+def kvmul_(n, w, x, y):
+    """w = x .* y (diagonal operator)."""
+    _ck(lib().khip_vmul(w.ctx._h, n, _p(w), _p(x), _p(y)))
+    return w
+
+
+def kvdiv_(n, w, x, y):
+    """w = x ./ y (Jacobi: z = r ./ diag(A))."""
+    _ck(lib().khip_vdiv(w.ctx._h, n, _p(w), _p(x), _p(y)))
+    return w
+
+
+class Jacobi:
+    """M = Diagonal(diag(A))^-1 on the device, usable as the M / N argument of cg_ / gmres_ / bicgstab_
+    (the reference's Jacobi examples: test/test_gmres.jl:105-128, docs/src/gpu.md)."""
+
+    def __init__(self, A: "CsrMatrix"):
+        self.ctx, self.n = A.ctx, A.m
+        self.op = COperator()
+        _ck(lib().khip_jacobi_create(A.ctx._h, A._h, C.byref(self.op)))
+
+    def __call__(self, x, y):
+        return self._apply(x, y)
+
+    def _apply(self, x, y):
+        rc = self.op.apply(self.op.self, _p(x), _p(y))
+        if rc:
+            raise KhipError(rc, lib().khip_last_error().decode())
+        return y
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                lib().khip_jacobi_destroy(C.byref(self.op))
+        except Exception:
+            pass
+
+
 # fused accelerators
 def spmv_dot(A, x, y) -> float:
     r = C.c_double()
@@ -538,6 +581,11 @@ class CsrMatrix:
         except Exception:
             pass
 
+    def diagonal(self) -> DeviceVector:
+        d = DeviceVector(self.ctx, self.m)
+        _ck(lib().khip_csr_diagonal(self.ctx._h, self._h, d.ptr))
+        return d
+
     def matvec(self, x: DeviceVector, y: DeviceVector | None = None) -> DeviceVector:
         y = y if y is not None else DeviceVector(self.ctx, self.m)
         return kmul_(y, self, x)
@@ -590,6 +638,9 @@ def _make_operator(ctx, op, n, keep):
     """CsrMatrix | callable(x: DeviceVector, y: DeviceVector) | None -> POINTER(COperator) or None."""
     if op is None:
         return None
+    if isinstance(op, Jacobi):          # native operator: no Python in the loop
+        keep.append(op)
+        return C.byref(op.op)
     co = COperator()
     if isinstance(op, CsrMatrix):
         co.csr = op._h

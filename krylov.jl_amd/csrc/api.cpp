@@ -8,7 +8,7 @@ using namespace khip;
 extern "C" int khip_comm_destroy_internal(khip_ctx *ctx);
 
 namespace khip {
-enum MapOpHost { H_COPY = 0, H_FILL, H_SCAL, H_SCALCOPY, H_DIVCOPY, H_AXPY, H_AXPBY, H_REF, H_WAXPY };
+enum MapOpHost { H_COPY = 0, H_FILL, H_SCAL, H_SCALCOPY, H_DIVCOPY, H_AXPY, H_AXPBY, H_REF, H_WAXPY, H_VMUL, H_VDIV };
 constexpr int kPadHost = 8;
 }  // namespace khip
 
@@ -390,6 +390,45 @@ int khip_waxpy(khip_ctx *ctx, int64_t n, double *w, const double *x, double b, c
   KHIP_VEC_ARGS("waxpy", w && x && y);
   // launch_map's WAXPY computes w = fma(b, Y, X) with X = x-argument, Y = y-argument
   return launch_map(ctx, H_WAXPY, n, 0, b, x, const_cast<double *>(y), w);
+}
+
+int khip_vmul(khip_ctx *ctx, int64_t n, double *w, const double *x, const double *y) {
+  KHIP_VEC_ARGS("vmul", w && x && y);
+  return launch_map(ctx, H_VMUL, n, 0, 0, x, const_cast<double *>(y), w);
+}
+int khip_vdiv(khip_ctx *ctx, int64_t n, double *w, const double *x, const double *y) {
+  KHIP_VEC_ARGS("vdiv", w && x && y);
+  return launch_map(ctx, H_VDIV, n, 0, 0, x, const_cast<double *>(y), w);
+}
+int khip_csr_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag) {
+  KHIP_REQUIRE(ctx && A && diag, "csr_diagonal: null argument");
+  return launch_diagonal(ctx, A, diag);
+}
+
+// Jacobi preconditioner as a khip_operator: z <- r ./ diag(A)
+struct khip_jacobi { khip_ctx *ctx; int64_t n; double *diag; };
+static int jacobi_apply(void *self, const double *x, double *y) {
+  khip_jacobi *j = static_cast<khip_jacobi *>(self);
+  return khip_vdiv(j->ctx, j->n, y, x, j->diag);
+}
+int khip_jacobi_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
+  KHIP_REQUIRE(ctx && A && op_out, "jacobi_create: null argument");
+  khip_jacobi *j = new khip_jacobi{ctx, A->m, nullptr};
+  int rc = khip_malloc(ctx, sizeof(double) * (size_t)((A->m + 33) & ~(int64_t)31), reinterpret_cast<void **>(&j->diag));
+  if (!rc) rc = launch_diagonal(ctx, A, j->diag);
+  if (rc) { khip_free(ctx, j->diag); delete j; return rc; }
+  op_out->csr = nullptr;
+  op_out->apply = jacobi_apply;
+  op_out->self = j;
+  return KHIP_OK;
+}
+int khip_jacobi_destroy(khip_operator *op) {
+  if (!op || op->apply != jacobi_apply || !op->self) return KHIP_OK;
+  khip_jacobi *j = static_cast<khip_jacobi *>(op->self);
+  khip_free(j->ctx, j->diag);
+  delete j;
+  op->self = nullptr;
+  return KHIP_OK;
 }
 
 int khip_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const double *q, double *x, double *r,

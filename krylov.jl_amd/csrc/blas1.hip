@@ -24,6 +24,8 @@ enum MapOp {
   OP_AXPBY = 6,     // y = fma(a, x, b * y)
   OP_REF = 7,       // (x, y) = (a x + b y, b x - a y)      [a = c, b = s]
   OP_WAXPY = 8,     // w = fma(b, y, x)
+  OP_VMUL = 9,      // w = x * y   (diagonal operator)
+  OP_VDIV = 10,     // w = x / y   (Jacobi: z = r ./ diag(A))
 };
 
 template <int VEC> struct VecT;
@@ -46,10 +48,10 @@ template <bool NT, typename T> __device__ __forceinline__ void stg(T v, T *p) {
 
 template <int OP> __host__ __device__ constexpr bool reads_x() {
   return OP == OP_COPY || OP == OP_SCALCOPY || OP == OP_DIVCOPY || OP == OP_AXPY || OP == OP_AXPBY ||
-         OP == OP_REF || OP == OP_WAXPY;
+         OP == OP_REF || OP == OP_WAXPY || OP == OP_VMUL || OP == OP_VDIV;
 }
 template <int OP> __host__ __device__ constexpr bool reads_y() {
-  return OP == OP_SCAL || OP == OP_AXPY || OP == OP_AXPBY || OP == OP_REF || OP == OP_WAXPY;
+  return OP == OP_SCAL || OP == OP_AXPY || OP == OP_AXPBY || OP == OP_REF || OP == OP_WAXPY || OP == OP_VMUL || OP == OP_VDIV;
 }
 
 template <int OP>
@@ -64,6 +66,8 @@ __device__ __forceinline__ void map_scalar(double a, double b, double xv, double
   else if (OP == OP_AXPBY) oy = fma(a, xv, b * yv);
   else if (OP == OP_REF) { ox = a * xv + b * yv; oy = b * xv - a * yv; }
   else if (OP == OP_WAXPY) oy = fma(b, yv, xv);
+  else if (OP == OP_VMUL) oy = xv * yv;
+  else if (OP == OP_VDIV) oy = xv / yv;
 }
 
 // x, y, w deliberately NOT __restrict__: exact aliasing is legal (BLAS semantics, src/bicgstab.jl:153-157).
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void map_kernel(int64_t n, double a, double
   const int64_t base = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
   const T *X = reinterpret_cast<const T *>(x);
   T *Y = reinterpret_cast<T *>(y);
-  T *W = reinterpret_cast<T *>(OP == OP_WAXPY ? w : y);
+  T *W = reinterpret_cast<T *>((OP == OP_WAXPY || OP == OP_VMUL || OP == OP_VDIV) ? w : y);
   T *XO = reinterpret_cast<T *>(const_cast<double *>(x));
   T xv[U] = {}, yv[U] = {};
 #pragma unroll
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void map_kernel(int64_t n, double a, double
     const int64_t t = n - 1;
     double sx, sy;
     map_scalar<OP>(a, b, reads_x<OP>() ? x[t] : 0.0, reads_y<OP>() ? y[t] : 0.0, sx, sy);
-    (OP == OP_WAXPY ? w : y)[t] = sy;
+    ((OP == OP_WAXPY || OP == OP_VMUL || OP == OP_VDIV) ? w : y)[t] = sy;
     if (OP == OP_REF) const_cast<double *>(x)[t] = sx;
   }
 }
@@ -123,7 +127,8 @@ static inline int64_t tiles_for(int64_t nvec, int u) {
 template <int OP>
 static int launch_map_op(khip_ctx *ctx, int64_t n, double a, double b, const double *x, double *y, double *w) {
   if (n <= 0) return KHIP_OK;
-  const bool v2 = (!reads_x<OP>() || aligned16(x)) && aligned16(y) && (OP != OP_WAXPY || aligned16(w)) && n >= 2;
+  constexpr bool uses_w = (OP == OP_WAXPY || OP == OP_VMUL || OP == OP_VDIV);
+  const bool v2 = (!reads_x<OP>() || aligned16(x)) && aligned16(y) && (!uses_w || aligned16(w)) && n >= 2;
   const bool nt = use_nt(ctx, n);
   const int64_t nvec = v2 ? n / 2 : n;
   const int64_t g = tiles_for(nvec, 1);
@@ -148,6 +153,8 @@ int launch_map(khip_ctx *ctx, int op, int64_t n, double a, double b, const doubl
     case OP_AXPBY: return launch_map_op<OP_AXPBY>(ctx, n, a, b, x, y, w);
     case OP_REF: return launch_map_op<OP_REF>(ctx, n, a, b, x, y, w);
     case OP_WAXPY: return launch_map_op<OP_WAXPY>(ctx, n, a, b, x, y, w);
+    case OP_VMUL: return launch_map_op<OP_VMUL>(ctx, n, a, b, x, y, w);
+    case OP_VDIV: return launch_map_op<OP_VDIV>(ctx, n, a, b, x, y, w);
     default: set_error("launch_map: unknown op %d", op); return KHIP_ERR_INVALID;
   }
 }

@@ -80,6 +80,27 @@ __global__ __launch_bounds__(kBlock) void row_stats_kernel(const int32_t *rowptr
   if ((threadIdx.x & 63) == 0) atomicMax(max_out, mx);
 }
 
+// diag[i] = A[i, i + row0] (0 when the entry is structurally absent)
+__global__ __launch_bounds__(kBlock) void diagonal_kernel(const int32_t *rowptr, const int32_t *col, const double *val, int64_t m,
+                                                           int64_t col_shift, double *diag) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    double d = 0.0;
+    for (int64_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+      if ((int64_t)col[j] == i + col_shift) d = val[j];
+    diag[i] = d;
+  }
+}
+
+int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag) {
+  if (A->m == 0) return KHIP_OK;
+  int64_t want = (A->m + kBlock - 1) / kBlock;
+  // distributed handles have their columns renumbered to [owned | ghost]: the diagonal is column i again
+  hipLaunchKernelGGL(diagonal_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col,
+                     A->val, A->m, (int64_t)0, diag);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 __global__ __launch_bounds__(kBlock) void blockptr_kernel(const int32_t *rowptr, int64_t m, int64_t nb, int32_t *bp) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= nb; i += (int64_t)gridDim.x * kBlock) {
     const int64_t r = i * 256 < m ? i * 256 : m;

@@ -157,6 +157,7 @@ int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64
                            unsigned long long *count_dev, int64_t cap);
 int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host);
 int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
+int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 
 // panel.hip
 void panel_scratch_destroy(khip_ctx *ctx);

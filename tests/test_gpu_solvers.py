@@ -155,6 +155,41 @@ def test_cg_jacobi_preconditioner_callable(K, ctx, oracle):
     assert ws.nbytes == 5 * 8 * A.n      # z allocated lazily (src/cg.jl:142)
 
 
+def test_jacobi_preconditioner_native(K, ctx, oracle, parity_log):
+    """Built-in Jacobi operator (khip_jacobi_create: z = r ./ diag(A)) on an SPD matrix with a strongly varying
+    diagonal; the oracle applies M = Diagonal(1 ./ diag(A)) as the reference's examples do
+    (test/test_gmres.jl:105-128).  Also checks the primitives khip_vmul / khip_vdiv / khip_csr_diagonal."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    P = oracle.poisson3d(10).to_scipy()
+    dvar = np.exp(rng.uniform(0, 6, P.shape[0]))
+    S = (P + sp.diags(dvar)).tocsr()
+    S.sort_indices()
+    n = S.shape[0]
+    d = S.diagonal()
+    bh = S @ np.ones(n)
+    dA = K.CsrMatrix.from_scipy(ctx, S)
+    assert np.array_equal(dA.diagonal().to_host(), d)
+    a, b2 = rng.standard_normal(n), rng.standard_normal(n) + 3.0
+    w = ctx.empty(n)
+    assert np.array_equal(K.kvmul_(n, w, ctx.array(a), ctx.array(b2)).to_host(), a * b2)
+    assert np.array_equal(K.kvdiv_(n, w, ctx.array(a), ctx.array(b2)).to_host(), a / b2)
+    ref = oracle.cg(lambda v: S @ v, bh, M=lambda r: r / d, history=True)
+    ref0 = oracle.cg(lambda v: S @ v, bh, history=True)
+    x, st, _ = K.cg(dA, ctx.array(bh), M=K.Jacobi(dA), history=True)
+    assert st.solved and st.niter == ref.niter < ref0.niter        # preconditioning pays off
+    dev = _hist_dev(st.residuals, ref.residuals)
+    parity_log(test="cg_jacobi_native", niter=st.niter, niter_unpreconditioned=ref0.niter, hist_tol_units=dev)
+    assert dev <= 1.0
+    # the same operator as right preconditioner of GMRES and BiCGSTAB
+    refg = oracle.gmres(lambda v: S @ v, bh, N=lambda r: r / d, memory=20, history=True)
+    x, stg, _ = K.gmres(dA, ctx.array(bh), N=K.Jacobi(dA), memory=20, history=True)
+    assert stg.niter == refg.niter and _hist_dev(stg.residuals, refg.residuals) <= 1.0
+    refb = oracle.bicgstab(lambda v: S @ v, bh, M=lambda r: r / d, history=True)
+    x, stb, _ = K.bicgstab(dA, ctx.array(bh), M=K.Jacobi(dA), history=True)
+    assert stb.niter == refb.niter and _hist_rel(stb.residuals, refb.residuals) <= HIST_RTOL_BICGSTAB
+
+
 # ------------------------------------------------------------------------------ GMRES
 
 @pytest.mark.parametrize("n1", [8, 16])
