@@ -26,7 +26,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkrylov_hip.so")
+LIB_PATH = os.environ.get("KHIP_LIBRARY") or os.path.join(_HERE, "libkrylov_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_void_pp = C.POINTER(C.c_void_p)

@@ -58,15 +58,46 @@ __device__ __forceinline__ dd dd_merge(dd a, dd b) {
   return r;
 }
 
+// Cross-lane moves as DPP modifiers (no LDS traffic, unlike ds_bpermute-based __shfl): lanes whose
+// source is outside the row / masked off receive 0.0, and dd_merge(v, {0, 0}) is an exact no-op.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ dd dpp_step(dd v) {
+  dd o;
+  o.hi = dpp_f64<CTRL, ROW_MASK>(v.hi);
+  o.lo = dpp_f64<CTRL, ROW_MASK>(v.lo);
+  return dd_merge(v, o);
+}
+
+constexpr int kResultLane = 63;   // wave_reduce leaves the wave total in the LAST lane
+
+// Fixed-order wave64 fold: inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then
+// row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2 and 3 (the GFX9 DPP reduction).
 __device__ __forceinline__ dd wave_reduce(dd v) {
+#ifdef KHIP_REDUCE_SHFL           // A/B experiment: ds_bpermute butterfly ending in the last lane
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int off = 1; off < 64; off <<= 1) {
     dd o;
-    o.hi = __shfl_down(v.hi, off, 64);
-    o.lo = __shfl_down(v.lo, off, 64);
+    o.hi = __shfl_up(v.hi, off, 64);
+    o.lo = __shfl_up(v.lo, off, 64);
+    if ((int)(threadIdx.x & 63) < off) o = dd{0.0, 0.0};
     v = dd_merge(v, o);
   }
-  return v;   // valid in lane 0
+  return v;
+#endif
+  v = dpp_step<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_step<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_step<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_step<0x118, 0xf>(v);   // row_shr:8
+  v = dpp_step<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+  v = dpp_step<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
+  return v;   // valid in lane kResultLane
 }
 
 struct RedArgs {
@@ -87,7 +118,7 @@ __device__ __forceinline__ void wave_publish(dd (&acc)[NOUT], const RedArgs &ra)
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     dd r = wave_reduce(acc[o]);
-    if ((threadIdx.x & 63) == 0) ra.wave_partials[(size_t)o * ra.cap + wid] = r;
+    if ((threadIdx.x & 63) == kResultLane) ra.wave_partials[(size_t)o * ra.cap + wid] = r;
   }
 }
 
@@ -98,7 +129,7 @@ __device__ __forceinline__ void block_reduce(dd (&acc)[NOUT], dd (*s_w)[kWavesPe
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     dd r = wave_reduce(acc[o]);
-    if (lane == 0) s_w[o][wave] = r;
+    if (lane == kResultLane) s_w[o][wave] = r;
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -59,6 +59,7 @@ struct Tuning {
   int spmv_nty = 0;         // non-temporal store of y
   int spmv_fake_gather = 0; // tuning experiment (wrong results): coalesced x reads
   int spmv_tiles = 1;       // staged kernel: consecutive row blocks per workgroup
+  int spmv_cap = 0;         // staged kernel LDS window in entries (0 = sized to the widest row block)
   int spmv_lds_pad = 0;     // experiment: extra dynamic LDS bytes per workgroup (lowers occupancy)
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
   int spmv_lanes = 0;       // vector kernel lanes per row (0 = auto)

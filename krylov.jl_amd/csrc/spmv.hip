@@ -151,10 +151,14 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
 template <int ROWS, bool NT, bool DOT, bool COMP, bool DIST>
 __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs ra) {
   static_assert(ROWS <= kBlock, "one lane per row");
-  constexpr int CAP = 2048;                  // window of staged entries: 8 per lane, moved as 16-byte vectors
+  // window of staged entries: up to 8 per lane, moved as 16-byte vectors.  Its size is a launch parameter
+  // (multiple of 4, <= 2048) sized to the widest row block of the matrix: LDS per workgroup is 12 * CAP
+  // bytes, so a 7-entries-per-row operator keeps 7 instead of 6 workgroups resident per CU.
+  const int CAP = a.stage_cap;
   constexpr int UK = 8;                      // row entries whose gathers are in flight together
-  __shared__ __attribute__((aligned(16))) double s_val[CAP];
-  __shared__ __attribute__((aligned(16))) int32_t s_col[CAP];
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_stage[];
+  double *s_val = reinterpret_cast<double *>(s_stage);
+  int32_t *s_col = reinterpret_cast<int32_t *>(s_stage + (size_t)CAP * sizeof(double));
   const int tid = threadIdx.x;
   const int64_t nrows = a.row_hi - a.row_lo;
   const int64_t nrb = (nrows + ROWS - 1) / ROWS;
@@ -176,29 +180,38 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
     // 4 val loads (2 entries each) + 2 col loads (4 entries each) per lane and window -- the
     // vector-memory instruction count, not HBM, is what bounds this kernel
     for (int64_t c0 = s & ~(int64_t)3; c0 < e; c0 += CAP) {
-      dbl2 v[4];
-      int4v c[2];
+      const int lim = (int)((e - c0) < (int64_t)CAP ? (e - c0) : (int64_t)CAP);   // entries of this window
+      // The window is read through buffer descriptors whose extent is the row block's own entries
+      // (rounded up to the 16-byte vector): lanes past it get zeros WITHOUT a memory request.  An
+      // over-read into the neighbouring block's entries would be fetched from HBM twice, since that block
+      // usually runs on another XCD (other L2); predicating with branches instead costs ~25 VGPRs.
+      const int lim4 = (lim + 3) & ~3;
+      const __amdgpu_buffer_rsrc_t rv =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(a.val + c0), 0, lim4 * 8, kBufRsrcWord3);
+      const __amdgpu_buffer_rsrc_t rc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.col + c0), 0, lim4 * 4, kBufRsrcWord3);
+      u32x4 v[4], c[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int o = q * (CAP / 2) + 4 * tid;
-        const int64_t j = (c0 + o + 4 <= a.nnz_bound) ? c0 + o : 0;
-        v[2 * q] = ld<NT>(reinterpret_cast<const dbl2 *>(a.val + j));
-        v[2 * q + 1] = ld<NT>(reinterpret_cast<const dbl2 *>(a.val + j + 2));
-        c[q] = ld<NT>(reinterpret_cast<const int4v *>(a.col + j));
+        const int o = q * (4 * kBlock) + 4 * tid;
+        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 0);
+        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 0);
+        c[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, o * 4, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int o = q * (CAP / 2) + 4 * tid;
-        *reinterpret_cast<dbl2 *>(s_val + o) = v[2 * q];
-        *reinterpret_cast<dbl2 *>(s_val + o + 2) = v[2 * q + 1];
-        *reinterpret_cast<int4v *>(s_col + o) = c[q];
+        const int o = q * (4 * kBlock) + 4 * tid;
+        if (o < CAP) {
+          *reinterpret_cast<u32x4 *>(s_val + o) = v[2 * q];
+          *reinterpret_cast<u32x4 *>(s_val + o + 2) = v[2 * q + 1];
+          *reinterpret_cast<u32x4 *>(s_col + o) = c[q];
+        }
       }
       __syncthreads();
       if (tid < nr) {
-        const int64_t wend = (e - c0) < CAP ? (e - c0) : CAP;
         const int rel_a = (int)(my_a - c0), rel_b = (int)(my_b - c0);
         const int lo = rel_a > 0 ? rel_a : 0;
-        const int hi = rel_b < (int)wend ? rel_b : (int)wend;
+        const int hi = rel_b < lim ? rel_b : lim;
         for (int k0 = lo; k0 < hi; k0 += UK) {
           int32_t cc[UK];
           double vv[UK], xx[UK];
@@ -349,7 +362,7 @@ template <int ROWS, bool NT>
 static void launch_stage_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                              bool dist) {
 #define KHIP_L(DOT, COMP, DIST) \
-  hipLaunchKernelGGL((spmv_stage_kernel<ROWS, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), (size_t)ctx->tune.spmv_lds_pad, ctx->stream, a, ra)
+  hipLaunchKernelGGL((spmv_stage_kernel<ROWS, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), (size_t)ctx->tune.spmv_lds_pad + 12u * (size_t)a.stage_cap, ctx->stream, a, ra)
   KHIP_DISPATCH_DCD(KHIP_L);
 #undef KHIP_L
 }
@@ -406,6 +419,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.xcd_remap = ctx->tune.spmv_xcd;
   a.nt_y = ctx->tune.spmv_nty;
   a.tiles_per_block = 1;
+  a.stage_cap = 2048;
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;
@@ -464,6 +478,11 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     if (rows != 256 && rows != 128 && rows != 64 && rows != 32) rows = 256;
     while (rows > 32 && rows * A->mean_row_nnz > 2048.0) rows >>= 1;
     a.tiles_per_block = ctx->tune.spmv_tiles > 0 ? ctx->tune.spmv_tiles : 1;
+    {   // LDS window: the widest row block (+3 for the 4-entry alignment of its start), at most 2048 entries
+      int64_t cap = ctx->tune.spmv_cap > 0 ? ctx->tune.spmv_cap : (int64_t)rows * A->max_row_nnz + 3;
+      cap = (cap + 3) & ~(int64_t)3;
+      a.stage_cap = (int)(cap < 64 ? 64 : (cap > 2048 ? 2048 : cap));
+    }
     const int64_t nrb4 = (nrows + rows - 1) / rows;
     grid = pick_grid(ctx, (nrb4 + a.tiles_per_block - 1) / a.tiles_per_block, false);
     if ((int64_t)grid * a.tiles_per_block < nrb4) a.tiles_per_block = (int)((nrb4 + grid - 1) / grid);

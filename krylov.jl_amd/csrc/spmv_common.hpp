@@ -8,6 +8,9 @@ namespace khip {
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef int int2v __attribute__((ext_vector_type(2)));
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBufRsrcWord3 = 0x00020000;   // gfx9 raw buffer descriptor: 32-bit data format, range checking on
 
 constexpr int kPad = 8;   // val/col are over-allocated by this many zeroed entries
 
@@ -25,6 +28,7 @@ struct SpmvArgs {
   int nt_y;              // non-temporal store of y
   int tiles_per_block;   // staged kernel: consecutive row blocks per workgroup (software pipeline depth)
   int64_t nnz_bound;     // nnz + pad: prefetches beyond it are clamped
+  int stage_cap;         // staged kernel: LDS window in entries (multiple of 4, <= 2048)
   int fake_gather;       // experiment: coalesced x reads instead of x[col] (WRONG results)
 };
 
