@@ -66,17 +66,25 @@ def cpu_baseline(n1, budget_s=30.0):
     A = ok.poisson3d(sample_n1)
     t_gen = time.time() - t0
     r = C.c_double()
-    iters_all = 3 if sample_n1 >= 512 else 10
-    spi_all = ok.lib().ko_cg_bench(C.byref(A.c), iters_all, ncores, C.byref(r))
-    spi_one = None
-    if time.time() - t0 < budget_s:
-        spi_one = ok.lib().ko_cg_bench(C.byref(A.c), 1 if sample_n1 >= 512 else 3, 1, C.byref(r))
-    best, cores = (spi_all, ncores)
-    if spi_one is not None and spi_one < spi_all:
-        best, cores = spi_one, 1
-    sample = (f"{iters_all} CG iterations of the oracle loop on get_div_grad({sample_n1}^3), OpenMP {ncores} threads: "
-              f"{1.0 / spi_all:.3f} it/s" + (f"; 1 thread (faithful serial SpMV): {1.0 / spi_one:.3f} it/s" if spi_one else "")
-              + f"; matrix generation {t_gen:.1f} s excluded")
+    iters = 2 if sample_n1 >= 512 else 6
+    # The box may cap CPU time below the visible core count (cgroup quota), where 256 OpenMP threads
+    # thrash: time a ladder of thread counts and report the best.  1 thread = the reference's own
+    # serial SparseMatrixCSC mul!.
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota_cpus = None if quota[0] == "max" else float(quota[0]) / float(quota[1])
+    except Exception:
+        quota_cpus = None
+    ladder = sorted({ncores, min(ncores, 64), min(ncores, 16), min(ncores, 4), 1}, reverse=True)
+    trials = {}
+    for th in ladder:
+        if trials and time.time() - t0 > budget_s:
+            break
+        trials[th] = ok.lib().ko_cg_bench(C.byref(A.c), iters, th, C.byref(r))
+    cores, best = min(trials.items(), key=lambda kv: kv[1])
+    sample = (f"{iters} CG iterations of the oracle loop (cg! recurrence, OpenMP SpMV/dot/axpy) on get_div_grad({sample_n1}^3); "
+              + "it/s by thread count: " + ", ".join(f"{th}: {1.0 / v:.3f}" for th, v in trials.items())
+              + f"; visible cores {ncores}, cgroup cpu quota {quota_cpus}; matrix generation {t_gen:.1f} s excluded")
     return {"value": 1.0 / best, "unit": "iter/s", "cores": cores, "kind": "port", "sample": sample,
             "sample_n1": sample_n1}
 
