@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1]): cg! on get_div_grad(512,512,512) (n = 134,217,728, nnz = 937,951,232),
 Float64, b = ones, x0 = 0.  A "step" is one CG iteration (1 SpMV + 2 dots + 2 axpy + 1 axpby, fused into
-3 kernels).  With --gpus N the SAME 512^3 problem is row-partitioned over N ranks (strong scaling, one
+3 kernels: SpMV+p.Ap | r update + r.r | x and p update).  With --gpus N the SAME 512^3 problem is row-partitioned over N ranks (strong scaling, one
 process per GPU, RCCL over xGMI inside libkrylov_hip: all-gather of the (hi, lo) dot partials, neighbour
 halo exchange before each SpMV).  Inputs are generated on the device, so the timed region starts with
 everything resident in HBM.
@@ -168,8 +168,8 @@ def main():
     if rank == 0:
         its = args.steps / elapsed
         spmv_bytes_local = A.spmv_bytes
-        # algorithmic bytes of one fused iteration on this rank: SpMV(+dot) + (x,r update + r.r: 48n) + (p update: 24n)
-        iter_bytes_local = spmv_bytes_local + 72 * nloc
+        # algorithmic bytes of one fused iteration on this rank: SpMV(+dot) + (r update + r.r: 24n) + (x and p update: 40n)
+        iter_bytes_local = spmv_bytes_local + 64 * nloc
         iter_bytes_unfused_local = spmv_bytes_local + 104 * nloc       # as the reference issues it
         spmv_per_iter = launches / max(args.steps, 1)
         avg_spmv_ms = spmv_ms / max(args.steps, 1)                    # all SpMV launches of one iteration

@@ -135,6 +135,11 @@ int khip_spmv_dot(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, 
 /* x <- x + a p ; r <- r - a q ; *result_host = r . r     (src/cg.jl:239-242 with M = I) */
 int khip_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const double *q,
                    double *x, double *r, double *result_host);
+/* y <- y + a x ; *result_host = y . y                      (src/cg.jl:240,242 with M = I: r <- r - alpha Ap ; r.r) */
+int khip_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, double *result_host);
+/* x <- x + a p ; p <- r + b p in one pass over p          (src/cg.jl:239 and :259 = kaxpy!(n, a, p, x) ; kaxpby!(n, 1, r, b, p)).
+ * Legal because x is not read between the two reference lines; 40n bytes instead of 48n. */
+int khip_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x);
 /* w <- x + b y  written to w (w may alias x or y): copy + axpy in one pass (src/bicgstab.jl:224-225,232-233) */
 int khip_waxpy(khip_ctx *ctx, int64_t n, double *w, const double *x, double b, const double *y);
 /* result_host[0] = x . y ; result_host[1] = x . x      (src/bicgstab.jl:230) */

@@ -104,6 +104,8 @@ SIGNATURES = {
     "khip_spmv_dot": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
     "khip_axpy2_dot": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
+    "khip_axpy_sqnorm": (_int, [_vp, _i64, _dbl, _vp, _vp, c_double_p]),
+    "khip_cg_update": (_int, [_vp, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "khip_dot2": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
     "khip_mgs": (_int, [_vp, _i64, _int, c_void_pp, _vp, c_double_p, c_double_p, _int]),
     "khip_multi_axpy": (_int, [_vp, _i64, _int, c_double_p, c_void_pp, _vp]),
@@ -467,6 +469,19 @@ def axpy2_dot(n, a, p, q, x, r) -> float:
     out = C.c_double()
     _ck(lib().khip_axpy2_dot(x.ctx._h, n, a, _p(p), _p(q), _p(x), _p(r), C.byref(out)))
     return out.value
+
+
+def axpy_sqnorm(n, a, x, y) -> float:
+    """y += a x ; returns y . y (src/cg.jl:240,242)."""
+    out = C.c_double()
+    _ck(lib().khip_axpy_sqnorm(y.ctx._h, n, a, _p(x), _p(y), C.byref(out)))
+    return out.value
+
+
+def cg_update_(n, a, b, r, p, x):
+    """x += a p ; p = r + b p in one pass (src/cg.jl:239,259)."""
+    _ck(lib().khip_cg_update(x.ctx._h, n, a, b, _p(r), _p(p), _p(x)))
+    return p, x
 
 
 def waxpy_(n, w, x, b, y):

@@ -439,6 +439,18 @@ int khip_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const do
   return fetch_results(ctx, slot, 1, result_host);
 }
 
+int khip_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, double *result_host) {
+  KHIP_REQUIRE(ctx && result_host && n >= 0 && (n == 0 || (x && y)), "axpy_sqnorm: null argument");
+  const int slot = take_slots(ctx, 1);
+  KHIP_TRY(launch_axpy_sqnorm(ctx, n, a, x, y, slot));
+  return fetch_results(ctx, slot, 1, result_host);
+}
+
+int khip_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x) {
+  KHIP_REQUIRE(ctx && n >= 0 && (n == 0 || (r && p && x)), "cg_update: null argument");
+  return launch_cg_update(ctx, n, a, b, r, p, x);
+}
+
 int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, double *q, double *h_host,
              double *nrm_host, int accumulate) {
   KHIP_REQUIRE(ctx && q && (k == 0 || (V_host && h_host)), "mgs: null argument");

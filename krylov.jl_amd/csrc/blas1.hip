@@ -159,6 +159,52 @@ int launch_map(khip_ctx *ctx, int op, int64_t n, double a, double b, const doubl
   }
 }
 
+// ---------------------------------------------------------------- CG direction update ----
+// x <- fma(a, p, x) ; p <- fma(1, r, b * p): kaxpy!(n, a, p, x) (src/cg.jl:239) and kaxpby!(n, 1, r, b, p)
+// (src/cg.jl:259) in ONE pass over p -- 40n bytes instead of 24n + 24n.  Same expressions as
+// OP_AXPY / OP_AXPBY, so both outputs are bit-identical to the two separate kernels.
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double a, double b, const double *r, double *p,
+                                                           double *x) {
+  using T = typename VecT<VEC>::type;
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T rv = ldg<NT>(reinterpret_cast<const T *>(r) + i);
+    const T pv = ldg<NT>(reinterpret_cast<T *>(p) + i);
+    const T xv = ldg<NT>(reinterpret_cast<T *>(x) + i);
+    T xo, po;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      vset(xo, e, fma(a, vget(pv, e), vget(xv, e)));
+      vset(po, e, fma(1.0, vget(rv, e), b * vget(pv, e)));
+    }
+    stg<NT>(xo, reinterpret_cast<T *>(x) + i);
+    stg<NT>(po, reinterpret_cast<T *>(p) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    const double pv = p[t];
+    x[t] = fma(a, pv, x[t]);
+    p[t] = fma(1.0, r[t], b * pv);
+  }
+}
+
+int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x) {
+  if (n <= 0) return KHIP_OK;
+  const bool v2 = n >= 2 && aligned16(r) && aligned16(p) && aligned16(x);
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_CGU(VEC, NT) \
+  hipLaunchKernelGGL((cg_update_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, a, b, r, p, x)
+  if (v2) { if (nt) KHIP_CGU(2, true); else KHIP_CGU(2, false); }
+  else    { if (nt) KHIP_CGU(1, true); else KHIP_CGU(1, false); }
+#undef KHIP_CGU
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 // ---------------------------------------------------------------- reductions ----
 enum RedOp {
   RED_DOT = 0,        // out0 = x . y
@@ -166,6 +212,7 @@ enum RedOp {
   RED_DOT2 = 2,       // out0 = x . y ; out1 = x . x
   RED_AXPY2 = 3,      // X += a p ; R -= a q ; out0 = R . R
   RED_AXPYDEV = 4,    // Y -= (*coef) x ; out0 = z . Y   (z == Y -> ||Y||^2)
+  RED_AXPYSQ = 5,     // Y += a x ; out0 = Y . Y
 };
 
 template <int ROP> struct RedOut { static constexpr int n = (ROP == RED_DOT2) ? 2 : 1; };
@@ -173,7 +220,7 @@ template <int ROP> struct RedOut { static constexpr int n = (ROP == RED_DOT2) ? 
 struct RedPtrs {
   const double *x;      // DOT: x | SQ: x | DOT2: x | AXPY2: p | AXPYDEV: x
   const double *y;      // DOT: y |       | DOT2: y | AXPY2: q | AXPYDEV: z
-  double *u;            //                           AXPY2: X | AXPYDEV: Y
+  double *u;            //                           AXPY2: X | AXPYDEV: Y | AXPYSQ: Y
   double *v;            //                           AXPY2: R
   const double *coef;   // AXPYDEV: device scalar
   double a;             // AXPY2
@@ -194,9 +241,9 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
   T *Vv = reinterpret_cast<T *>(p.v);
   double a = p.a;
   if (ROP == RED_AXPYDEV) a = -(*p.coef);
-  const bool z_is_y = (ROP == RED_AXPYDEV) && (p.y == p.u);
+  const bool z_is_y = (ROP == RED_AXPYSQ) || ((ROP == RED_AXPYDEV) && (p.y == p.u));
   constexpr bool rd_y = (ROP == RED_DOT || ROP == RED_DOT2 || ROP == RED_AXPY2 || ROP == RED_AXPYDEV);
-  constexpr bool rd_u = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV);
+  constexpr bool rd_u = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV || ROP == RED_AXPYSQ);
   constexpr bool rd_v = (ROP == RED_AXPY2);
 
   T xv[U] = {}, yv[U] = {}, uv[U] = {}, vv[U] = {};
@@ -225,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
         }
         stg<NT>(un, Uv + j);
         stg<NT>(vn, Vv + j);
-      } else if (ROP == RED_AXPYDEV) {
+      } else if (ROP == RED_AXPYDEV || ROP == RED_AXPYSQ) {
         T un;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -260,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
       p.v[t] = rn;
       acc_prod<COMP>(acc[0], rn, rn);
     }
-    if (ROP == RED_AXPYDEV) {
+    if (ROP == RED_AXPYDEV || ROP == RED_AXPYSQ) {
       double yn = fma(a, xe, p.u[t]);
       double ze = z_is_y ? yn : p.y[t];
       p.u[t] = yn;
@@ -313,6 +360,10 @@ int launch_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *pv, const
                      int slot) {
   RedPtrs p{pv, q, x, r, nullptr, a};
   return launch_reduce<RED_AXPY2>(ctx, n, p, slot);
+}
+int launch_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, int slot) {
+  RedPtrs p{x, nullptr, y, nullptr, nullptr, a};
+  return launch_reduce<RED_AXPYSQ>(ctx, n, p, slot);
 }
 int launch_axpy_dev_dot(khip_ctx *ctx, int64_t n, const double *coef_dev, const double *x, double *y, const double *z,
                         int slot) {

@@ -136,6 +136,8 @@ int launch_nrm2sq(khip_ctx *ctx, int64_t n, const double *x, int slot);
 int launch_dot2(khip_ctx *ctx, int64_t n, const double *x, const double *y, int slot);  // slot: x.y, slot+1: x.x
 int launch_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const double *q, double *x,
                      double *r, int slot);
+int launch_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, int slot);   // y += a x ; y.y
+int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x);
 // y <- y - (*coef_dev) x ; out[slot] = z . y (z == y -> ||y||^2), coef read from device memory
 int launch_axpy_dev_dot(khip_ctx *ctx, int64_t n, const double *coef_dev, const double *x, double *y,
                         const double *z, int slot);

@@ -314,8 +314,11 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     }
 
     double gamma_next;
+    bool x_pending = false;
     if (fused && MisI) {
-      K(khip_axpy2_dot(ctx, n, alpha, p, Ap, x, r, &gamma_next));                  // :239-242 fused
+      // :240,:242 fused; the x update (:239) is carried to the p update below -- nothing reads x in between
+      K(khip_axpy_sqnorm(ctx, n, -alpha, Ap, r, &gamma_next));
+      x_pending = true;
     } else {
       K(khip_axpy(ctx, n, alpha, p, x));                                           // :239
       K(khip_axpy(ctx, n, -alpha, Ap, r));                                         // :240
@@ -337,7 +340,10 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
       const double beta = gamma_next / gamma;
       pNorm2 = gamma_next + beta * beta * pNorm2;
       gamma = gamma_next;
-      K(khip_axpby(ctx, n, 1.0, z, beta, p));
+      if (x_pending) K(khip_cg_update(ctx, n, alpha, beta, r, p, x));               // :239 + :259 in one pass over p
+      else K(khip_axpby(ctx, n, 1.0, z, beta, p));
+    } else if (x_pending) {
+      K(khip_axpy(ctx, n, alpha, p, x));                                           // :239
     }
 
     iter = iter + 1;

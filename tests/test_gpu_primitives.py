@@ -109,6 +109,33 @@ def test_empty_vectors(K, ctx):
     K.kaxpy_(0, 1.0, v, v)
 
 
+@pytest.mark.parametrize("n", [1, 2, 1001, 300007])
+def test_fused_axpy_sqnorm_and_cg_update(K, ctx, oracle, n):
+    """The two kernels of the fused CG iteration (src/cg.jl:239-242,259) against the unfused device
+    sequence (bit-identical vectors) and the oracle."""
+    rng = np.random.default_rng(100 + n)
+    p, q, x, r = (_vec(rng, n) for _ in range(4))
+    alpha, beta = 0.3, 0.7
+    dp_, dq, dx, dr = (ctx.array(v) for v in (p, q, x, r))
+    g = K.axpy_sqnorm(n, -alpha, dq, dr)            # r -= alpha q ; r.r
+    K.cg_update_(n, alpha, beta, dr, dp_, dx)       # x += alpha p ; p = r + beta p
+    ux, ur, up = ctx.array(x), ctx.array(r), ctx.array(p)
+    K.kaxpy_(n, alpha, up, ux)
+    K.kaxpy_(n, -alpha, dq, ur)
+    g2 = K.kdot(n, ur, ur)
+    K.kaxpby_(n, 1.0, ur, beta, up)
+    assert np.array_equal(dx.to_host(), ux.to_host())
+    assert np.array_equal(dr.to_host(), ur.to_host())
+    assert np.array_equal(dp_.to_host(), up.to_host())
+    assert abs(g - g2) <= 2 * EPS * abs(g2)
+    hx, hr, hp = x.copy(), r.copy(), p.copy()
+    oracle.axpy(alpha, hp, hx)
+    oracle.axpy(-alpha, q, hr)
+    oracle.axpby(1.0, hr, beta, hp)
+    assert np.array_equal(dx.to_host(), hx) and np.array_equal(dr.to_host(), hr) and np.array_equal(dp_.to_host(), hp)
+    assert abs(g - oracle.dot(hr, hr)) <= 2 * EPS * g
+
+
 @pytest.mark.parametrize("n", [2, 1001, 300007])
 def test_fused_axpy2_dot(K, ctx, oracle, n):
     rng = np.random.default_rng(n)
