@@ -95,7 +95,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n1", type=int, default=512, help="grid size per dimension (default: cfg 2, 512^3)")
-    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--fused", type=int, default=2,
+                    help="0 = reference primitive sequence, 1 = fused kernels, 2 = fused + device-resident scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (khip_ctx_set_option)")
     args = ap.parse_args()
@@ -147,12 +148,12 @@ def main():
 
     # warm-up iterations (untimed)
     if args.warmup > 0:
-        K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.warmup, fused=bool(args.fused))
+        K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.warmup, fused=args.fused)
     ctx.set_option("profile_spmv", 1)
     ctx.profile_spmv()
     barrier()
     t0 = time.perf_counter()
-    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.steps, history=True, fused=bool(args.fused))
+    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.steps, history=True, fused=args.fused)
     barrier()
     elapsed = time.perf_counter() - t0
     st = ws.stats
@@ -169,7 +170,7 @@ def main():
         its = args.steps / elapsed
         spmv_bytes_local = A.spmv_bytes
         # algorithmic bytes of one fused iteration on this rank: SpMV(+dot) + (r update + r.r: 24n) + (x and p update: 40n)
-        iter_bytes_local = spmv_bytes_local + 64 * nloc
+        iter_bytes_local = spmv_bytes_local + (64 if args.fused else 104) * nloc
         iter_bytes_unfused_local = spmv_bytes_local + 104 * nloc       # as the reference issues it
         spmv_per_iter = launches / max(args.steps, 1)
         avg_spmv_ms = spmv_ms / max(args.steps, 1)                    # all SpMV launches of one iteration
@@ -180,7 +181,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cg! on get_div_grad({n1},{n1},{n1}) CSR (cfg 2), b=ones, Float64, int32 indices",
-                       "n": n, "nnz_global": 7 * n - 6 * n1 * n1, "fused": bool(args.fused),
+                       "n": n, "nnz_global": 7 * n - 6 * n1 * n1, "fused": args.fused,
                        "partition": f"1-D rows over {world} GPU(s)", "atol": 0.0, "rtol": 0.0},
             "hbm_gbps_iteration": its * iter_bytes_local * world / 1e9,
             "hbm_gbps_iteration_reference_sequence": its * iter_bytes_unfused_local * world / 1e9,

@@ -271,7 +271,8 @@ int khip_spmv_bytes(const khip_csr *A, int64_t *bytes) {
 // y <- A x (optionally fused with x . y into results[dot_slot]), handling the halo exchange and the
 // interior / boundary split of distributed handles.  The up to three launches of a split product feed a
 // single finish kernel, so every rank contributes exactly one partial to the all-reduce.
-static int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot) {
+}  // extern "C"
+int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot) {
   if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m);
   KHIP_TRY(comm_halo_exchange_begin(ctx, A, x));
   const bool split = ctx->tune.overlap_halo && A->interior_hi > A->interior_lo;
@@ -286,6 +287,7 @@ static int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y
   KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_hi, A->m, &cursor, true));
   return KHIP_OK;
 }
+extern "C" {
 
 int khip_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y) {
   KHIP_REQUIRE(ctx && A && x && y, "spmv: null argument");

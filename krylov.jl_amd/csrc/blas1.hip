@@ -205,6 +205,98 @@ int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double 
   return KHIP_OK;
 }
 
+// Device-scalar variant for the device-resident CG loop: alpha, beta and the `solved` flag come from
+// the CgDevState the epilogues maintain; when the stopping test has fired only x is updated
+// (src/cg.jl:255-260 skips the direction update once solved).
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void cg_update_dev_kernel(int64_t n, const CgDevState *st, long long seq,
+                                                               const double *r, double *p, double *x) {
+  using T = typename VecT<VEC>::type;
+  if (seq >= st->stop_seq) return;
+  const double a = st->alpha, b = st->beta;
+  const bool solved = st->solved != 0;
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T pv = ldg<NT>(reinterpret_cast<T *>(p) + i);
+    const T xv = ldg<NT>(reinterpret_cast<T *>(x) + i);
+    T rv = {};
+    if (!solved) rv = ldg<NT>(reinterpret_cast<const T *>(r) + i);
+    T xo, po;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      vset(xo, e, fma(a, vget(pv, e), vget(xv, e)));
+      vset(po, e, fma(1.0, vget(rv, e), b * vget(pv, e)));
+    }
+    stg<NT>(xo, reinterpret_cast<T *>(x) + i);
+    if (!solved) stg<NT>(po, reinterpret_cast<T *>(p) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    const double pv = p[t];
+    x[t] = fma(a, pv, x[t]);
+    if (!solved) p[t] = fma(1.0, r[t], b * pv);
+  }
+}
+
+int launch_cg_update_dev(khip_ctx *ctx, int64_t n, const void *cg_state_dev, long long seq, const double *r, double *p,
+                         double *x) {
+  if (n <= 0) return KHIP_OK;
+  const CgDevState *st = static_cast<const CgDevState *>(cg_state_dev);
+  const bool v2 = n >= 2 && aligned16(r) && aligned16(p) && aligned16(x);
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_CGU(VEC, NT) \
+  hipLaunchKernelGGL((cg_update_dev_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, st, seq, r, p, x)
+  if (v2) { if (nt) KHIP_CGU(2, true); else KHIP_CGU(2, false); }
+  else    { if (nt) KHIP_CGU(1, true); else KHIP_CGU(1, false); }
+#undef KHIP_CGU
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+// Scalar epilogue on its own (the reduction value was written to results[slot] by other means).
+__global__ void epilogue_kernel(RedArgs ra) {
+  if (seq_skip(ra.stop_seq, ra.seq)) return;
+  if (ra.epi) solver_epilogue(ra.epi, ra.epi_state, ra.results + ra.slot, ra.seq);
+}
+
+int launch_epilogue_only(khip_ctx *ctx, int slot) {
+  RedArgs ra = make_red_args(ctx, slot);
+  hipLaunchKernelGGL(epilogue_kernel, dim3(1), dim3(1), 0, ctx->stream, ra);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+// Cross-rank fold of all-gathered (hi, lo) partials, gathered[rank][count], in rank order with TwoSum --
+// the same operations as the host loop of comm_allreduce_dd, so every rank gets the bit-identical scalar.
+__global__ void combine_kernel(const dd *gathered, int nranks, int count, RedArgs ra) {
+  if (seq_skip(ra.stop_seq, ra.seq)) return;
+  const int i = threadIdx.x;
+  if (i < count) {
+    double hi = 0.0, lo = 0.0;
+    for (int r = 0; r < nranks; ++r) {
+      const dd v = gathered[(size_t)r * count + i];
+      double s, e;
+      two_sum(hi, v.hi, s, e);
+      hi = s;
+      lo += v.lo + e;
+    }
+    ra.results[ra.slot + i] = hi + lo;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && ra.epi) solver_epilogue(ra.epi, ra.epi_state, ra.results + ra.slot, ra.seq);
+}
+
+int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot) {
+  if (count > 64) { set_error("combine: too many scalars"); return KHIP_ERR_INVALID; }
+  RedArgs ra = make_red_args(ctx, slot);
+  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, gathered_dev, nranks, count, ra);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 // ---------------------------------------------------------------- reductions ----
 enum RedOp {
   RED_DOT = 0,        // out0 = x . y
@@ -230,6 +322,7 @@ template <int ROP, bool COMP, int VEC, bool NT, int U>
 __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, RedArgs ra) {
   using T = typename VecT<VEC>::type;
   constexpr int NOUT = RedOut<ROP>::n;
+  if (seq_skip(ra.stop_seq, ra.seq)) return;
   dd acc[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) acc[o] = dd{0.0, 0.0};
@@ -474,6 +567,7 @@ int ensure_reduction_scratch(khip_ctx *ctx, int64_t nwaves, int nout) {
 // fold `nwaves` per-wave partials of the kernel just launched on ctx->stream into results[slot..]
 int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot) {
   RedArgs ra = make_red_args(ctx, slot);
+  if (ctx->comm) ra.epi = EPI_NONE;      // the cross-rank combine kernel owns the epilogue
   int64_t want = (nwaves + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
   const unsigned g = (unsigned)(want < 1 ? 1 : (want > kFinishMaxBlocks ? kFinishMaxBlocks : want));
   if (nout == 1) hipLaunchKernelGGL((reduce_finish_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);

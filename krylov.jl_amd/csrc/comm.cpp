@@ -367,6 +367,25 @@ int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host) 
   return KHIP_OK;
 }
 
+// Device-side variant for the device-resident solver loops: nothing waits on the host with RCCL.
+// finish kernel -> results_dd[slot] (local partial) -> ncclAllGather (16 bytes per rank and scalar) ->
+// combine kernel (rank-ordered TwoSum, then the solver's scalar epilogue).  The local backend has no
+// device-side transport, so it goes through the host and then launches the epilogue alone.
+int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count) {
+  Comm *c = ctx->comm;
+  if (!c) return launch_epilogue_only(ctx, slot);
+  if (count > kMaxRedOut) { set_error("allreduce: too many scalars"); return KHIP_ERR_INVALID; }
+  if (c->hub) {
+    double vals[kMaxRedOut];
+    KHIP_TRY(comm_allreduce_dd(ctx, ctx->results_dd + slot, count, vals));
+    KHIP_CHECK_HIP(hipMemcpyAsync(ctx->results + slot, vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));      // vals lives on this stack frame
+    return launch_epilogue_only(ctx, slot);
+  }
+  KHIP_CHECK_NCCL(g_rccl.AllGather(ctx->results_dd + slot, c->gather_dev, (size_t)count * 2, ncclFloat64, c->comm, ctx->stream));
+  return launch_combine(ctx, c->gather_dev, c->nranks, count, slot);
+}
+
 }  // namespace khip
 
 using namespace khip;

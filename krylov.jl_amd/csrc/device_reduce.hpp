@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "khip_internal.hpp"
+#include "solver_device.hpp"
 
 namespace khip {
 
@@ -109,6 +110,11 @@ struct RedArgs {
   int64_t cap;
   int64_t wave_offset;  // first partial index of this launch (several launches may feed one finish)
   int slot;
+  // device-resident loop control (solver_device.hpp); all zero outside "fused = 2" solves
+  const long long *stop_seq;
+  long long seq;
+  int epi;
+  void *epi_state;
 };
 
 // Streaming-kernel side: every wave folds its lanes and stores one partial per output.
@@ -148,6 +154,7 @@ template <int NOUT>
 __global__ __launch_bounds__(kBlock) void reduce_finish_kernel(RedArgs ra, int64_t P) {
   __shared__ dd s_w[NOUT][kWavesPerBlock];
   __shared__ int s_last;
+  if (seq_skip(ra.stop_seq, ra.seq)) return;
   const int G = gridDim.x;
   const int64_t chunk = (P + G - 1) / G;
   const int64_t lo = chunk * blockIdx.x;
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void reduce_finish_kernel(RedArgs ra, int64
         ra.results[ra.slot + o] = acc[o].hi + acc[o].lo;
         ra.results_dd[ra.slot + o] = acc[o];
       }
+      if (ra.epi) solver_epilogue(ra.epi, ra.epi_state, ra.results + ra.slot, ra.seq);
     }
     return;
   }
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(kBlock) void reduce_finish_kernel(RedArgs ra, int64
       ra.results_dd[ra.slot + o] = fin[o];
     }
     __hip_atomic_store(ra.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ra.epi) solver_epilogue(ra.epi, ra.epi_state, ra.results + ra.slot, ra.seq);
   }
 }
 
@@ -219,6 +228,10 @@ inline RedArgs make_red_args(khip_ctx *ctx, int slot) {
   ra.cap = ctx->red_cap1;
   ra.wave_offset = 0;
   ra.slot = slot;
+  ra.stop_seq = ctx->ctl.stop_seq;
+  ra.seq = ctx->ctl.seq;
+  ra.epi = ctx->ctl.epi;
+  ra.epi_state = ctx->ctl.epi_state;
   return ra;
 }
 

@@ -70,6 +70,14 @@ struct Tuning {
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
 
+// Device-resident loop control attached to the launches of a "fused = 2" solve (solver_device.hpp).
+struct SeqCtl {
+  const long long *stop_seq = nullptr;   // device word; kernels with seq >= *stop_seq return immediately
+  long long seq = 0;
+  int epi = 0;                           // scalar epilogue run by the kernel that finalises a reduction
+  void *epi_state = nullptr;
+};
+
 }  // namespace khip
 
 struct khip_ctx {
@@ -90,6 +98,7 @@ struct khip_ctx {
   double *results_pinned = nullptr;    // pinned host mirror [kResultSlots * 2]
   int next_slot = 0;
   khip::Tuning tune;
+  khip::SeqCtl ctl;                    // empty except inside a device-resident solver loop
   khip::Comm *comm = nullptr;
   void *panel_scratch = nullptr;       // panel.hip: V^T Q partial tiles + Psi staging ring
   // SpMV launch profiling (events recorded on `stream`, resolved lazily)
@@ -138,6 +147,13 @@ int launch_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const 
                      double *r, int slot);
 int launch_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, int slot);   // y += a x ; y.y
 int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x);
+// same with alpha / beta / solved read from a CgDevState in device memory (solver_device.hpp)
+int launch_cg_update_dev(khip_ctx *ctx, int64_t n, const void *cg_state_dev, long long seq, const double *r, double *p,
+                         double *x);
+// run the scalar epilogue in ctx->ctl on results[slot..] (1-thread kernel; used when the reduction result was
+// produced outside a finish kernel) / fold nranks gathered (hi, lo) partials per scalar and run it
+int launch_epilogue_only(khip_ctx *ctx, int slot);
+int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot);
 // y <- y - (*coef_dev) x ; out[slot] = z . y (z == y -> ||y||^2), coef read from device memory
 int launch_axpy_dev_dot(khip_ctx *ctx, int64_t n, const double *coef_dev, const double *x, double *y,
                         const double *z, int slot);
@@ -162,12 +178,17 @@ int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host
 int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
 int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 
+// api.cpp: y = A x (dot_slot >= 0: also results[dot_slot] = x . y) incl. halo exchange; launches only, no host sync
+int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot);
+
 // panel.hip
 void panel_scratch_destroy(khip_ctx *ctx);
 
 // comm.cpp
 int comm_nranks(const khip_ctx *ctx);
 int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host);
+// all-reduce results_dd[slot..slot+count) into results[slot..] ON THE DEVICE (no host sync with RCCL), then run ctx->ctl's epilogue
+int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count);
 int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x);
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A);
 int comm_build_plan(khip_ctx *ctx, khip_csr *A);

@@ -9,12 +9,15 @@
 // opts.fused = 0 issues exactly the primitive sequence of the reference (one launch per k* call,
 // one host sync per kdot/knorm).  opts.fused = 1 replaces legal groups by fused kernels
 // (SpMV+dot, axpy+axpy+dot, copy+axpy, MGS cascade with device-resident coefficients, multi-axpy);
-// elementwise results are bit-identical, reductions agree to one ulp.
+// elementwise results are bit-identical, reductions agree to one ulp.  opts.fused = 2 (cg!
+// only so far) additionally keeps the scalar recurrences and stopping tests on the device
+// (solver_device.hpp): no host round trip inside the loop, iterations are enqueued ahead.
 #include <chrono>
 #include <cmath>
 #include <limits>
 
 #include "khip_internal.hpp"
+#include "solver_device.hpp"
 
 using namespace khip;
 
@@ -94,7 +97,101 @@ struct khip_cg_workspace {
   double *dx = nullptr, *x = nullptr, *r = nullptr, *npc_dir = nullptr, *p = nullptr, *Ap = nullptr, *z = nullptr;
   bool warm_start = false;
   StatsBox box;
+  // device-resident loop state (fused = 2), allocated on first use
+  CgDevState *dev_state = nullptr;
+  CgDevState *snap = nullptr;          // pinned host snapshots [2]
+  double *hist_dev = nullptr;
+  hipEvent_t snap_ev[2] = {nullptr, nullptr};
 };
+
+namespace {
+
+constexpr int kDevChunk = 4;             // iterations enqueued between two snapshots of the device state
+constexpr long long kHistWindow = 1 << 14;
+
+// The loop of src/cg.jl:195-268 with scalars and stopping tests on the device.  Preconditions (checked by
+// the caller): CSR operator, M = I, radius = 0, no linesearch, no callback.  On return the vectors are in
+// the state the reference's loop leaves them in and `out` holds the final scalar state.
+int cg_device_loop(khip_cg_workspace *ws, const khip_csr *A, double gamma, double eps_tol, int64_t itmax, bool history,
+                   double t0, double timemax, CgDevState *out, bool *overtimed) {
+  khip_ctx *ctx = ws->ctx;
+  const int64_t n = ws->n;
+  if (!ws->dev_state) {
+    KHIP_CHECK_HIP(hipMalloc(&ws->dev_state, sizeof(CgDevState)));
+    KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->snap), 2 * sizeof(CgDevState), hipHostMallocDefault));
+    KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindow));
+    for (auto &e : ws->snap_ev) KHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  CgDevState *dev = ws->dev_state;
+  CgDevState h;
+  memset(&h, 0, sizeof(h));
+  h.gamma = gamma; h.pNorm2 = gamma; h.eps_tol = eps_tol; h.keps = kEps; h.rNorm = std::sqrt(gamma);
+  h.stop_seq = kSeqNever;
+  h.hist = history ? ws->hist_dev : nullptr;
+  h.hist_cap = kHistWindow;
+  KHIP_CHECK_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));          // h is a stack object
+
+  int64_t enq = 0;            // iterations enqueued
+  long long hist_base = 0;
+  std::vector<double> win;
+  auto drain_history = [&](long long upto_iter) -> int {      // entries for iterations (hist_base, upto_iter]
+    const long long cnt = upto_iter - hist_base;
+    if (!history || cnt <= 0) return KHIP_OK;
+    win.resize((size_t)cnt);
+    KHIP_CHECK_HIP(hipMemcpy(win.data(), ws->hist_dev, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    for (double v : win) ws->box.push(v);
+    return KHIP_OK;
+  };
+  int rc = KHIP_OK;
+  bool stopped = false;
+  for (int chunk = 0; !stopped; ++chunk) {
+    const int64_t c = std::min<int64_t>(kDevChunk, itmax - enq);
+    if (history && enq + c - hist_base > kHistWindow) {        // window full: empty it (rare: every 16384 iterations)
+      KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      CgDevState cur;
+      KHIP_CHECK_HIP(hipMemcpy(&cur, dev, sizeof(cur), hipMemcpyDeviceToHost));
+      if (cur.stop_seq != kSeqNever) break;
+      if ((rc = drain_history(cur.iter)) != KHIP_OK) break;
+      hist_base = cur.iter;
+      KHIP_CHECK_HIP(hipMemcpy(&dev->hist_base, &hist_base, sizeof(hist_base), hipMemcpyHostToDevice));
+    }
+    for (int64_t i = 0; i < c && rc == KHIP_OK; ++i) {
+      const long long j = (long long)(enq + i);
+      ctx->ctl = SeqCtl{&dev->stop_seq, 3 * j, EPI_CG_STEP1, dev};
+      const int s1 = take_slots(ctx, 1);
+      rc = spmv_any(ctx, A, ws->p, ws->Ap, s1);                                     // :196-197, epilogue :198-213
+      if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, s1, 1);
+      if (rc != KHIP_OK) break;
+      ctx->ctl = SeqCtl{&dev->stop_seq, 3 * j + 1, EPI_CG_STEP2, dev};
+      const int s2 = take_slots(ctx, 1);
+      rc = launch_axpy_dev_dot(ctx, n, &dev->alpha, ws->Ap, ws->r, ws->r, s2);      // :240, :242, epilogue :243-262
+      if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, s2, 1);
+      ctx->ctl = SeqCtl{};
+      if (rc != KHIP_OK) break;
+      rc = launch_cg_update_dev(ctx, n, dev, 3 * j + 2, ws->r, ws->p, ws->x);       // :239 and :259
+    }
+    ctx->ctl = SeqCtl{};
+    if (rc != KHIP_OK) break;
+    enq += c;
+    const int b = chunk & 1;
+    KHIP_CHECK_HIP(hipMemcpyAsync(&ws->snap[b], dev, sizeof(CgDevState), hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipEventRecord(ws->snap_ev[b], ctx->stream));
+    if (chunk >= 1) {                                        // look at the PREVIOUS chunk: the queue never runs dry
+      KHIP_CHECK_HIP(hipEventSynchronize(ws->snap_ev[b ^ 1]));
+      if (ws->snap[b ^ 1].stop_seq != kSeqNever) stopped = true;
+    }
+    if (enq >= itmax) stopped = true;
+    if (!stopped && (now_s() - t0) > timemax) { *overtimed = true; stopped = true; }
+  }
+  ctx->ctl = SeqCtl{};
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (rc != KHIP_OK) return rc;
+  KHIP_CHECK_HIP(hipMemcpy(out, dev, sizeof(CgDevState), hipMemcpyDeviceToHost));
+  return drain_history(out->iter);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -123,6 +220,10 @@ int khip_cg_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_cg_worksp
 int khip_cg_workspace_destroy(khip_cg_workspace *ws) {
   if (!ws) return KHIP_OK;
   for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z}) khip_free(ws->ctx, v);
+  if (ws->dev_state) (void)hipFree(ws->dev_state);
+  if (ws->snap) (void)hipHostFree(ws->snap);
+  if (ws->hist_dev) (void)hipFree(ws->hist_dev);
+  for (auto e : ws->snap_ev) if (e) (void)hipEventDestroy(e);
   delete ws;
   return KHIP_OK;
 }
@@ -265,7 +366,22 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
        overtimed = false;
   const char *status = "unknown";
 
-  while (!(solved || tired || zero_curvature || user_requested_exit || overtimed)) {
+  const bool device_loop = o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback;
+  if (device_loop && !(solved || tired)) {
+    CgDevState fin;
+    K(cg_device_loop(ws, A->csr, gamma, eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
+    if (fin.not_spd)
+      return ws->box.fail(KHIP_ERR_NUMERIC,
+                          "The linear operator `A` or the preconditioner `M` is not symmetric positive definite.");
+    iter = fin.iter;
+    rNorm = fin.rNorm;
+    solved = fin.solved != 0;
+    zero_curvature = fin.zero_curvature != 0;
+    inconsistent = fin.inconsistent != 0;
+    tired = iter >= itmax;
+  }
+
+  while (!device_loop && !(solved || tired || zero_curvature || user_requested_exit || overtimed)) {
     if (fused && !A->apply) {
       K(khip_spmv_dot(ctx, A->csr, p, Ap, &pAp));                                  // :196-197 fused
     } else {

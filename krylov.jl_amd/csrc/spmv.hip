@@ -49,6 +49,7 @@ __device__ __forceinline__ int chunk_id(int b, int G, int xcd_run) {
 // ---------------------------------------------------------------- stream (LDS-staged) ----
 template <int ROWS, int VEC, bool NT, bool DOT, bool COMP, bool DIST>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
   static_assert(ROWS <= kBlock, "one lane per row");
   constexpr int CAP = 2048;   // products staged per pass (16 KB)
   __shared__ double s_prod[CAP + 4];
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
 // LDS reads are conflict-free for odd row lengths (stride 7 doubles -> distinct bank pairs).
 template <int ROWS, bool NT, bool DOT, bool COMP, bool DIST>
 __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
   static_assert(ROWS <= kBlock, "one lane per row");
   // window of staged entries: up to 8 per lane, moved as 16-byte vectors.  Its size is a launch parameter
   // (multiple of 4, <= 2048) sized to the widest row block of the matrix: LDS per workgroup is 12 * CAP
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
 // wave touches one contiguous span of the val / col streams.
 template <int L, int RPG, bool NT, bool DOT, bool COMP, bool DIST>
 __global__ __launch_bounds__(kBlock) void spmv_ordered_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
   constexpr int NG = 64 / L;                       // lane groups per wave
   constexpr int ROWS_PER_WAVE = NG * RPG;
   constexpr int ROWS_PER_BLOCK = ROWS_PER_WAVE * kWavesPerBlock;
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void spmv_ordered_kernel(SpmvArgs a, RedArg
 // ---------------------------------------------------------------- vector (long rows) -----
 template <int LPR, bool DOT, bool COMP, bool DIST>
 __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
   constexpr int RPB = kBlock / LPR;   // rows per workgroup per sweep
   const int tid = threadIdx.x;
   const int sub = tid / LPR, sl = tid % LPR;
@@ -420,6 +424,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.nt_y = ctx->tune.spmv_nty;
   a.tiles_per_block = 1;
   a.stage_cap = 2048;
+  a.stop_seq = ctx->ctl.stop_seq;
+  a.seq = ctx->ctl.seq;
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;

@@ -102,7 +102,7 @@ def test_distributed_spmv_and_cg_local_ranks(K, oracle, world, n1):
         c.set_option("overlap_halo", 1)
         b = c.empty(r1 - r0)
         K.kfill_(b, 1.0)
-        for fused in (True, False):
+        for fused in (2, True, False):
             xs, st, _ = K.cg(A, b, history=True, fused=fused)
             out[f"cg{int(fused)}"] = (st.niter, st.residuals, xs.to_host(), st.status)
         return out
@@ -114,13 +114,15 @@ def test_distributed_spmv_and_cg_local_ranks(K, oracle, world, n1):
         for overlap in (1, 0):
             assert np.array_equal(out[f"y{overlap}"], y_ref[r0:r1]), (rank, overlap)        # bit-identical to the oracle
             assert abs(out[f"d{overlap}"] - d_ref) <= 4 * np.finfo(float).eps * abs(d_ref) + 1e-16 * np.abs(x * y_ref).sum()
-        for fused in (1, 0):
+        for fused in (2, 1, 0):
             niter, hist, xs, status = out[f"cg{fused}"]
             assert niter == ref.niter and status == ref.status
             assert np.max(np.abs(hist - ref.residuals) / ref.residuals) <= 1e-10
             assert np.allclose(xs, ref.x[r0:r1], atol=1e-10)
         # every rank computed the bit-identical scalars
         assert np.array_equal(out["cg1"][1], res[0]["cg1"][1])
+        # device-resident scalars (fused = 2): the same histories and iterates as the host-scalar loop
+        assert np.array_equal(out["cg2"][1], out["cg1"][1]) and np.array_equal(out["cg2"][2], out["cg1"][2])
 
 
 def test_distributed_gmres_bicgstab_local_ranks(K, oracle):

@@ -46,7 +46,7 @@ def _hist_rel(h_gpu, h_cpu):
 # ------------------------------------------------------------------------------ CG
 
 @pytest.mark.parametrize("n1", [16, 32, 64])
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, 2])
 def test_cg_poisson_matches_oracle(K, ctx, oracle, parity_log, n1, fused):
     """cfg 1 (64^3) and the reference's own sparse_laplacian(16) case (test/test_cg.jl:22-28)."""
     A = oracle.poisson3d(n1)
@@ -102,11 +102,50 @@ def test_cg_device_generated_operator_64(K, ctx, oracle):
     assert _hist_dev(st.residuals, ref.residuals) <= 1.0
 
 
+def test_cg_device_resident_loop_equals_host_loop(K, ctx, oracle):
+    """fused = 2 keeps alpha, beta, pNorm^2 and the stopping tests on the device (csrc/solver_device.hpp).  Same
+    double operations in the same order as the host loop => histories, iteration counts, status strings and
+    the final x are BIT-identical to fused = 1, for every way the loop can end."""
+    A = oracle.poisson3d(24)
+    dA = _upload(K, ctx, A)
+    rng = np.random.default_rng(7)
+    bh = rng.standard_normal(A.n)
+    b = ctx.array(bh)
+    for kw in (dict(), dict(rtol=1e-12, atol=0.0), dict(itmax=5), dict(itmax=1), dict(atol=0.0, rtol=0.0, itmax=23),
+               dict(history=False), dict(x0=ctx.array(rng.standard_normal(A.n)))):
+        kw = dict(dict(history=True), **kw)
+        x1, st1, _ = K.cg(dA, b, fused=1, **kw)
+        x2, st2, _ = K.cg(dA, b, fused=2, **kw)
+        assert (st2.niter, st2.status, st2.solved, st2.inconsistent) == (st1.niter, st1.status, st1.solved, st1.inconsistent), kw
+        if kw["history"]:
+            assert np.array_equal(st2.residuals, st1.residuals), kw
+        else:
+            assert len(st2.residuals) == 0
+        assert np.array_equal(x2.to_host(), x1.to_host()), kw
+    # more iterations than the 4-iteration look-ahead chunks and than one history window would need a drain
+    ref = oracle.cg(A, bh, history=True)
+    x2, st2, ws = K.cg(dA, b, fused=2, history=True)
+    assert st2.niter == ref.niter and _hist_dev(st2.residuals, ref.residuals) <= 1.0
+    # the r vector of the workspace is the residual of the returned x (nothing ran after the stop)
+    r = ws.vector("r").to_host()
+    assert np.allclose(r, bh - A.matvec(x2.to_host()), atol=1e-9 * np.linalg.norm(bh))
+    # zero curvature: singular operator, b in the null space direction gives p.Ap = 0
+    Z = oracle.tridiag(6, 0.0, 0.0, 0.0)
+    bz = ctx.array(np.ones(6))
+    _, s1, _ = K.cg(_upload(K, ctx, Z), bz, fused=1)
+    _, s2, _ = K.cg(_upload(K, ctx, Z), bz, fused=2)
+    assert s1.status == s2.status == "zero curvature detected" and s2.niter == s1.niter == 0 and s2.inconsistent
+    # fall back to the host loop whenever the mode does not apply (preconditioner, callback, linesearch, radius)
+    x3, st3, _ = K.cg(dA, b, fused=2, radius=1.0)
+    x4, st4, _ = K.cg(dA, b, fused=1, radius=1.0)
+    assert st3.status == st4.status == "on trust-region boundary" and np.array_equal(x3.to_host(), x4.to_host())
+
+
 def test_cg_edge_cases(K, ctx, oracle):
     A = oracle.tridiag(10, -1.0, 4.0, -1.0)                               # symmetric_definite(10)
     bh = A.matvec(np.arange(1.0, 11.0))
     dA, b = _upload(K, ctx, A), ctx.array(bh)
-    for fused in (False, True):
+    for fused in (False, True, 2):
         x, st, _ = K.cg(dA, b, itmax=10, fused=fused)
         assert st.solved and np.linalg.norm(bh - A.matvec(x.to_host())) / np.linalg.norm(bh) <= 1e-6
     # zero right-hand side (test/test_cg.jl)
