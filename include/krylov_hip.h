@@ -214,6 +214,19 @@ typedef struct {
 int khip_jacobi_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out);
 int khip_jacobi_destroy(khip_operator *op);
 
+/* ILU(0) of A on its own pattern as an operator y <- U^{-1} L^{-1} x for the M / N arguments; for SPD A this is
+ * the IC(0) preconditioner (U = D L^T).  Replaces the vendor ic02 / ilu02 + triangular ldiv! of the
+ * reference's GPU recipes (docs/src/gpu.md:74-163, test/gpu/nvidia.jl:37-100).  A must outlive the operator,
+ * its column indices must be sorted within rows, every row needs a diagonal entry (KHIP_ERR_NUMERIC
+ * otherwise, as for a zero pivot).  Distributed handle: block-Jacobi ILU(0) of the owned diagonal block. */
+int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out);
+int khip_ilu0_destroy(khip_operator *op);
+/* introspection: number of level-scheduling levels of the two triangular solves; device pointer to the
+ * factor values (strict lower part = L without its unit diagonal, upper part incl. diagonal = U) on A's pattern */
+int khip_ilu0_info(const khip_operator *op, int64_t *levels_lower, int64_t *levels_upper, const double **lu_dev);
+/* replay the 2 x levels launches of one application from a cached hipGraph (default 1) or enqueue them one by one (0) */
+int khip_ilu0_set_graph(khip_operator *op, int enable);
+
 typedef int (*khip_callback_fn)(void *workspace, void *userdata);       /* callback(workspace)::Bool */
 
 typedef struct {

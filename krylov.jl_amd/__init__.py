@@ -101,6 +101,10 @@ SIGNATURES = {
     "khip_csr_diagonal": (_int, [_vp, _vp, _vp]),
     "khip_jacobi_create": (_int, [_vp, _vp, C.POINTER(COperator)]),
     "khip_jacobi_destroy": (_int, [C.POINTER(COperator)]),
+    "khip_ilu0_create": (_int, [_vp, _vp, C.POINTER(COperator)]),
+    "khip_ilu0_destroy": (_int, [C.POINTER(COperator)]),
+    "khip_ilu0_info": (_int, [C.POINTER(COperator), C.POINTER(_i64), C.POINTER(_i64), c_void_pp]),
+    "khip_ilu0_set_graph": (_int, [C.POINTER(COperator), _int]),
     "khip_spmv_dot": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
     "khip_axpy2_dot": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
@@ -649,11 +653,48 @@ class SimpleStats:
         return f"SimpleStats(niter={self.niter}, solved={self.solved}, status={self.status!r})"
 
 
+class Ilu0:
+    """ILU(0) of A on its own pattern as the operator y = U \\ (L \\ x); for SPD A this is IC(0).  Usable as the
+    M / N argument of cg_ / gmres_ / bicgstab_ (the reference's ic02 / ilu02 recipes, docs/src/gpu.md:74-163)."""
+
+    def __init__(self, A: "CsrMatrix", graph: bool = True):
+        self.ctx, self.n, self.A = A.ctx, A.m, A
+        self.op = COperator()
+        _ck(lib().khip_ilu0_create(A.ctx._h, A._h, C.byref(self.op)))
+        if not graph:
+            _ck(lib().khip_ilu0_set_graph(C.byref(self.op), 0))
+
+    def __call__(self, x, y):
+        rc = self.op.apply(self.op.self, _p(x), _p(y))
+        if rc:
+            raise KhipError(rc, lib().khip_last_error().decode())
+        return y
+
+    @property
+    def levels(self):
+        lo, up = _i64(), _i64()
+        _ck(lib().khip_ilu0_info(C.byref(self.op), C.byref(lo), C.byref(up), None))
+        return lo.value, up.value
+
+    def values(self):
+        """Factor values on A's pattern (host copy)."""
+        p = C.c_void_p()
+        _ck(lib().khip_ilu0_info(C.byref(self.op), None, None, C.byref(p)))
+        return DeviceVector(self.ctx, self.A.nnz, ptr=p.value, owner=self).to_host()
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                lib().khip_ilu0_destroy(C.byref(self.op))
+        except Exception:
+            pass
+
+
 def _make_operator(ctx, op, n, keep):
     """CsrMatrix | callable(x: DeviceVector, y: DeviceVector) | None -> POINTER(COperator) or None."""
     if op is None:
         return None
-    if isinstance(op, Jacobi):          # native operator: no Python in the loop
+    if isinstance(op, (Jacobi, Ilu0)):  # native operator: no Python in the loop
         keep.append(op)
         return C.byref(op.op)
     co = COperator()

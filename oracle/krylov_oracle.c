@@ -206,6 +206,59 @@ void ko_spmv(const ko_csr *A, const double *x, double *y) {
   }
 }
 
+/* ILU(0), IKJ variant (Saad alg. 10.4) on the pattern of A; see krylov_oracle.h */
+int ko_ilu0(const ko_csr *A, double *lu, int64_t *diag) {
+  const int64_t n = A->n;
+  memcpy(lu, A->val, sizeof(double) * (size_t)A->nnz);
+  for (int64_t i = 0; i < n; ++i) {
+    diag[i] = -1;
+    for (int64_t q = A->rowptr[i]; q < A->rowptr[i + 1]; ++q)
+      if (A->col[q] == i) { diag[i] = q; break; }
+    if (diag[i] < 0) return -(int)(i + 1);
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t rb = A->rowptr[i], re = A->rowptr[i + 1];
+    for (int64_t kk = rb; kk < diag[i]; ++kk) {
+      const int64_t k = A->col[kk];
+      const double piv = lu[diag[k]];
+      if (piv == 0.0) return -(int)(k + 1);
+      const double lik = lu[kk] / piv;
+      lu[kk] = lik;
+      int64_t p = kk + 1;
+      for (int64_t q = diag[k] + 1; q < A->rowptr[k + 1]; ++q) {
+        const int32_t j = A->col[q];
+        while (p < re && A->col[p] < j) ++p;
+        if (p < re && A->col[p] == j) {
+          const double t = lik * lu[q];
+          lu[p] = lu[p] - t;
+        }
+      }
+    }
+    if (lu[diag[i]] == 0.0) return -(int)(i + 1);
+  }
+  return 0;
+}
+
+void ko_ilu0_solve(const ko_csr *A, const double *lu, const int64_t *diag, const double *x, double *y) {
+  const int64_t n = A->n;
+  for (int64_t i = 0; i < n; ++i) {            /* L z = x, unit lower; z overwrites y */
+    double acc = x[i];
+    for (int64_t q = A->rowptr[i]; q < diag[i]; ++q) {
+      const double t = lu[q] * y[A->col[q]];
+      acc = acc - t;
+    }
+    y[i] = acc;
+  }
+  for (int64_t i = n - 1; i >= 0; --i) {       /* U y = z */
+    double acc = y[i];
+    for (int64_t q = diag[i] + 1; q < A->rowptr[i + 1]; ++q) {
+      const double t = lu[q] * y[A->col[q]];
+      acc = acc - t;
+    }
+    y[i] = acc / lu[diag[i]];
+  }
+}
+
 void ko_spmv_omp(const ko_csr *A, const double *x, double *y) {
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < A->n; i++) {

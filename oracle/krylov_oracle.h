@@ -65,6 +65,19 @@ void ko_csr_matvec(const double *x, double *y, void *csr);        /* ko_matvec a
 void ko_csr_matvec_omp(const double *x, double *y, void *csr);
 void ko_csr_block_matvec(const double *X, double *Y, int p, void *csr);
 
+/* ---- ILU(0) / IC(0) preconditioner -------------------------
+ * The reference gets these from the vendor library (ic02 / ilu02 of CUSPARSE resp. rocSPARSE,
+ * docs/src/gpu.md:74-163, test/gpu/nvidia.jl:37-100) -- an un-vendored dependency.  Restated from the
+ * published algorithm (Saad, Iterative Methods, alg. 10.4, IKJ variant on the pattern of A): for SPD A the
+ * ILU(0) factors are L and U = D L^T, so M^{-1} = U^{-1} L^{-1} is the IC(0) preconditioner L_c L_c^T = A on
+ * the pattern in exact arithmetic.  Column indices must be sorted within each row.
+ * lu: nnz values (strict lower = L without its unit diagonal, upper incl. diagonal = U); diag[i] = position of
+ * (i,i).  Returns 0, or -(i+1) for a missing / zero pivot in row i. */
+int  ko_ilu0(const ko_csr *A, double *lu, int64_t *diag);
+/* y = U^{-1} L^{-1} x: forward then backward substitution, each row accumulated in stored order with one
+ * rounded multiply and one rounded subtract per entry (docs/src/gpu.md:95-99 ldiv_ic0!) */
+void ko_ilu0_solve(const ko_csr *A, const double *lu, const int64_t *diag, const double *x, double *y);
+
 /* ---- BLAS-1 shim (src/krylov_utils.jl:305-349) --------------------------- */
 double ko_dot(int64_t n, const double *x, const double *y);                 /* :309-311 */
 double ko_nrm2(int64_t n, const double *x);                                 /* :316-317 */

@@ -97,6 +97,8 @@ def lib():
         "ko_csr_free": (None, [C.POINTER(Csr)]),
         "ko_csr_row_slice": (C.c_int, [C.POINTER(Csr), i64, i64, C.POINTER(Csr)]),
         "ko_spmv": (None, [C.POINTER(Csr), dp, dp]),
+        "ko_ilu0": (C.c_int, [C.POINTER(Csr), dp, C.POINTER(C.c_int64)]),
+        "ko_ilu0_solve": (None, [C.POINTER(Csr), dp, C.POINTER(C.c_int64), dp, dp]),
         "ko_spmv_omp": (None, [C.POINTER(Csr), dp, dp]),
         "ko_spmm": (None, [C.POINTER(Csr), dp, dp, C.c_int]),
         "ko_dot": (C.c_double, [i64, dp, dp]),
@@ -167,8 +169,9 @@ NULL_BLOCK_MATVEC = C.cast(None, BLOCK_MATVEC)
 class CsrMatrix:
     """Owning wrapper of a ko_csr; .rowptr/.col/.val are numpy views of the C arrays."""
 
-    def __init__(self, c: Csr):
+    def __init__(self, c: Csr, keep=None):
         self.c = c
+        self._keep = keep          # numpy arrays backing the struct (from_arrays); None: the C side owns them
         self.n, self.nnz = int(c.n), int(c.nnz)
         self.rowptr = np.ctypeslib.as_array(c.rowptr, shape=(self.n + 1,))
         self.col = np.ctypeslib.as_array(c.col, shape=(max(self.nnz, 1),))[: self.nnz]
@@ -176,9 +179,23 @@ class CsrMatrix:
 
     def __del__(self):
         try:
-            lib().ko_csr_free(C.byref(self.c))
+            if self._keep is None:
+                lib().ko_csr_free(C.byref(self.c))
         except Exception:
             pass
+
+    @classmethod
+    def from_arrays(cls, rowptr, col, val):
+        """Square CSR over caller-provided arrays (0-based; int64 row pointers, int32 columns)."""
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        c = Csr()
+        c.n, c.nnz = rowptr.size - 1, int(rowptr[-1])
+        c.rowptr = rowptr.ctypes.data_as(C.POINTER(C.c_int64))
+        c.col = col.ctypes.data_as(C.POINTER(C.c_int32))
+        c.val = val.ctypes.data_as(c_double_p)
+        return cls(c, keep=(rowptr, col, val))
 
     def ptr(self):
         return C.cast(C.pointer(self.c), C.c_void_p)
@@ -197,6 +214,26 @@ class CsrMatrix:
         rc = lib().ko_csr_row_slice(C.byref(self.c), r0, r1, C.byref(out))
         assert rc == 0
         return CsrMatrix(out)
+
+
+class Ilu0:
+    """ILU(0) / IC(0) of a CsrMatrix (krylov_oracle.h): .lu values on A's pattern, .diag positions; solve(x) = U\\(L\\x)."""
+
+    def __init__(self, A: CsrMatrix):
+        self.A = A
+        self.lu = np.empty(max(A.nnz, 1))
+        self.diag = np.empty(max(A.n, 1), dtype=np.int64)
+        rc = lib().ko_ilu0(C.byref(A.c), _dp(self.lu), self.diag.ctypes.data_as(C.POINTER(C.c_int64)))
+        if rc != 0:
+            raise ZeroDivisionError(f"ilu0: missing or zero pivot in row {-rc - 1}")
+        self.lu = self.lu[: A.nnz]
+
+    def solve(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.A.n)
+        lu = np.ascontiguousarray(self.lu)
+        lib().ko_ilu0_solve(C.byref(self.A.c), _dp(lu), self.diag.ctypes.data_as(C.POINTER(C.c_int64)), _dp(x), _dp(y))
+        return y
 
 
 def _gen(fn, *args):

@@ -394,3 +394,45 @@ def test_ref_fortran_clients(refbin):
         if "block_minres" in name:
             continue
         assert not fails, (name, fails)
+
+
+# ---- ILU(0) / IC(0) (the vendor ic02 / ilu02 of the reference's GPU recipes) ------------
+
+def test_ilu0_defining_property_and_reference_known_answer(oracle):
+    """(L U)_ij = a_ij on the pattern of A (the definition of ILU(0)); for SPD A: U = D L^T (IC(0)); and the
+    reference's only preconditioned-GPU known answer: IC(0)-CG on sparse_laplacian(16) converges in <= 19
+    iterations with ||b - A x|| <= 1e-6 (test/gpu/nvidia.jl:37-70)."""
+    A = oracle.poisson3d(6)
+    P = oracle.Ilu0(A)
+    n = A.n
+    L, U = np.eye(n), np.zeros((n, n))
+    for i in range(n):
+        for q in range(A.rowptr[i], A.rowptr[i + 1]):
+            (L if A.col[q] < i else U)[i, A.col[q]] = P.lu[q]
+    S = A.to_scipy().toarray()
+    assert np.abs((L @ U - S)[S != 0]).max() <= 1e-14
+    D = np.diag(np.diag(U))
+    assert np.allclose(U, D @ L.T, atol=1e-14)                         # SPD: ILU(0) == IC(0) up to the diagonal scaling
+    x = np.linspace(1.0, 2.0, n)
+    assert np.allclose(L @ U @ P.solve(x), x, atol=1e-12)
+    # unsymmetric pattern with unsymmetric values
+    B = oracle.kron_unsymmetric(4)
+    Q = oracle.Ilu0(B)
+    n = B.n
+    L, U = np.eye(n), np.zeros((n, n))
+    for i in range(n):
+        for q in range(B.rowptr[i], B.rowptr[i + 1]):
+            (L if B.col[q] < i else U)[i, B.col[q]] = Q.lu[q]
+    S = B.to_scipy().toarray()
+    assert np.abs((L @ U - S)[S != 0]).max() <= 1e-13
+    # known answer of the reference
+    A16 = oracle.poisson3d(16)
+    P16 = oracle.Ilu0(A16)
+    b = np.ones(A16.n)
+    r = oracle.cg(A16, b, M=lambda v: P16.solve(v))
+    assert r.solved and r.niter <= 19 and np.linalg.norm(b - A16.matvec(r.x)) <= 1e-6
+    assert oracle.cg(A16, b).niter == 38                                   # unpreconditioned, for scale
+    # zero pivot is reported, not divided by
+    Z = oracle.tridiag(4, 1.0, 0.0, 1.0)
+    with pytest.raises(ZeroDivisionError):
+        oracle.Ilu0(Z)
