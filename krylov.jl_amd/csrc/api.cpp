@@ -39,8 +39,10 @@ int khip_ctx_create(int device, void *stream, khip_ctx **out) {
     ctx->own_stream = true;
   }
   KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-  KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_a, hipEventDisableTiming));
-  KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
+  for (int i = 0; i < khip_ctx::kEvRing; ++i) {
+    KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_a[i], hipEventDisableTiming));
+    KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_b[i], hipEventDisableTiming));
+  }
   hipDeviceProp_t prop;
   KHIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -68,8 +70,10 @@ int khip_ctx_destroy(khip_ctx *ctx) {
   (void)hipFree(ctx->results);
   (void)hipFree(ctx->results_dd);
   (void)hipHostFree(ctx->results_pinned);
-  (void)hipEventDestroy(ctx->ev_a);
-  (void)hipEventDestroy(ctx->ev_b);
+  for (int i = 0; i < khip_ctx::kEvRing; ++i) {
+    if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
+    if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
+  }
   (void)hipStreamDestroy(ctx->comm_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

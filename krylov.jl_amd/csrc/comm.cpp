@@ -303,8 +303,9 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x) 
   }
   hipStream_t cs = ctx->tune.overlap_halo ? ctx->comm_stream : ctx->stream;
   if (cs != ctx->stream) {
-    KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a, ctx->stream));
-    KHIP_CHECK_HIP(hipStreamWaitEvent(cs, ctx->ev_a, 0));
+    ctx->ev_cur = (ctx->ev_cur + 1) % khip_ctx::kEvRing;           // begin/end pairs alternate strictly
+    KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a[ctx->ev_cur], ctx->stream));
+    KHIP_CHECK_HIP(hipStreamWaitEvent(cs, ctx->ev_a[ctx->ev_cur], 0));
   }
   KHIP_CHECK_NCCL(g_rccl.GroupStart());
   for (int r = 0; r < c->nranks; ++r) {
@@ -315,7 +316,7 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x) 
     if (nr > 0) KHIP_CHECK_NCCL(g_rccl.Recv(A->ghost + A->recv_off[r], (size_t)nr, ncclFloat64, r, c->comm, cs));
   }
   KHIP_CHECK_NCCL(g_rccl.GroupEnd());
-  if (cs != ctx->stream) KHIP_CHECK_HIP(hipEventRecord(ctx->ev_b, cs));
+  if (cs != ctx->stream) KHIP_CHECK_HIP(hipEventRecord(ctx->ev_b[ctx->ev_cur], cs));
   return KHIP_OK;
 }
 
@@ -327,7 +328,7 @@ int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A) {
     c->hub->barrier();                                          // ... and so are theirs out of mine
     return KHIP_OK;
   }
-  if (ctx->tune.overlap_halo) KHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_b, 0));
+  if (ctx->tune.overlap_halo) KHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_b[ctx->ev_cur], 0));
   return KHIP_OK;
 }
 

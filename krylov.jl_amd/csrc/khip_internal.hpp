@@ -85,7 +85,12 @@ struct khip_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  // halo exchange hand-off events main stream <-> comm stream: a ring, so that an exchange enqueued while
+  // earlier ones are still pending (device-resident loops run several iterations ahead) never re-records
+  // an event something still waits on
+  static constexpr int kEvRing = 16;
+  hipEvent_t ev_a[kEvRing] = {}, ev_b[kEvRing] = {};
+  unsigned ev_cur = 0;
   int num_cu = 256;
   // reduction scratch (grown on demand by ensure_reduction_scratch)
   khip::dd *partials = nullptr;        // [kMaxNout][red_cap1]  one per wave of the streaming kernel
