@@ -140,6 +140,18 @@ int khip_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double
 /* x <- x + a p ; p <- r + b p in one pass over p          (src/cg.jl:239 and :259 = kaxpy!(n, a, p, x) ; kaxpby!(n, 1, r, b, p)).
  * Legal because x is not read between the two reference lines; 40n bytes instead of 48n. */
 int khip_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x);
+/* y <- A x ; *result_host = w . y               (src/bicgstab.jl:221-223: v = A p ; c . v in one pass) */
+int khip_spmv_dotw(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, const double *w, double *result_host);
+/* y <- A x ; result_host[0] = x . y ; result_host[1] = y . y        (src/bicgstab.jl:228-230: t = A s ; t.s ; t.t) */
+int khip_spmv_dot2(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, double *result_host);
+/* s <- r - alpha v ; x <- x + alpha y                                (src/bicgstab.jl:224-226) */
+int khip_bicgstab_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y,
+                     double *s, double *x);
+/* x <- x + omega z ; r <- s - omega t ; result_host = {c . r, r . r}  (src/bicgstab.jl:231-234,240; z may alias s) */
+int khip_bicgstab_xr(khip_ctx *ctx, int64_t n, double omega, const double *s, const double *t, const double *z,
+                     const double *c, double *x, double *r, double *result_host);
+/* p <- r + beta (p - omega v)                                         (src/bicgstab.jl:236-237) */
+int khip_bicgstab_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p);
 /* w <- x + b y  written to w (w may alias x or y): copy + axpy in one pass (src/bicgstab.jl:224-225,232-233) */
 int khip_waxpy(khip_ctx *ctx, int64_t n, double *w, const double *x, double b, const double *y);
 /* result_host[0] = x . y ; result_host[1] = x . x      (src/bicgstab.jl:230) */

@@ -110,6 +110,11 @@ SIGNATURES = {
     "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
     "khip_axpy_sqnorm": (_int, [_vp, _i64, _dbl, _vp, _vp, c_double_p]),
     "khip_cg_update": (_int, [_vp, _i64, _dbl, _dbl, _vp, _vp, _vp]),
+    "khip_spmv_dotw": (_int, [_vp, _vp, _vp, _vp, _vp, c_double_p]),
+    "khip_spmv_dot2": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
+    "khip_bicgstab_sx": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp]),
+    "khip_bicgstab_xr": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, c_double_p]),
+    "khip_bicgstab_p": (_int, [_vp, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "khip_dot2": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
     "khip_mgs": (_int, [_vp, _i64, _int, c_void_pp, _vp, c_double_p, c_double_p, _int]),
     "khip_multi_axpy": (_int, [_vp, _i64, _int, c_double_p, c_void_pp, _vp]),
@@ -473,6 +478,34 @@ def axpy2_dot(n, a, p, q, x, r) -> float:
     out = C.c_double()
     _ck(lib().khip_axpy2_dot(x.ctx._h, n, a, _p(p), _p(q), _p(x), _p(r), C.byref(out)))
     return out.value
+
+
+def spmv_dotw(A, x, y, w) -> float:
+    """y = A x ; returns w . y (src/bicgstab.jl:221-223)."""
+    r = C.c_double()
+    _ck(lib().khip_spmv_dotw(A.ctx._h, A._h, _p(x), _p(y), _p(w), C.byref(r)))
+    return r.value
+
+
+def spmv_dot2(A, x, y):
+    """y = A x ; returns (x . y, y . y) (src/bicgstab.jl:228-230)."""
+    out = (C.c_double * 2)()
+    _ck(lib().khip_spmv_dot2(A.ctx._h, A._h, _p(x), _p(y), out))
+    return out[0], out[1]
+
+
+def bicgstab_sx_(n, alpha, r, v, y, s, x):
+    _ck(lib().khip_bicgstab_sx(x.ctx._h, n, alpha, _p(r), _p(v), _p(y), _p(s), _p(x)))
+
+
+def bicgstab_xr_(n, omega, s, t, z, c, x, r):
+    out = (C.c_double * 2)()
+    _ck(lib().khip_bicgstab_xr(x.ctx._h, n, omega, _p(s), _p(t), _p(z), _p(c), _p(x), _p(r), out))
+    return out[0], out[1]
+
+
+def bicgstab_p_(n, omega, beta, v, r, p):
+    _ck(lib().khip_bicgstab_p(p.ctx._h, n, omega, beta, _p(v), _p(r), _p(p)))
 
 
 def axpy_sqnorm(n, a, x, y) -> float:

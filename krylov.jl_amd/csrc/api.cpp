@@ -276,19 +276,24 @@ int khip_spmv_bytes(const khip_csr *A, int64_t *bytes) {
 // interior / boundary split of distributed handles.  The up to three launches of a split product feed a
 // single finish kernel, so every rank contributes exactly one partial to the all-reduce.
 }  // extern "C"
-int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot) {
-  if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m);
+int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw,
+                   bool dot_sq) {
+  if (dot_sq && spmv_kernel_choice(ctx, A) != 4) {      // only the staged kernel carries the second reduction
+    KHIP_TRY(spmv_any(ctx, A, x, y, dot_slot, dotw, false));
+    return launch_nrm2sq(ctx, A->m, y, dot_slot + 1);
+  }
+  if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m, nullptr, true, dotw, dot_sq);
   KHIP_TRY(comm_halo_exchange_begin(ctx, A, x));
   const bool split = ctx->tune.overlap_halo && A->interior_hi > A->interior_lo;
   if (!split) {
     KHIP_TRY(comm_halo_exchange_end(ctx, A));
-    return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m);
+    return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m, nullptr, true, dotw, dot_sq);
   }
   int64_t cursor = 0;
-  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_lo, A->interior_hi, &cursor, false));
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_lo, A->interior_hi, &cursor, false, dotw, dot_sq));
   KHIP_TRY(comm_halo_exchange_end(ctx, A));
-  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, 0, A->interior_lo, &cursor, false));
-  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_hi, A->m, &cursor, true));
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, 0, A->interior_lo, &cursor, false, dotw, dot_sq));
+  KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, A->interior_hi, A->m, &cursor, true, dotw, dot_sq));
   return KHIP_OK;
 }
 extern "C" {
@@ -305,6 +310,22 @@ int khip_spmv_dot(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, 
   const int slot = take_slots(ctx, 1);
   KHIP_TRY(spmv_any(ctx, A, x, y, slot));
   return fetch_results(ctx, slot, 1, result_host);
+}
+
+int khip_spmv_dotw(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, const double *w, double *result_host) {
+  KHIP_REQUIRE(ctx && A && x && y && w && result_host, "spmv_dotw: null argument");
+  KHIP_REQUIRE(x != y && w != y, "spmv_dotw: y must not alias x or w");
+  const int slot = take_slots(ctx, 1);
+  KHIP_TRY(spmv_any(ctx, A, x, y, slot, w, false));
+  return fetch_results(ctx, slot, 1, result_host);
+}
+
+int khip_spmv_dot2(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, double *result_host) {
+  KHIP_REQUIRE(ctx && A && x && y && result_host, "spmv_dot2: null argument");
+  KHIP_REQUIRE(x != y, "spmv_dot2: x and y must not alias");
+  const int slot = take_slots(ctx, 2);
+  KHIP_TRY(spmv_any(ctx, A, x, y, slot, nullptr, true));
+  return fetch_results(ctx, slot, 2, result_host);
 }
 
 int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms) {
@@ -455,6 +476,25 @@ int khip_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double
 int khip_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x) {
   KHIP_REQUIRE(ctx && n >= 0 && (n == 0 || (r && p && x)), "cg_update: null argument");
   return launch_cg_update(ctx, n, a, b, r, p, x);
+}
+
+int khip_bicgstab_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y, double *s,
+                     double *x) {
+  KHIP_REQUIRE(ctx && n >= 0 && (n == 0 || (r && v && y && s && x)), "bicgstab_sx: null argument");
+  return launch_bicg_sx(ctx, n, alpha, r, v, y, s, x);
+}
+
+int khip_bicgstab_xr(khip_ctx *ctx, int64_t n, double omega, const double *s, const double *t, const double *z,
+                     const double *c, double *x, double *r, double *result_host) {
+  KHIP_REQUIRE(ctx && result_host && n >= 0 && (n == 0 || (s && t && z && c && x && r)), "bicgstab_xr: null argument");
+  const int slot = take_slots(ctx, 2);
+  KHIP_TRY(launch_bicg_xr(ctx, n, omega, s, t, z, c, x, r, slot));
+  return fetch_results(ctx, slot, 2, result_host);
+}
+
+int khip_bicgstab_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p) {
+  KHIP_REQUIRE(ctx && n >= 0 && (n == 0 || (v && r && p)), "bicgstab_p: null argument");
+  return launch_bicg_p(ctx, n, omega, beta, v, r, p);
 }
 
 int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, double *q, double *h_host,

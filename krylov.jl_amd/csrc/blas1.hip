@@ -205,6 +205,152 @@ int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double 
   return KHIP_OK;
 }
 
+// ---------------------------------------------------------------- BiCGSTAB fused updates ----
+// The elementwise work of one bicgstab! iteration (src/bicgstab.jl:224-237) in three passes instead of
+// nine; every expression is the one the separate kernels use (OP_WAXPY, OP_AXPY, OP_AXPBY), so all vectors
+// are bit-identical to the unfused sequence.
+//   sx:  s = r - alpha v  (:224-225) ; x += alpha y  (:226)                                  48n bytes
+//   xr:  x += omega z (:231) ; r = s - omega t (:232-233) ; c.r (:234) ; r.r (:240)          48n (40n if z === s)
+//   p :  p = r + beta (p - omega v)  (:236-237)                                              32n
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void bicg_sx_kernel(int64_t n, double alpha, const double *r, const double *v,
+                                                         const double *y, double *s, double *x) {
+  using T = typename VecT<VEC>::type;
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T rv = ldg<NT>(reinterpret_cast<const T *>(r) + i), vv = ldg<NT>(reinterpret_cast<const T *>(v) + i);
+    const T yv = ldg<NT>(reinterpret_cast<const T *>(y) + i), xv = ldg<NT>(reinterpret_cast<T *>(x) + i);
+    T so, xo;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      vset(so, e, fma(-alpha, vget(vv, e), vget(rv, e)));
+      vset(xo, e, fma(alpha, vget(yv, e), vget(xv, e)));
+    }
+    stg<NT>(so, reinterpret_cast<T *>(s) + i);
+    stg<NT>(xo, reinterpret_cast<T *>(x) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    const double rt = r[t], vt = v[t], yt = y[t];
+    s[t] = fma(-alpha, vt, rt);
+    x[t] = fma(alpha, yt, x[t]);
+  }
+}
+
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void bicg_p_kernel(int64_t n, double omega, double beta, const double *v,
+                                                        const double *r, double *p) {
+  using T = typename VecT<VEC>::type;
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T vv = ldg<NT>(reinterpret_cast<const T *>(v) + i), rv = ldg<NT>(reinterpret_cast<const T *>(r) + i);
+    const T pv = ldg<NT>(reinterpret_cast<T *>(p) + i);
+    T po;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const double p1 = fma(-omega, vget(vv, e), vget(pv, e));      // kaxpy!(n, -omega, v, p)
+      vset(po, e, fma(1.0, vget(rv, e), beta * p1));               // kaxpby!(n, 1, r, beta, p)
+    }
+    stg<NT>(po, reinterpret_cast<T *>(p) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    const double p1 = fma(-omega, v[t], p[t]);
+    p[t] = fma(1.0, r[t], beta * p1);
+  }
+}
+
+template <bool COMP, int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void bicg_xr_kernel(int64_t n, double omega, const double *s, const double *t,
+                                                         const double *z, const double *c, double *x, double *r,
+                                                         RedArgs ra) {
+  using T = typename VecT<VEC>::type;
+  if (seq_skip(ra.stop_seq, ra.seq)) return;
+  dd acc[2] = {dd{0.0, 0.0}, dd{0.0, 0.0}};
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T sv = ldg<NT>(reinterpret_cast<const T *>(s) + i), tv = ldg<NT>(reinterpret_cast<const T *>(t) + i);
+    const T zv = (z == s) ? sv : ldg<NT>(reinterpret_cast<const T *>(z) + i);
+    const T cv = ldg<NT>(reinterpret_cast<const T *>(c) + i), xv = ldg<NT>(reinterpret_cast<T *>(x) + i);
+    T xo, ro;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      vset(xo, e, fma(omega, vget(zv, e), vget(xv, e)));
+      const double rn = fma(-omega, vget(tv, e), vget(sv, e));
+      vset(ro, e, rn);
+      acc_prod<COMP>(acc[0], vget(cv, e), rn);
+      acc_prod<COMP>(acc[1], rn, rn);
+    }
+    stg<NT>(xo, reinterpret_cast<T *>(x) + i);
+    stg<NT>(ro, reinterpret_cast<T *>(r) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t k = n - 1;
+    const double sk = s[k], tk = t[k], zk = z[k], ck = c[k];
+    x[k] = fma(omega, zk, x[k]);
+    const double rn = fma(-omega, tk, sk);
+    r[k] = rn;
+    acc_prod<COMP>(acc[0], ck, rn);
+    acc_prod<COMP>(acc[1], rn, rn);
+  }
+  wave_publish<2>(acc, ra);
+}
+
+int launch_bicg_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y, double *s,
+                   double *x) {
+  if (n <= 0) return KHIP_OK;
+  const bool v2 = n >= 2 && aligned16(r) && aligned16(v) && aligned16(y) && aligned16(s) && aligned16(x);
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_L(VEC, NT) \
+  hipLaunchKernelGGL((bicg_sx_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, alpha, r, v, y, s, x)
+  if (v2) { if (nt) KHIP_L(2, true); else KHIP_L(2, false); }
+  else    { if (nt) KHIP_L(1, true); else KHIP_L(1, false); }
+#undef KHIP_L
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+int launch_bicg_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p) {
+  if (n <= 0) return KHIP_OK;
+  const bool v2 = n >= 2 && aligned16(r) && aligned16(v) && aligned16(p);
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_L(VEC, NT) \
+  hipLaunchKernelGGL((bicg_p_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, omega, beta, v, r, p)
+  if (v2) { if (nt) KHIP_L(2, true); else KHIP_L(2, false); }
+  else    { if (nt) KHIP_L(1, true); else KHIP_L(1, false); }
+#undef KHIP_L
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+int launch_bicg_xr(khip_ctx *ctx, int64_t n, double omega, const double *s, const double *t, const double *z,
+                   const double *c, double *x, double *r, int slot) {
+  if (n < 0) { set_error("negative length"); return KHIP_ERR_INVALID; }
+  const bool v2 = n >= 2 && aligned16(s) && aligned16(t) && aligned16(z) && aligned16(c) && aligned16(x) && aligned16(r);
+  const bool comp = ctx->tune.compensated != 0;
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+  KHIP_TRY(ensure_reduction_scratch(ctx, g * kWavesPerBlock, 2));
+  RedArgs ra = make_red_args(ctx, slot);
+#define KHIP_L(COMP, VEC, NT) \
+  hipLaunchKernelGGL((bicg_xr_kernel<COMP, VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, omega, s, t, z, c, x, r, ra)
+#define KHIP_L2(COMP) do { if (v2) { if (nt) KHIP_L(COMP, 2, true); else KHIP_L(COMP, 2, false); } \
+                           else    { if (nt) KHIP_L(COMP, 1, true); else KHIP_L(COMP, 1, false); } } while (0)
+  if (comp) KHIP_L2(true); else KHIP_L2(false);
+#undef KHIP_L2
+#undef KHIP_L
+  KHIP_CHECK_HIP(hipGetLastError());
+  return launch_finish(ctx, g * kWavesPerBlock, 2, slot);
+}
+
 // Device-scalar variant for the device-resident CG loop: alpha, beta and the `solved` flag come from
 // the CgDevState the epilogues maintain; when the stopping test has fired only x is updated
 // (src/cg.jl:255-260 skips the direction update once solved).

@@ -159,6 +159,12 @@ int launch_cg_update_dev(khip_ctx *ctx, int64_t n, const void *cg_state_dev, lon
 // produced outside a finish kernel) / fold nranks gathered (hi, lo) partials per scalar and run it
 int launch_epilogue_only(khip_ctx *ctx, int slot);
 int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot);
+// fused elementwise passes of one bicgstab! iteration (blas1.hip)
+int launch_bicg_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y, double *s,
+                   double *x);
+int launch_bicg_xr(khip_ctx *ctx, int64_t n, double omega, const double *s, const double *t, const double *z,
+                   const double *c, double *x, double *r, int slot);   // slot: c.r, slot+1: r.r
+int launch_bicg_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p);
 // y <- y - (*coef_dev) x ; out[slot] = z . y (z == y -> ||y||^2), coef read from device memory
 int launch_axpy_dev_dot(khip_ctx *ctx, int64_t n, const double *coef_dev, const double *x, double *y,
                         const double *z, int slot);
@@ -171,8 +177,11 @@ int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host,
 int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host);
 
 // spmv.hip
+// dot_slot >= 0: results[dot_slot] = dotw . y (dotw = x when null); dot_sq: also results[dot_slot + 1] = y . y
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot /* -1 = none */,
-                int64_t row_lo, int64_t row_hi, int64_t *wave_cursor = nullptr, bool finish = true);
+                int64_t row_lo, int64_t row_hi, int64_t *wave_cursor = nullptr, bool finish = true,
+                const double *dotw = nullptr, bool dot_sq = false);
+int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A);
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
 int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays are resident
 int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out);
@@ -184,7 +193,8 @@ int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
 int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 
 // api.cpp: y = A x (dot_slot >= 0: also results[dot_slot] = x . y) incl. halo exchange; launches only, no host sync
-int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot);
+int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw = nullptr,
+             bool dot_sq = false);
 
 // panel.hip
 void panel_scratch_destroy(khip_ctx *ctx);

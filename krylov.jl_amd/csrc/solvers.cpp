@@ -930,9 +930,41 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   bool breakdown = false, user_requested_exit = false, overtimed = false;
   const char *status = "unknown";
 
+  const bool fast = fused && MisI && NisI && !A->apply && A->csr;
   while (!(solved || tired || breakdown || user_requested_exit || overtimed)) {
     iter = iter + 1;
     rho = next_rho;
+
+    if (fast) {
+      // M = N = I on a CSR operator: the iteration in 5 passes (2 SpMV with their dots fused + 128n bytes of
+      // vector work instead of 216n), every elementwise expression unchanged.  q = A p is written straight
+      // into v (the reference copies it there, :222, and q's storage is reused for d in the same iteration).
+      double cv, two[2];
+      int slot = take_slots(ctx, 1);
+      K(spmv_any(ctx, A->csr, p, v, slot, c, false));                              // :221-223  v = A p ; c.v
+      K(fetch_results(ctx, slot, 1, &cv));
+      alpha = rho / cv;                                                            // :223
+      K(launch_bicg_sx(ctx, n, alpha, r, v, p, s, x));                             // :224-226
+      slot = take_slots(ctx, 2);
+      K(spmv_any(ctx, A->csr, s, t, slot, nullptr, true));                         // :228-230  t = A s ; t.s ; t.t
+      K(fetch_results(ctx, slot, 2, two));
+      omega = two[0] / two[1];                                                     // :230
+      slot = take_slots(ctx, 2);
+      K(launch_bicg_xr(ctx, n, omega, s, t, s, c, x, r, slot));                    // :231-234, :240
+      K(fetch_results(ctx, slot, 2, two));
+      next_rho = two[0];
+      const double beta = (next_rho / rho) * (alpha / omega);                      // :235
+      K(launch_bicg_p(ctx, n, omega, beta, v, r, p));                              // :236-237
+      rNorm = std::sqrt(two[1]);                                                   // :240
+      if (o.history) ws->box.push(rNorm);
+      const bool rdm = (rNorm + 1.0 <= 1.0);
+      if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+      solved = (rNorm <= eps_tol) || rdm;
+      tired = iter >= itmax;
+      breakdown = (alpha == 0 || std::isnan(alpha));
+      overtimed = (now_s() - t0) > timemax;
+      continue;
+    }
 
     if (!NisI) K(apply_op(ctx, N, p, y));
     K(apply_op(ctx, A, y, q));                                                     // :221

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
     }
     if (tid < nr) {
       if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
-      if (DOT) acc_prod<COMP>(dacc[0], a.x[r0 + tid], acc);
+      if (DOT) acc_prod<COMP>(dacc[0], a.dotw[r0 + tid], acc);
     }
   }
   if (DOT) wave_publish<1>(dacc, ra);
@@ -168,8 +168,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
   const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap);
   const int64_t rb_begin = (int64_t)cid * tpb;
   const int64_t rb_end = (rb_begin + tpb < nrb) ? rb_begin + tpb : nrb;
-  dd dacc[1];
+  dd dacc[2];                                // [0] = w . y ; [1] = y . y (only when a.dot_sq)
   dacc[0] = dd{0.0, 0.0};
+  dacc[1] = dd{0.0, 0.0};
 
   for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
     const int64_t r0 = a.row_lo + rb * ROWS;
@@ -241,10 +242,16 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
     }
     if (tid < nr) {
       if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
-      if (DOT) acc_prod<COMP>(dacc[0], a.x[r0 + tid], acc);
+      if (DOT) {
+        acc_prod<COMP>(dacc[0], a.dotw[r0 + tid], acc);
+        if (a.dot_sq) acc_prod<COMP>(dacc[1], acc, acc);
+      }
     }
   }
-  if (DOT) wave_publish<1>(dacc, ra);
+  if (DOT) {
+    if (a.dot_sq) wave_publish<2>(dacc, ra);
+    else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
+  }
 }
 
 // ---------------------------------------------------------------- ordered sub-wave -------
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void spmv_ordered_kernel(SpmvArgs a, RedArg
       const int64_t row = wrow0 + k * NG + g;
       if (row < a.row_hi) {
         a.y[row] = mine;
-        if (DOT) acc_prod<COMP>(dacc[0], a.x[row], mine);
+        if (DOT) acc_prod<COMP>(dacc[0], a.dotw[row], mine);
       }
     }
   }
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void spmv_vector_kernel(SpmvArgs a, RedArgs
     for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, LPR);
     if (sl == 0) {
       a.y[row] = acc;
-      if (DOT) acc_prod<COMP>(dacc[0], a.x[row], acc);
+      if (DOT) acc_prod<COMP>(dacc[0], a.dotw[row], acc);
     }
   }
   if (DOT) wave_publish<1>(dacc, ra);
@@ -404,14 +411,28 @@ static inline unsigned pick_grid(khip_ctx *ctx, int64_t tiles, bool persist) {
 // dot_slot >= 0 fuses x . y.  Several launches (interior + boundary ranges of a distributed operator) can
 // feed ONE reduction: each passes the running partial count in *wave_cursor (updated here) and only the
 // last one sets `finish`, which folds all partials written so far into results[dot_slot].
+// which kernel launch_spmv will pick for this operator (the staged one is the only one with the y.y output)
+int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A) {
+  int kernel = ctx->tune.spmv_kernel;
+  // short rows (stencils, <= 8 entries on average): staged-rows kernel; mid-size rows: ordered
+  // sub-wave kernel; very long rows: strided vector kernel
+  if (kernel == 0) kernel = (A->mean_row_nnz <= 8.0 && A->max_row_nnz <= 64) ? 4 : (A->mean_row_nnz <= 96.0 ? 3 : 2);
+  return kernel;
+}
+
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, int64_t row_lo,
-                int64_t row_hi, int64_t *wave_cursor, bool finish) {
+                int64_t row_hi, int64_t *wave_cursor, bool finish, const double *dotw, bool dot_sq) {
   int64_t local_cursor = 0;
   if (!wave_cursor) wave_cursor = &local_cursor;
+  const int nout = dot_sq ? 2 : 1;
+  if (dot_sq && spmv_kernel_choice(ctx, A) != 4) { set_error("spmv: the y.y output needs the staged kernel"); return KHIP_ERR_UNSUPPORTED; }
   if (row_hi <= row_lo) {
     if (dot_slot >= 0 && finish) {
-      if (*wave_cursor == 0) return launch_nrm2sq(ctx, 0, x, dot_slot);   // nothing at all: writes 0
-      return launch_finish(ctx, *wave_cursor, 1, dot_slot);
+      if (*wave_cursor == 0) {                                              // nothing at all: writes 0
+        KHIP_TRY(launch_nrm2sq(ctx, 0, x, dot_slot));
+        return dot_sq ? launch_nrm2sq(ctx, 0, x, dot_slot + 1) : KHIP_OK;
+      }
+      return launch_finish(ctx, *wave_cursor, nout, dot_slot);
     }
     return KHIP_OK;
   }
@@ -426,6 +447,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.stage_cap = 2048;
   a.stop_seq = ctx->ctl.stop_seq;
   a.seq = ctx->ctl.seq;
+  a.dotw = dotw ? dotw : x;
+  a.dot_sq = dot_sq ? 1 : 0;
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;
@@ -448,10 +471,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     ctx->prof_used += 2;
   }
 
-  int kernel = ctx->tune.spmv_kernel;
-  // short rows (stencils, <= 8 entries on average): staged-rows kernel; mid-size rows: ordered
-  // sub-wave kernel; very long rows: strided vector kernel
-  if (kernel == 0) kernel = (A->mean_row_nnz <= 8.0 && A->max_row_nnz <= 64) ? 4 : (A->mean_row_nnz <= 96.0 ? 3 : 2);
+  const int kernel = spmv_kernel_choice(ctx, A);
   unsigned grid = 1;
   RedArgs ra;
   if (kernel == 1) {
@@ -462,7 +482,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
     if (rows != 256 && rows != 128 && rows != 64 && rows != 32) rows = 256;
     grid = pick_grid(ctx, (nrows + rows - 1) / rows, persist);
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
     ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
     const int vec = ctx->tune.spmv_vec == 2 ? 2 : 1;
 #define KHIP_ROWS(R)                                                                              \
@@ -492,7 +512,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     const int64_t nrb4 = (nrows + rows - 1) / rows;
     grid = pick_grid(ctx, (nrb4 + a.tiles_per_block - 1) / a.tiles_per_block, false);
     if ((int64_t)grid * a.tiles_per_block < nrb4) a.tiles_per_block = (int)((nrb4 + grid - 1) / grid);
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
     ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
 #define KHIP_STG(R) do { if (nt) launch_stage_cfg<R, true>(ctx, a, ra, grid, dot, comp, dist); \
                          else launch_stage_cfg<R, false>(ctx, a, ra, grid, dot, comp, dist); } while (0)
@@ -514,7 +534,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   do {                                                                                        \
     constexpr int rpb = (64 / LL) * RPG * kWavesPerBlock;                                     \
     grid = pick_grid(ctx, (nrows + rpb - 1) / rpb, persist);                                  \
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));                                \
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));                                \
     ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;                                              \
     if (nt) launch_ordered_cfg<LL, RPG, true>(ctx, a, ra, grid, dot, comp, dist);             \
     else launch_ordered_cfg<LL, RPG, false>(ctx, a, ra, grid, dot, comp, dist);               \
@@ -535,7 +555,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
     const int rpb = kBlock / lpr;
     grid = pick_grid(ctx, (nrows + rpb - 1) / rpb, persist);
-    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, 1));
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
     ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
     switch (lpr) {
       case 4: launch_vector_cfg<4>(ctx, a, ra, grid, dot, comp, dist); break;
@@ -548,7 +568,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   KHIP_CHECK_HIP(hipGetLastError());
   if (dot) {
     *wave_cursor += (int64_t)grid * kWavesPerBlock;
-    if (finish) KHIP_TRY(launch_finish(ctx, *wave_cursor, 1, dot_slot));
+    if (finish) KHIP_TRY(launch_finish(ctx, *wave_cursor, nout, dot_slot));
   }
   if (ev_stop) KHIP_CHECK_HIP(hipEventRecord(ev_stop, ctx->stream));
   return KHIP_OK;

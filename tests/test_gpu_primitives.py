@@ -406,3 +406,71 @@ def test_full_size_spmv_properties_512(K, ctx, parity_log):
     lin = K.knorm(n, Ax) / K.knorm(n, Az)
     assert lin <= 1e-14
     parity_log(test="spmv_512_properties", linearity_rel=lin, symmetry_rel=sym)
+
+
+@pytest.mark.parametrize("n1", [5, 12])
+def test_fused_bicgstab_passes(K, ctx, oracle, n1):
+    """The five passes of the fused bicgstab! iteration (src/bicgstab.jl:221-240) against the unfused device
+    sequence (vectors bit-identical, reductions within an ulp) and the oracle."""
+    A = oracle.kron_unsymmetric(n1)
+    n = A.n
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (n, n))
+    rng = np.random.default_rng(n1)
+    p, c, r, x0 = (_vec(rng, n) for _ in range(4))
+    dp_, dc, dr = ctx.array(p), ctx.array(c), ctx.array(r)
+    # v = A p ; c . v
+    dv = ctx.empty(n)
+    cv = K.spmv_dotw(dA, dp_, dv, dc)
+    v = A.matvec(p)
+    assert np.array_equal(dv.to_host(), v)
+    assert abs(cv - oracle.dot(c, v)) <= 4 * EPS * np.abs(c * v).sum()
+    # s = r - alpha v ; x += alpha p
+    alpha = 0.37
+    ds, dx = ctx.empty(n), ctx.array(x0)
+    K.bicgstab_sx_(n, alpha, dr, dv, dp_, ds, dx)
+    us, ux = ctx.empty(n), ctx.array(x0)
+    K.waxpy_(n, us, dr, -alpha, dv)
+    K.kaxpy_(n, alpha, dp_, ux)
+    assert np.array_equal(ds.to_host(), us.to_host()) and np.array_equal(dx.to_host(), ux.to_host())
+    s = r.copy(); oracle.axpy(-alpha, v, s)
+    assert np.array_equal(ds.to_host(), s)
+    # t = A s ; (t . s, t . t)
+    dt = ctx.empty(n)
+    ts, tt = K.spmv_dot2(dA, ds, dt)
+    t = A.matvec(s)
+    assert np.array_equal(dt.to_host(), t)
+    assert abs(ts - oracle.dot(t, s)) <= 4 * EPS * np.abs(t * s).sum() and abs(tt - oracle.dot(t, t)) <= 4 * EPS * tt
+    # x += omega s ; r = s - omega t ; (c . r, r . r)
+    omega = ts / tt
+    rho, rr = K.bicgstab_xr_(n, omega, ds, dt, ds, dc, dx, dr)
+    K.kaxpy_(n, omega, ds, ux)
+    ur = ctx.empty(n)
+    K.waxpy_(n, ur, ds, -omega, dt)
+    assert np.array_equal(dx.to_host(), ux.to_host()) and np.array_equal(dr.to_host(), ur.to_host())
+    rn = ur.to_host()
+    assert abs(rho - oracle.dot(c, rn)) <= 4 * EPS * np.abs(c * rn).sum() and abs(rr - oracle.dot(rn, rn)) <= 4 * EPS * rr
+    assert abs(rho - K.kdot(n, dc, ur)) <= 4 * EPS * np.abs(c * rn).sum()
+    # p = r + beta (p - omega v)
+    beta = -0.81
+    up = ctx.array(p)
+    K.bicgstab_p_(n, omega, beta, dv, dr, dp_)
+    K.kaxpy_(n, -omega, dv, up)
+    K.kaxpby_(n, 1.0, ur, beta, up)
+    assert np.array_equal(dp_.to_host(), up.to_host())
+    hp = p.copy(); oracle.axpy(-omega, v, hp); oracle.axpby(1.0, rn, beta, hp)
+    assert np.array_equal(dp_.to_host(), hp)
+
+
+def test_spmv_dot2_on_long_rows_falls_back(K, ctx, oracle):
+    """Only the staged-rows kernel carries the second reduction; other row shapes get y.y from a separate pass."""
+    rng = np.random.default_rng(3)
+    import scipy.sparse as sp
+    M = sp.random(300, 300, density=0.4, random_state=3, format="csr") + sp.eye(300, format="csr")
+    M.sort_indices()
+    dA = K.CsrMatrix.from_host(ctx, M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data, (300, 300))
+    x = rng.standard_normal(300)
+    dy = ctx.empty(300)
+    xy, yy = K.spmv_dot2(dA, ctx.array(x), dy)
+    y = dy.to_host()
+    assert np.allclose(y, M @ x, rtol=1e-13, atol=1e-13)
+    assert abs(xy - x @ y) <= 1e-12 * np.abs(x * y).sum() and abs(yy - y @ y) <= 1e-12 * yy
