@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_dev_kernel(int64_t n, const 
       vset(po, e, fma(1.0, vget(rv, e), b * vget(pv, e)));
     }
     stg<NT>(xo, reinterpret_cast<T *>(x) + i);
-    if (!solved) stg<NT>(po, reinterpret_cast<T *>(p) + i);
+    if (!solved) stg<NT>(po, reinterpret_cast<T *>(p) + i);   // (a cacheable store of p for the next SpMV's gather was measured: slower)
   }
   if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t t = n - 1;
@@ -464,8 +464,11 @@ struct RedPtrs {
   double a;             // AXPY2
 };
 
-template <int ROP, bool COMP, int VEC, bool NT, int U>
+// KEEP: the y / u streams use ordinary (cacheable) accesses even when NT is set for x -- the MGS cascade
+// re-reads q (u) and the basis vector it just dotted (y becomes the next step's x) in the very next kernel.
+template <int ROP, bool COMP, int VEC, bool NT, int U, bool KEEP = false>
 __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, RedArgs ra) {
+  constexpr bool NTK = NT && !KEEP;
   using T = typename VecT<VEC>::type;
   constexpr int NOUT = RedOut<ROP>::n;
   if (seq_skip(ra.stop_seq, ra.seq)) return;
@@ -491,8 +494,8 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
     const int64_t j = base + u * kBlock;
     if (j < nvec) {
       xv[u] = ldg<NT>(X + j);
-      if (rd_y && !(ROP == RED_AXPYDEV && z_is_y)) yv[u] = ldg<NT>(Y + j);
-      if (rd_u) uv[u] = ldg<NT>(Uv + j);
+      if (rd_y && !(ROP == RED_AXPYDEV && z_is_y)) yv[u] = ldg<NTK>(Y + j);
+      if (rd_u) uv[u] = ldg<NTK>(Uv + j);
       if (rd_v) vv[u] = ldg<NT>(Vv + j);
     }
   }
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
           vset(vn, e, rn);
           acc_prod<COMP>(acc[0], rn, rn);
         }
-        stg<NT>(un, Uv + j);
+        stg<NTK>(un, Uv + j);
         stg<NT>(vn, Vv + j);
       } else if (ROP == RED_AXPYDEV || ROP == RED_AXPYSQ) {
         T un;
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
           vset(un, e, yn);
           acc_prod<COMP>(acc[0], z_is_y ? yn : vget(yv[u], e), yn);
         }
-        stg<NT>(un, Uv + j);
+        stg<NTK>(un, Uv + j);
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -562,7 +565,12 @@ static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   const bool v2 = n >= 2 && aligned16(p.x) && (p.y == nullptr || aligned16(p.y)) && (p.u == nullptr || aligned16(p.u)) &&
                   (p.v == nullptr || aligned16(p.v));
   const bool comp = ctx->tune.compensated != 0;
-  const bool nt = use_nt(ctx, n);
+  // MGS cascade (AXPYDEV): q and the basis vector just dotted are read again by the very next kernel; when both
+  // fit in the 256 MiB Infinity Cache, leaving them cacheable beats streaming them (GMRES(30) at 256^3:
+  // 1.91 -> 1.71 ms per inner iteration; at 384^3 it costs 2-5 %: profiles/r01h_mgs_keep.log)
+  int keep = ctx->tune.mgs_keep;
+  if (keep < 0) keep = (ROP == RED_AXPYDEV && (size_t)n * sizeof(double) <= (size_t)144 << 20) ? 1 : 0;
+  const bool nt = use_nt(ctx, n) && !(ROP == RED_AXPYDEV && keep == 2);
   const int64_t nvec = v2 ? n / 2 : n;
   const bool u4 = nvec >= (int64_t)kBlock * 4 * 1024;          // big vectors: 4 independent accesses per lane
   const int64_t g = tiles_for(nvec, u4 ? 4 : 1);
@@ -573,8 +581,10 @@ static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   hipLaunchKernelGGL((reduce_kernel<ROP, COMP, VEC, NT, U>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra)
 #define KHIP_RED_U(COMP, VEC, NT) do { if (u4) KHIP_RED(COMP, VEC, NT, 4); else KHIP_RED(COMP, VEC, NT, 1); } while (0)
 #define KHIP_RED_NT(COMP, VEC) do { if (nt) KHIP_RED_U(COMP, VEC, true); else KHIP_RED_U(COMP, VEC, false); } while (0)
-  if (comp) { if (v2) KHIP_RED_NT(true, 2); else KHIP_RED_NT(true, 1); }
-  else      { if (v2) KHIP_RED_NT(false, 2); else KHIP_RED_NT(false, 1); }
+  if (ROP == RED_AXPYDEV && nt && v2 && u4 && comp && keep == 1) {
+    hipLaunchKernelGGL((reduce_kernel<ROP, true, 2, true, 4, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra);
+  } else if (comp) { if (v2) KHIP_RED_NT(true, 2); else KHIP_RED_NT(true, 1); }
+  else             { if (v2) KHIP_RED_NT(false, 2); else KHIP_RED_NT(false, 1); }
 #undef KHIP_RED_NT
 #undef KHIP_RED_U
 #undef KHIP_RED

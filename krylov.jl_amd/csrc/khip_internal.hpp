@@ -66,6 +66,7 @@ struct Tuning {
   int spmv_persist = 0;     // 1 = persistent grid (<= 8 workgroups per CU) instead of one row block per workgroup
   int compensated = 1;      // Dot2 (TwoSum/TwoProd) reductions
   int nt_min_elems = 1 << 22;  // BLAS-1 vectors at least this long use non-temporal accesses (32 MiB)
+  int mgs_keep = -1;        // MGS cascade: keep q and the freshly dotted basis vector cacheable for the next step (-1 auto: when they fit the Infinity Cache; 0 off; 1 on; 2 nothing streamed)
   int overlap_halo = 1;     // overlap halo exchange with interior rows
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
