@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--fused", type=int, default=2,
                     help="0 = reference primitive sequence, 1 = fused kernels, 2 = fused + device-resident scalars")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compress", action="store_true",
+                    help="NOT the headline: re-encode the operator as row templates (khip_csr_compress, 2 B of matrix data per row)")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (khip_ctx_set_option)")
     args = ap.parse_args()
 
@@ -135,6 +137,7 @@ def main():
     nloc = r1 - r0
     t_setup = time.time()
     A = K.CsrMatrix.stencil(ctx, "poisson", n1, rows=(r0, r1), distributed=use_comm)
+    templates = A.compress() if args.compress else 0
     b = ctx.empty(nloc)
     K.kfill_(b, 1.0)
     ws = K.CgWorkspace(ctx, nloc, nloc)
@@ -168,7 +171,7 @@ def main():
 
     if rank == 0:
         its = args.steps / elapsed
-        spmv_bytes_local = A.spmv_bytes
+        spmv_bytes_local = A.spmv_bytes_stored if templates else A.spmv_bytes     # compressed: what that format moves
         # algorithmic bytes of one fused iteration on this rank: SpMV(+dot) + (r update + r.r: 24n) + (x and p update: 40n)
         iter_bytes_local = spmv_bytes_local + (64 if args.fused else 104) * nloc
         iter_bytes_unfused_local = spmv_bytes_local + 104 * nloc       # as the reference issues it
@@ -182,13 +185,14 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"cg! on get_div_grad({n1},{n1},{n1}) CSR (cfg 2), b=ones, Float64, int32 indices",
                        "n": n, "nnz_global": 7 * n - 6 * n1 * n1, "fused": args.fused,
-                       "partition": f"1-D rows over {world} GPU(s)", "atol": 0.0, "rtol": 0.0},
+                       "partition": f"1-D rows over {world} GPU(s)", "atol": 0.0, "rtol": 0.0,
+                       "operator_format": f"row templates ({templates})" if templates else "CSR"},
             "hbm_gbps_iteration": its * iter_bytes_local * world / 1e9,
             "hbm_gbps_iteration_reference_sequence": its * iter_bytes_unfused_local * world / 1e9,
             "final_residual_norm": float(st.residuals[-1]),
-            "roofline": {"bound": "hbm", "kernel": "spmv_stage_kernel (CSR SpMV fused with p.Ap)",
+            "roofline": {"bound": "hbm", "kernel": ("spmv_template_kernel" if templates else "spmv_stage_kernel") + " (SpMV fused with p.Ap)",
                          "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic(n1) if world == 1 else None,
+                         "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic(n1) if (world == 1 and not templates) else None,
                          "traffic_note": "L2-miss-side bytes per launch from separate rocprofv3 --pmc passes (profiles/r01g_spmv_pmc.json); includes Infinity-Cache hits",
                          "bytes_per_launch": spmv_bytes_local, "avg_ms": avg_spmv_ms,
                          "launches_per_iteration": spmv_per_iter},

@@ -83,6 +83,13 @@ int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t 
                          const void *rowptr, int rowptr_bits, const int32_t *col,
                          const double *val, int index_base, int on_device, khip_csr **out);
 int khip_csr_destroy(khip_csr *A);
+/* Optional internal re-encoding of a handle whose rows repeat few (column - row, value) sequences (stencils):
+ * one 16-bit row-template id per row instead of 12 bytes per nonzero (csrc/template.hip).  *templates = number
+ * of distinct templates, 0 when the operator is not compressible (it then stays plain CSR).  Results of
+ * khip_spmv & co. are bit-identical either way; ctx option "spmv_template" = 0 ignores the compressed form. */
+int khip_csr_compress(khip_ctx *ctx, khip_csr *A, int *templates);
+/* bytes one SpMV of this handle moves in its CURRENT representation (khip_spmv_bytes: always the CSR formula) */
+int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes);
 int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
 /* device-side generators of the benchmark operators (rows [row0, row0+m) of the global matrix,
  * global columns; ref: test/get_div_grad.jl:8-25, test/test_utils.jl:160-169).

@@ -78,6 +78,8 @@ SIGNATURES = {
     "khip_csr_create": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, c_void_pp]),
     "khip_csr_create_dist": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, c_void_pp]),
     "khip_csr_destroy": (_int, [_vp]),
+    "khip_csr_compress": (_int, [_vp, _vp, C.POINTER(_int)]),
+    "khip_spmv_bytes_stored": (_int, [_vp, C.POINTER(_i64)]),
     "khip_csr_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "khip_gen_stencil": (_int, [_vp, _int, _int, _int, _int, _i64, _i64, c_void_pp, c_void_pp, c_void_pp,
                                 C.POINTER(_i64)]),
@@ -576,6 +578,19 @@ class CsrMatrix:
         b = C.c_int64()
         _ck(lib().khip_spmv_bytes(self._h, C.byref(b)))
         return b.value
+
+    @property
+    def spmv_bytes_stored(self) -> int:
+        b = C.c_int64()
+        _ck(lib().khip_spmv_bytes_stored(self._h, C.byref(b)))
+        return b.value
+
+    def compress(self) -> int:
+        """Re-encode as row templates when the operator repeats few (column - row, value) rows (stencils);
+        returns the number of templates, 0 if it stays CSR.  SpMV results are bit-identical either way."""
+        t = C.c_int()
+        _ck(lib().khip_csr_compress(self.ctx._h, self._h, C.byref(t)))
+        return t.value
 
     @classmethod
     def from_host(cls, ctx, rowptr, col, val, shape, index_base=0, dist_rows=None, n_global=None):

@@ -94,7 +94,7 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
       {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"mgs_keep", &t.mgs_keep}};
+      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;
@@ -253,6 +253,7 @@ int khip_csr_destroy(khip_csr *A) {
   if (A->ctx) (void)hipStreamSynchronize(A->ctx->stream);
   (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val); (void)hipFree(A->blockptr);
   (void)hipFree(A->ghost); (void)hipFree(A->sendbuf); (void)hipFree(A->send_idx);
+  csr_free_templates(A);
   delete A;
   return KHIP_OK;
 }
@@ -278,7 +279,7 @@ int khip_spmv_bytes(const khip_csr *A, int64_t *bytes) {
 }  // extern "C"
 int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw,
                    bool dot_sq) {
-  if (dot_sq && spmv_kernel_choice(ctx, A) != 4) {      // only the staged kernel carries the second reduction
+  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5) {   // only the staged / template kernels carry the second reduction
     KHIP_TRY(spmv_any(ctx, A, x, y, dot_slot, dotw, false));
     return launch_nrm2sq(ctx, A->m, y, dot_slot + 1);
   }
@@ -326,6 +327,14 @@ int khip_spmv_dot2(khip_ctx *ctx, const khip_csr *A, const double *x, double *y,
   const int slot = take_slots(ctx, 2);
   KHIP_TRY(spmv_any(ctx, A, x, y, slot, nullptr, true));
   return fetch_results(ctx, slot, 2, result_host);
+}
+
+int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes) {
+  KHIP_REQUIRE(A && bytes, "spmv_bytes_stored: null argument");
+  const int64_t ncols_read = A->dist ? A->m + A->n_ghost : A->n;
+  if (A->tmpl_id) *bytes = 2 * A->m + 8 * ncols_read + 8 * A->m;        // template id + x + y
+  else *bytes = 12 * A->nnz + 4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
+  return KHIP_OK;
 }
 
 int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms) {

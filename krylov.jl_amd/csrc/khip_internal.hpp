@@ -59,6 +59,8 @@ struct Tuning {
   int spmv_nty = 0;         // non-temporal store of y
   int spmv_fake_gather = 0; // tuning experiment (wrong results): coalesced x reads
   int spmv_tiles = 1;       // staged kernel: consecutive row blocks per workgroup
+  int spmv_template = 1;    // use the row-template kernel on handles that khip_csr_compress compressed
+  int spmv_tmpl_rows = 8;   // template kernel: rows per lane (amortises the per-workgroup table load; 1.02 -> 0.86 ms at 512^3)
   int spmv_cap = 0;         // staged kernel LDS window in entries (0 = sized to the widest row block)
   int spmv_lds_pad = 0;     // experiment: extra dynamic LDS bytes per workgroup (lowers occupancy)
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
@@ -131,6 +133,12 @@ struct khip_csr {
   int64_t n_send = 0;
   std::vector<int64_t> send_off, recv_off;   // per-peer offsets (size nranks+1)
   int64_t interior_lo = 0, interior_hi = 0;  // rows [lo,hi) reference no ghost column
+  // optional row-template compression (template.hip): one 16-bit template id per row + a small table
+  uint16_t *tmpl_id = nullptr;
+  int32_t *tmpl_off = nullptr;         // [T][K] column - row
+  double *tmpl_val = nullptr;          // [T][K]
+  int32_t *tmpl_cnt = nullptr;         // [T]
+  int tmpl_T = 0, tmpl_K = 0;
 };
 
 namespace khip {
@@ -192,6 +200,9 @@ int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64
 int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host);
 int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta);
 int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
+
+// template.hip
+void csr_free_templates(khip_csr *A);
 
 // api.cpp: y = A x (dot_slot >= 0: also results[dot_slot] = x . y) incl. halo exchange; launches only, no host sync
 int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw = nullptr,

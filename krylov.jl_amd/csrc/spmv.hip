@@ -254,6 +254,63 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
   }
 }
 
+// ---------------------------------------------------------------- row templates ----------
+// Compressed handles (template.hip): a row is a 16-bit id into a table of (column - row, value) sequences
+// held in LDS.  One lane per row; lanes of a wave mostly share the template (LDS broadcast), and at step k
+// they gather x at row + off_k for 64 consecutive rows: coalesced.  Same rounded multiply / rounded add per
+// entry in stored order as every other kernel here => bit-identical y.  Matrix traffic: 2 bytes per row.
+template <bool DOT, bool COMP, bool DIST>
+__global__ __launch_bounds__(kBlock) void spmv_template_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
+  constexpr int UK = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_tab[];
+  const int T = a.tmpl_T, K = a.tmpl_K;
+  double *s_val = reinterpret_cast<double *>(s_tab);
+  int32_t *s_off = reinterpret_cast<int32_t *>(s_val + (size_t)T * K);
+  int32_t *s_cnt = s_off + (size_t)T * K;
+  for (int i = threadIdx.x; i < T * K; i += kBlock) { s_val[i] = a.tmpl_val[i]; s_off[i] = a.tmpl_off[i]; }
+  for (int i = threadIdx.x; i < T; i += kBlock) s_cnt[i] = a.tmpl_cnt[i];
+  __syncthreads();
+  dd dacc[2];
+  dacc[0] = dd{0.0, 0.0};
+  dacc[1] = dd{0.0, 0.0};
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t row = a.row_lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; row < a.row_hi; row += stride) {
+    const int t = a.tmpl_id[row];
+    const int cnt = s_cnt[t];
+    const double *tv = s_val + (size_t)t * K;
+    const int32_t *to = s_off + (size_t)t * K;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < cnt; k0 += UK) {
+      double vv[UK], xx[UK];
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        xx[u] = 0.0;
+        if (k0 + u < cnt) {
+          vv[u] = tv[k0 + u];
+          xx[u] = gather_x<DIST>(a, (int32_t)row + to[k0 + u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        if (k0 + u < cnt) {
+          const double prod = vv[u] * xx[u];
+          acc = acc + prod;
+        }
+      }
+    }
+    if (a.nt_y) __builtin_nontemporal_store(acc, a.y + row); else a.y[row] = acc;
+    if (DOT) {
+      acc_prod<COMP>(dacc[0], a.dotw[row], acc);
+      if (a.dot_sq) acc_prod<COMP>(dacc[1], acc, acc);
+    }
+  }
+  if (DOT) {
+    if (a.dot_sq) wave_publish<2>(dacc, ra);
+    else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
+  }
+}
+
 // ---------------------------------------------------------------- ordered sub-wave -------
 // L lanes per row, RPG rows per lane group in flight.  Wave layout: NG = 64 / L groups; step u of a
 // wave covers rows wave_row0 + u * NG + g (g = group index) so that each load instruction of the
@@ -396,6 +453,15 @@ static void launch_vector_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &r
 #undef KHIP_L
 }
 
+static void launch_template_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
+                                bool dist) {
+  const size_t lds = (size_t)a.tmpl_T * a.tmpl_K * 12 + (size_t)a.tmpl_T * 4;
+#define KHIP_L(DOT, COMP, DIST) \
+  hipLaunchKernelGGL((spmv_template_kernel<DOT, COMP, DIST>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
 static inline unsigned pick_grid(khip_ctx *ctx, int64_t tiles, bool persist) {
   if (tiles < 1) tiles = 1;
   if (persist) {
@@ -413,6 +479,7 @@ static inline unsigned pick_grid(khip_ctx *ctx, int64_t tiles, bool persist) {
 // last one sets `finish`, which folds all partials written so far into results[dot_slot].
 // which kernel launch_spmv will pick for this operator (the staged one is the only one with the y.y output)
 int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A) {
+  if (A->tmpl_id && ctx->tune.spmv_template) return 5;      // compressed handle (khip_csr_compress)
   int kernel = ctx->tune.spmv_kernel;
   // short rows (stencils, <= 8 entries on average): staged-rows kernel; mid-size rows: ordered
   // sub-wave kernel; very long rows: strided vector kernel
@@ -425,7 +492,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   int64_t local_cursor = 0;
   if (!wave_cursor) wave_cursor = &local_cursor;
   const int nout = dot_sq ? 2 : 1;
-  if (dot_sq && spmv_kernel_choice(ctx, A) != 4) { set_error("spmv: the y.y output needs the staged kernel"); return KHIP_ERR_UNSUPPORTED; }
+  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5) { set_error("spmv: the y.y output needs the staged kernel"); return KHIP_ERR_UNSUPPORTED; }
   if (row_hi <= row_lo) {
     if (dot_slot >= 0 && finish) {
       if (*wave_cursor == 0) {                                              // nothing at all: writes 0
@@ -448,6 +515,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.stop_seq = ctx->ctl.stop_seq;
   a.seq = ctx->ctl.seq;
   a.dotw = dotw ? dotw : x;
+  a.tmpl_id = A->tmpl_id; a.tmpl_off = A->tmpl_off; a.tmpl_val = A->tmpl_val; a.tmpl_cnt = A->tmpl_cnt;
+  a.tmpl_T = A->tmpl_T; a.tmpl_K = A->tmpl_K;
   a.dot_sq = dot_sq ? 1 : 0;
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
@@ -474,7 +543,13 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   const int kernel = spmv_kernel_choice(ctx, A);
   unsigned grid = 1;
   RedArgs ra;
-  if (kernel == 1) {
+  if (kernel == 5) {
+    const int rpt = ctx->tune.spmv_tmpl_rows > 0 ? ctx->tune.spmv_tmpl_rows : 1;      // rows per lane: amortises the table load
+    grid = pick_grid(ctx, (nrows + (int64_t)kBlock * rpt - 1) / ((int64_t)kBlock * rpt), false);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
+    ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
+    launch_template_cfg(ctx, a, ra, grid, dot, comp, dist);
+  } else if (kernel == 1) {
     int rows = ctx->tune.spmv_rows;
     if (rows * A->mean_row_nnz > 2048.0) {           // keep one LDS pass per row block
       rows = 256;

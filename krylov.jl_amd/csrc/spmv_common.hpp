@@ -29,6 +29,11 @@ struct SpmvArgs {
   int tiles_per_block;   // staged kernel: consecutive row blocks per workgroup (software pipeline depth)
   int64_t nnz_bound;     // nnz + pad: prefetches beyond it are clamped
   int stage_cap;         // staged kernel: LDS window in entries (multiple of 4, <= 2048)
+  const uint16_t *tmpl_id;   // row-template compressed handle (template kernel only)
+  const int32_t *tmpl_off;
+  const double *tmpl_val;
+  const int32_t *tmpl_cnt;
+  int tmpl_T, tmpl_K;
   const double *dotw;    // left vector of the fused dot: results[slot] = dotw . y   (x for p.Ap; another vector for c.(A p))
   int dot_sq;            // staged kernel: also results[slot + 1] = y . y
   const long long *stop_seq;   // device-resident loop control (solver_device.hpp); null outside such loops
