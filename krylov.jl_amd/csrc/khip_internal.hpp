@@ -56,6 +56,8 @@ struct Tuning {
   int spmv_vec = 1;         // nnz per lane per load in the stream kernel (1, 2)
   int spmv_nt = 0;          // non-temporal loads for the val/col streams (measured slower on MI355X)
   int spmv_xcd = 0;         // XCD-aware tile remap: R > 0 runs of R tiles per XCD, -1 contiguous eighths, 0 off
+  int spmv_sweep_s = 0;     // plane sweep (spmv_xcd = -2): tiles per grid plane (0 = from the handle's band width)
+  int spmv_sweep_w = 16;    // plane sweep: consecutive tiles per XCD column
   int spmv_nty = 0;         // non-temporal store of y
   int spmv_fake_gather = 0; // tuning experiment (wrong results): coalesced x reads
   int spmv_tiles = 1;       // staged kernel: consecutive row blocks per workgroup

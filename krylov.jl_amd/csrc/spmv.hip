@@ -28,6 +28,12 @@
 //    its y value by x[row]; one partial per wave + the tiny finish kernel (device_reduce.hpp).
 #include "spmv_common.hpp"
 
+// cache-policy bits of the staged kernel's val/col window loads when spmv_nt = 1 (gfx940+: 1 = sc0, 2 = nt, 16 = sc1);
+// every combination measured slower than the default policy (profiles/r01h_stage_aux.log)
+#ifndef KHIP_STAGE_AUX
+#define KHIP_STAGE_AUX 2
+#endif
+
 namespace khip {
 
 // Logical tile id of workgroup b (of G).  The dispatcher places workgroup b on XCD b % 8 (observed,
@@ -35,7 +41,24 @@ namespace khip {
 // CONSECUTIVE tiles inside each window of 8R workgroups, so the x entries shared by neighbouring rows
 // (a stencil's +-n1 couplings) are fetched into ONE L2 instead of three, while the chip-wide access
 // front stays compact (window = 8R tiles).  xcd_run = -1: one contiguous eighth per XCD.
-__device__ __forceinline__ int chunk_id(int b, int G, int xcd_run) {
+//
+// xcd_run = -2: PLANE SWEEP.  A 3-D stencil couples row i to i +- S tiles (the neighbouring grid planes); with
+// the natural order those x lines are long gone from the 4 MiB L2 when the sweep reaches the next plane
+// (S = 1024 tiles = 27 MB of matrix stream at 512^3), so x is fetched ~4x.  Here every XCD takes a column of W
+// consecutive tiles and walks it THROUGH all planes before moving on: tile order (t, k, w) -> k*S + t*W + w,
+// XCD p owning the columns t = p (mod 8).  The plane-to-plane reuse distance shrinks from S to W tiles.
+// Any (S, W) gives a permutation of the tiles, so results never depend on it.
+__device__ __forceinline__ int chunk_id(int b, int G, int xcd_run, int S = 0, int W = 0) {
+  if (xcd_run == -2) {
+    if (S <= 0 || W <= 0 || S % (8 * W) != 0) return b;
+    const int K = G / S;                       // full planes
+    if (b >= K * S) return b;
+    const int p = b & 7, l = b >> 3;
+    const int per = K * W;
+    const int tt = l / per, rem = l - tt * per;
+    const int k = rem / W, w = rem - k * W;
+    return k * S + (tt * 8 + p) * W + w;
+  }
   if (xcd_run > 0) {
     const int win = 8 * xcd_run;
     const int full = (G / win) * win;
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
   const int64_t nrows = a.row_hi - a.row_lo;
   const int64_t nrb = (nrows + ROWS - 1) / ROWS;
   const int tpb = a.tiles_per_block > 0 ? a.tiles_per_block : 1;
-  const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap);
+  const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap, a.sweep_s, a.sweep_w);
   const int64_t rb_begin = (int64_t)cid * tpb;
   const int64_t rb_end = (rb_begin + tpb < nrb) ? rb_begin + tpb : nrb;
   dd dacc[2];                                // [0] = w . y ; [1] = y . y (only when a.dot_sq)
@@ -197,9 +220,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int o = q * (4 * kBlock) + 4 * tid;
-        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, NT ? 2 : 0);      // aux 2 = nt (streaming)
-        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, NT ? 2 : 0);
-        c[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, o * 4, 0, NT ? 2 : 0);
+        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, NT ? KHIP_STAGE_AUX : 0);
+        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, NT ? KHIP_STAGE_AUX : 0);
+        c[q] = __builtin_amdgcn_raw_buffer_load_b128(rc, o * 4, 0, NT ? KHIP_STAGE_AUX : 0);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -509,6 +532,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.n_owned = A->dist ? A->m : A->n;
   a.row_lo = row_lo; a.row_hi = row_hi;
   a.xcd_remap = ctx->tune.spmv_xcd;
+  a.sweep_s = ctx->tune.spmv_sweep_s;
+  a.sweep_w = ctx->tune.spmv_sweep_w;
   a.nt_y = ctx->tune.spmv_nty;
   a.tiles_per_block = 1;
   a.stage_cap = 2048;

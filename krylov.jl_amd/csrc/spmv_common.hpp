@@ -25,6 +25,7 @@ struct SpmvArgs {
   int64_t n_owned;       // columns < n_owned read x, others read ghost
   int64_t row_lo, row_hi;
   int xcd_remap;         // see chunk_id() in spmv.hip
+  int sweep_s, sweep_w;  // plane sweep (xcd_remap == -2): tiles per plane, tiles per XCD column
   int nt_y;              // non-temporal store of y
   int tiles_per_block;   // staged kernel: consecutive row blocks per workgroup (software pipeline depth)
   int64_t nnz_bound;     // nnz + pad: prefetches beyond it are clamped
