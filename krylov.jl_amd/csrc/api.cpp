@@ -510,9 +510,8 @@ int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, doubl
              double *nrm_host, int accumulate) {
   KHIP_REQUIRE(ctx && q && (k == 0 || (V_host && h_host)), "mgs: null argument");
   KHIP_REQUIRE(k >= 0, "mgs: negative k");
-  if (comm_nranks(ctx) > 1 || k + 1 > kResultSlots) {
-    // distributed (every coefficient needs the all-reduced value before the next update) or a basis
-    // larger than the device scalar ring: the reference's own sequence, one sync per coefficient
+  if (k + 1 > kResultSlots) {
+    // a basis larger than the device scalar ring: the reference's own sequence, one sync per coefficient
     for (int i = 0; i < k; ++i) {
       double h;
       KHIP_TRY(khip_dot(ctx, n, V_host[i], q, &h));
@@ -522,20 +521,25 @@ int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, doubl
     if (nrm_host) KHIP_TRY(khip_nrm2(ctx, n, q, nrm_host));
     return KHIP_OK;
   }
-  // single GPU: chain through device-resident scalars, one sync at the end.
+  // chain through device-resident scalars, one host sync at the end.
   //   h_0 = V_0 . q ; then for i: q -= h_i V_i fused with h_{i+1} = V_{i+1} . q (or ||q||^2 at the end)
+  // Multi-GPU: every coefficient is all-reduced ON THE DEVICE (ncclAllGather of the 16-byte partials + combine
+  // kernel, comm_allreduce_dd_device) before the next step reads it -- still no host in the cascade.
   if (k == 0) {
     if (nrm_host) return khip_nrm2(ctx, n, q, nrm_host);
     return KHIP_OK;
   }
+  const bool multi = comm_nranks(ctx) > 1;
   const int slot = take_slots(ctx, k + 1);
   KHIP_TRY(launch_dot(ctx, n, V_host[0], q, slot));
+  if (multi) KHIP_TRY(comm_allreduce_dd_device(ctx, slot, 1));
   for (int i = 0; i < k; ++i) {
     const double *znext = (i + 1 < k) ? V_host[i + 1] : q;   // last step: ||q||^2
     KHIP_TRY(launch_axpy_dev_dot(ctx, n, ctx->results + slot + i, V_host[i], q, znext, slot + i + 1));
+    if (multi) KHIP_TRY(comm_allreduce_dd_device(ctx, slot + i + 1, 1));
   }
   std::vector<double> tmp((size_t)k + 1);
-  KHIP_TRY(fetch_results(ctx, slot, k + 1, tmp.data()));
+  KHIP_TRY(fetch_results(ctx, slot, k + 1, tmp.data(), /*already_global=*/multi));
   for (int i = 0; i < k; ++i) h_host[i] = accumulate ? h_host[i] + tmp[i] : tmp[i];
   if (nrm_host) *nrm_host = std::sqrt(tmp[k]);
   return KHIP_OK;

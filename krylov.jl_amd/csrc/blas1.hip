@@ -733,8 +733,8 @@ int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot) {
   return KHIP_OK;
 }
 
-int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host) {
-  if (ctx->comm) return comm_allreduce_dd(ctx, ctx->results_dd + slot, count, out_host);
+int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host, bool already_global) {
+  if (ctx->comm && !already_global) return comm_allreduce_dd(ctx, ctx->results_dd + slot, count, out_host);
   KHIP_CHECK_HIP(hipMemcpyAsync(ctx->results_pinned, ctx->results + slot, sizeof(double) * (size_t)count,
                                 hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));

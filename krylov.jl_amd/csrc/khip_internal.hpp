@@ -185,7 +185,8 @@ int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host,
                       const double *const *V_host, double *x);
 // fetch `count` results starting at slot into host memory (synchronises the stream; all-reduces
 // across ranks when a communicator is attached).
-int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host);
+// already_global: results[slot..] were all-reduced on the device (comm_allreduce_dd_device): plain copy
+int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host, bool already_global = false);
 
 // spmv.hip
 // dot_slot >= 0: results[dot_slot] = dotw . y (dotw = x when null); dot_sq: also results[dot_slot + 1] = y . y
