@@ -82,6 +82,10 @@ int khip_csr_create(khip_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const void
 int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t m, int64_t nnz,
                          const void *rowptr, int rowptr_bits, const int32_t *col,
                          const double *val, int index_base, int on_device, khip_csr **out);
+/* The adjoint operator A' as its own handle (built on the device; entries of a row of A' in increasing column
+ * order = the order of a column of A).  khip_spmv(At, x, y) is then `mul!(y, A', x)` (docs/src/matrix_free.md:36-42),
+ * what MINRES-QLP / LSQR / LSMR / BiLQ / QMR ... ask of an operator besides `mul!(y, A, x)`. */
+int khip_csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr **At_out);
 int khip_csr_destroy(khip_csr *A);
 /* Optional internal re-encoding of a handle whose rows repeat few (column - row, value) sequences (stencils):
  * one 16-bit row-template id per row instead of 12 bytes per nonzero (csrc/template.hip).  *templates = number

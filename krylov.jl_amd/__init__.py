@@ -78,6 +78,7 @@ SIGNATURES = {
     "khip_csr_create": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, c_void_pp]),
     "khip_csr_create_dist": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _int, _vp, _vp, _int, _int, c_void_pp]),
     "khip_csr_destroy": (_int, [_vp]),
+    "khip_csr_transpose": (_int, [_vp, _vp, c_void_pp]),
     "khip_csr_compress": (_int, [_vp, _vp, C.POINTER(_int)]),
     "khip_spmv_bytes_stored": (_int, [_vp, C.POINTER(_i64)]),
     "khip_csr_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
@@ -584,6 +585,12 @@ class CsrMatrix:
         b = C.c_int64()
         _ck(lib().khip_spmv_bytes_stored(self._h, C.byref(b)))
         return b.value
+
+    def transpose(self) -> "CsrMatrix":
+        """A' as its own handle: `At.matvec(x, y)` is `mul!(y, A', x)` (docs/src/matrix_free.md:36-42)."""
+        h = C.c_void_p()
+        _ck(lib().khip_csr_transpose(self.ctx._h, self._h, C.byref(h)))
+        return CsrMatrix(self.ctx, h)
 
     def compress(self) -> int:
         """Re-encode as row templates when the operator repeats few (column - row, value) rows (stencils);

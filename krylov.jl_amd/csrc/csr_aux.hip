@@ -410,3 +410,96 @@ extern "C" int khip_gen_stencil(khip_ctx *ctx, int kind, int n1, int n2, int n3,
   *rowptr_dev = rp; *col_dev = cl; *val_dev = vl; *nnz_out = total;
   return KHIP_OK;
 }
+
+
+// ---------------------------------------------------------------- transpose (adjoint operator) ----
+// A' as its own CSR handle, built on the device: column histogram -> exclusive scan -> scatter with an atomic
+// cursor per column -> every row of A' sorted by its column index (= row of A).  The sort makes the result
+// deterministic and gives each row of A' the entry order of a column of A, i.e. the summation order of
+// `mul!(y, A', x)` on the CSC matrix the reference's users hold (the adjoint product that
+// MINRES-QLP / LSQR / LSMR / BiLQ / QMR ... need on the device type).
+namespace khip {
+
+__global__ __launch_bounds__(kBlock) void tr_count_kernel(const int32_t *col, int64_t nnz, int32_t *count) {
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * kBlock)
+    atomicAdd(&count[col[q]], 1);
+}
+
+__global__ __launch_bounds__(kBlock) void tr_scatter_kernel(const int32_t *rowptr, const int32_t *col, const double *val,
+                                                            int64_t m, int32_t *cursor, int32_t *colT, double *valT) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock)
+    for (int32_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+      const int32_t pos = atomicAdd(&cursor[col[q]], 1);
+      colT[pos] = (int32_t)i;
+      valT[pos] = val[q];
+    }
+}
+
+// insertion sort of each row of A' by column index (rows are short; a row of A' is a column of A)
+__global__ __launch_bounds__(kBlock) void tr_sort_rows_kernel(const int32_t *rowptrT, int64_t n, int32_t *colT, double *valT) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += (int64_t)gridDim.x * kBlock) {
+    const int32_t s = rowptrT[j], e = rowptrT[j + 1];
+    for (int32_t a = s + 1; a < e; ++a) {
+      const int32_t c = colT[a];
+      const double v = valT[a];
+      int32_t b = a - 1;
+      while (b >= s && colT[b] > c) { colT[b + 1] = colT[b]; valT[b + 1] = valT[b]; --b; }
+      colT[b + 1] = c;
+      valT[b + 1] = v;
+    }
+  }
+}
+
+// in-place exclusive scan of `cnt` int32 values (the generators' three-phase scan); *total = their sum
+static int exclusive_scan_i32(khip_ctx *ctx, int32_t *data, int64_t cnt, long long *total) {
+  const int64_t ntiles = (cnt + kScanTile - 1) / kScanTile;
+  long long *tiles = nullptr;
+  KHIP_CHECK_HIP(hipMalloc(&tiles, sizeof(long long) * (size_t)(ntiles + 1)));
+  hipLaunchKernelGGL(scan_tile_sums, dim3((unsigned)ntiles), dim3(kBlock), 0, ctx->stream, data, cnt, tiles);
+  hipLaunchKernelGGL(scan_tiles_serial, dim3(1), dim3(64), 0, ctx->stream, tiles, ntiles, tiles + ntiles);
+  hipLaunchKernelGGL(scan_apply, dim3((unsigned)ntiles), dim3(kBlock), 0, ctx->stream, data, cnt, tiles);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(total, tiles + ntiles, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(tiles);
+  if (e != hipSuccess) { set_error("scan: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
+  return KHIP_OK;
+}
+
+int csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr *T) {
+  const int64_t m = A->m, n = A->n, nnz = A->nnz;
+  T->ctx = ctx; T->m = n; T->n = m; T->nnz = nnz;
+  KHIP_CHECK_HIP(hipMalloc(&T->rowptr, sizeof(int32_t) * (size_t)(n + 1)));
+  KHIP_CHECK_HIP(hipMalloc(&T->col, sizeof(int32_t) * (size_t)(nnz + kPad)));
+  KHIP_CHECK_HIP(hipMalloc(&T->val, sizeof(double) * (size_t)(nnz + kPad)));
+  KHIP_CHECK_HIP(hipMemsetAsync(T->rowptr, 0, sizeof(int32_t) * (size_t)(n + 1), ctx->stream));
+  KHIP_CHECK_HIP(hipMemsetAsync(T->col + nnz, 0, sizeof(int32_t) * kPad, ctx->stream));
+  KHIP_CHECK_HIP(hipMemsetAsync(T->val + nnz, 0, sizeof(double) * kPad, ctx->stream));
+  if (nnz > 0) {
+    int64_t want = (nnz + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream, A->col, nnz,
+                       T->rowptr);
+    KHIP_CHECK_HIP(hipGetLastError());
+  }
+  long long total = 0;
+  KHIP_TRY(exclusive_scan_i32(ctx, T->rowptr, n + 1, &total));
+  if (total != nnz) { set_error("csr_transpose: a column index lies outside [0, n)"); return KHIP_ERR_INVALID; }
+  if (nnz > 0) {
+    int32_t *cursor = nullptr;
+    KHIP_CHECK_HIP(hipMalloc(&cursor, sizeof(int32_t) * (size_t)(n + 1)));
+    KHIP_CHECK_HIP(hipMemcpyAsync(cursor, T->rowptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    int64_t want = (m + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream, A->rowptr,
+                       A->col, A->val, m, cursor, T->col, T->val);
+    want = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(tr_sort_rows_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(kBlock), 0, ctx->stream,
+                       T->rowptr, n, T->col, T->val);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(cursor);
+    if (e != hipSuccess) { set_error("csr_transpose: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
+  }
+  return csr_finalize(ctx, T);
+}
+
+}  // namespace khip

@@ -196,6 +196,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
 int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A);
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
 int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays are resident
+int csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr *T);   // T = A' (fresh handle, deterministic entry order)
 int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out);
 int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost);
 int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64_t row1, int32_t *out_dev,

@@ -474,3 +474,44 @@ def test_spmv_dot2_on_long_rows_falls_back(K, ctx, oracle):
     y = dy.to_host()
     assert np.allclose(y, M @ x, rtol=1e-13, atol=1e-13)
     assert abs(xy - x @ y) <= 1e-12 * np.abs(x * y).sum() and abs(yy - y @ y) <= 1e-12 * yy
+
+
+@pytest.mark.parametrize("case", ["kron", "rect", "random", "empty_cols"])
+def test_adjoint_operator_bit_exact(K, ctx, oracle, case):
+    """khip_csr_transpose: y = A' x (`mul!(y, A', x)`, docs/src/matrix_free.md:36-42) accumulates each entry of a
+    column of A in increasing row order -- the serial loop over the CSC column, reproduced bit for bit."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    if case == "kron":
+        A = oracle.kron_unsymmetric(7)
+        S = A.to_scipy().tocsr()
+    elif case == "rect":
+        S = sp.random(230, 517, density=0.03, random_state=5, format="csr")
+    elif case == "random":
+        S = (sp.random(400, 400, density=0.05, random_state=9, format="csr") + sp.eye(400, format="csr")).tocsr()
+    else:
+        S = sp.random(64, 300, density=0.01, random_state=2, format="csr")     # many empty columns -> empty rows of A'
+    S.sort_indices()
+    m, n = S.shape
+    dA = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data, (m, n))
+    dT = dA.transpose()
+    assert dT.shape == (n, m) and dT.nnz == dA.nnz
+    x = rng.standard_normal(m)
+    y = dT.matvec(ctx.array(x), ctx.empty(n)).to_host()
+    # reference: serial loop over the columns of A in row order = rows of the (sorted) CSR of A'
+    St = S.T.tocsr()
+    St.sort_indices()
+    ref = oracle.CsrMatrix.from_arrays(St.indptr.astype(np.int64), St.indices.astype(np.int32), St.data.copy()) if m == n else None
+    y_ref = np.zeros(n)
+    for j in range(n):
+        acc = 0.0
+        for q in range(St.indptr[j], St.indptr[j + 1]):
+            acc = acc + St.data[q] * x[St.indices[q]]
+        y_ref[j] = acc
+    assert np.array_equal(y, y_ref)
+    if ref is not None:
+        assert np.array_equal(y, ref.matvec(x))
+    # (A')' == A
+    dTT = dT.transpose()
+    z = rng.standard_normal(n)
+    assert np.array_equal(dTT.matvec(ctx.array(z), ctx.empty(m)).to_host(), dA.matvec(ctx.array(z), ctx.empty(m)).to_host())
