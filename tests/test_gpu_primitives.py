@@ -515,3 +515,54 @@ def test_adjoint_operator_bit_exact(K, ctx, oracle, case):
     dTT = dT.transpose()
     z = rng.standard_normal(n)
     assert np.array_equal(dTT.matvec(ctx.array(z), ctx.empty(m)).to_host(), dA.matvec(ctx.array(z), ctx.empty(m)).to_host())
+
+
+def test_spmv_fuzz_all_kernels_bit_exact(K, ctx, oracle):
+    """Random shapes through every CSR kernel: empty rows, ragged rows, rows longer than the staged kernel's LDS
+    window, rectangular operators, a single row.  y must equal the serial loop bit for bit (kernels 1, 3, 4, 5),
+    and the fused dot must agree to an ulp of its condition."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2024)
+    cases = []
+    for (m, n, mean, heavy) in [(1, 1, 1, 0), (3, 700, 5, 0), (257, 257, 1, 0), (1000, 999, 3, 0), (513, 2000, 7, 0),
+                                (900, 900, 8, 3), (300, 300, 20, 2), (2049, 64, 6, 0), (64, 5000, 2, 1)]:
+        rows, cols, vals = [], [], []
+        for i in range(m):
+            k = int(rng.poisson(mean)) if rng.random() > 0.1 else 0                 # 10 % empty rows
+            if heavy and i % 97 == heavy:
+                k = min(n, 2500 if heavy == 1 else 300)                             # longer than one 2048-entry window
+            k = min(k, n)
+            cs = np.sort(rng.choice(n, size=k, replace=False))
+            rows += [i] * k; cols += list(cs); vals += list(rng.standard_normal(k))
+        S = sp.csr_matrix((vals, (rows, cols)), shape=(m, n))
+        S.sort_indices()
+        cases.append(S)
+    defaults = {k: ctx.get_option(k) for k in ("spmv_kernel", "spmv_lanes", "spmv_rows")}
+    try:
+        for S in cases:
+            m, n = S.shape
+            dA = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data, (m, n))
+            x = rng.standard_normal(n)
+            y_ref = np.zeros(m)
+            for i in range(m):
+                acc = 0.0
+                for q in range(S.indptr[i], S.indptr[i + 1]):
+                    acc = acc + S.data[q] * x[S.indices[q]]
+                y_ref[i] = acc
+            dx = ctx.array(x)
+            for kern in (0, 1, 3, 4):
+                ctx.set_option("spmv_kernel", kern)
+                dy = ctx.zeros(m)
+                dA.matvec(dx, dy)
+                assert np.array_equal(dy.to_host(), y_ref), (S.shape, S.nnz, kern)
+            ctx.set_option("spmv_kernel", 0)
+            if m == n:
+                d = K.spmv_dot(dA, dx, ctx.empty(m))
+                assert abs(d - float(np.dot(x, y_ref))) <= 1e-13 * float(np.abs(x * y_ref).sum()) + 1e-300
+            T = dA.compress()                              # random values: not compressible, must stay correct
+            dy = ctx.zeros(m)
+            dA.matvec(dx, dy)
+            assert np.array_equal(dy.to_host(), y_ref), (S.shape, "after compress", T)
+    finally:
+        for k, v in defaults.items():
+            ctx.set_option(k, v)
