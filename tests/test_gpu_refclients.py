@@ -79,3 +79,15 @@ def test_hip_fortran_clients():
         if "block_minres" in name:
             continue
         assert not fails, (name, fails)
+
+
+def test_plain_c_example_against_the_abi():
+    """examples/cg_poisson.c: a C program on include/krylov_hip.h alone (no Python, no shim) -- built by
+    __graft_entry__.build(), run here.  64^3 Poisson, rtol 1e-8: 159 iterations, residual < 1e-6."""
+    exe = os.path.join(ROOT, "examples", "cg_poisson")
+    if not os.path.exists(exe):
+        pytest.skip("examples/cg_poisson not built")
+    out = subprocess.run([exe, "64"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Solved: yes" in out.stdout and "niter: 159" in out.stdout
+    assert "solution good enough given atol and rtol" in out.stdout
