@@ -11,9 +11,10 @@
 // at HBM speed.  Q spans the same space and R = R2 R1 has a positive diagonal (LAPACK's has
 // Householder signs): block-GMRES residual norms ||C||_F and the iterates X are invariant under
 // that column-sign change, so parity with the reference holds on residual norms / solutions, not on
-// the individual Psi blocks (SURVEY.md section 7 "hard parts").  If the Cholesky factorisation
-// breaks down (numerically rank-deficient block, which the reference does not support either:
-// docs/src/interfaces/reference.md:236) the panel is factored with host Householder instead.
+// the individual Psi blocks (SURVEY.md section 7 "hard parts").  An ill-conditioned block (cond(Q)^2 > 1/eps)
+// first takes a SHIFTED Cholesky pass (shifted CholeskyQR3) -- still entirely on the device (an exactly
+// rank-deficient block, which the reference does not support either, docs/src/interfaces/reference.md:236,
+// comes out like LAPACK's: A = QR with a tiny diagonal entry).  Only p x p matrices are ever handled on the host.
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -132,47 +133,51 @@ struct StatsBoxB {
 extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host) {
   KHIP_REQUIRE(ctx && Q && R_host && p >= 1 && p <= 32, "panel_qr: bad argument (1 <= p <= 32)");
   const size_t pp = (size_t)p * p;
-  std::vector<double> G(pp), R1(pp), R2(pp), Ri(pp);
-  bool ok = true, pass0_applied = false;
-  for (int pass = 0; pass < 2 && ok; ++pass) {
+  std::vector<double> G(pp), R(pp), Ri(pp), Racc(pp, 0.0), tmp(pp);
+  for (int i = 0; i < p; ++i) Racc[(size_t)i * p + i] = 1.0;             // accumulated R = R_k ... R_1 (R_0)
+  // CholeskyQR2: two rounds of G = Q'Q (FP64 MFMA), host Cholesky of the p x p Gram matrix, Q <- Q R^-1 in place.
+  // Safe while cond(Q)^2 < 1/eps.  When the first Cholesky says otherwise (pivot ratio below 1e-7, or a
+  // breakdown), a SHIFTED pass comes first (shifted CholeskyQR3, Fukaya-Kannan-Nakatsukasa-Yamamoto-Yanagisawa,
+  // SISC 2020): chol(G + s I) with s = 11 (n p + p (p + 1)) eps ||Q||^2 always exists and brings cond(Q) down to
+  // ~eps^-1/2, after which the two ordinary rounds converge.  Everything touching the n x p panel stays on the
+  // device; only p x p matrices visit the host, as in the reference (src/block_gmres.jl:250-283).
+  bool shifted_done = false;
+  for (int pass = 0; pass < 2; ++pass) {
     KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, Q, Q, G.data()));
-    std::vector<double> &R = pass == 0 ? R1 : R2;
-    // guard against a numerically rank-deficient block: the diagonal of chol must stay well above eps * ||G||
-    ok = chol_upper(p, G.data(), R.data());
-    if (ok) {
+    bool ok = chol_upper(p, G.data(), R.data());
+    if (ok && pass == 0 && !shifted_done) {
       double dmax = 0, dmin = std::numeric_limits<double>::infinity();
       for (int i = 0; i < p; ++i) { dmax = std::fmax(dmax, R[(size_t)i * p + i]); dmin = std::fmin(dmin, R[(size_t)i * p + i]); }
-      if (pass == 0 && !(dmin > 1e-7 * dmax)) ok = false;      // cond(Q)^2 would exceed 1/eps: CholQR is not safe
+      if (!(dmin > 1e-7 * dmax)) ok = false;                             // cond(Q)^2 would exceed 1/eps
     }
-    if (ok) {
-      inv_upper(p, R.data(), Ri.data());
-      KHIP_TRY(khip_panel_gemm_nn(ctx, n, p, 1.0, Q, Ri.data(), 0.0, Q));   // in place: Q <- Q R^-1
-      if (pass == 0) pass0_applied = true;
+    if (!ok) {
+      if (shifted_done || pass != 0) {
+        set_error("panel_qr: the block is numerically rank deficient (block_gmres! needs full column rank)");
+        return KHIP_ERR_NUMERIC;
+      }
+      double tr = 0;
+      for (int i = 0; i < p; ++i) tr += G[(size_t)i * p + i];             // ||Q||_F^2 >= ||Q||_2^2
+      if (!(tr > 0) || !std::isfinite(tr)) {
+        set_error("panel_qr: the block is zero or not finite");
+        return KHIP_ERR_NUMERIC;
+      }
+      const double shift = 11.0 * ((double)n * p + (double)p * (p + 1)) * std::numeric_limits<double>::epsilon() * tr;
+      for (int i = 0; i < p; ++i) G[(size_t)i * p + i] += shift;
+      if (!chol_upper(p, G.data(), R.data())) {
+        set_error("panel_qr: shifted Cholesky broke down");
+        return KHIP_ERR_NUMERIC;
+      }
+      shifted_done = true;
+      pass = -1;                                                          // two ordinary rounds follow
     }
+    inv_upper(p, R.data(), Ri.data());
+    KHIP_TRY(khip_panel_gemm_nn(ctx, n, p, 1.0, Q, Ri.data(), 0.0, Q));   // in place: Q <- Q R^-1
+    matmul_pp(p, R.data(), Racc.data(), tmp.data());                      // Racc <- R * Racc
+    Racc = tmp;
   }
-  if (ok) {
-    matmul_pp(p, R2.data(), R1.data(), R_host);
-    for (int j = 0; j < p; ++j)
-      for (int i = j + 1; i < p; ++i) R_host[(size_t)j * p + i] = 0;
-    return KHIP_OK;
-  }
-  // Householder fallback on the host (rare path): same convention as the reference's householder!
-  int64_t np = 0;
-  khip_panel_rows(n, &np);
-  std::vector<double> rowm((size_t)np * p), colm((size_t)n * p), tau(p), Rh(pp, 0.0);
-  KHIP_TRY(khip_memcpy_d2h(ctx, rowm.data(), Q, sizeof(double) * rowm.size()));
-  for (int64_t r = 0; r < n; ++r)
-    for (int c = 0; c < p; ++c) colm[(size_t)c * n + r] = rowm[(size_t)r * p + c];
-  geqr2((int)n, p, colm.data(), (int)n, tau.data());
+  memcpy(R_host, Racc.data(), sizeof(double) * pp);
   for (int j = 0; j < p; ++j)
-    for (int i = 0; i <= j && i < n; ++i) Rh[(size_t)j * p + i] = colm[(size_t)j * n + i];
-  org2r((int)n, p, p, colm.data(), (int)n, tau.data());
-  for (int64_t r = 0; r < n; ++r)
-    for (int c = 0; c < p; ++c) rowm[(size_t)r * p + c] = colm[(size_t)c * n + r];
-  KHIP_TRY(khip_memcpy_h2d(ctx, Q, rowm.data(), sizeof(double) * rowm.size()));
-  // if pass 0 had been applied before the breakdown the panel was already multiplied by R1^-1
-  if (pass0_applied) matmul_pp(p, Rh.data(), R1.data(), R_host);
-  else memcpy(R_host, Rh.data(), sizeof(double) * pp);
+    for (int i = j + 1; i < p; ++i) R_host[(size_t)j * p + i] = 0;
   return KHIP_OK;
 }
 

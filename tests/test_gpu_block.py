@@ -52,15 +52,35 @@ def test_panel_qr(K, ctx, n, p):
     assert np.allclose(Qh, Ql * S, atol=1e-10) and np.allclose(R, (Rl.T * S).T, atol=1e-10 * np.abs(Rl).max())
 
 
-def test_panel_qr_rank_deficient_falls_back(K, ctx):
+@pytest.mark.parametrize("eps_col", [1e-6, 1e-9, 1e-12])
+def test_panel_qr_ill_conditioned_takes_the_shifted_pass(K, ctx, eps_col):
+    """cond(A) up to ~1e12: CholeskyQR2 alone is unsafe (cond^2 > 1/eps); the shifted first pass (shifted
+    CholeskyQR3) keeps the whole factorisation on the device and still delivers an orthonormal Q and A = Q R."""
     rng = np.random.default_rng(3)
     A = rng.standard_normal((500, 6))
-    A[:, 5] = A[:, 0] + 1e-12 * rng.standard_normal(500)               # cond ~ 1e12: CholQR unsafe
+    A[:, 5] = A[:, 0] + eps_col * rng.standard_normal(500)
     dQ = K.Panel.from_host(ctx, A)
     R = K.panel_qr_(dQ)
     Qh = dQ.to_host()
+    assert np.allclose(np.tril(R, -1), 0) and np.all(np.diag(R) > 0)
     assert np.allclose(Qh.T @ Qh, np.eye(6), atol=1e-10)
     assert np.allclose(Qh @ R, A, atol=1e-10)
+
+
+def test_panel_qr_rank_deficient_block(K, ctx):
+    """An exactly dependent column behaves as with LAPACK's Householder QR: A = Q R still holds, the dependent
+    direction shows up as a (relatively) tiny diagonal entry of R and an arbitrary unit column of Q.  (block_gmres!
+    itself requires full column rank, docs/src/interfaces/reference.md:236.)  A zero block is an error."""
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((300, 4))
+    A[:, 3] = 2.0 * A[:, 1]
+    dQ = K.Panel.from_host(ctx, A)
+    R = K.panel_qr_(dQ)
+    Qh = dQ.to_host()
+    assert np.allclose(Qh @ R, A, atol=1e-9) and np.allclose(Qh.T @ Qh, np.eye(4), atol=1e-8)
+    assert abs(R[3, 3]) <= 1e-5 * abs(R[1, 1])
+    with pytest.raises(K.KhipError):
+        K.panel_qr_(K.Panel.from_host(ctx, np.zeros((64, 3))))
 
 
 def test_spmm_panel(K, ctx, oracle):
