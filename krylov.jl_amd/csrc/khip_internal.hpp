@@ -71,6 +71,7 @@ struct Tuning {
   int compensated = 1;      // Dot2 (TwoSum/TwoProd) reductions
   int nt_min_elems = 1 << 22;  // BLAS-1 vectors at least this long use non-temporal accesses (32 MiB)
   int mgs_keep = -1;        // MGS cascade: keep q and the freshly dotted basis vector cacheable for the next step (-1 auto: when they fit the Infinity Cache; 0 off; 1 on; 2 nothing streamed)
+  int hist_window = 1 << 14;   // device-resident loops: residual-history entries kept on the device between drains
   int overlap_halo = 1;     // overlap halo exchange with interior rows
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };

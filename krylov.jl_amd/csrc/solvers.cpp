@@ -107,7 +107,7 @@ struct khip_cg_workspace {
 namespace {
 
 constexpr int kDevChunk = 4;             // iterations enqueued between two snapshots of the device state
-constexpr long long kHistWindow = 1 << 14;
+constexpr long long kHistWindowMax = 1 << 14;   // device history window (entries); ctx option "hist_window" shrinks it (tests)
 
 // The loop of src/cg.jl:195-268 with scalars and stopping tests on the device.  Preconditions (checked by
 // the caller): CSR operator, M = I, radius = 0, no linesearch, no callback.  On return the vectors are in
@@ -119,9 +119,12 @@ int cg_device_loop(khip_cg_workspace *ws, const khip_csr *A, double gamma, doubl
   if (!ws->dev_state) {
     KHIP_CHECK_HIP(hipMalloc(&ws->dev_state, sizeof(CgDevState)));
     KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->snap), 2 * sizeof(CgDevState), hipHostMallocDefault));
-    KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindow));
+    KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindowMax));
     for (auto &e : ws->snap_ev) KHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  long long kHistWindow = ctx->tune.hist_window;
+  if (kHistWindow < kDevChunk) kHistWindow = kDevChunk;
+  if (kHistWindow > kHistWindowMax) kHistWindow = kHistWindowMax;
   CgDevState *dev = ws->dev_state;
   CgDevState h;
   memset(&h, 0, sizeof(h));

@@ -129,6 +129,15 @@ def test_cg_device_resident_loop_equals_host_loop(K, ctx, oracle):
     # the r vector of the workspace is the residual of the returned x (nothing ran after the stop)
     r = ws.vector("r").to_host()
     assert np.allclose(r, bh - A.matvec(x2.to_host()), atol=1e-9 * np.linalg.norm(bh))
+    # a history longer than the device window: drained in pieces, still identical
+    ctx.set_option("hist_window", 8)
+    try:
+        x5, st5, _ = K.cg(dA, b, fused=2, history=True, rtol=1e-12, atol=0.0)
+    finally:
+        ctx.set_option("hist_window", 1 << 14)
+    x6, st6, _ = K.cg(dA, b, fused=1, history=True, rtol=1e-12, atol=0.0)
+    assert st5.niter == st6.niter > 40 and np.array_equal(st5.residuals, st6.residuals)
+    assert np.array_equal(x5.to_host(), x6.to_host())
     # zero curvature: singular operator, b in the null space direction gives p.Ap = 0
     Z = oracle.tridiag(6, 0.0, 0.0, 0.0)
     bz = ctx.array(np.ones(6))
