@@ -21,3 +21,12 @@ done
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs -ldl
 echo "built $OUT"
+# libkrylov_hip_capi.so: the reference's C / Fortran interface on top (needs ITS header, which is not redistributed)
+KH="${KRYLOV_H_DIR:-/root/reference/interfaces/include}"
+if [ -f "$KH/krylov.h" ]; then
+  g++ -O2 -fPIC -shared -std=c++17 -I"$KH" -I"$HERE/../include" -o "$HERE/libkrylov_hip_capi.so" "$SRC/capi_compat.cpp" \
+      -L"$HERE" -lkrylov_hip -Wl,-rpath,'$ORIGIN'
+  echo "built $HERE/libkrylov_hip_capi.so"
+else
+  echo "krylov.h not found (KRYLOV_H_DIR): libkrylov_hip_capi.so not rebuilt"
+fi

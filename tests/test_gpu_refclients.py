@@ -1,6 +1,6 @@
 """The reference's OWN C clients (interfaces/test/C/*.c, interfaces/examples/C/*.c -- compiled from where they
 lie by `make -C oracle refhip`, only possible where /root/reference exists) driving the HIP path through
-oracle/ref_capi_hip_shim.cpp.  The prebuilt binaries travel to the GPU box inside oracle/_ref/."""
+krylov.jl_amd/csrc/capi_compat.cpp (libkrylov_hip_capi.so).  The prebuilt binaries travel to the GPU box inside oracle/_ref/."""
 import os
 import subprocess
 
@@ -91,3 +91,11 @@ def test_plain_c_example_against_the_abi():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Solved: yes" in out.stdout and "niter: 159" in out.stdout
     assert "solution good enough given atol and rtol" in out.stdout
+
+
+def test_capi_device_mode():
+    """tests/c/capi_device.c: the KRYLOV_HIP device enumerator of libkrylov_hip_capi.so (include/krylov_hip_ext.h) --
+    device right-hand sides, the built-in CSR operator with matvec_A = NULL, a device callback, the block interface."""
+    out = _run("hip_capi_device")
+    assert out.returncode == 0 and "0 failure(s)" in out.stdout, out.stdout + out.stderr[-800:]
+    assert "FAIL" not in out.stdout
