@@ -44,6 +44,21 @@ def pmc_traffic(n1):
     return None
 
 
+def parity_vs_golden(n1, residuals):
+    """Compare this run's residual history (any GPU count / fusion level / operator format) with the 1-GPU history of
+    the reference's primitive sequence (tests/golden/cg512_residuals.json, made by tools/make_cg512_golden.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "cg512_residuals.json")
+    if n1 != 512 or not os.path.exists(path):
+        return None
+    g = json.load(open(path))["residuals"]
+    k = min(len(g), len(residuals))
+    if k == 0:
+        return None
+    dev = max(abs(float(residuals[i]) - g[i]) / g[i] for i in range(k))
+    return {"against": "1-GPU history of the unfused primitive sequence (tests/golden/cg512_residuals.json)",
+            "iterations_compared": k - 1, "max_rel_dev": dev, "tolerance": 1e-12, "ok": bool(dev <= 1e-12)}
+
+
 def cpu_baseline(n1, budget_s=30.0):
     """Oracle CG loop (the reference's cg! recurrence, src/cg.jl:195-268) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -190,6 +205,7 @@ def main():
             "hbm_gbps_iteration": its * iter_bytes_local * world / 1e9,
             "hbm_gbps_iteration_reference_sequence": its * iter_bytes_unfused_local * world / 1e9,
             "final_residual_norm": float(st.residuals[-1]),
+            "parity": parity_vs_golden(n1, st.residuals),
             "roofline": {"bound": "hbm", "kernel": ("spmv_template_kernel" if templates else "spmv_stage_kernel") + " (SpMV fused with p.Ap)",
                          "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic(n1) if (world == 1 and not templates) else None,
