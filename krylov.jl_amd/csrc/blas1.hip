@@ -572,7 +572,10 @@ static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   if (keep < 0) keep = (ROP == RED_AXPYDEV && (size_t)n * sizeof(double) <= (size_t)144 << 20) ? 1 : 0;
   const bool nt = use_nt(ctx, n) && !(ROP == RED_AXPYDEV && keep == 2);
   const int64_t nvec = v2 ? n / 2 : n;
-  const bool u4 = nvec >= (int64_t)kBlock * 4 * 1024;          // big vectors: 4 independent accesses per lane
+  // 16-byte accesses per lane: 4 for the read-only reductions of long vectors (dot 6.1 vs 5.8 TB/s, nrm2 6.1 vs 4.3),
+  // 1 for the ones that also write (r -= a Ap ; r.r: 5.96 vs 5.72 TB/s) -- measured at n = 512^3, tools/sweep8.py
+  constexpr bool writes = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV || ROP == RED_AXPYSQ);
+  const bool u4 = ctx->tune.red_u == 0 ? (!writes && nvec >= (int64_t)kBlock * 4 * 1024) : ctx->tune.red_u == 4;
   const int64_t g = tiles_for(nvec, u4 ? 4 : 1);
   if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
   KHIP_TRY(ensure_reduction_scratch(ctx, g * kWavesPerBlock, RedOut<ROP>::n));
@@ -581,8 +584,9 @@ static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   hipLaunchKernelGGL((reduce_kernel<ROP, COMP, VEC, NT, U>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra)
 #define KHIP_RED_U(COMP, VEC, NT) do { if (u4) KHIP_RED(COMP, VEC, NT, 4); else KHIP_RED(COMP, VEC, NT, 1); } while (0)
 #define KHIP_RED_NT(COMP, VEC) do { if (nt) KHIP_RED_U(COMP, VEC, true); else KHIP_RED_U(COMP, VEC, false); } while (0)
-  if (ROP == RED_AXPYDEV && nt && v2 && u4 && comp && keep == 1) {
-    hipLaunchKernelGGL((reduce_kernel<ROP, true, 2, true, 4, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra);
+  if (ROP == RED_AXPYDEV && nt && v2 && comp && keep == 1) {
+    if (u4) hipLaunchKernelGGL((reduce_kernel<ROP, true, 2, true, 4, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra);
+    else hipLaunchKernelGGL((reduce_kernel<ROP, true, 2, true, 1, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra);
   } else if (comp) { if (v2) KHIP_RED_NT(true, 2); else KHIP_RED_NT(true, 1); }
   else             { if (v2) KHIP_RED_NT(false, 2); else KHIP_RED_NT(false, 1); }
 #undef KHIP_RED_NT

@@ -72,6 +72,7 @@ struct Tuning {
   int nt_min_elems = 1 << 22;  // BLAS-1 vectors at least this long use non-temporal accesses (32 MiB)
   int mgs_keep = -1;        // MGS cascade: keep q and the freshly dotted basis vector cacheable for the next step (-1 auto: when they fit the Infinity Cache; 0 off; 1 on; 2 nothing streamed)
   int hist_window = 1 << 14;   // device-resident loops: residual-history entries kept on the device between drains
+  int red_u = 0;            // reductions: 16-byte accesses per lane (0 auto: 4 for long vectors, else 1)
   int overlap_halo = 1;     // overlap halo exchange with interior rows
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
