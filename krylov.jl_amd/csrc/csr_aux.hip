@@ -10,11 +10,36 @@ namespace khip {
 // entry is broadcast with a shuffle and all P gathers of X rows (one contiguous 8p-byte line each)
 // are issued before the first use; accumulation in stored order with a rounded multiply and a rounded
 // add => column j of Y is bit-identical to the SpMV of column j.
+//
+// Tile order (a.sweep_s > 0): PLANE SWEEP.  The gathers of a 3-D stencil row reach the panel rows of the two
+// neighbouring grid planes; in the natural order those are S tiles back, long evicted from the XCD's 4 MiB L2
+// (216^3, p = 16: three planes of panel rows = 18 MB), so every panel row is fetched ~3x (FETCH_SIZE 16.6 GB for
+// 5.85 GB algorithmic) and the kernel runs at the L2<->fabric rate.  With the sweep every XCD takes a column of W
+// consecutive tiles and walks it through all planes: the k+-1 reuse distance is W tiles.  S is padded to a
+// multiple of 8 W with empty tiles; any (S, W) only permutes the tiles, so Y never depends on it.
 template <int P>
 __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
   constexpr int RPB = kBlock / P;
   const int sub = threadIdx.x / P, c = threadIdx.x % P;
-  for (int64_t row = a.row_lo + (int64_t)blockIdx.x * RPB + sub; row < a.row_hi; row += (int64_t)gridDim.x * RPB) {
+  int64_t first_tile = blockIdx.x, tile_stride = gridDim.x;
+  if (a.sweep_s > 0) {
+    const int S = a.sweep_s, W = a.sweep_w;
+    const int Spad = (S + 8 * W - 1) / (8 * W) * (8 * W);
+    const int64_t ntiles = (a.row_hi - a.row_lo + RPB - 1) / RPB;
+    const int64_t K = (ntiles + S - 1) / S;
+    const int64_t b = blockIdx.x;
+    const int pxcd = (int)(b & 7);
+    const int64_t l = b >> 3, per = K * W;
+    const int64_t tt = l / per, rem = l - tt * per;
+    const int64_t k = rem / W;
+    const int w = (int)(rem - k * W);
+    const int64_t ti = (tt * 8 + pxcd) * W + w;
+    if (ti >= S) return;                           // padding tile
+    first_tile = k * S + ti;
+    if (first_tile >= ntiles) return;
+    tile_stride = ntiles;                          // exactly one tile per workgroup
+  }
+  for (int64_t row = a.row_lo + first_tile * RPB + sub; row < a.row_hi; row += tile_stride * RPB) {
     const int64_t s = a.rowptr[row], e = a.rowptr[row + 1];
     double acc = 0.0;
     for (int64_t base = s; base < e; base += P) {
@@ -41,6 +66,43 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
   }
 }
 
+// Two panel columns per lane (16-byte gathers): L = p / 2 lanes per row, twice the rows per wave and half the
+// gather instructions per row of spmm_kernel -- the kernel is bound by the number of gather instructions (27 per
+// row for the 27-point operator), not by bytes.  Same per-column arithmetic and order => Y bit-identical.
+template <int L>
+__global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
+  constexpr int RPB = kBlock / L;
+  const int sub = threadIdx.x / L, c = threadIdx.x % L;
+  const bool col_ok = 2 * c + 1 < p;
+  for (int64_t row = a.row_lo + (int64_t)blockIdx.x * RPB + sub; row < a.row_hi; row += (int64_t)gridDim.x * RPB) {
+    const int64_t s = a.rowptr[row], e = a.rowptr[row + 1];
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int64_t base = s; base < e; base += L) {
+      const int cnt = (int)((e - base) < L ? (e - base) : L);
+      const bool mine = c < cnt;
+      const double myv = mine ? a.val[base + c] : 0.0;
+      const int32_t myc = mine ? a.col[base + c] : 0;
+      dbl2 xs[L];
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const int32_t cc = __shfl(myc, t, L);
+        xs[t] = dbl2{0.0, 0.0};
+        if (t < cnt && col_ok) xs[t] = *reinterpret_cast<const dbl2 *>(a.x + (int64_t)cc * p + 2 * c);
+      }
+#pragma unroll
+      for (int t = 0; t < L; ++t) {
+        const double vv = __shfl(myv, t, L);
+        if (t < cnt) {
+          const double p0 = vv * xs[t].x, p1 = vv * xs[t].y;
+          acc0 = acc0 + p0;
+          acc1 = acc1 + p1;
+        }
+      }
+    }
+    if (col_ok) *reinterpret_cast<dbl2 *>(a.y + row * p + 2 * c) = dbl2{acc0, acc1};
+  }
+}
+
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {
   if (A->dist) { set_error("spmm: distributed operator not supported"); return KHIP_ERR_UNSUPPORTED; }
   if (p < 1 || p > 64) { set_error("spmm: 1 <= p <= 64 required (got %d)", p); return KHIP_ERR_INVALID; }
@@ -54,6 +116,40 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
   int64_t gcap = 1 << 22;
   int grid = (int)(want < gcap ? want : gcap);     // loop-free: one row group per workgroup slot
   if (grid < 1) grid = 1;
+  a.sweep_s = 0; a.sweep_w = 0;
+  a.stop_seq = nullptr; a.seq = 0; a.dotw = nullptr; a.dot_sq = 0; a.stage_cap = 0;
+  a.tmpl_id = nullptr; a.tmpl_off = nullptr; a.tmpl_val = nullptr; a.tmpl_cnt = nullptr; a.tmpl_T = 0; a.tmpl_K = 0;
+  {   // plane sweep when the band is wide enough for the k+-1 panel rows to fall out of L2
+    const int W = ctx->tune.spmm_sweep_w > 0 ? ctx->tune.spmm_sweep_w : 64;
+    int64_t S = ctx->tune.spmm_sweep_s > 0 ? ctx->tune.spmm_sweep_s : (A->band + rpb / 2) / rpb;
+    const size_t window = (size_t)A->band * 2 * (size_t)p * sizeof(double);          // panel rows between the extremes of a row
+    if (ctx->tune.spmm_sweep != 0 && S >= 8 * W && (ctx->tune.spmm_sweep_s > 0 || window > ((size_t)2 << 20))) {
+      const int64_t Spad = (S + 8 * W - 1) / (8 * W) * (8 * W);
+      const int64_t K = (want + S - 1) / S;
+      if (K * Spad <= gcap) {
+        a.sweep_s = (int)S; a.sweep_w = W;
+        grid = (int)(K * Spad);
+      }
+    }
+  }
+  if (ctx->tune.spmm_wide && (p & 1) == 0 && p >= 4 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+    int L = 2;
+    while (2 * L < p) L <<= 1;                       // L lanes cover 2 L >= p columns
+    const int rpb2 = kBlock / L;
+    int64_t want2 = (A->m + rpb2 - 1) / rpb2;
+    const int grid2 = (int)(want2 < gcap ? (want2 > 0 ? want2 : 1) : gcap);
+    a.sweep_s = 0;
+    switch (L) {
+      case 2: hipLaunchKernelGGL((spmm2_kernel<2>), dim3(grid2), dim3(kBlock), 0, ctx->stream, a, p); break;
+      case 4: hipLaunchKernelGGL((spmm2_kernel<4>), dim3(grid2), dim3(kBlock), 0, ctx->stream, a, p); break;
+      case 8: hipLaunchKernelGGL((spmm2_kernel<8>), dim3(grid2), dim3(kBlock), 0, ctx->stream, a, p); break;
+      case 16: hipLaunchKernelGGL((spmm2_kernel<16>), dim3(grid2), dim3(kBlock), 0, ctx->stream, a, p); break;
+      default: hipLaunchKernelGGL((spmm2_kernel<32>), dim3(grid2), dim3(kBlock), 0, ctx->stream, a, p); break;
+    }
+    KHIP_CHECK_HIP(hipGetLastError());
+    return KHIP_OK;
+  }
   switch (P) {
     case 4: hipLaunchKernelGGL((spmm_kernel<4>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
     case 8: hipLaunchKernelGGL((spmm_kernel<8>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, p); break;
@@ -71,6 +167,25 @@ __global__ __launch_bounds__(kBlock) void row_stats_kernel(const int32_t *rowptr
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
     int len = rowptr[i + 1] - rowptr[i];
     mx = len > mx ? len : mx;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(max_out, mx);
+}
+
+// largest |column - row| over the handle (band half-width): the plane distance of a 3-D stencil
+__global__ __launch_bounds__(kBlock) void band_kernel(const int32_t *rowptr, const int32_t *col, int64_t m, int *max_out) {
+  int mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const int32_t s = rowptr[i], e = rowptr[i + 1];
+    if (e > s) {                                   // sorted rows: the extremes are the first and last entry; unsorted: scan
+      int d0 = (int)i - col[s], d1 = col[e - 1] - (int)i;
+      d0 = d0 < 0 ? -d0 : d0; d1 = d1 < 0 ? -d1 : d1;
+      mx = d0 > mx ? d0 : mx; mx = d1 > mx ? d1 : mx;
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -130,6 +245,12 @@ int csr_finalize(khip_ctx *ctx, khip_csr *A) {
   KHIP_CHECK_HIP(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->max_row_nnz = h;
+  KHIP_CHECK_HIP(hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(band_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, A->m, d);
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  A->band = h;
   return KHIP_OK;
 }
 

@@ -73,6 +73,10 @@ struct Tuning {
   int mgs_keep = -1;        // MGS cascade: keep q and the freshly dotted basis vector cacheable for the next step (-1 auto: when they fit the Infinity Cache; 0 off; 1 on; 2 nothing streamed)
   int hist_window = 1 << 14;   // device-resident loops: residual-history entries kept on the device between drains
   int red_u = 0;            // reductions: 16-byte accesses per lane (0 auto: 4 for long vectors, else 1)
+  int spmm_wide = 1;        // SpMM: two panel columns per lane (16-byte gathers) when p is even
+  int spmm_sweep = 0;       // SpMM: plane-sweep tile order when the band is wider than the L2 can hold (csr_aux.hip)
+  int spmm_sweep_s = 0;     // tiles per plane (0 = from the handle's band width)
+  int spmm_sweep_w = 64;    // tiles per XCD column
   int overlap_halo = 1;     // overlap halo exchange with interior rows
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
@@ -126,6 +130,7 @@ struct khip_csr {
   int32_t *col = nullptr;              // device, nnz (+pad), 0-based; remapped when distributed
   double *val = nullptr;               // device, nnz (+pad)
   int64_t max_row_nnz = 0;
+  int64_t band = 0;                    // max |column - row| (local indices)
   double mean_row_nnz = 0;
   // distributed state (null / zero when single GPU)
   bool dist = false;
