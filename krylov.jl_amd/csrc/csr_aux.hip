@@ -23,8 +23,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
   const int sub = threadIdx.x / P, c = threadIdx.x % P;
   int64_t first_tile = blockIdx.x, tile_stride = gridDim.x;
   if (a.sweep_s > 0) {
-    const int S = a.sweep_s, W = a.sweep_w;
-    const int Spad = (S + 8 * W - 1) / (8 * W) * (8 * W);
+    const int S = a.sweep_s, W = a.sweep_w;          // the host pads S to a multiple of 8 W when it sizes the grid
     const int64_t ntiles = (a.row_hi - a.row_lo + RPB - 1) / RPB;
     const int64_t K = (ntiles + S - 1) / S;
     const int64_t b = blockIdx.x;

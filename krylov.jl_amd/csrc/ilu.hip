@@ -197,6 +197,7 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
   KHIP_REQUIRE(A->m == A->n || A->dist, "ilu0_create: the operator must be square");
   const int64_t n = A->m, nnz = A->nnz;
   khip_ilu0 *P = new khip_ilu0();
+  struct Guard { khip_ilu0 *p; ~Guard() { if (p) ilu0_free(p); } } guard{P};      // any early return frees P
   P->ctx = ctx; P->A = A; P->n = n; P->nnz = nnz;
   P->use_graph = true;
   // ---- host analysis of the pattern (index arrays only) ---------------------------------
@@ -216,7 +217,6 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
     for (int32_t q = a; q < b; ++q) {
       const int32_t j = col[q];
       if (j >= n || (q > a && col[q - 1] >= j)) {
-        ilu0_free(P);
         set_error("ilu0_create: row %lld: column indices must be sorted and unique", (long long)i);
         return KHIP_ERR_INVALID;
       }
@@ -224,7 +224,6 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
       if (j < i) lv = std::max(lv, lev_lo[j] + 1);
     }
     if (d < 0) {
-      ilu0_free(P);
       set_error("ilu0_create: row %lld has no diagonal entry (structurally zero pivot)", (long long)i);
       return KHIP_ERR_NUMERIC;
     }
@@ -246,10 +245,10 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
   if (!rc) rc = upload(ctx, row_hi, &P->row_hi);
   if (!rc) rc = upload(ctx, perm_lo, &P->perm_lo);
   if (!rc) rc = upload(ctx, perm_up, &P->perm_up);
-  if (rc) { ilu0_free(P); return rc; }
+  if (rc) return rc;
   hipError_t e = hipMalloc(&P->lu, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
   if (e == hipSuccess) e = hipMalloc(&P->bad_row, sizeof(int));
-  if (e != hipSuccess) { ilu0_free(P); set_error("ilu0_create: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
+  if (e != hipSuccess) { set_error("ilu0_create: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
   const int none = 0x7fffffff;
   KHIP_CHECK_HIP(hipMemcpyAsync(P->bad_row, &none, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   if (nnz) KHIP_CHECK_HIP(hipMemcpyAsync(P->lu, A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->stream));
@@ -264,12 +263,12 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
   e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(&bad, P->bad_row, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { ilu0_free(P); set_error("ilu0_create: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
+  if (e != hipSuccess) { set_error("ilu0_create: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
   if (bad != none) {
-    ilu0_free(P);
     set_error("ilu0_create: zero pivot in row %d", bad);
     return KHIP_ERR_NUMERIC;
   }
+  guard.p = nullptr;
   op_out->csr = nullptr;
   op_out->apply = ilu0_apply;
   op_out->self = P;

@@ -127,7 +127,15 @@ extern "C" int khip_csr_compress(khip_ctx *ctx, khip_csr *A, int *templates_out)
   KHIP_CHECK_HIP(hipMalloc(&keys, sizeof(unsigned long long) * kTmplHash));
   KHIP_CHECK_HIP(hipMalloc(&rep, sizeof(int) * kTmplHash));
   KHIP_CHECK_HIP(hipMalloc(&cnt_fail, sizeof(int) * 2));
-  auto cleanup = [&]() { (void)hipFree(keys); (void)hipFree(rep); (void)hipFree(cnt_fail); };
+  int *d_id_of_slot = nullptr, *d_rep_of_id = nullptr;
+  bool keep_templates = false;
+  struct Scratch {                       // frees the scratch (and a half-built table) on every path out of this function
+    unsigned long long *&keys; int *&rep; int *&cnt_fail; int *&a; int *&b; khip_csr *A; bool &keep;
+    ~Scratch() {
+      (void)hipFree(keys); (void)hipFree(rep); (void)hipFree(cnt_fail); (void)hipFree(a); (void)hipFree(b);
+      if (!keep) csr_free_templates(A);
+    }
+  } scratch{keys, rep, cnt_fail, d_id_of_slot, d_rep_of_id, A, keep_templates};
   KHIP_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * kTmplHash, ctx->stream));
   KHIP_CHECK_HIP(hipMemsetAsync(rep, 0x7f, sizeof(int) * kTmplHash, ctx->stream));
   KHIP_CHECK_HIP(hipMemsetAsync(cnt_fail, 0, sizeof(int) * 2, ctx->stream));
@@ -140,8 +148,8 @@ extern "C" int khip_csr_compress(khip_ctx *ctx, khip_csr *A, int *templates_out)
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(cf, cnt_fail, sizeof(cf), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { cleanup(); set_error("csr_compress: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
-  if (cf[1] != TMPL_OK) { cleanup(); return KHIP_OK; }                                   // too many templates / rows too long
+  if (e != hipSuccess) { set_error("csr_compress: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
+  if (cf[1] != TMPL_OK) return KHIP_OK;                                   // too many templates / rows too long
   KHIP_CHECK_HIP(hipMemcpy(hkeys.data(), keys, sizeof(unsigned long long) * kTmplHash, hipMemcpyDeviceToHost));
   KHIP_CHECK_HIP(hipMemcpy(hrep.data(), rep, sizeof(int) * kTmplHash, hipMemcpyDeviceToHost));
   // ids in order of the representative (smallest) row: deterministic
@@ -150,10 +158,9 @@ extern "C" int khip_csr_compress(khip_ctx *ctx, khip_csr *A, int *templates_out)
   std::sort(occ.begin(), occ.end());
   const int T = (int)occ.size();
   const int K = (int)A->max_row_nnz;
-  if (T == 0 || T > kTmplMax || (size_t)T * K * 12 + (size_t)T * 4 > kTmplLdsMax) { cleanup(); return KHIP_OK; }
+  if (T == 0 || T > kTmplMax || (size_t)T * K * 12 + (size_t)T * 4 > kTmplLdsMax) return KHIP_OK;
   std::vector<int> id_of_slot(kTmplHash, -1), rep_of_id((size_t)T);
   for (int t = 0; t < T; ++t) { id_of_slot[occ[t].second] = t; rep_of_id[t] = occ[t].first; }
-  int *d_id_of_slot = nullptr, *d_rep_of_id = nullptr;
   KHIP_CHECK_HIP(hipMalloc(&d_id_of_slot, sizeof(int) * kTmplHash));
   KHIP_CHECK_HIP(hipMalloc(&d_rep_of_id, sizeof(int) * (size_t)T));
   KHIP_CHECK_HIP(hipMemcpy(d_id_of_slot, id_of_slot.data(), sizeof(int) * kTmplHash, hipMemcpyHostToDevice));
@@ -169,10 +176,9 @@ extern "C" int khip_csr_compress(khip_ctx *ctx, khip_csr *A, int *templates_out)
   e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(cf, cnt_fail, sizeof(cf), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_id_of_slot); (void)hipFree(d_rep_of_id);
-  cleanup();
-  if (e != hipSuccess) { csr_free_templates(A); set_error("csr_compress: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
-  if (cf[1] != TMPL_OK) { csr_free_templates(A); return KHIP_OK; }                       // hash collision: stay with CSR
+  if (e != hipSuccess) { set_error("csr_compress: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
+  if (cf[1] != TMPL_OK) return KHIP_OK;                                                  // hash collision: stay with CSR
+  keep_templates = true;
   A->tmpl_T = T;
   A->tmpl_K = K;
   if (templates_out) *templates_out = T;
