@@ -263,6 +263,7 @@ int khip_csr_destroy(khip_csr *A) {
   if (A->ctx) (void)hipStreamSynchronize(A->ctx->stream);
   (void)hipFree(A->rowptr); (void)hipFree(A->col); (void)hipFree(A->val); (void)hipFree(A->blockptr);
   (void)hipFree(A->ghost); (void)hipFree(A->sendbuf); (void)hipFree(A->send_idx);
+  (void)hipFree(A->ghost_w); (void)hipFree(A->sendbuf_w);
   csr_free_templates(A);
   delete A;
   return KHIP_OK;

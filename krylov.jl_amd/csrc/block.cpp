@@ -317,7 +317,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   int npass = 0;
   int64_t iter = 0;
   int inner_iter = 0;
-  const int64_t itmax = o.itmax == 0 ? 2 * (n / p) : o.itmax;
+  const int64_t itmax = o.itmax == 0 ? 2 * (global_rows(ctx, A, n) / p) : o.itmax;
   int64_t inner_itmax = itmax;
 
   bool solved = RNorm <= eps_tol;

@@ -281,23 +281,43 @@ int comm_build_plan(khip_ctx *ctx, khip_csr *A) {
   return KHIP_OK;
 }
 
-// --------------------------------------------------------------------------- per-SpMV exchange
-int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x) {
+// --------------------------------------------------------------------------- per-SpMV / per-SpMM exchange
+// width = 1: vectors (A->sendbuf / A->ghost).  width = p > 1: row-major panels, every exchanged entry is a
+// panel row of p doubles (A->sendbuf_w / A->ghost_w, grown on demand).
+static int ensure_panel_halo(khip_csr *A, int width) {
+  if (width <= A->halo_w_cap) return KHIP_OK;
+  if (A->sendbuf_w) KHIP_CHECK_HIP(hipFree(A->sendbuf_w));
+  if (A->ghost_w) KHIP_CHECK_HIP(hipFree(A->ghost_w));
+  A->sendbuf_w = nullptr; A->ghost_w = nullptr; A->halo_w_cap = 0;
+  KHIP_CHECK_HIP(hipMalloc(&A->sendbuf_w, sizeof(double) * (size_t)std::max<int64_t>(A->n_send, 1) * width));
+  KHIP_CHECK_HIP(hipMalloc(&A->ghost_w, sizeof(double) * (size_t)std::max<int64_t>(A->n_ghost, 1) * width));
+  A->halo_w_cap = width;
+  return KHIP_OK;
+}
+
+int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *x, int width) {
   Comm *c = ctx->comm;
+  khip_csr *A = const_cast<khip_csr *>(A_in);
   if (!c || c->nranks == 1 || (A->n_send == 0 && A->n_ghost == 0)) return KHIP_OK;
-  KHIP_TRY(launch_gather(ctx, A->n_send, A->send_idx, x, A->sendbuf));
+  double *sendbuf = A->sendbuf, *ghost = A->ghost;
+  if (width > 1) {
+    KHIP_TRY(ensure_panel_halo(A, width));
+    sendbuf = A->sendbuf_w; ghost = A->ghost_w;
+  }
+  const size_t w = (size_t)width;
+  KHIP_TRY(launch_gather(ctx, A->n_send, A->send_idx, x, sendbuf, width));
   if (c->hub) {
     LocalHub *h = c->hub;
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));          // my send buffer is packed
-    h->sendbuf[c->rank] = A->sendbuf;
+    h->sendbuf[c->rank] = sendbuf;
     h->send_off[c->rank] = A->send_off;
     h->barrier();                                                // everybody's buffers are packed and published
     for (int r = 0; r < c->nranks; ++r) {
       if (r == c->rank) continue;
       const int64_t nr = A->recv_off[r + 1] - A->recv_off[r];
       if (nr > 0)
-        KHIP_CHECK_HIP(hipMemcpyAsync(A->ghost + A->recv_off[r], h->sendbuf[r] + h->send_off[r][c->rank], sizeof(double) * (size_t)nr,
-                                      hipMemcpyDeviceToDevice, ctx->stream));
+        KHIP_CHECK_HIP(hipMemcpyAsync(ghost + A->recv_off[r] * w, h->sendbuf[r] + h->send_off[r][c->rank] * w,
+                                      sizeof(double) * (size_t)nr * w, hipMemcpyDeviceToDevice, ctx->stream));
     }
     return KHIP_OK;
   }
@@ -312,8 +332,8 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x) 
     if (r == c->rank) continue;
     const int64_t ns = A->send_off[r + 1] - A->send_off[r];
     const int64_t nr = A->recv_off[r + 1] - A->recv_off[r];
-    if (ns > 0) KHIP_CHECK_NCCL(g_rccl.Send(A->sendbuf + A->send_off[r], (size_t)ns, ncclFloat64, r, c->comm, cs));
-    if (nr > 0) KHIP_CHECK_NCCL(g_rccl.Recv(A->ghost + A->recv_off[r], (size_t)nr, ncclFloat64, r, c->comm, cs));
+    if (ns > 0) KHIP_CHECK_NCCL(g_rccl.Send(sendbuf + A->send_off[r] * w, (size_t)ns * w, ncclFloat64, r, c->comm, cs));
+    if (nr > 0) KHIP_CHECK_NCCL(g_rccl.Recv(ghost + A->recv_off[r] * w, (size_t)nr * w, ncclFloat64, r, c->comm, cs));
   }
   KHIP_CHECK_NCCL(g_rccl.GroupEnd());
   if (cs != ctx->stream) KHIP_CHECK_HIP(hipEventRecord(ctx->ev_b[ctx->ev_cur], cs));
@@ -364,6 +384,21 @@ int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host) 
       lo += v.lo + e;
     }
     out_host[i] = hi + lo;
+  }
+  return KHIP_OK;
+}
+
+// In-place sum over ranks of `count` host doubles, added in rank order (identical on every rank): the p x p blocks of
+// the panel products (src/block_gmres.jl:244-247 on a row-partitioned panel) and small integers such as row counts.
+int comm_allreduce_sum_host(khip_ctx *ctx, double *vals, int count) {
+  Comm *c = ctx->comm;
+  if (!c || c->nranks == 1 || count <= 0) return KHIP_OK;
+  std::vector<double> all((size_t)count * c->nranks);
+  KHIP_TRY(allgather_host(ctx, vals, all.data(), sizeof(double) * (size_t)count));
+  for (int i = 0; i < count; ++i) {
+    double acc = 0.0;
+    for (int r = 0; r < c->nranks; ++r) acc += all[(size_t)r * count + i];
+    vals[i] = acc;
   }
   return KHIP_OK;
 }

@@ -50,7 +50,10 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmvArgs a, int p) {
 #pragma unroll
       for (int t = 0; t < P; ++t) {
         const int32_t cc = __shfl(myc, t, P);
-        xs[t] = (t < cnt && c < p) ? a.x[(int64_t)cc * p + c] : 0.0;
+        const bool own = cc < a.n_owned;                 // else: a ghost panel row of a distributed handle
+        const double *src = own ? a.x : a.ghost;
+        const int64_t r = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
+        xs[t] = (t < cnt && c < p) ? src[r * p + c] : 0.0;
       }
 #pragma unroll
       for (int t = 0; t < P; ++t) {
@@ -86,7 +89,10 @@ __global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
       for (int t = 0; t < L; ++t) {
         const int32_t cc = __shfl(myc, t, L);
         xs[t] = dbl2{0.0, 0.0};
-        if (t < cnt && col_ok) xs[t] = *reinterpret_cast<const dbl2 *>(a.x + (int64_t)cc * p + 2 * c);
+        const bool own = cc < a.n_owned;
+        const double *src = own ? a.x : a.ghost;
+        const int64_t r = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
+        if (t < cnt && col_ok) xs[t] = *reinterpret_cast<const dbl2 *>(src + r * p + 2 * c);
       }
 #pragma unroll
       for (int t = 0; t < L; ++t) {
@@ -103,11 +109,16 @@ __global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
 }
 
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {
-  if (A->dist) { set_error("spmm: distributed operator not supported"); return KHIP_ERR_UNSUPPORTED; }
   if (p < 1 || p > 64) { set_error("spmm: 1 <= p <= 64 required (got %d)", p); return KHIP_ERR_INVALID; }
   SpmvArgs a;
-  a.rowptr = A->rowptr; a.blockptr = nullptr; a.col = A->col; a.val = A->val; a.x = X; a.ghost = nullptr; a.y = Y;
-  a.n_owned = A->n; a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.fake_gather = 0; a.tiles_per_block = 1; a.nnz_bound = A->nnz + kPad;
+  a.rowptr = A->rowptr; a.blockptr = nullptr; a.col = A->col; a.val = A->val; a.x = X; a.ghost = X; a.y = Y;
+  a.n_owned = (int64_t)1 << 40;                      // single GPU: every column is owned
+  if (A->dist && ctx->comm) {                        // row-partitioned: fetch the remote panel rows first (no overlap yet)
+    KHIP_TRY(comm_halo_exchange_begin(ctx, A, X, p));
+    KHIP_TRY(comm_halo_exchange_end(ctx, A));
+    if (A->n_ghost > 0) { a.ghost = A->ghost_w; a.n_owned = A->m; }
+  }
+  a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.fake_gather = 0; a.tiles_per_block = 1; a.nnz_bound = A->nnz + kPad;
   int P = 4;
   while (P < p) P <<= 1;
   const int rpb = kBlock / P;
@@ -266,16 +277,20 @@ int launch_index_shift(khip_ctx *ctx, int32_t *data, int64_t n, int32_t delta) {
 }
 
 // ---------------------------------------------------------------- halo helpers ---
-__global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t *idx, const double *x, double *out) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-    out[i] = x[idx[i]];
+__global__ __launch_bounds__(kBlock) void gather_kernel(int64_t n, const int32_t *idx, const double *x, double *out, int width) {
+  const int64_t total = n * width;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = i / width;
+    const int c = (int)(i - e * width);
+    out[i] = x[(int64_t)idx[e] * width + c];
+  }
 }
 
-int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out) {
+int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out, int width) {
   if (n <= 0) return KHIP_OK;
-  int64_t want = (n + kBlock - 1) / kBlock;
-  int grid = (int)(want < 1024 ? want : 1024);
-  hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, n, idx, x, out);
+  int64_t want = (n * width + kBlock - 1) / kBlock;
+  int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, n, idx, x, out, width);
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }

@@ -139,6 +139,8 @@ struct khip_csr {
   double *ghost = nullptr;             // device, n_ghost : received remote x entries
   double *sendbuf = nullptr;           // device, n_send
   int32_t *send_idx = nullptr;         // device, n_send : owned indices to pack
+  double *ghost_w = nullptr, *sendbuf_w = nullptr;   // panel versions (n_ghost / n_send rows of halo_w_cap doubles)
+  int halo_w_cap = 0;
   int64_t n_send = 0;
   std::vector<int64_t> send_off, recv_off;   // per-peer offsets (size nranks+1)
   int64_t interior_lo = 0, interior_hi = 0;  // rows [lo,hi) reference no ghost column
@@ -204,7 +206,7 @@ int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A);
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
 int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays are resident
 int csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr *T);   // T = A' (fresh handle, deterministic entry order)
-int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out);
+int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out, int width = 1);
 int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost);
 int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64_t row1, int32_t *out_dev,
                            unsigned long long *count_dev, int64_t cap);
@@ -227,8 +229,19 @@ int comm_nranks(const khip_ctx *ctx);
 int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host);
 // all-reduce results_dd[slot..slot+count) into results[slot..] ON THE DEVICE (no host sync with RCCL), then run ctx->ctl's epilogue
 int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count);
-int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x);
+int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x, int width = 1);   // width p: row-major panel
+int comm_allreduce_sum_host(khip_ctx *ctx, double *vals, int count);
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A);
 int comm_build_plan(khip_ctx *ctx, khip_csr *A);
+
+// rows of the GLOBAL operator (= n on one GPU): a distributed handle knows it, otherwise the local counts are summed
+inline int64_t global_rows(khip_ctx *ctx, const khip_operator *A, int64_t n_local) {
+  if (A && A->csr && !A->apply && A->csr->dist) return A->csr->n_global;
+  if (comm_nranks(ctx) > 1) {
+    double v = (double)n_local;
+    if (comm_allreduce_sum_host(ctx, &v, 1) == KHIP_OK) return (int64_t)v;
+  }
+  return n_local;
+}
 
 }  // namespace khip

@@ -288,7 +288,8 @@ int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const d
   KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned, g_ps.psi_dev, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   memcpy(Psi_host, g_ps.psi_pinned, sizeof(double) * (size_t)p * p);
-  return KHIP_OK;
+  // row-partitioned panels: the block is the sum of the ranks' partial blocks (2 KB at p = 16), added in rank order
+  return comm_allreduce_sum_host(ctx, Psi_host, p * p);
 }
 
 int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const double *V, const double *Psi_host, double beta,

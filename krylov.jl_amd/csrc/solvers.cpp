@@ -358,7 +358,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
   }
 
   int64_t iter = 0;
-  const int64_t itmax = o.itmax == 0 ? 2 * n : o.itmax;
+  const int64_t itmax = o.itmax == 0 ? 2 * global_rows(ctx, A, n) : o.itmax;   // 2n of the GLOBAL system on every rank
   double pAp = 0.0;
   double pNorm2 = gamma;
   const double eps_tol = atol + rtol * rNorm;
@@ -642,7 +642,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   int npass = 0;
   int64_t iter = 0;
   int inner_iter = 0;
-  const int64_t itmax = o.itmax == 0 ? 2 * n : o.itmax;
+  const int64_t itmax = o.itmax == 0 ? 2 * global_rows(ctx, A, n) : o.itmax;   // 2n of the GLOBAL system on every rank
   int64_t inner_itmax = itmax;
   const double btol = std::pow(kEps, 0.75);                                        // :195
 
@@ -913,7 +913,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   }
 
   int64_t iter = 0;
-  const int64_t itmax = o.itmax == 0 ? 2 * n : o.itmax;
+  const int64_t itmax = o.itmax == 0 ? 2 * global_rows(ctx, A, n) : o.itmax;   // 2n of the GLOBAL system on every rank
   const double eps_tol = atol + rtol * rNorm;
 
   double next_rho;
