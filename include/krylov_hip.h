@@ -262,8 +262,8 @@ typedef struct {
   int    restart;             /* gmres / block_gmres              (src/gmres.jl:219-226) */
   int    reorthogonalization; /* gmres / block_gmres              (src/gmres.jl:265-271) */
   int    fused;               /* 0 = issue primitives exactly as the reference does; 1 = fused kernels;
-                               * 2 = fused kernels + scalar recurrences and stopping tests on the device (cg: no host
-                               * round trip inside the loop; bit-identical to 1; falls back to 1 where it does not apply) */
+                               * 2 = fused kernels + scalar recurrences and stopping tests on the device (cg, bicgstab: no
+                               * host round trip inside the loop; bit-identical to 1; falls back to 1 where it does not apply) */
   khip_callback_fn callback; void *callback_data;
 } khip_options;
 

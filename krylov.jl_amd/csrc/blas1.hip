@@ -213,9 +213,14 @@ int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double 
 //   xr:  x += omega z (:231) ; r = s - omega t (:232-233) ; c.r (:234) ; r.r (:240)          48n (40n if z === s)
 //   p :  p = r + beta (p - omega v)  (:236-237)                                              32n
 template <int VEC, bool NT>
-__global__ __launch_bounds__(kBlock) void bicg_sx_kernel(int64_t n, double alpha, const double *r, const double *v,
-                                                         const double *y, double *s, double *x) {
+__global__ __launch_bounds__(kBlock) void bicg_sx_kernel(int64_t n, double alpha, const BicgDevState *st, long long seq,
+                                                         const double *r, const double *v, const double *y, double *s,
+                                                         double *x) {
   using T = typename VecT<VEC>::type;
+  if (st) {                                          // device-resident loop: scalar and stop word from the state
+    if (seq >= st->stop_seq) return;
+    alpha = st->alpha;
+  }
   const int64_t nvec = n / VEC;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < nvec) {
@@ -239,9 +244,14 @@ __global__ __launch_bounds__(kBlock) void bicg_sx_kernel(int64_t n, double alpha
 }
 
 template <int VEC, bool NT>
-__global__ __launch_bounds__(kBlock) void bicg_p_kernel(int64_t n, double omega, double beta, const double *v,
-                                                        const double *r, double *p) {
+__global__ __launch_bounds__(kBlock) void bicg_p_kernel(int64_t n, double omega, double beta, const BicgDevState *st,
+                                                        long long seq, const double *v, const double *r, double *p) {
   using T = typename VecT<VEC>::type;
+  if (st) {
+    if (seq >= st->stop_seq) return;
+    omega = st->omega;
+    beta = st->beta;
+  }
   const int64_t nvec = n / VEC;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < nvec) {
@@ -263,11 +273,12 @@ __global__ __launch_bounds__(kBlock) void bicg_p_kernel(int64_t n, double omega,
 }
 
 template <bool COMP, int VEC, bool NT>
-__global__ __launch_bounds__(kBlock) void bicg_xr_kernel(int64_t n, double omega, const double *s, const double *t,
-                                                         const double *z, const double *c, double *x, double *r,
-                                                         RedArgs ra) {
+__global__ __launch_bounds__(kBlock) void bicg_xr_kernel(int64_t n, double omega, const BicgDevState *st, const double *s,
+                                                         const double *t, const double *z, const double *c, double *x,
+                                                         double *r, RedArgs ra) {
   using T = typename VecT<VEC>::type;
   if (seq_skip(ra.stop_seq, ra.seq)) return;
+  if (st) omega = st->omega;
   dd acc[2] = {dd{0.0, 0.0}, dd{0.0, 0.0}};
   const int64_t nvec = n / VEC;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -300,14 +311,15 @@ __global__ __launch_bounds__(kBlock) void bicg_xr_kernel(int64_t n, double omega
 }
 
 int launch_bicg_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y, double *s,
-                   double *x) {
+                   double *x, const void *st_dev, long long seq) {
+  const BicgDevState *st = static_cast<const BicgDevState *>(st_dev);
   if (n <= 0) return KHIP_OK;
   const bool v2 = n >= 2 && aligned16(r) && aligned16(v) && aligned16(y) && aligned16(s) && aligned16(x);
   const bool nt = use_nt(ctx, n);
   const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
   if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
 #define KHIP_L(VEC, NT) \
-  hipLaunchKernelGGL((bicg_sx_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, alpha, r, v, y, s, x)
+  hipLaunchKernelGGL((bicg_sx_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, alpha, st, seq, r, v, y, s, x)
   if (v2) { if (nt) KHIP_L(2, true); else KHIP_L(2, false); }
   else    { if (nt) KHIP_L(1, true); else KHIP_L(1, false); }
 #undef KHIP_L
@@ -315,14 +327,16 @@ int launch_bicg_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, cons
   return KHIP_OK;
 }
 
-int launch_bicg_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p) {
+int launch_bicg_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p,
+                  const void *st_dev, long long seq) {
+  const BicgDevState *st = static_cast<const BicgDevState *>(st_dev);
   if (n <= 0) return KHIP_OK;
   const bool v2 = n >= 2 && aligned16(r) && aligned16(v) && aligned16(p);
   const bool nt = use_nt(ctx, n);
   const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
   if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
 #define KHIP_L(VEC, NT) \
-  hipLaunchKernelGGL((bicg_p_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, omega, beta, v, r, p)
+  hipLaunchKernelGGL((bicg_p_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, omega, beta, st, seq, v, r, p)
   if (v2) { if (nt) KHIP_L(2, true); else KHIP_L(2, false); }
   else    { if (nt) KHIP_L(1, true); else KHIP_L(1, false); }
 #undef KHIP_L
@@ -331,7 +345,8 @@ int launch_bicg_p(khip_ctx *ctx, int64_t n, double omega, double beta, const dou
 }
 
 int launch_bicg_xr(khip_ctx *ctx, int64_t n, double omega, const double *s, const double *t, const double *z,
-                   const double *c, double *x, double *r, int slot) {
+                   const double *c, double *x, double *r, int slot, const void *st_dev) {
+  const BicgDevState *st = static_cast<const BicgDevState *>(st_dev);
   if (n < 0) { set_error("negative length"); return KHIP_ERR_INVALID; }
   const bool v2 = n >= 2 && aligned16(s) && aligned16(t) && aligned16(z) && aligned16(c) && aligned16(x) && aligned16(r);
   const bool comp = ctx->tune.compensated != 0;
@@ -341,7 +356,7 @@ int launch_bicg_xr(khip_ctx *ctx, int64_t n, double omega, const double *s, cons
   KHIP_TRY(ensure_reduction_scratch(ctx, g * kWavesPerBlock, 2));
   RedArgs ra = make_red_args(ctx, slot);
 #define KHIP_L(COMP, VEC, NT) \
-  hipLaunchKernelGGL((bicg_xr_kernel<COMP, VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, omega, s, t, z, c, x, r, ra)
+  hipLaunchKernelGGL((bicg_xr_kernel<COMP, VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, omega, st, s, t, z, c, x, r, ra)
 #define KHIP_L2(COMP) do { if (v2) { if (nt) KHIP_L(COMP, 2, true); else KHIP_L(COMP, 2, false); } \
                            else    { if (nt) KHIP_L(COMP, 1, true); else KHIP_L(COMP, 1, false); } } while (0)
   if (comp) KHIP_L2(true); else KHIP_L2(false);

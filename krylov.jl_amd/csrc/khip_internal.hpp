@@ -180,11 +180,13 @@ int launch_cg_update_dev(khip_ctx *ctx, int64_t n, const void *cg_state_dev, lon
 int launch_epilogue_only(khip_ctx *ctx, int slot);
 int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot);
 // fused elementwise passes of one bicgstab! iteration (blas1.hip)
+// st_dev != null: alpha / omega / beta and the stop word are read from a BicgDevState (solver_device.hpp)
 int launch_bicg_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y, double *s,
-                   double *x);
+                   double *x, const void *st_dev = nullptr, long long seq = 0);
 int launch_bicg_xr(khip_ctx *ctx, int64_t n, double omega, const double *s, const double *t, const double *z,
-                   const double *c, double *x, double *r, int slot);   // slot: c.r, slot+1: r.r
-int launch_bicg_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p);
+                   const double *c, double *x, double *r, int slot, const void *st_dev = nullptr);   // slot: c.r, slot+1: r.r
+int launch_bicg_p(khip_ctx *ctx, int64_t n, double omega, double beta, const double *v, const double *r, double *p,
+                  const void *st_dev = nullptr, long long seq = 0);
 // y <- y - (*coef_dev) x ; out[slot] = z . y (z == y -> ||y||^2), coef read from device memory
 int launch_axpy_dev_dot(khip_ctx *ctx, int64_t n, const double *coef_dev, const double *x, double *y,
                         const double *z, int slot);

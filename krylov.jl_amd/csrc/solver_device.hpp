@@ -14,7 +14,7 @@
 
 namespace khip {
 
-enum Epilogue { EPI_NONE = 0, EPI_CG_STEP1 = 1, EPI_CG_STEP2 = 2 };
+enum Epilogue { EPI_NONE = 0, EPI_CG_STEP1 = 1, EPI_CG_STEP2 = 2, EPI_BICG_A = 3, EPI_BICG_B = 4, EPI_BICG_C = 5 };
 
 struct CgDevState {
   double gamma;        // r.z of the current iterate              (src/cg.jl:162, 257)
@@ -31,6 +31,22 @@ struct CgDevState {
   long long hist_cap;
   double *hist;        // device history window (null: no history)
   int solved, zero_curvature, inconsistent, not_spd;
+};
+
+// bicgstab! (src/bicgstab.jl:213-253) with M = N = I: the scalars of one iteration
+struct BicgDevState {
+  double rho;          // c.r of the current iterate                 (:215)
+  double alpha;        // rho / c.v                                   (:223)
+  double omega;        // t.s / t.t                                   (:230)
+  double beta;         // (next_rho / rho) (alpha / omega)            (:235)
+  double rNorm;        // ||r||                                        (:240)
+  double eps_tol;      // atol + rtol * rNorm0                        (:189)
+  long long stop_seq;
+  long long iter;
+  long long hist_base;
+  long long hist_cap;
+  double *hist;
+  int solved, breakdown;
 };
 
 constexpr long long kSeqNever = 0x7fffffffffffffffLL;
@@ -79,6 +95,30 @@ __device__ inline void solver_epilogue(int epi, void *state, const double *v, lo
     st->solved = solved ? 1 : 0;
     st->iter = k;
     if (solved) st->stop_seq = seq + 2;            // the x update of this iteration (seq + 1) still runs
+  } else if (epi == EPI_BICG_A) {                  // v[0] = c.v                 src/bicgstab.jl:223
+    BicgDevState *st = static_cast<BicgDevState *>(state);
+    st->alpha = st->rho / v[0];
+  } else if (epi == EPI_BICG_B) {                  // v = (t.s, t.t)             :230
+    BicgDevState *st = static_cast<BicgDevState *>(state);
+    st->omega = v[0] / v[1];
+  } else if (epi == EPI_BICG_C) {                  // v = (c.r, r.r)             :234-252
+    BicgDevState *st = static_cast<BicgDevState *>(state);
+    const double next_rho = v[0];
+    st->beta = (next_rho / st->rho) * (st->alpha / st->omega);
+    const double rNorm = sqrt(v[1]);
+    st->rNorm = rNorm;
+    const long long k = st->iter + 1;
+    if (st->hist) {
+      const long long idx = k - 1 - st->hist_base;
+      if (idx >= 0 && idx < st->hist_cap) st->hist[idx] = rNorm;
+    }
+    const bool solved = (rNorm <= st->eps_tol) || (rNorm + 1.0 <= 1.0);
+    const bool breakdown = (st->alpha == 0.0) || (st->alpha != st->alpha);
+    st->solved = solved ? 1 : 0;
+    st->breakdown = breakdown ? 1 : 0;
+    st->rho = next_rho;
+    st->iter = k;
+    if (solved || breakdown) st->stop_seq = seq + 2;   // the p update of this iteration (seq + 1) still runs (:236-237)
   }
 }
 

@@ -820,7 +820,109 @@ struct khip_bicgstab_workspace {
          *yz = nullptr, *t = nullptr;
   bool warm_start = false;
   StatsBox box;
+  // device-resident loop state (fused = 2), allocated on first use
+  BicgDevState *dev_state = nullptr;
+  BicgDevState *snap = nullptr;        // pinned host snapshots [2]
+  double *hist_dev = nullptr;
+  hipEvent_t snap_ev[2] = {nullptr, nullptr};
 };
+
+namespace {
+
+// The loop of src/bicgstab.jl:213-253 (M = N = I, CSR operator, no callback) with rho, alpha, omega, beta and the
+// stopping tests on the device: five passes per iteration, each carrying its sequence number; see cg_device_loop.
+int bicgstab_device_loop(khip_bicgstab_workspace *ws, const khip_csr *A, const double *c, double rho0, double rNorm0,
+                         double eps_tol, int64_t itmax, bool history, double t0, double timemax, BicgDevState *out,
+                         bool *overtimed) {
+  khip_ctx *ctx = ws->ctx;
+  const int64_t n = ws->n;
+  if (!ws->dev_state) {
+    KHIP_CHECK_HIP(hipMalloc(&ws->dev_state, sizeof(BicgDevState)));
+    KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->snap), 2 * sizeof(BicgDevState), hipHostMallocDefault));
+    KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindowMax));
+    for (auto &e : ws->snap_ev) KHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  long long window = ctx->tune.hist_window;
+  if (window < kDevChunk) window = kDevChunk;
+  if (window > kHistWindowMax) window = kHistWindowMax;
+  BicgDevState *dev = ws->dev_state;
+  BicgDevState h;
+  memset(&h, 0, sizeof(h));
+  h.rho = rho0; h.alpha = 1.0; h.omega = 1.0; h.rNorm = rNorm0; h.eps_tol = eps_tol;
+  h.stop_seq = kSeqNever;
+  h.hist = history ? ws->hist_dev : nullptr;
+  h.hist_cap = window;
+  KHIP_CHECK_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double *x = ws->x, *r = ws->r, *p = ws->p, *v = ws->v, *s = ws->s, *t = ws->qd;
+  int64_t enq = 0;
+  long long hist_base = 0;
+  std::vector<double> win;
+  auto drain_history = [&](long long upto_iter) -> int {
+    const long long cnt = upto_iter - hist_base;
+    if (!history || cnt <= 0) return KHIP_OK;
+    win.resize((size_t)cnt);
+    KHIP_CHECK_HIP(hipMemcpy(win.data(), ws->hist_dev, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    for (double val : win) ws->box.push(val);
+    return KHIP_OK;
+  };
+  int rc = KHIP_OK;
+  bool stopped = false;
+  for (int chunk = 0; !stopped; ++chunk) {
+    const int64_t cnt = std::min<int64_t>(kDevChunk, itmax - enq);
+    if (history && enq + cnt - hist_base > window) {
+      KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      BicgDevState cur;
+      KHIP_CHECK_HIP(hipMemcpy(&cur, dev, sizeof(cur), hipMemcpyDeviceToHost));
+      if (cur.stop_seq != kSeqNever) break;
+      if ((rc = drain_history(cur.iter)) != KHIP_OK) break;
+      hist_base = cur.iter;
+      KHIP_CHECK_HIP(hipMemcpy(&dev->hist_base, &hist_base, sizeof(hist_base), hipMemcpyHostToDevice));
+    }
+    for (int64_t i = 0; i < cnt && rc == KHIP_OK; ++i) {
+      const long long j = (long long)(enq + i);
+      ctx->ctl = SeqCtl{&dev->stop_seq, 5 * j, EPI_BICG_A, dev};
+      int slot = take_slots(ctx, 1);
+      rc = spmv_any(ctx, A, p, v, slot, c, false);                                  // :221-223  v = A p ; c.v -> alpha
+      if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, slot, 1);
+      ctx->ctl = SeqCtl{};
+      if (rc != KHIP_OK) break;
+      rc = launch_bicg_sx(ctx, n, 0.0, r, v, p, s, x, dev, 5 * j + 1);               // :224-226
+      if (rc != KHIP_OK) break;
+      ctx->ctl = SeqCtl{&dev->stop_seq, 5 * j + 2, EPI_BICG_B, dev};
+      slot = take_slots(ctx, 2);
+      rc = spmv_any(ctx, A, s, t, slot, nullptr, true);                             // :228-230  t = A s ; t.s, t.t -> omega
+      if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, slot, 2);
+      if (rc != KHIP_OK) break;
+      ctx->ctl = SeqCtl{&dev->stop_seq, 5 * j + 3, EPI_BICG_C, dev};
+      slot = take_slots(ctx, 2);
+      rc = launch_bicg_xr(ctx, n, 0.0, s, t, s, c, x, r, slot, dev);                // :231-234, :240 -> beta, tests
+      if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, slot, 2);
+      ctx->ctl = SeqCtl{};
+      if (rc != KHIP_OK) break;
+      rc = launch_bicg_p(ctx, n, 0.0, 0.0, v, r, p, dev, 5 * j + 4);                // :236-237
+    }
+    ctx->ctl = SeqCtl{};
+    if (rc != KHIP_OK) break;
+    enq += cnt;
+    const int b = chunk & 1;
+    KHIP_CHECK_HIP(hipMemcpyAsync(&ws->snap[b], dev, sizeof(BicgDevState), hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipEventRecord(ws->snap_ev[b], ctx->stream));
+    if (chunk >= 1) {
+      KHIP_CHECK_HIP(hipEventSynchronize(ws->snap_ev[b ^ 1]));
+      if (ws->snap[b ^ 1].stop_seq != kSeqNever) stopped = true;
+    }
+    if (enq >= itmax) stopped = true;
+    if (!stopped && (now_s() - t0) > timemax) { *overtimed = true; stopped = true; }
+  }
+  ctx->ctl = SeqCtl{};
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (rc != KHIP_OK) return rc;
+  KHIP_CHECK_HIP(hipMemcpy(out, dev, sizeof(BicgDevState), hipMemcpyDeviceToHost));
+  return drain_history(out->iter);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -839,6 +941,10 @@ int khip_bicgstab_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_bic
 int khip_bicgstab_workspace_destroy(khip_bicgstab_workspace *ws) {
   if (!ws) return KHIP_OK;
   for (double *v : {ws->dx, ws->x, ws->r, ws->p, ws->v, ws->s, ws->qd, ws->yz, ws->t}) khip_free(ws->ctx, v);
+  if (ws->dev_state) (void)hipFree(ws->dev_state);
+  if (ws->snap) (void)hipHostFree(ws->snap);
+  if (ws->hist_dev) (void)hipFree(ws->hist_dev);
+  for (auto e : ws->snap_ev) if (e) (void)hipEventDestroy(e);
   delete ws;
   return KHIP_OK;
 }
@@ -934,7 +1040,17 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   const char *status = "unknown";
 
   const bool fast = fused && MisI && NisI && !A->apply && A->csr;
-  while (!(solved || tired || breakdown || user_requested_exit || overtimed)) {
+  const bool device_loop = fast && o.fused >= 2 && !o.callback;
+  if (device_loop && !(solved || tired)) {
+    BicgDevState fin;
+    K(bicgstab_device_loop(ws, A->csr, c, next_rho, rNorm, eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
+    iter = fin.iter;
+    rNorm = fin.rNorm;
+    solved = fin.solved != 0;
+    breakdown = fin.breakdown != 0;
+    tired = iter >= itmax;
+  }
+  while (!device_loop && !(solved || tired || breakdown || user_requested_exit || overtimed)) {
     iter = iter + 1;
     rho = next_rho;
 

@@ -139,7 +139,10 @@ def test_distributed_gmres_bicgstab_local_ranks(K, oracle):
         A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
         b = c.array(bh[r0:r1])
         _, stg, _ = K.gmres(A, b, memory=10, restart=True, history=True)
-        _, stb, _ = K.bicgstab(A, b, history=True)
+        xb1, stb, _ = K.bicgstab(A, b, history=True, fused=1)
+        xb2, stb2, _ = K.bicgstab(A, b, history=True, fused=2)          # scalars and stopping tests on the device
+        assert stb2.niter == stb.niter and stb2.status == stb.status
+        assert np.array_equal(stb2.residuals, stb.residuals) and np.array_equal(xb2.to_host(), xb1.to_host())
         return stg.niter, stg.residuals, stb.niter, stb.residuals
 
     for rank, (gi, gh, bi, bhist) in enumerate(_run_ranks(K, world, 777, body)):

@@ -316,6 +316,41 @@ def test_bicgstab_matches_oracle(K, ctx, oracle, parity_log, n1, fused):
     assert ws.nbytes == 6 * 8 * A.n                                                # storage 6n
 
 
+def test_bicgstab_device_resident_loop_equals_host_loop(K, ctx, oracle):
+    """fused = 2 for bicgstab! (M = N = I, CSR operator): rho, alpha, omega, beta and the stopping tests live on
+    the device (csrc/solver_device.hpp); histories, iteration counts, status strings and x are bit-identical to
+    fused = 1 however the loop ends."""
+    A = oracle.kron_unsymmetric(10)
+    dA = _upload(K, ctx, A)
+    rng = np.random.default_rng(11)
+    bh = A.matvec(rng.standard_normal(A.n))
+    b = ctx.array(bh)
+    for kw in (dict(), dict(rtol=1e-12, atol=0.0), dict(itmax=3), dict(itmax=1), dict(atol=0.0, rtol=0.0, itmax=17),
+               dict(history=False), dict(x0=ctx.array(rng.standard_normal(A.n))), dict(c=ctx.array(rng.standard_normal(A.n)))):
+        kw = dict(dict(history=True), **kw)
+        x1, st1, _ = K.bicgstab(dA, b, fused=1, **kw)
+        x2, st2, _ = K.bicgstab(dA, b, fused=2, **kw)
+        assert (st2.niter, st2.status, st2.solved) == (st1.niter, st1.status, st1.solved), kw
+        if kw["history"]:
+            assert np.array_equal(st2.residuals, st1.residuals), kw
+        assert np.array_equal(x2.to_host(), x1.to_host()), kw
+    ref = oracle.bicgstab(A, bh, history=True)
+    x2, st2, _ = K.bicgstab(dA, b, fused=2, history=True)
+    assert st2.niter == ref.niter and np.max(np.abs(st2.residuals - ref.residuals) / ref.residuals) <= HIST_RTOL_BICGSTAB
+    ctx.set_option("hist_window", 8)
+    try:
+        x3, st3, _ = K.bicgstab(dA, b, fused=2, history=True, rtol=1e-13, atol=0.0)
+    finally:
+        ctx.set_option("hist_window", 1 << 14)
+    x4, st4, _ = K.bicgstab(dA, b, fused=1, history=True, rtol=1e-13, atol=0.0)
+    assert st3.niter == st4.niter > 8 and np.array_equal(st3.residuals, st4.residuals) and np.array_equal(x3.to_host(), x4.to_host())
+    # preconditioned or callback runs fall back to the host loop
+    P = K.Jacobi(dA)
+    x5, st5, _ = K.bicgstab(dA, b, M=P, fused=2)
+    x6, st6, _ = K.bicgstab(dA, b, M=P, fused=1)
+    assert st5.niter == st6.niter and np.array_equal(x5.to_host(), x6.to_host())
+
+
 def test_bicgstab_edge_cases(K, ctx, oracle):
     A = oracle.kron_unsymmetric(6)
     bh = A.matvec(np.ones(A.n))
