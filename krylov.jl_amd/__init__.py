@@ -787,7 +787,7 @@ def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, ra
     o.linesearch = int(linesearch)
     o.restart = int(restart)
     o.reorthogonalization = int(reorthogonalization)
-    o.fused = int(fused)
+    o.fused = 2 if fused is True else int(fused)     # True = everything that is bit-identical: fused kernels + device-resident scalars
     if callback is not None:
         def cb(_ws, _ud):
             try:

@@ -202,7 +202,7 @@ khip_options khip_default_options(void) {
   khip_options o;
   memset(&o, 0, sizeof(o));
   o.atol = NAN; o.rtol = NAN; o.timemax = NAN;
-  o.fused = 1;
+  o.fused = 2;
   return o;
 }
 
