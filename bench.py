@@ -31,7 +31,7 @@ def pmc_traffic(n1):
     (tools/gpu_prof.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/spmv_only.py at 512^3).
     Correction per MI355X_MICROARCH.md: counters are in KiB and FETCH_SIZE tallies 128-B line fetches
     as 64 B, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  None when no matching profile exists."""
-    path = os.path.join(ROOT, "profiles", "r01h_spmv_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01i_spmv_pmc.json")
     if n1 != 512 or not os.path.exists(path):
         return None
     try:
@@ -209,7 +209,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": ("spmv_template_kernel" if templates else "spmv_stage_kernel") + " (SpMV fused with p.Ap)",
                          "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": pmc_traffic(n1) if (world == 1 and not templates) else None,
-                         "traffic_note": "L2-miss-side bytes per launch from separate rocprofv3 --pmc passes (profiles/r01h_spmv_pmc.json); includes Infinity-Cache hits",
+                         "traffic_note": "L2-miss-side bytes per launch from separate rocprofv3 --pmc passes (profiles/r01i_spmv_pmc.json); includes Infinity-Cache hits",
                          "bytes_per_launch": spmv_bytes_local, "avg_ms": avg_spmv_ms,
                          "launches_per_iteration": spmv_per_iter},
         }
