@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--compress", action="store_true",
                     help="NOT the headline: re-encode the operator as row templates (khip_csr_compress, 2 B of matrix data per row)")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="NOT the headline: 1 = single-reduction CG (one all-reduce per iteration; different rounding)")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (khip_ctx_set_option)")
     args = ap.parse_args()
 
@@ -166,12 +168,12 @@ def main():
 
     # warm-up iterations (untimed)
     if args.warmup > 0:
-        K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.warmup, fused=args.fused)
+        K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.warmup, fused=args.fused, variant=args.variant)
     ctx.set_option("profile_spmv", 1)
     ctx.profile_spmv()
     barrier()
     t0 = time.perf_counter()
-    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.steps, history=True, fused=args.fused)
+    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.steps, history=True, fused=args.fused, variant=args.variant)
     barrier()
     elapsed = time.perf_counter() - t0
     st = ws.stats
@@ -188,7 +190,7 @@ def main():
         its = args.steps / elapsed
         spmv_bytes_local = A.spmv_bytes_stored if templates else A.spmv_bytes     # compressed: what that format moves
         # algorithmic bytes of one fused iteration on this rank: SpMV(+dot) + (r update + r.r: 24n) + (x and p update: 40n)
-        iter_bytes_local = spmv_bytes_local + (64 if args.fused else 104) * nloc
+        iter_bytes_local = spmv_bytes_local + ((72 if args.variant == 1 else 64) if args.fused else 104) * nloc
         iter_bytes_unfused_local = spmv_bytes_local + 104 * nloc       # as the reference issues it
         spmv_per_iter = launches / max(args.steps, 1)
         avg_spmv_ms = spmv_ms / max(args.steps, 1)                    # all SpMV launches of one iteration
@@ -201,7 +203,8 @@ def main():
             "config": {"workload": f"cg! on get_div_grad({n1},{n1},{n1}) CSR (cfg 2), b=ones, Float64, int32 indices",
                        "n": n, "nnz_global": 7 * n - 6 * n1 * n1, "fused": args.fused,
                        "partition": f"1-D rows over {world} GPU(s)", "atol": 0.0, "rtol": 0.0,
-                       "operator_format": f"row templates ({templates})" if templates else "CSR"},
+                       "operator_format": f"row templates ({templates})" if templates else "CSR",
+                       "recurrence": "single-reduction CG (Chronopoulos-Gear)" if args.variant == 1 else "cg! (src/cg.jl)"},
             "hbm_gbps_iteration": its * iter_bytes_local * world / 1e9,
             "hbm_gbps_iteration_reference_sequence": its * iter_bytes_unfused_local * world / 1e9,
             "final_residual_norm": float(st.residuals[-1]),

@@ -265,6 +265,11 @@ typedef struct {
                                * 2 = fused kernels + scalar recurrences and stopping tests on the device (cg, bicgstab: no
                                * host round trip inside the loop; bit-identical to 1; falls back to 1 where it does not apply) */
   khip_callback_fn callback; void *callback_data;
+  int    variant;             /* 0 = the reference's recurrences.  cg: 1 = single-reduction CG (Chronopoulos & Gear 1989): the two
+                               * dots of an iteration are computed by ONE reduction (one all-reduce per iteration on N GPUs,
+                               * 2 passes per iteration).  Different rounding: same solution to the requested tolerance, iteration
+                               * counts within a few of the reference recurrence -- opt-in, own parity budget.
+                               * Needs M = I, a CSR operator, no trust region / linesearch / callback (else KHIP_ERR_UNSUPPORTED). */
 } khip_options;
 
 typedef struct {              /* SimpleStats, src/krylov_stats.jl:24-44 */

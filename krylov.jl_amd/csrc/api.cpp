@@ -289,10 +289,10 @@ int khip_spmv_bytes(const khip_csr *A, int64_t *bytes) {
 // single finish kernel, so every rank contributes exactly one partial to the all-reduce.
 }  // extern "C"
 int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw,
-                   bool dot_sq) {
+                   int dot_sq) {
   if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5) {   // only the staged / template kernels carry the second reduction
-    KHIP_TRY(spmv_any(ctx, A, x, y, dot_slot, dotw, false));
-    return launch_nrm2sq(ctx, A->m, y, dot_slot + 1);
+    KHIP_TRY(spmv_any(ctx, A, x, y, dot_slot, dotw, 0));
+    return launch_nrm2sq(ctx, A->m, dot_sq == 1 ? y : (dotw ? dotw : x), dot_slot + 1);
   }
   if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m, nullptr, true, dotw, dot_sq);
   KHIP_TRY(comm_halo_exchange_begin(ctx, A, x));
@@ -328,7 +328,7 @@ int khip_spmv_dotw(khip_ctx *ctx, const khip_csr *A, const double *x, double *y,
   KHIP_REQUIRE(ctx && A && x && y && w && result_host, "spmv_dotw: null argument");
   KHIP_REQUIRE(x != y && w != y, "spmv_dotw: y must not alias x or w");
   const int slot = take_slots(ctx, 1);
-  KHIP_TRY(spmv_any(ctx, A, x, y, slot, w, false));
+  KHIP_TRY(spmv_any(ctx, A, x, y, slot, w, 0));
   return fetch_results(ctx, slot, 1, result_host);
 }
 
@@ -336,7 +336,7 @@ int khip_spmv_dot2(khip_ctx *ctx, const khip_csr *A, const double *x, double *y,
   KHIP_REQUIRE(ctx && A && x && y && result_host, "spmv_dot2: null argument");
   KHIP_REQUIRE(x != y, "spmv_dot2: x and y must not alias");
   const int slot = take_slots(ctx, 2);
-  KHIP_TRY(spmv_any(ctx, A, x, y, slot, nullptr, true));
+  KHIP_TRY(spmv_any(ctx, A, x, y, slot, nullptr, 1));
   return fetch_results(ctx, slot, 2, result_host);
 }
 

@@ -205,6 +205,63 @@ int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double 
   return KHIP_OK;
 }
 
+// ---------------------------------------------------------------- single-reduction CG update ----
+// p <- r + beta p ; s <- w + beta s (s = A p without a product) ; x <- x + alpha p ; r <- r - alpha s
+// (Chronopoulos & Gear 1989): all the vector work of one iteration in one pass, 72n bytes; alpha, beta from the
+// device state the reduction epilogue maintains.
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void cgcg_update_kernel(int64_t n, const CgcgDevState *st, long long seq, const double *w,
+                                                             double *r, double *p, double *s, double *x) {
+  using T = typename VecT<VEC>::type;
+  if (seq >= st->stop_seq) return;
+  const double a = st->alpha, b = st->beta;
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T wv = ldg<NT>(reinterpret_cast<const T *>(w) + i), rv = ldg<NT>(reinterpret_cast<T *>(r) + i);
+    const T pv = ldg<NT>(reinterpret_cast<T *>(p) + i), sv = ldg<NT>(reinterpret_cast<T *>(s) + i);
+    const T xv = ldg<NT>(reinterpret_cast<T *>(x) + i);
+    T po, so, xo, ro;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const double pn = fma(b, vget(pv, e), vget(rv, e));
+      const double sn = fma(b, vget(sv, e), vget(wv, e));
+      vset(po, e, pn);
+      vset(so, e, sn);
+      vset(xo, e, fma(a, pn, vget(xv, e)));
+      vset(ro, e, fma(-a, sn, vget(rv, e)));
+    }
+    stg<NT>(po, reinterpret_cast<T *>(p) + i);
+    stg<NT>(so, reinterpret_cast<T *>(s) + i);
+    stg<NT>(xo, reinterpret_cast<T *>(x) + i);
+    stg<NT>(ro, reinterpret_cast<T *>(r) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    const double pn = fma(b, p[t], r[t]), sn = fma(b, s[t], w[t]);
+    p[t] = pn; s[t] = sn;
+    x[t] = fma(a, pn, x[t]);
+    r[t] = fma(-a, sn, r[t]);
+  }
+}
+
+int launch_cgcg_update(khip_ctx *ctx, int64_t n, const void *st_dev, long long seq, const double *w, double *r, double *p,
+                       double *s, double *x) {
+  if (n <= 0) return KHIP_OK;
+  const CgcgDevState *st = static_cast<const CgcgDevState *>(st_dev);
+  const bool v2 = n >= 2 && aligned16(w) && aligned16(r) && aligned16(p) && aligned16(s) && aligned16(x);
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_L(VEC, NT) \
+  hipLaunchKernelGGL((cgcg_update_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, st, seq, w, r, p, s, x)
+  if (v2) { if (nt) KHIP_L(2, true); else KHIP_L(2, false); }
+  else    { if (nt) KHIP_L(1, true); else KHIP_L(1, false); }
+#undef KHIP_L
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 // ---------------------------------------------------------------- BiCGSTAB fused updates ----
 // The elementwise work of one bicgstab! iteration (src/bicgstab.jl:224-237) in three passes instead of
 // nine; every expression is the one the separate kernels use (OP_WAXPY, OP_AXPY, OP_AXPBY), so all vectors

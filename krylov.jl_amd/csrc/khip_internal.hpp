@@ -179,6 +179,9 @@ int launch_cg_update_dev(khip_ctx *ctx, int64_t n, const void *cg_state_dev, lon
 // produced outside a finish kernel) / fold nranks gathered (hi, lo) partials per scalar and run it
 int launch_epilogue_only(khip_ctx *ctx, int slot);
 int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot);
+// single-reduction CG: p, s, x, r updated in one pass with alpha / beta from a CgcgDevState
+int launch_cgcg_update(khip_ctx *ctx, int64_t n, const void *st_dev, long long seq, const double *w, double *r, double *p,
+                       double *s, double *x);
 // fused elementwise passes of one bicgstab! iteration (blas1.hip)
 // st_dev != null: alpha / omega / beta and the stop word are read from a BicgDevState (solver_device.hpp)
 int launch_bicg_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y, double *s,
@@ -203,7 +206,7 @@ int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host, bool alr
 // dot_slot >= 0: results[dot_slot] = dotw . y (dotw = x when null); dot_sq: also results[dot_slot + 1] = y . y
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot /* -1 = none */,
                 int64_t row_lo, int64_t row_hi, int64_t *wave_cursor = nullptr, bool finish = true,
-                const double *dotw = nullptr, bool dot_sq = false);
+                const double *dotw = nullptr, int dot_sq = 0);     // dot_sq: 0 none, 1 second output y.y, 2 second output dotw.dotw
 int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A);
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
 int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays are resident
@@ -221,7 +224,7 @@ void csr_free_templates(khip_csr *A);
 
 // api.cpp: y = A x (dot_slot >= 0: also results[dot_slot] = x . y) incl. halo exchange; launches only, no host sync
 int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw = nullptr,
-             bool dot_sq = false);
+             int dot_sq = 0);
 
 // panel.hip
 void panel_scratch_destroy(khip_ctx *ctx);

@@ -14,7 +14,7 @@
 
 namespace khip {
 
-enum Epilogue { EPI_NONE = 0, EPI_CG_STEP1 = 1, EPI_CG_STEP2 = 2, EPI_BICG_A = 3, EPI_BICG_B = 4, EPI_BICG_C = 5 };
+enum Epilogue { EPI_NONE = 0, EPI_CG_STEP1 = 1, EPI_CG_STEP2 = 2, EPI_BICG_A = 3, EPI_BICG_B = 4, EPI_BICG_C = 5, EPI_CGCG = 6 };
 
 struct CgDevState {
   double gamma;        // r.z of the current iterate              (src/cg.jl:162, 257)
@@ -31,6 +31,15 @@ struct CgDevState {
   long long hist_cap;
   double *hist;        // device history window (null: no history)
   int solved, zero_curvature, inconsistent, not_spd;
+};
+
+// Single-reduction CG (Chronopoulos & Gear 1989): per iteration ONE reduction delivers
+// gamma' = r.r and delta = (A r).r, from which beta = gamma'/gamma and alpha = gamma' / (delta - beta gamma'/alpha).
+struct CgcgDevState {
+  double gamma, alpha, beta, rNorm, eps_tol;
+  long long stop_seq, iter, hist_base, hist_cap;
+  double *hist;
+  int solved, breakdown;      // breakdown: the alpha denominator is not positive (operator not SPD / loss of accuracy)
 };
 
 // bicgstab! (src/bicgstab.jl:213-253) with M = N = I: the scalars of one iteration
@@ -95,6 +104,27 @@ __device__ inline void solver_epilogue(int epi, void *state, const double *v, lo
     st->solved = solved ? 1 : 0;
     st->iter = k;
     if (solved) st->stop_seq = seq + 2;            // the x update of this iteration (seq + 1) still runs
+  } else if (epi == EPI_CGCG) {                    // v = (r.w, r.r) with w = A r
+    CgcgDevState *st = static_cast<CgcgDevState *>(state);
+    const double delta = v[0], gamma_next = v[1];
+    const double rNorm = sqrt(gamma_next);
+    st->rNorm = rNorm;
+    const long long k = st->iter + 1;
+    if (st->hist) {
+      const long long idx = k - 1 - st->hist_base;
+      if (idx >= 0 && idx < st->hist_cap) st->hist[idx] = rNorm;
+    }
+    const bool solved = (rNorm <= st->eps_tol) || (rNorm + 1.0 <= 1.0);
+    const double beta = gamma_next / st->gamma;
+    const double denom = delta - beta * gamma_next / st->alpha;
+    const bool breakdown = !solved && !(denom > 0.0);
+    st->solved = solved ? 1 : 0;
+    st->breakdown = breakdown ? 1 : 0;
+    st->iter = k;
+    if (solved || breakdown) { st->stop_seq = seq + 1; return; }     // x, r already hold iterate k
+    st->beta = beta;
+    st->alpha = gamma_next / denom;
+    st->gamma = gamma_next;
   } else if (epi == EPI_BICG_A) {                  // v[0] = c.v                 src/bicgstab.jl:223
     BicgDevState *st = static_cast<BicgDevState *>(state);
     st->alpha = st->rho / v[0];

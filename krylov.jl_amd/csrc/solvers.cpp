@@ -100,6 +100,7 @@ struct khip_cg_workspace {
   // device-resident loop state (fused = 2), allocated on first use
   CgDevState *dev_state = nullptr;
   CgDevState *snap = nullptr;          // pinned host snapshots [2]
+  CgcgDevState *cgcg_state = nullptr, *cgcg_snap = nullptr;   // single-reduction variant
   double *hist_dev = nullptr;
   hipEvent_t snap_ev[2] = {nullptr, nullptr};
 };
@@ -194,6 +195,88 @@ int cg_device_loop(khip_cg_workspace *ws, const khip_csr *A, double gamma, doubl
   return drain_history(out->iter);
 }
 
+// Single-reduction CG (options.variant = 1; Chronopoulos & Gear 1989): two passes per iteration --
+//   update:  p = r + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s            (72n bytes)
+//   product: w = A r fused with BOTH dots (r.w, r.r) in one reduction; its epilogue forms beta, alpha, the tests
+// -- i.e. ONE all-reduce per iteration on N GPUs instead of two, and 2 + 1 kernels instead of 3 + 2.  Not the
+// reference's recurrence: same Krylov space, different rounding (tests/test_gpu_solvers.py holds its parity budget).
+int cg_single_reduction_loop(khip_cg_workspace *ws, const khip_csr *A, double gamma0, double delta0, double eps_tol,
+                             int64_t itmax, bool history, double t0, double timemax, CgcgDevState *out, bool *overtimed) {
+  khip_ctx *ctx = ws->ctx;
+  const int64_t n = ws->n;
+  if (!ws->cgcg_state) {
+    KHIP_CHECK_HIP(hipMalloc(&ws->cgcg_state, sizeof(CgcgDevState)));
+    KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->cgcg_snap), 2 * sizeof(CgcgDevState), hipHostMallocDefault));
+  }
+  if (!ws->hist_dev) KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindowMax));
+  for (auto &e : ws->snap_ev) if (!e) KHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  long long window = ctx->tune.hist_window;
+  if (window < kDevChunk) window = kDevChunk;
+  if (window > kHistWindowMax) window = kHistWindowMax;
+  CgcgDevState *dev = ws->cgcg_state;
+  CgcgDevState h;
+  memset(&h, 0, sizeof(h));
+  h.gamma = gamma0; h.alpha = gamma0 / delta0; h.beta = 0.0; h.rNorm = std::sqrt(gamma0); h.eps_tol = eps_tol;
+  h.stop_seq = kSeqNever;
+  h.hist = history ? ws->hist_dev : nullptr;
+  h.hist_cap = window;
+  KHIP_CHECK_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double *x = ws->x, *r = ws->r, *p = ws->p, *s = ws->Ap, *w = ws->z;
+  int64_t enq = 0;
+  long long hist_base = 0;
+  std::vector<double> win;
+  auto drain_history = [&](long long upto_iter) -> int {
+    const long long cnt = upto_iter - hist_base;
+    if (!history || cnt <= 0) return KHIP_OK;
+    win.resize((size_t)cnt);
+    KHIP_CHECK_HIP(hipMemcpy(win.data(), ws->hist_dev, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    for (double val : win) ws->box.push(val);
+    return KHIP_OK;
+  };
+  int rc = KHIP_OK;
+  bool stopped = false;
+  for (int chunk = 0; !stopped; ++chunk) {
+    const int64_t cnt = std::min<int64_t>(kDevChunk, itmax - enq);
+    if (history && enq + cnt - hist_base > window) {
+      KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      CgcgDevState cur;
+      KHIP_CHECK_HIP(hipMemcpy(&cur, dev, sizeof(cur), hipMemcpyDeviceToHost));
+      if (cur.stop_seq != kSeqNever) break;
+      if ((rc = drain_history(cur.iter)) != KHIP_OK) break;
+      hist_base = cur.iter;
+      KHIP_CHECK_HIP(hipMemcpy(&dev->hist_base, &hist_base, sizeof(hist_base), hipMemcpyHostToDevice));
+    }
+    for (int64_t i = 0; i < cnt && rc == KHIP_OK; ++i) {
+      const long long j = (long long)(enq + i);
+      rc = launch_cgcg_update(ctx, n, dev, 2 * j, w, r, p, s, x);
+      if (rc != KHIP_OK) break;
+      ctx->ctl = SeqCtl{&dev->stop_seq, 2 * j + 1, EPI_CGCG, dev};
+      const int slot = take_slots(ctx, 2);
+      rc = spmv_any(ctx, A, r, w, slot, nullptr, 2);                              // w = A r ; (r.w, r.r)
+      if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, slot, 2);
+      ctx->ctl = SeqCtl{};
+    }
+    ctx->ctl = SeqCtl{};
+    if (rc != KHIP_OK) break;
+    enq += cnt;
+    const int b = chunk & 1;
+    KHIP_CHECK_HIP(hipMemcpyAsync(&ws->cgcg_snap[b], dev, sizeof(CgcgDevState), hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipEventRecord(ws->snap_ev[b], ctx->stream));
+    if (chunk >= 1) {
+      KHIP_CHECK_HIP(hipEventSynchronize(ws->snap_ev[b ^ 1]));
+      if (ws->cgcg_snap[b ^ 1].stop_seq != kSeqNever) stopped = true;
+    }
+    if (enq >= itmax) stopped = true;
+    if (!stopped && (now_s() - t0) > timemax) { *overtimed = true; stopped = true; }
+  }
+  ctx->ctl = SeqCtl{};
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (rc != KHIP_OK) return rc;
+  KHIP_CHECK_HIP(hipMemcpy(out, dev, sizeof(CgcgDevState), hipMemcpyDeviceToHost));
+  return drain_history(out->iter);
+}
+
 }  // namespace
 
 extern "C" {
@@ -225,6 +308,8 @@ int khip_cg_workspace_destroy(khip_cg_workspace *ws) {
   for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z}) khip_free(ws->ctx, v);
   if (ws->dev_state) (void)hipFree(ws->dev_state);
   if (ws->snap) (void)hipHostFree(ws->snap);
+  if (ws->cgcg_state) (void)hipFree(ws->cgcg_state);
+  if (ws->cgcg_snap) (void)hipHostFree(ws->cgcg_snap);
   if (ws->hist_dev) (void)hipFree(ws->hist_dev);
   for (auto e : ws->snap_ev) if (e) (void)hipEventDestroy(e);
   delete ws;
@@ -369,7 +454,30 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
        overtimed = false;
   const char *status = "unknown";
 
-  const bool device_loop = o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback;
+  if (o.variant == 1) {                                                           // single-reduction CG, opt-in
+    if (A->apply || !A->csr || !MisI || radius != 0 || linesearch || o.callback)
+      return ws->box.fail(KHIP_ERR_UNSUPPORTED, "cg variant 1 needs a CSR operator, M = I, no trust region / linesearch / callback");
+    if (!(solved || tired)) {
+      if (!ws->z) K(alloc_vec(ctx, n, &ws->z));                                     // w = A r lives in the (unused) z slot
+      K(khip_fill(ctx, n, Ap, 0.0));                                                // s = A p starts as 0 (beta_0 = 0)
+      double two[2];
+      const int slot = take_slots(ctx, 2);
+      K(spmv_any(ctx, A->csr, r, ws->z, slot, nullptr, 2));                         // w = A r ; (r.w, r.r)
+      K(fetch_results(ctx, slot, 2, two));
+      if (!(two[0] > 0))
+        return ws->box.fail(KHIP_ERR_NUMERIC,
+                            "The linear operator `A` or the preconditioner `M` is not symmetric positive definite.");
+      CgcgDevState fin;
+      K(cg_single_reduction_loop(ws, A->csr, gamma, two[0], eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
+      iter = fin.iter;
+      rNorm = fin.rNorm;
+      solved = fin.solved != 0;
+      inconsistent = false;
+      tired = iter >= itmax;
+      if (fin.breakdown && !solved) zero_curvature = true;                          // reported with the reference's status string
+    }
+  }
+  const bool device_loop = o.variant == 0 && o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback;
   if (device_loop && !(solved || tired)) {
     CgDevState fin;
     K(cg_device_loop(ws, A->csr, gamma, eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
@@ -384,7 +492,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     tired = iter >= itmax;
   }
 
-  while (!device_loop && !(solved || tired || zero_curvature || user_requested_exit || overtimed)) {
+  while (!device_loop && o.variant == 0 && !(solved || tired || zero_curvature || user_requested_exit || overtimed)) {
     if (fused && !A->apply) {
       K(khip_spmv_dot(ctx, A->csr, p, Ap, &pAp));                                  // :196-197 fused
     } else {
@@ -883,7 +991,7 @@ int bicgstab_device_loop(khip_bicgstab_workspace *ws, const khip_csr *A, const d
       const long long j = (long long)(enq + i);
       ctx->ctl = SeqCtl{&dev->stop_seq, 5 * j, EPI_BICG_A, dev};
       int slot = take_slots(ctx, 1);
-      rc = spmv_any(ctx, A, p, v, slot, c, false);                                  // :221-223  v = A p ; c.v -> alpha
+      rc = spmv_any(ctx, A, p, v, slot, c, 0);                                  // :221-223  v = A p ; c.v -> alpha
       if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, slot, 1);
       ctx->ctl = SeqCtl{};
       if (rc != KHIP_OK) break;
@@ -891,7 +999,7 @@ int bicgstab_device_loop(khip_bicgstab_workspace *ws, const khip_csr *A, const d
       if (rc != KHIP_OK) break;
       ctx->ctl = SeqCtl{&dev->stop_seq, 5 * j + 2, EPI_BICG_B, dev};
       slot = take_slots(ctx, 2);
-      rc = spmv_any(ctx, A, s, t, slot, nullptr, true);                             // :228-230  t = A s ; t.s, t.t -> omega
+      rc = spmv_any(ctx, A, s, t, slot, nullptr, 1);                             // :228-230  t = A s ; t.s, t.t -> omega
       if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device(ctx, slot, 2);
       if (rc != KHIP_OK) break;
       ctx->ctl = SeqCtl{&dev->stop_seq, 5 * j + 3, EPI_BICG_C, dev};
@@ -1060,12 +1168,12 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
       // into v (the reference copies it there, :222, and q's storage is reused for d in the same iteration).
       double cv, two[2];
       int slot = take_slots(ctx, 1);
-      K(spmv_any(ctx, A->csr, p, v, slot, c, false));                              // :221-223  v = A p ; c.v
+      K(spmv_any(ctx, A->csr, p, v, slot, c, 0));                              // :221-223  v = A p ; c.v
       K(fetch_results(ctx, slot, 1, &cv));
       alpha = rho / cv;                                                            // :223
       K(launch_bicg_sx(ctx, n, alpha, r, v, p, s, x));                             // :224-226
       slot = take_slots(ctx, 2);
-      K(spmv_any(ctx, A->csr, s, t, slot, nullptr, true));                         // :228-230  t = A s ; t.s ; t.t
+      K(spmv_any(ctx, A->csr, s, t, slot, nullptr, 1));                         // :228-230  t = A s ; t.s ; t.t
       K(fetch_results(ctx, slot, 2, two));
       omega = two[0] / two[1];                                                     // :230
       slot = take_slots(ctx, 2);

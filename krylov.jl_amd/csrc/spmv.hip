@@ -266,8 +266,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
     if (tid < nr) {
       if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
       if (DOT) {
-        acc_prod<COMP>(dacc[0], a.dotw[r0 + tid], acc);
-        if (a.dot_sq) acc_prod<COMP>(dacc[1], acc, acc);
+        const double wv = a.dotw[r0 + tid];
+        acc_prod<COMP>(dacc[0], wv, acc);
+        if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);        // y . y
+        else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);     // w . w (single-reduction CG: r.r beside r.(A r))
       }
     }
   }
@@ -324,8 +326,10 @@ __global__ __launch_bounds__(kBlock) void spmv_template_kernel(SpmvArgs a, RedAr
     }
     if (a.nt_y) __builtin_nontemporal_store(acc, a.y + row); else a.y[row] = acc;
     if (DOT) {
-      acc_prod<COMP>(dacc[0], a.dotw[row], acc);
-      if (a.dot_sq) acc_prod<COMP>(dacc[1], acc, acc);
+      const double wv = a.dotw[row];
+      acc_prod<COMP>(dacc[0], wv, acc);
+      if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
+      else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);
     }
   }
   if (DOT) {
@@ -511,7 +515,7 @@ int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A) {
 }
 
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, int64_t row_lo,
-                int64_t row_hi, int64_t *wave_cursor, bool finish, const double *dotw, bool dot_sq) {
+                int64_t row_hi, int64_t *wave_cursor, bool finish, const double *dotw, int dot_sq) {
   int64_t local_cursor = 0;
   if (!wave_cursor) wave_cursor = &local_cursor;
   const int nout = dot_sq ? 2 : 1;
@@ -542,7 +546,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.dotw = dotw ? dotw : x;
   a.tmpl_id = A->tmpl_id; a.tmpl_off = A->tmpl_off; a.tmpl_val = A->tmpl_val; a.tmpl_cnt = A->tmpl_cnt;
   a.tmpl_T = A->tmpl_T; a.tmpl_K = A->tmpl_K;
-  a.dot_sq = dot_sq ? 1 : 0;
+  a.dot_sq = dot_sq;
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;

@@ -105,6 +105,8 @@ def test_distributed_spmv_and_cg_local_ranks(K, oracle, world, n1):
         for fused in (2, True, False):
             xs, st, _ = K.cg(A, b, history=True, fused=fused)
             out[f"cg{int(fused)}"] = (st.niter, st.residuals, xs.to_host(), st.status)
+        xs, st, _ = K.cg(A, b, history=True, variant=1)                    # single-reduction variant: one all-reduce per iteration
+        out["cgv1"] = (st.niter, st.residuals, xs.to_host(), st.solved)
         return out
 
     res = _run_ranks(K, world, 100 + world * 10 + n1, body)
@@ -121,6 +123,10 @@ def test_distributed_spmv_and_cg_local_ranks(K, oracle, world, n1):
             assert np.allclose(xs, ref.x[r0:r1], atol=1e-10)
         # every rank computed the bit-identical scalars
         assert np.array_equal(out["cg1"][1], res[0]["cg1"][1])
+        # single-reduction variant: converges to the same solution, identical scalars on every rank
+        assert out["cgv1"][3] and abs(out["cgv1"][0] - ref.niter) <= 2
+        assert np.allclose(out["cgv1"][2], ref.x[r0:r1], atol=1e-7 * np.abs(ref.x).max())
+        assert np.array_equal(out["cgv1"][1], res[0]["cgv1"][1])
         # device-resident scalars (fused = 2): the same histories and iterates as the host-scalar loop
         assert np.array_equal(out["cg2"][1], out["cg1"][1]) and np.array_equal(out["cg2"][2], out["cg1"][2])
 

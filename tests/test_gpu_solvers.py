@@ -150,6 +150,41 @@ def test_cg_device_resident_loop_equals_host_loop(K, ctx, oracle):
     assert st3.status == st4.status == "on trust-region boundary" and np.array_equal(x3.to_host(), x4.to_host())
 
 
+@pytest.mark.parametrize("n1", [16, 32, 48])
+def test_cg_single_reduction_variant_parity_budget(K, ctx, oracle, parity_log, n1):
+    """options.variant = 1: Chronopoulos-Gear single-reduction CG (one reduction = one all-reduce per
+    iteration).  NOT the reference's recurrence -- its own parity budget against the oracle's cg!: the same solution to
+    the requested tolerance, an iteration count within 2, residual histories within 1e-6 relative while above 1e-6 r_0."""
+    A = oracle.poisson3d(n1)
+    b = np.ones(A.n)
+    ref = oracle.cg(A, b, history=True)
+    dA = _upload(K, ctx, A)
+    x, st, ws = K.cg(dA, ctx.array(b), history=True, variant=1)
+    assert st.solved and st.status == ref.status
+    assert abs(st.niter - ref.niter) <= 2
+    k = min(len(st.residuals), len(ref.residuals))
+    big = ref.residuals[:k] >= 1e-6 * ref.residuals[0]
+    dev = float(np.max(np.abs(st.residuals[:k] - ref.residuals[:k])[big] / ref.residuals[:k][big]))
+    xh = x.to_host()
+    res = np.linalg.norm(b - A.matvec(xh)) / np.linalg.norm(b)
+    parity_log(test="cg_single_reduction", n1=n1, niter=st.niter, niter_ref=ref.niter, hist_max_rel=dev, res=res)
+    assert dev <= 1e-6
+    assert res <= 2e-8 * 1.5 or res <= 1.5 * np.linalg.norm(b - A.matvec(ref.x)) / np.linalg.norm(b)
+    assert np.allclose(xh, ref.x, rtol=0, atol=1e-7 * np.abs(ref.x).max())
+    # ways to stop / refuse
+    _, st2, _ = K.cg(dA, ctx.array(b), variant=1, itmax=5)
+    assert st2.niter == 5 and not st2.solved and st2.status == "maximum number of iterations exceeded"
+    with pytest.raises(K.KhipError):
+        K.cg(dA, ctx.array(b), variant=1, radius=1.0)
+    with pytest.raises(K.KhipError):
+        K.cg(dA, ctx.array(b), variant=1, M=K.Jacobi(dA))
+    # compressed operator: same numbers (the SpMV and both dots are bit-identical)
+    dC = _upload(K, ctx, A)
+    assert dC.compress() > 0
+    x3, st3, _ = K.cg(dC, ctx.array(b), history=True, variant=1)
+    assert st3.niter == st.niter and np.array_equal(x3.to_host(), xh)
+
+
 def test_cg_edge_cases(K, ctx, oracle):
     A = oracle.tridiag(10, -1.0, 4.0, -1.0)                               # symmetric_definite(10)
     bh = A.matvec(np.arange(1.0, 11.0))
