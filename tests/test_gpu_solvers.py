@@ -430,3 +430,43 @@ def test_cg_full_size_512_properties(K, ctx, parity_log):
     dev = float(np.max(np.abs(ws.stats.residuals - hist_fused) / hist_fused))
     parity_log(test="cg_512_fused_vs_unfused", hist_max_rel=dev, true_res_gap=abs(true_res - hist_fused[-1]))
     assert dev <= 1e-11
+
+
+def test_no_device_memory_leak_over_object_lifecycles(K, oracle):
+    """Create / use / drop every kind of object repeatedly on a fresh context: free device memory must come back
+    (workspaces incl. their device-resident loop state, CSR handles with templates / transposes / panel halos,
+    preconditioners with their captured graphs, panels)."""
+    import gc
+    ctx = K.Context(0)
+    A_cpu = oracle.poisson3d(12)
+    B_cpu = oracle.kron_unsymmetric(8)
+
+    def cycle():
+        A = K.CsrMatrix.from_host(ctx, A_cpu.rowptr, A_cpu.col, A_cpu.val, (A_cpu.n, A_cpu.n))
+        Bm = K.CsrMatrix.from_host(ctx, B_cpu.rowptr, B_cpu.col, B_cpu.val, (B_cpu.n, B_cpu.n))
+        b = ctx.array(np.ones(A_cpu.n))
+        for kw in (dict(fused=0), dict(fused=1), dict(fused=2), dict(variant=1), dict(fused=2, history=True)):
+            K.cg(A, b, **kw)
+        P = K.Ilu0(A)
+        K.cg(A, b, M=P)
+        J = K.Jacobi(A)
+        K.cg(A, b, M=J)
+        At = Bm.transpose()
+        Bm.compress()
+        bb = ctx.array(B_cpu.matvec(np.ones(B_cpu.n)))
+        K.bicgstab(Bm, bb, fused=2, history=True)
+        K.gmres(Bm, bb, memory=10, restart=True)
+        K.gmres(At, bb, memory=10)
+        rng = np.random.default_rng(0)
+        K.block_gmres(Bm, rng.standard_normal((B_cpu.n, 4)), memory=4)
+        del A, Bm, b, P, J, At, bb
+        gc.collect()
+        ctx.sync()
+
+    cycle()                                  # first cycle grows the context's own scratch (reduction partials, panels)
+    free0, _ = ctx.mem_info()
+    for _ in range(5):
+        cycle()
+    free1, _ = ctx.mem_info()
+    ctx.close()
+    assert free0 - free1 <= 8 << 20, (free0, free1)      # allow allocator granularity, not a per-cycle leak
