@@ -61,6 +61,11 @@ res = {
     "recurrence_vs_true_residual_rel": abs(o["true_res"] - float(o["hist"][-1])) / float(o["hist"][0]),
     "wall_s": round(time.time() - t0, 1),
 }
+golden = os.path.join(ROOT, "tests", "golden", "cg512_residuals.json")
+if n1 == 512 and os.path.exists(golden):          # the 1-GPU history bench.py's `parity` uses
+    g = json.load(open(golden))["residuals"]
+    k = min(len(g), len(o["hist"]))
+    res["max_rel_dev_vs_1gpu_golden"] = max(abs(float(o["hist"][i]) - g[i]) / g[i] for i in range(k))
 res["ok"] = bool(res["nnz_total"] == res["nnz_expected"] and res["sum_A_times_ones"] == res["sum_expected"]
                  and res["norm_b"] == res["norm_b_expected"] and res["history_identical_on_all_ranks"]
                  and res["recurrence_vs_true_residual_rel"] < 1e-10)
