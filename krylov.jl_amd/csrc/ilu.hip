@@ -94,6 +94,59 @@ __global__ __launch_bounds__(kIluBlock) void trsv_upper_level_kernel(IluView v, 
   y[i] = acc / v.lu[di];
 }
 
+// Runs of consecutive SMALL levels (<= kIluBlock rows each: the tips of a stencil's wavefront pyramid, or every level of
+// a chain-like operator such as a tridiagonal matrix) are executed by ONE workgroup that steps through them with a
+// workgroup barrier in between: one launch instead of one per level.  lvl = device copy of the level pointers.
+template <int KIND>     // 0: factorisation, 1: lower solve, 2: upper solve
+__global__ __launch_bounds__(kIluBlock) void ilu_small_levels_kernel(IluView v, const int32_t *perm, const int64_t *lvl, int l0,
+                                                                      int l1, const double *x, double *y, int *bad_row) {
+  for (int l = l0; l < l1; ++l) {
+    const int64_t idx = lvl[l] + threadIdx.x;
+    if (idx < lvl[l + 1]) {
+      const int32_t i = perm[idx];
+      const int32_t re = v.row_hi[i], di = v.diag[i];
+      if (KIND == 0) {
+        bool dead = false;
+        for (int32_t kk = v.row_lo[i]; kk < di && !dead; ++kk) {
+          const int32_t k = v.col[kk];
+          const int32_t dk = v.diag[k];
+          const double piv = v.lu[dk];
+          if (piv == 0.0) { atomicMin(bad_row, (int)k); dead = true; break; }
+          const double lik = v.lu[kk] / piv;
+          v.lu[kk] = lik;
+          int32_t p = kk + 1;
+          const int32_t ke = v.row_hi[k];
+          for (int32_t q = dk + 1; q < ke; ++q) {
+            const int32_t j = v.col[q];
+            while (p < re && v.col[p] < j) ++p;
+            if (p < re && v.col[p] == j) {
+              const double t = lik * v.lu[q];
+              v.lu[p] = v.lu[p] - t;
+            }
+          }
+        }
+        if (!dead && v.lu[di] == 0.0) atomicMin(bad_row, (int)i);
+      } else if (KIND == 1) {
+        double acc = x[i];
+        for (int32_t q = v.row_lo[i]; q < di; ++q) {
+          const double t = v.lu[q] * y[v.col[q]];
+          acc = acc - t;
+        }
+        y[i] = acc;
+      } else {
+        double acc = y[i];
+        for (int32_t q = di + 1; q < re; ++q) {
+          const double t = v.lu[q] * y[v.col[q]];
+          acc = acc - t;
+        }
+        y[i] = acc / v.lu[di];
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 }  // namespace khip
 
 using namespace khip;
@@ -106,6 +159,7 @@ struct khip_ilu0 {
   int32_t *row_lo = nullptr, *diag = nullptr, *row_hi = nullptr;
   int32_t *perm_lo = nullptr, *perm_up = nullptr;
   std::vector<int64_t> lvl_lo, lvl_up;       // level pointers into perm_lo / perm_up
+  int64_t *d_lvl_lo = nullptr, *d_lvl_up = nullptr;   // device copies (for the batched small levels)
   int *bad_row = nullptr;
   // cached hipGraph of one application, keyed by the (x, y) pointers it was captured with
   hipGraphExec_t graph = nullptr;
@@ -120,21 +174,36 @@ IluView view_of(const khip_ilu0 *P) { return IluView{P->A->col, P->row_lo, P->di
 
 unsigned grid_for(int64_t rows) { return (unsigned)((rows + kIluBlock - 1) / kIluBlock); }
 
-int enqueue_solve(khip_ilu0 *P, const double *x, double *y) {
+// all levels of one triangle: runs of small levels in one single-workgroup launch, every other level its own launch
+template <int KIND>
+int enqueue_levels(khip_ilu0 *P, const std::vector<int64_t> &lvl, const int64_t *d_lvl, const int32_t *perm, const double *x,
+                   double *y) {
   khip_ctx *ctx = P->ctx;
   const IluView v = view_of(P);
-  for (size_t l = 0; l + 1 < P->lvl_lo.size(); ++l) {
-    const int64_t lo = P->lvl_lo[l], hi = P->lvl_lo[l + 1];
-    hipLaunchKernelGGL(trsv_lower_level_kernel, dim3(grid_for(hi - lo)), dim3(kIluBlock), 0, ctx->stream, v, P->perm_lo, lo,
-                       hi, x, y);
-  }
-  for (size_t l = 0; l + 1 < P->lvl_up.size(); ++l) {
-    const int64_t lo = P->lvl_up[l], hi = P->lvl_up[l + 1];
-    hipLaunchKernelGGL(trsv_upper_level_kernel, dim3(grid_for(hi - lo)), dim3(kIluBlock), 0, ctx->stream, v, P->perm_up, lo,
-                       hi, y);
+  const int nl = (int)lvl.size() - 1;
+  int l = 0;
+  while (l < nl) {
+    int e = l;
+    while (e < nl && lvl[e + 1] - lvl[e] <= kIluBlock) ++e;
+    if (e - l >= 2) {                                  // a run of at least two small levels
+      hipLaunchKernelGGL((ilu_small_levels_kernel<KIND>), dim3(1), dim3(kIluBlock), 0, ctx->stream, v, perm, d_lvl, l, e, x, y,
+                         P->bad_row);
+      l = e;
+      continue;
+    }
+    const int64_t lo = lvl[l], hi = lvl[l + 1];
+    if (KIND == 0) hipLaunchKernelGGL(ilu0_factor_level_kernel, dim3(grid_for(hi - lo)), dim3(kIluBlock), 0, ctx->stream, v, perm, lo, hi, P->bad_row);
+    else if (KIND == 1) hipLaunchKernelGGL(trsv_lower_level_kernel, dim3(grid_for(hi - lo)), dim3(kIluBlock), 0, ctx->stream, v, perm, lo, hi, x, y);
+    else hipLaunchKernelGGL(trsv_upper_level_kernel, dim3(grid_for(hi - lo)), dim3(kIluBlock), 0, ctx->stream, v, perm, lo, hi, y);
+    ++l;
   }
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
+}
+
+int enqueue_solve(khip_ilu0 *P, const double *x, double *y) {
+  KHIP_TRY((enqueue_levels<1>(P, P->lvl_lo, P->d_lvl_lo, P->perm_lo, x, y)));
+  return enqueue_levels<2>(P, P->lvl_up, P->d_lvl_up, P->perm_up, x, y);
 }
 
 int ilu0_apply(void *self, const double *x, double *y) {
@@ -165,7 +234,7 @@ void ilu0_free(khip_ilu0 *P) {
   if (!P) return;
   if (P->graph) (void)hipGraphExecDestroy(P->graph);
   for (void *p : {(void *)P->lu, (void *)P->row_lo, (void *)P->diag, (void *)P->row_hi, (void *)P->perm_lo,
-                  (void *)P->perm_up, (void *)P->bad_row})
+                  (void *)P->perm_up, (void *)P->bad_row, (void *)P->d_lvl_lo, (void *)P->d_lvl_up})
     if (p) (void)hipFree(p);
   delete P;
 }
@@ -245,6 +314,8 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
   if (!rc) rc = upload(ctx, row_hi, &P->row_hi);
   if (!rc) rc = upload(ctx, perm_lo, &P->perm_lo);
   if (!rc) rc = upload(ctx, perm_up, &P->perm_up);
+  if (!rc) rc = upload(ctx, P->lvl_lo, &P->d_lvl_lo);
+  if (!rc) rc = upload(ctx, P->lvl_up, &P->d_lvl_up);
   if (rc) return rc;
   hipError_t e = hipMalloc(&P->lu, sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
   if (e == hipSuccess) e = hipMalloc(&P->bad_row, sizeof(int));
@@ -253,12 +324,7 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
   KHIP_CHECK_HIP(hipMemcpyAsync(P->bad_row, &none, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   if (nnz) KHIP_CHECK_HIP(hipMemcpyAsync(P->lu, A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->stream));
   // ---- numeric factorisation, level by level (same dependency graph as the lower solve) ------
-  const IluView v = view_of(P);
-  for (size_t l = 0; l + 1 < P->lvl_lo.size(); ++l) {
-    const int64_t lo = P->lvl_lo[l], hi = P->lvl_lo[l + 1];
-    hipLaunchKernelGGL(ilu0_factor_level_kernel, dim3(grid_for(hi - lo)), dim3(kIluBlock), 0, ctx->stream, v, P->perm_lo,
-                       lo, hi, P->bad_row);
-  }
+  KHIP_TRY((enqueue_levels<0>(P, P->lvl_lo, P->d_lvl_lo, P->perm_lo, nullptr, nullptr)));
   int bad = none;
   e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(&bad, P->bad_row, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);

@@ -146,3 +146,26 @@ def test_block_jacobi_ilu0_on_distributed_handle(K, oracle):
             assert np.array_equal(y, oracle.Ilu0(B).solve(np.linspace(1, 2, r1 - r0)))
         assert solved and np.allclose(xs, x_ref[r0:r1], atol=1e-7)
     assert len({o[2] for o in out}) == 1          # every rank ran the same number of iterations
+
+
+def test_ilu0_chain_operator_uses_batched_small_levels(K, ctx, oracle):
+    """A tridiagonal matrix is one dependency chain: n levels of one row.  Runs of small levels are executed by one
+    workgroup with barriers in between (one launch per triangle instead of n): still bit-identical, and not n launches slow."""
+    import time
+    n = 20000
+    A = oracle.tridiag(n, -1.0, 2.5, -1.5)
+    ref = oracle.Ilu0(A)
+    P = K.Ilu0(_upload(K, ctx, A))
+    assert P.levels == (n, n)
+    assert np.array_equal(P.values(), ref.lu)
+    x = np.linspace(-1.0, 1.0, n)
+    dx, dy = ctx.array(x), ctx.empty(n)
+    P(dx, dy)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        P(dx, dy)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / 3
+    assert np.array_equal(dy.to_host(), ref.solve(x))
+    assert dt < 0.1, dt          # 2 n per-level launches would take ~0.2 s
