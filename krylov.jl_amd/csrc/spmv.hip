@@ -670,11 +670,12 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
   }
   KHIP_CHECK_HIP(hipGetLastError());
+  // the profiling bracket closes right behind the SpMV kernel: the tiny finish kernel of a fused dot is another kernel
+  if (ev_stop) KHIP_CHECK_HIP(hipEventRecord(ev_stop, ctx->stream));
   if (dot) {
     *wave_cursor += (int64_t)grid * kWavesPerBlock;
     if (finish) KHIP_TRY(launch_finish(ctx, *wave_cursor, nout, dot_slot));
   }
-  if (ev_stop) KHIP_CHECK_HIP(hipEventRecord(ev_stop, ctx->stream));
   return KHIP_OK;
 }
 
