@@ -263,7 +263,8 @@ typedef struct {
   int    reorthogonalization; /* gmres / block_gmres              (src/gmres.jl:265-271) */
   int    fused;               /* 0 = issue primitives exactly as the reference does; 1 = fused kernels;
                                * 2 = fused kernels + scalar recurrences and stopping tests on the device (cg, bicgstab: no
-                               * host round trip inside the loop; bit-identical to 1; falls back to 1 where it does not apply) */
+                               * host round trip inside the loop; gmres: one-step look-ahead behind the single sync per inner
+                               * iteration); bit-identical to 1; falls back to 1 where it does not apply */
   khip_callback_fn callback; void *callback_data;
   int    variant;             /* 0 = the reference's recurrences.  cg: 1 = single-reduction CG (Chronopoulos & Gear 1989): the two
                                * dots of an iteration are computed by ONE reduction (one all-reduce per iteration on N GPUs,

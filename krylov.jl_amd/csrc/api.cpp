@@ -70,6 +70,7 @@ int khip_ctx_destroy(khip_ctx *ctx) {
   (void)hipFree(ctx->results);
   (void)hipFree(ctx->results_dd);
   (void)hipHostFree(ctx->results_pinned);
+  if (ctx->ev_fetch) (void)hipEventDestroy(ctx->ev_fetch);
   for (int i = 0; i < khip_ctx::kEvRing; ++i) {
     if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
     if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
@@ -541,6 +542,18 @@ int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, doubl
     return KHIP_OK;
   }
   const bool multi = comm_nranks(ctx) > 1;
+  int slot = 0;
+  KHIP_TRY(mgs_enqueue(ctx, n, k, V_host, q, &slot));
+  std::vector<double> tmp((size_t)k + 1);
+  KHIP_TRY(fetch_results(ctx, slot, k + 1, tmp.data(), /*already_global=*/multi));
+  for (int i = 0; i < k; ++i) h_host[i] = accumulate ? h_host[i] + tmp[i] : tmp[i];
+  if (nrm_host) *nrm_host = std::sqrt(tmp[k]);
+  return KHIP_OK;
+}
+
+}  // extern "C"
+int khip::mgs_enqueue(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, double *q, int *slot_out) {
+  const bool multi = comm_nranks(ctx) > 1;
   const int slot = take_slots(ctx, k + 1);
   KHIP_TRY(launch_dot(ctx, n, V_host[0], q, slot));
   if (multi) KHIP_TRY(comm_allreduce_dd_device(ctx, slot, 1));
@@ -549,12 +562,10 @@ int khip_mgs(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, doubl
     KHIP_TRY(launch_axpy_dev_dot(ctx, n, ctx->results + slot + i, V_host[i], q, znext, slot + i + 1));
     if (multi) KHIP_TRY(comm_allreduce_dd_device(ctx, slot + i + 1, 1));
   }
-  std::vector<double> tmp((size_t)k + 1);
-  KHIP_TRY(fetch_results(ctx, slot, k + 1, tmp.data(), /*already_global=*/multi));
-  for (int i = 0; i < k; ++i) h_host[i] = accumulate ? h_host[i] + tmp[i] : tmp[i];
-  if (nrm_host) *nrm_host = std::sqrt(tmp[k]);
+  *slot_out = slot;
   return KHIP_OK;
 }
+extern "C" {
 
 int khip_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *y_host, const double *const *V_host, double *x) {
   KHIP_REQUIRE(ctx && (k == 0 || (y_host && V_host)) && (n == 0 || x), "multi_axpy: null argument");

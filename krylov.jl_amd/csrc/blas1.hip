@@ -818,4 +818,52 @@ int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host, bool alr
   return KHIP_OK;
 }
 
+// Split form of fetch_results for look-ahead: `begin` enqueues the copy of results[slot..] (already all-reduced if
+// there are several ranks) and records an event; work enqueued afterwards does not delay `end`, which waits for
+// the event only.
+int results_copy_begin(khip_ctx *ctx, int slot, int count) {
+  if (!ctx->ev_fetch) KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_fetch, hipEventDisableTiming));
+  KHIP_CHECK_HIP(hipMemcpyAsync(ctx->results_pinned, ctx->results + slot, sizeof(double) * (size_t)count,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipEventRecord(ctx->ev_fetch, ctx->stream));
+  return KHIP_OK;
+}
+int results_copy_end(khip_ctx *ctx, int count, double *out_host) {
+  KHIP_CHECK_HIP(hipEventSynchronize(ctx->ev_fetch));
+  for (int i = 0; i < count; ++i) out_host[i] = ctx->results_pinned[i];
+  return KHIP_OK;
+}
+
+// y = x / sqrt(*sumsq): kdivcopy!(n, V[k+1], q, Hbis) (src/gmres.jl:325) with Hbis = ||q|| still on the device
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void divcopy_dev_kernel(int64_t n, const double *sumsq, const double *x, double *y) {
+  using T = typename VecT<VEC>::type;
+  const double s = sqrt(*sumsq);
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T xv = ldg<NT>(reinterpret_cast<const T *>(x) + i);
+    T yo;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) vset(yo, e, vget(xv, e) / s);
+    stg<NT>(yo, reinterpret_cast<T *>(y) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = x[n - 1] / s;
+}
+
+int launch_divcopy_dev(khip_ctx *ctx, int64_t n, const double *sumsq_dev, const double *x, double *y) {
+  if (n <= 0) return KHIP_OK;
+  const bool v2 = n >= 2 && aligned16(x) && aligned16(y);
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_L(VEC, NT) \
+  hipLaunchKernelGGL((divcopy_dev_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, sumsq_dev, x, y)
+  if (v2) { if (nt) KHIP_L(2, true); else KHIP_L(2, false); }
+  else    { if (nt) KHIP_L(1, true); else KHIP_L(1, false); }
+#undef KHIP_L
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 }  // namespace khip

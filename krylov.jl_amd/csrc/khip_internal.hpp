@@ -102,6 +102,7 @@ struct khip_ctx {
   static constexpr int kEvRing = 16;
   hipEvent_t ev_a[kEvRing] = {}, ev_b[kEvRing] = {};
   unsigned ev_cur = 0;
+  hipEvent_t ev_fetch = nullptr;       // results_copy_begin / _end (look-ahead fetch of device scalars)
   int num_cu = 256;
   // reduction scratch (grown on demand by ensure_reduction_scratch)
   khip::dd *partials = nullptr;        // [kMaxNout][red_cap1]  one per wave of the streaming kernel
@@ -163,6 +164,9 @@ inline int take_slots(khip_ctx *ctx, int count) {
 }
 
 // blas1.hip
+int results_copy_begin(khip_ctx *ctx, int slot, int count);
+int results_copy_end(khip_ctx *ctx, int count, double *out_host);
+int launch_divcopy_dev(khip_ctx *ctx, int64_t n, const double *sumsq_dev, const double *x, double *y);   // y = x / sqrt(*sumsq)
 int ensure_reduction_scratch(khip_ctx *ctx, int64_t nwaves, int nout);
 int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot);
 int launch_dot(khip_ctx *ctx, int64_t n, const double *x, const double *y, int slot);
@@ -221,6 +225,10 @@ int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 
 // template.hip
 void csr_free_templates(khip_csr *A);
+
+// api.cpp: the MGS cascade of khip_mgs in two halves (enqueue: launches only; the k coefficients and ||q||^2 end up in
+// results[slot .. slot + k], all-reduced on the device when there are several ranks)
+int mgs_enqueue(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, double *q, int *slot_out);
 
 // api.cpp: y = A x (dot_slot >= 0: also results[dot_slot] = x . y) incl. halo exchange; launches only, no host sync
 int spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw = nullptr,

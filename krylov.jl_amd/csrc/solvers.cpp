@@ -709,6 +709,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
 
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
+  const bool look = fused && o.fused >= 2 && MisI && NisI && !reorth && !o.callback && !A->apply && A->csr;
   if (!MisI && !ws->q) K(alloc_vec(ctx, n, &ws->q));                               // src/gmres.jl:142-144
   if (!NisI && !ws->p) K(alloc_vec(ctx, n, &ws->p));
   if (restart && !ws->dx) K(alloc_vec(ctx, n, &ws->dx));
@@ -790,6 +791,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
     npass = npass + 1;
     ws->inner_iter = 0;
     inner_tired = false;
+    bool spec_done = false;                    // w already holds A * V[inner_iter] (enqueued by the look-ahead)
 
     while (!(solved || inner_tired || breakdown || user_requested_exit || overtimed)) {
       ws->inner_iter = ws->inner_iter + 1;
@@ -803,12 +805,34 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
 
       double *Vk = V[inner_iter - 1];
       double *pp = NisI ? Vk : ws->p;
-      if (!NisI) K(apply_op(ctx, N, Vk, pp));
-      K(apply_op(ctx, A, pp, w));                                                  // :257
-      if (!MisI) K(apply_op(ctx, M, w, q));
+      if (!spec_done) {
+        if (!NisI) K(apply_op(ctx, N, Vk, pp));
+        K(apply_op(ctx, A, pp, w));                                                // :257
+        if (!MisI) K(apply_op(ctx, M, w, q));
+      }
+      spec_done = false;
 
       double Hbis;
-      if (fused) {
+      if (look && inner_iter + 1 <= kResultSlots) {
+        // ONE-STEP LOOK-AHEAD: the MGS cascade leaves its coefficients and ||q||^2 on the device.  Before the host
+        // waits for them, the next basis vector V[k+1] = q / ||q|| (device scalar) and its product A V[k+1] are
+        // enqueued, so the queue stays busy while the host applies the Givens rotations and tests convergence.
+        // If the test says stop, that work was wasted and touched nothing that is read again.  Same operations on the
+        // same values as the plain sequence: bit-identical.
+        int slot = 0;
+        K(mgs_enqueue(ctx, n, inner_iter, V.data(), q, &slot));
+        K(results_copy_begin(ctx, slot, inner_iter + 1));
+        const int64_t lim = restart ? ((int64_t)mem < inner_itmax ? (int64_t)mem : inner_itmax) : inner_itmax;
+        if (inner_iter < lim && (int)V.size() > inner_iter && (restart || inner_iter < mem)) {
+          K(launch_divcopy_dev(ctx, n, ctx->results + slot + inner_iter, q, V[inner_iter]));   // :325
+          K(apply_op(ctx, A, V[inner_iter], w));                                                // the next :257
+          spec_done = true;
+        }
+        std::vector<double> tmp((size_t)inner_iter + 1);
+        K(results_copy_end(ctx, inner_iter + 1, tmp.data()));
+        for (int i = 0; i < inner_iter; ++i) R[nr + i] = tmp[i];
+        Hbis = std::sqrt(tmp[inner_iter]);
+      } else if (fused) {
         // MGS cascade with device-resident coefficients; ||q|| of :274 comes out of the last pass
         K(khip_mgs(ctx, n, inner_iter, V.data(), q, &R[nr], reorth ? nullptr : &Hbis, 0));
         if (reorth) K(khip_mgs(ctx, n, inner_iter, V.data(), q, &R[nr], &Hbis, 1));
@@ -861,8 +885,10 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
           if ((int)V.size() <= inner_iter) K(gmres_grow_basis(ws, mem > 4 ? mem : 4));
           if ((int)z.size() <= inner_iter) z.resize(inner_iter + 1, 0.0);
         }
-        K(khip_divcopy(ctx, n, V[inner_iter], q, Hbis));                           // :325
+        if (!spec_done) K(khip_divcopy(ctx, n, V[inner_iter], q, Hbis));           // :325 (already enqueued by the look-ahead)
         z[inner_iter] = zeta_next;
+      } else {
+        spec_done = false;                                                         // the speculative product is abandoned
       }
     }
 

@@ -305,6 +305,29 @@ def test_gmres_memory30_restart_cfg3_shape(K, ctx, oracle, parity_log):
     assert dev <= 1.0
 
 
+def test_gmres_look_ahead_equals_plain_sequence(K, ctx, oracle):
+    """fused = 2 for gmres! (M = N = I, CSR operator): V[k+1] = q / ||q|| (device scalar) and the next product are enqueued
+    before the host reads the Hessenberg column -- same operations on the same values, so histories, iteration counts
+    and x are bit-identical to fused = 1, with and without restart, when the loop ends on convergence or on itmax."""
+    A = oracle.kron_unsymmetric(10)
+    dA = _upload(K, ctx, A)
+    rng = np.random.default_rng(21)
+    bh = A.matvec(rng.standard_normal(A.n))
+    b = ctx.array(bh)
+    for kw in (dict(memory=10, restart=True), dict(memory=10), dict(memory=20), dict(memory=5, restart=True, itmax=13),
+               dict(memory=30, rtol=1e-12, atol=0.0), dict(memory=8, restart=True, history=False), dict(memory=4, itmax=9)):
+        kw = dict(dict(history=True), **kw)
+        x1, st1, _ = K.gmres(dA, b, fused=1, **kw)
+        x2, st2, _ = K.gmres(dA, b, fused=2, **kw)
+        assert (st2.niter, st2.status, st2.solved, st2.inconsistent) == (st1.niter, st1.status, st1.solved, st1.inconsistent), kw
+        if kw["history"]:
+            assert np.array_equal(st2.residuals, st1.residuals), kw
+        assert np.array_equal(x2.to_host(), x1.to_host()), kw
+    ref = oracle.gmres(A, bh, memory=10, restart=True, history=True)
+    _, st, _ = K.gmres(dA, b, memory=10, restart=True, history=True, fused=2)
+    assert st.niter == ref.niter
+
+
 def test_gmres_edge_cases(K, ctx, oracle):
     A = oracle.kron_unsymmetric(6)
     bh = A.matvec(np.ones(A.n))
