@@ -120,6 +120,12 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (khip_ctx_set_option)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: anything a library prints there (RCCL writes a version banner to stdout at
+    # communicator creation) is sent to stderr by pointing fd 1 at fd 2 for the life of the process.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -230,7 +236,7 @@ def main():
             except Exception as e:          # never lose the GPU line to a host-side problem
                 out["cpu_baseline"] = {"value": None, "unit": "iter/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
