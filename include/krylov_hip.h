@@ -335,6 +335,30 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
 int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor);
 const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws);
 
+/* ---- Krylov processes (src/krylov_processes.jl) --------------------------------------------------------------
+ * The bases are dense COLUMN-MAJOR device arrays as in the reference (`M(undef, n, k+1)`): column j starts at
+ * V + j*ldv, ldv >= n and even, V 16-byte aligned.  The small matrices come back on the HOST in the reference's
+ * own storage.  An exact breakdown returns KHIP_ERR_NUMERIC with the reference's message in khip_last_error()
+ * unless allow_breakdown != 0 (the new basis vector is then zero-filled, as the reference does).
+ * Row-partitioned operators: n (and m) are the local row counts; dots and norms are all-reduced inside. */
+/* V, beta1, T = hermitian_lanczos(A, b, k; allow_breakdown, reorthogonalization)     src/krylov_processes.jl:28-102
+ * T_nzval_host[3k-1] = nzval of the (k+1) x k tridiagonal SparseMatrixCSC of :35-48: column 1 holds (T11, T21),
+ * column i >= 2 holds (T[i-1,i], T[i,i], T[i+1,i]). */
+int khip_hermitian_lanczos(khip_ctx *ctx, const khip_operator *A, int64_t n, const double *b, int k,
+                           int allow_breakdown, int reorthogonalization, double *V, int64_t ldv,
+                           double *beta1_host, double *T_nzval_host);
+/* V, beta, H = arnoldi(A, b, k; allow_breakdown, reorthogonalization)                 src/krylov_processes.jl:250-296
+ * H_host = dense (k+1) x k upper Hessenberg, column-major with leading dimension k+1. */
+int khip_arnoldi(khip_ctx *ctx, const khip_operator *A, int64_t n, const double *b, int k, int allow_breakdown,
+                 int reorthogonalization, double *V, int64_t ldv, double *beta_host, double *H_host);
+/* V, U, beta1, L = golub_kahan(A, b, k; allow_breakdown)                              src/krylov_processes.jl:323-398
+ * A is m x n, At its adjoint (khip_csr_transpose or a callback); V is n x (k+1), U is m x (k+1);
+ * L_nzval_host[2k+1] = nzval of the (k+1) x (k+1) lower bidiagonal SparseMatrixCSC of :331-347:
+ * (L11, L21, L22, L32, ..., L[k+1,k], L[k+1,k+1]). */
+int khip_golub_kahan(khip_ctx *ctx, const khip_operator *A, const khip_operator *At, int64_t m, int64_t n,
+                     const double *b, int k, int allow_breakdown, double *V, int64_t ldv, double *U, int64_t ldu,
+                     double *beta1_host, double *L_nzval_host);
+
 #ifdef __cplusplus
 }
 #endif

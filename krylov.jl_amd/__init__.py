@@ -120,6 +120,10 @@ SIGNATURES = {
     "khip_bicgstab_p": (_int, [_vp, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "khip_dot2": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
     "khip_mgs": (_int, [_vp, _i64, _int, c_void_pp, _vp, c_double_p, c_double_p, _int]),
+    "khip_hermitian_lanczos": (_int, [_vp, C.POINTER(COperator), _i64, _vp, _int, _int, _int, _vp, _i64, c_double_p, c_double_p]),
+    "khip_arnoldi": (_int, [_vp, C.POINTER(COperator), _i64, _vp, _int, _int, _int, _vp, _i64, c_double_p, c_double_p]),
+    "khip_golub_kahan": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _i64, _i64, _vp, _int, _int, _vp, _i64, _vp, _i64,
+                                c_double_p, c_double_p]),
     "khip_multi_axpy": (_int, [_vp, _i64, _int, c_double_p, c_void_pp, _vp]),
     "khip_panel_rows": (_int, [_i64, C.POINTER(_i64)]),
     "khip_panel_from_colmajor": (_int, [_vp, _i64, _int, _vp, _vp]),
@@ -931,6 +935,125 @@ def bicgstab(A, b: DeviceVector, x0=None, **kw):
         ws.warm_start_(x0)
     bicgstab_(ws, A, b, **kw)
     return ws.x, ws.stats, ws
+
+
+# --------------------------------------------------------------------------- Krylov processes
+# src/krylov_processes.jl: same names, arguments and return values; the bases live in HBM.
+
+class DeviceMatrix:
+    """Dense column-major n x ncols Float64 matrix in HBM (`M(undef, n, k+1)`, src/krylov_processes.jl:52):
+    column j is the DeviceVector `col(j)`; the leading dimension is n rounded up to 32 doubles."""
+
+    def __init__(self, ctx: Context, n: int, ncols: int):
+        self.ctx, self.n, self.ncols = ctx, int(n), int(ncols)
+        self.ld = max(32, (self.n + 31) & ~31)
+        self.buf = DeviceVector(ctx, self.ld * self.ncols)
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    @property
+    def shape(self):
+        return (self.n, self.ncols)
+
+    def col(self, j: int) -> DeviceVector:
+        return self.buf.slice(j * self.ld, j * self.ld + self.n)
+
+    def to_host(self) -> np.ndarray:
+        return np.asfortranarray(self.buf.to_host().reshape(self.ncols, self.ld)[:, :self.n].T)
+
+
+def _tridiag_from_nzval(k, nz):
+    """The (k+1) x k SparseMatrixCSC of src/krylov_processes.jl:35-48 as scipy CSC."""
+    import scipy.sparse as sp
+    colptr = np.zeros(k + 1, dtype=np.int64)
+    rowval = np.zeros(3 * k - 1, dtype=np.int64)
+    for i in range(1, k + 1):
+        pos = colptr[i - 1]
+        colptr[i] = 3 * i - 1
+        if i == 1:
+            rowval[pos], rowval[pos + 1] = 0, 1
+        else:
+            rowval[pos], rowval[pos + 1], rowval[pos + 2] = i - 2, i - 1, i
+    return sp.csc_matrix((nz, rowval, colptr), shape=(k + 1, k))
+
+
+def _bidiag_from_nzval(k, nz):
+    """The (k+1) x (k+1) lower bidiagonal SparseMatrixCSC of src/krylov_processes.jl:331-347 as scipy CSC."""
+    import scipy.sparse as sp
+    colptr = np.zeros(k + 2, dtype=np.int64)
+    rowval = np.zeros(2 * k + 1, dtype=np.int64)
+    for i in range(1, k + 2):
+        pos = colptr[i - 1]
+        if i <= k:
+            colptr[i] = pos + 2
+            rowval[pos], rowval[pos + 1] = i - 1, i
+        else:
+            colptr[i] = pos + 1
+            rowval[pos] = i - 1
+    return sp.csc_matrix((nz, rowval, colptr), shape=(k + 1, k + 1))
+
+
+def hermitian_lanczos(A, b: DeviceVector, k: int, allow_breakdown=False, reorthogonalization=False):
+    """V, beta1, T = hermitian_lanczos(A, b, k; allow_breakdown, reorthogonalization) (src/krylov_processes.jl:28-102).
+    V: DeviceMatrix n x (k+1); T: scipy CSC (k+1) x k."""
+    ctx, n, keep = b.ctx, len(b), []
+    V = DeviceMatrix(ctx, n, k + 1)
+    beta, nz = C.c_double(), np.zeros(3 * k - 1)
+    _ck(lib().khip_hermitian_lanczos(ctx._h, _make_operator(ctx, A, n, keep), n, b.ptr, k, int(allow_breakdown),
+                                     int(reorthogonalization), V.ptr, V.ld, C.byref(beta), nz.ctypes.data_as(c_double_p)))
+    return V, beta.value, _tridiag_from_nzval(k, nz)
+
+
+def arnoldi(A, b: DeviceVector, k: int, allow_breakdown=False, reorthogonalization=False):
+    """V, beta, H = arnoldi(A, b, k; allow_breakdown, reorthogonalization) (src/krylov_processes.jl:250-296).
+    V: DeviceMatrix n x (k+1); H: dense (k+1) x k numpy array."""
+    ctx, n, keep = b.ctx, len(b), []
+    V = DeviceMatrix(ctx, n, k + 1)
+    beta, H = C.c_double(), np.zeros((k + 1, k), order="F")
+    _ck(lib().khip_arnoldi(ctx._h, _make_operator(ctx, A, n, keep), n, b.ptr, k, int(allow_breakdown),
+                           int(reorthogonalization), V.ptr, V.ld, C.byref(beta), H.ctypes.data_as(c_double_p)))
+    return V, beta.value, H
+
+
+def golub_kahan(A, b: DeviceVector, k: int, allow_breakdown=False, At=None, n=None):
+    """V, U, beta1, L = golub_kahan(A, b, k; allow_breakdown) (src/krylov_processes.jl:323-398).  A: CsrMatrix (its
+    adjoint is built with A.transpose() unless `At` is given) or a callable together with a callable `At` and the
+    column count `n` (`size(A, 2)`)."""
+    ctx, m, keep = b.ctx, len(b), []
+    if At is None:
+        if not isinstance(A, CsrMatrix):
+            raise TypeError("golub_kahan: a callable A needs the adjoint callable At")
+        At = A.transpose()
+    if isinstance(A, CsrMatrix):
+        n = A.n
+    elif n is None:
+        raise TypeError("golub_kahan: a callable A needs n = size(A, 2)")
+    V, U = DeviceMatrix(ctx, n, k + 1), DeviceMatrix(ctx, m, k + 1)
+    beta, nz = C.c_double(), np.zeros(2 * k + 1)
+    # callbacks receive (x, y) sized for their own direction
+    opA = _make_operator(ctx, A, n, keep) if isinstance(A, CsrMatrix) else _make_operator_mn(ctx, A, n, m, keep)
+    opAt = _make_operator(ctx, At, m, keep) if isinstance(At, CsrMatrix) else _make_operator_mn(ctx, At, m, n, keep)
+    _ck(lib().khip_golub_kahan(ctx._h, opA, opAt, m, n, b.ptr, k, int(allow_breakdown), V.ptr, V.ld, U.ptr, U.ld,
+                               C.byref(beta), nz.ctypes.data_as(c_double_p)))
+    return V, U, beta.value, _bidiag_from_nzval(k, nz)
+
+
+def _make_operator_mn(ctx, op, nin, nout, keep):
+    """callable(x: DeviceVector[nin], y: DeviceVector[nout]) -> POINTER(COperator) for rectangular operators."""
+    def thunk(_self, xp, yp):
+        try:
+            op(DeviceVector(ctx, nin, ptr=xp), DeviceVector(ctx, nout, ptr=yp))
+            return 0
+        except Exception as e:
+            sys.stderr.write(f"operator callback failed: {e}\n")
+            return 1
+    fn = APPLY_FN(thunk)
+    co = COperator()
+    co.csr, co.apply = None, fn
+    keep.extend([fn, co])
+    return C.byref(co)
 
 
 # --------------------------------------------------------------------------- host-only partition helpers

@@ -190,3 +190,35 @@ def test_distributed_block_gmres_local_ranks(K, oracle):
         assert np.max(np.abs(out["hist"] - ref.residuals) / (1e-8 * ref.residuals + 100 * np.finfo(float).eps * ref.residuals[0])) <= 1.0
         assert np.allclose(out["X"], ref.x[r0:r1], atol=1e-8 * np.abs(ref.x).max())
         assert np.array_equal(out["hist"], res[0]["hist"])            # identical on every rank
+
+
+def test_distributed_krylov_processes_local_ranks(K, oracle):
+    """arnoldi / hermitian_lanczos on a row-partitioned operator (3 in-process ranks): every rank gets the same H / T
+    as the oracle's serial run, and the row slabs of V stack to the oracle's basis."""
+    import oracle_processes as P
+    world, n1, k = 3, 9, 12
+    A_cpu, S_cpu = oracle.kron_unsymmetric(n1), oracle.poisson3d(n1)
+    n = A_cpu.n
+    bh = np.random.default_rng(3).random(n)
+    Vr, beta_r, Hr = P.arnoldi(A_cpu.matvec, bh, k, reorthogonalization=True)
+    Wr, gamma_r, Tr = P.hermitian_lanczos(S_cpu.matvec, bh, k)
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        b = c.array(bh[r0:r1])
+        A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+        V, beta, H = K.arnoldi(A, b, k, reorthogonalization=True)
+        S = K.CsrMatrix.stencil(c, "poisson", n1, rows=(r0, r1), distributed=True)
+        W, gamma, T = K.hermitian_lanczos(S, b, k)
+        return beta, H, V.to_host(), gamma, T.data.copy(), W.to_host()
+
+    res = _run_ranks(K, world, 424242, body)
+    eps = np.finfo(float).eps
+    for rank, (beta, H, Vloc, gamma, Tnz, Wloc) in enumerate(res):
+        r0, r1 = starts[rank], starts[rank + 1]
+        assert abs(beta - beta_r) <= 4 * eps * beta_r and abs(gamma - gamma_r) <= 4 * eps * gamma_r
+        assert np.max(np.abs(H - Hr)) <= 1e-10 * np.max(np.abs(Hr))
+        assert np.max(np.abs(Tnz - Tr)) <= 1e-10 * np.max(np.abs(Tr))
+        assert np.max(np.abs(Vloc - Vr[r0:r1])) <= 1e-8 and np.max(np.abs(Wloc - Wr[r0:r1])) <= 1e-8
+        assert np.array_equal(H, res[0][1]) and np.array_equal(Tnz, res[0][4])      # identical on every rank

@@ -436,3 +436,78 @@ def test_ilu0_defining_property_and_reference_known_answer(oracle):
     Z = oracle.tridiag(4, 1.0, 0.0, 1.0)
     with pytest.raises(ZeroDivisionError):
         oracle.Ilu0(Z)
+
+
+# ---- Krylov processes: the assertions of the reference's own test/test_processes.jl -------------------
+
+def _approx(a, b):          # Julia's `≈` for arrays: norm(a - b) <= sqrt(eps) * max(norm(a), norm(b))
+    return np.linalg.norm(a - b) <= math.sqrt(np.finfo(float).eps) * max(np.linalg.norm(a), np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("reorth", [False, True])
+def test_processes_hermitian_lanczos_and_arnoldi_reference_assertions(oracle, reorth):
+    """test/test_processes.jl:31-49 (Hermitian Lanczos) and :76-95 (Arnoldi), Float64, n = 500, k = 20, s = 5."""
+    import oracle_processes as P
+    import scipy.sparse as sp
+    n, k, s = 500, 20, 5
+    rng = np.random.default_rng(1)
+    A = rng.random((n, n))
+    A = A.T @ A
+    b = rng.random(n)
+    V, beta1, nz = P.hermitian_lanczos(lambda x: A @ x, b, k, reorthogonalization=reorth)
+    colptr, rowval = P.tridiag_pattern(k)
+    T = sp.csc_matrix((nz, rowval, colptr), shape=(k + 1, k)).toarray()
+    assert np.linalg.norm(V[:, :s].T @ V[:, :s] - np.eye(s)) <= 1e-4
+    assert _approx(beta1 * V[:, 0], b)
+    assert _approx(A @ V[:, :k], V @ T)
+    assert np.array_equal(np.diag(T, 1), np.diag(T, -1)[:k - 1])          # symmetric tridiagonal by construction
+
+    A = rng.random((n, n))
+    V, beta, H = P.arnoldi(lambda x: A @ x, b, k, reorthogonalization=reorth)
+    assert np.linalg.norm(V[:, :s].T @ V[:, :s] - np.eye(s)) <= 1e-4
+    assert _approx(beta * V[:, 0], b)
+    assert _approx(A @ V[:, :k], V @ H)
+    assert np.all(np.tril(H, -2) == 0.0)
+
+
+def test_processes_golub_kahan_reference_assertions(oracle):
+    """test/test_processes.jl:98-118, Float64, m = 250, n = 500, k = 20."""
+    import oracle_processes as P
+    import scipy.sparse as sp
+    m, n, k, s = 250, 500, 20, 5
+    rng = np.random.default_rng(2)
+    A = rng.random((m, n))
+    b = rng.random(m)
+    V, U, beta1, nz = P.golub_kahan(lambda x: A @ x, lambda y: A.T @ y, b, n, k)
+    colptr, rowval = P.bidiag_pattern(k)
+    L = sp.csc_matrix((nz, rowval, colptr), shape=(k + 1, k + 1)).toarray()
+    B = L[:k + 1, :k]
+    assert np.linalg.norm(V[:, :s].T @ V[:, :s] - np.eye(s)) <= 1e-4
+    assert np.linalg.norm(U[:, :s].T @ U[:, :s] - np.eye(s)) <= 1e-4
+    assert _approx(beta1 * U[:, 0], b)
+    assert _approx(A @ V[:, :k], U @ B)
+    assert _approx(A.T @ U, V @ L.T)
+    assert _approx(A.T @ A @ V[:, :k], V @ L.T @ B)
+    assert _approx(A @ A.T @ U[:, :k], U @ B @ L[:k, :k].T)
+
+
+def test_processes_exact_breakdown_messages(oracle):
+    """test/test_processes.jl:194-218: A0 = I (2 x 2), b0 = 0 -- the error text and the allow_breakdown path."""
+    import oracle_processes as P
+    b0 = np.zeros(2)
+    A0 = lambda x: x.copy()
+    with pytest.raises(P.Breakdown, match="Exact breakdown β₁ == 0."):
+        P.hermitian_lanczos(A0, b0, 2)
+    P.hermitian_lanczos(A0, b0, 2, allow_breakdown=True)
+    with pytest.raises(P.Breakdown, match="Exact breakdown β == 0."):
+        P.arnoldi(A0, b0, 2)
+    V, beta, H = P.arnoldi(A0, b0, 2, allow_breakdown=True)
+    assert beta == 0.0 and not V.any() and not H.any()
+    with pytest.raises(P.Breakdown, match="Exact breakdown β₁ == 0."):
+        P.golub_kahan(A0, A0, b0, 2, 2)
+    P.golub_kahan(A0, A0, b0, 2, 2, allow_breakdown=True)
+    # beyond the reference's cases: an invariant subspace after one step (A = I, b = e1)
+    with pytest.raises(P.Breakdown, match="Exact breakdown βᵢ₊₁ == 0 at iteration i = 1."):
+        P.hermitian_lanczos(A0, np.array([1.0, 0.0]), 2)
+    with pytest.raises(P.Breakdown, match="Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 1."):
+        P.arnoldi(A0, np.array([1.0, 0.0]), 2)

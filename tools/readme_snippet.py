@@ -6,3 +6,4 @@ b = ctx.array(np.ones(A.n))
 x, stats, ws = K.cg(A, b, rtol=1e-8, history=True); print(stats.niter, stats.status)
 x, stats, ws = K.cg(A, b, M=K.Ilu0(A)); print(stats.niter)
 x, stats, ws = K.gmres(A, b, memory=30, restart=True); print(stats.niter, stats.solved)
+V, beta, H = K.arnoldi(A, b, 20, reorthogonalization=True); print(V.shape, H.shape, beta)
