@@ -995,29 +995,37 @@ def _bidiag_from_nzval(k, nz):
     return sp.csc_matrix((nz, rowval, colptr), shape=(k + 1, k + 1))
 
 
-def hermitian_lanczos(A, b: DeviceVector, k: int, allow_breakdown=False, reorthogonalization=False):
+def _basis(ctx, n, ncols, out):
+    if out is None:
+        return DeviceMatrix(ctx, n, ncols)
+    if out.shape != (n, ncols):
+        raise ValueError(f"basis storage is {out.shape}, need {(n, ncols)}")
+    return out
+
+
+def hermitian_lanczos(A, b: DeviceVector, k: int, allow_breakdown=False, reorthogonalization=False, V=None):
     """V, beta1, T = hermitian_lanczos(A, b, k; allow_breakdown, reorthogonalization) (src/krylov_processes.jl:28-102).
-    V: DeviceMatrix n x (k+1); T: scipy CSC (k+1) x k."""
+    V: DeviceMatrix n x (k+1) (pass `V=` to reuse storage); T: scipy CSC (k+1) x k."""
     ctx, n, keep = b.ctx, len(b), []
-    V = DeviceMatrix(ctx, n, k + 1)
+    V = _basis(ctx, n, k + 1, V)
     beta, nz = C.c_double(), np.zeros(3 * k - 1)
     _ck(lib().khip_hermitian_lanczos(ctx._h, _make_operator(ctx, A, n, keep), n, b.ptr, k, int(allow_breakdown),
                                      int(reorthogonalization), V.ptr, V.ld, C.byref(beta), nz.ctypes.data_as(c_double_p)))
     return V, beta.value, _tridiag_from_nzval(k, nz)
 
 
-def arnoldi(A, b: DeviceVector, k: int, allow_breakdown=False, reorthogonalization=False):
+def arnoldi(A, b: DeviceVector, k: int, allow_breakdown=False, reorthogonalization=False, V=None):
     """V, beta, H = arnoldi(A, b, k; allow_breakdown, reorthogonalization) (src/krylov_processes.jl:250-296).
-    V: DeviceMatrix n x (k+1); H: dense (k+1) x k numpy array."""
+    V: DeviceMatrix n x (k+1) (pass `V=` to reuse storage); H: dense (k+1) x k numpy array."""
     ctx, n, keep = b.ctx, len(b), []
-    V = DeviceMatrix(ctx, n, k + 1)
+    V = _basis(ctx, n, k + 1, V)
     beta, H = C.c_double(), np.zeros((k + 1, k), order="F")
     _ck(lib().khip_arnoldi(ctx._h, _make_operator(ctx, A, n, keep), n, b.ptr, k, int(allow_breakdown),
                            int(reorthogonalization), V.ptr, V.ld, C.byref(beta), H.ctypes.data_as(c_double_p)))
     return V, beta.value, H
 
 
-def golub_kahan(A, b: DeviceVector, k: int, allow_breakdown=False, At=None, n=None):
+def golub_kahan(A, b: DeviceVector, k: int, allow_breakdown=False, At=None, n=None, V=None, U=None):
     """V, U, beta1, L = golub_kahan(A, b, k; allow_breakdown) (src/krylov_processes.jl:323-398).  A: CsrMatrix (its
     adjoint is built with A.transpose() unless `At` is given) or a callable together with a callable `At` and the
     column count `n` (`size(A, 2)`)."""
@@ -1030,7 +1038,7 @@ def golub_kahan(A, b: DeviceVector, k: int, allow_breakdown=False, At=None, n=No
         n = A.n
     elif n is None:
         raise TypeError("golub_kahan: a callable A needs n = size(A, 2)")
-    V, U = DeviceMatrix(ctx, n, k + 1), DeviceMatrix(ctx, m, k + 1)
+    V, U = _basis(ctx, n, k + 1, V), _basis(ctx, m, k + 1, U)
     beta, nz = C.c_double(), np.zeros(2 * k + 1)
     # callbacks receive (x, y) sized for their own direction
     opA = _make_operator(ctx, A, n, keep) if isinstance(A, CsrMatrix) else _make_operator_mn(ctx, A, n, m, keep)
