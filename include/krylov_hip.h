@@ -358,6 +358,25 @@ int khip_arnoldi(khip_ctx *ctx, const khip_operator *A, int64_t n, const double 
 int khip_golub_kahan(khip_ctx *ctx, const khip_operator *A, const khip_operator *At, int64_t m, int64_t n,
                      const double *b, int k, int allow_breakdown, double *V, int64_t ldv, double *U, int64_t ldu,
                      double *beta1_host, double *L_nzval_host);
+/* V, beta1, T, U, gamma1, Tt = nonhermitian_lanczos(A, b, c, k; allow_breakdown)   src/krylov_processes.jl:133-222
+ * A square, At its adjoint; V, U are n x (k+1); T_nzval_host / Tt_nzval_host [3k-1] = nzval of T and of T^H in the
+ * tridiagonal pattern above (column i: T[i-1,i] = gamma_i, T[i,i] = alpha_i, T[i+1,i] = beta_{i+1}). */
+int khip_nonhermitian_lanczos(khip_ctx *ctx, const khip_operator *A, const khip_operator *At, int64_t n, const double *b,
+                              const double *c, int k, int allow_breakdown, double *V, int64_t ldv, double *U, int64_t ldu,
+                              double *beta1_host, double *gamma1_host, double *T_nzval_host, double *Tt_nzval_host);
+/* V, beta1, T, U, gamma1, Tt = saunders_simon_yip(A, b, c, k; allow_breakdown)      src/krylov_processes.jl:431-524
+ * A is m x n; V is m x (k+1), U is n x (k+1); same storage of T and T^H as above. */
+int khip_saunders_simon_yip(khip_ctx *ctx, const khip_operator *A, const khip_operator *At, int64_t m, int64_t n,
+                            const double *b, const double *c, int k, int allow_breakdown, double *V, int64_t ldv,
+                            double *U, int64_t ldu, double *beta1_host, double *gamma1_host, double *T_nzval_host,
+                            double *Tt_nzval_host);
+/* V, beta, H, U, gamma, F = montoison_orban(A, B, b, c, k; allow_breakdown, reorthogonalization)
+ *                                                                                   src/krylov_processes.jl:553-632
+ * A is m x n, B is n x m; V is m x (k+1), U is n x (k+1); H_host, F_host dense (k+1) x k column-major. */
+int khip_montoison_orban(khip_ctx *ctx, const khip_operator *A, const khip_operator *B, int64_t m, int64_t n,
+                         const double *b, const double *c, int k, int allow_breakdown, int reorthogonalization,
+                         double *V, int64_t ldv, double *U, int64_t ldu, double *beta_host, double *gamma_host,
+                         double *H_host, double *F_host);
 
 #ifdef __cplusplus
 }

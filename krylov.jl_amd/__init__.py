@@ -124,6 +124,12 @@ SIGNATURES = {
     "khip_arnoldi": (_int, [_vp, C.POINTER(COperator), _i64, _vp, _int, _int, _int, _vp, _i64, c_double_p, c_double_p]),
     "khip_golub_kahan": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _i64, _i64, _vp, _int, _int, _vp, _i64, _vp, _i64,
                                 c_double_p, c_double_p]),
+    "khip_nonhermitian_lanczos": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _i64, _vp, _vp, _int, _int, _vp, _i64, _vp, _i64,
+                                         c_double_p, c_double_p, c_double_p, c_double_p]),
+    "khip_saunders_simon_yip": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _i64, _i64, _vp, _vp, _int, _int, _vp, _i64, _vp, _i64,
+                                       c_double_p, c_double_p, c_double_p, c_double_p]),
+    "khip_montoison_orban": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _i64, _i64, _vp, _vp, _int, _int, _int, _vp, _i64, _vp, _i64,
+                                    c_double_p, c_double_p, c_double_p, c_double_p]),
     "khip_multi_axpy": (_int, [_vp, _i64, _int, c_double_p, c_void_pp, _vp]),
     "khip_panel_rows": (_int, [_i64, C.POINTER(_i64)]),
     "khip_panel_from_colmajor": (_int, [_vp, _i64, _int, _vp, _vp]),
@@ -1046,6 +1052,55 @@ def golub_kahan(A, b: DeviceVector, k: int, allow_breakdown=False, At=None, n=No
     _ck(lib().khip_golub_kahan(ctx._h, opA, opAt, m, n, b.ptr, k, int(allow_breakdown), V.ptr, V.ld, U.ptr, U.ld,
                                C.byref(beta), nz.ctypes.data_as(c_double_p)))
     return V, U, beta.value, _bidiag_from_nzval(k, nz)
+
+
+def _op_mn(ctx, op, nin, nout, keep):
+    return _make_operator(ctx, op, nin, keep) if isinstance(op, CsrMatrix) else _make_operator_mn(ctx, op, nin, nout, keep)
+
+
+def nonhermitian_lanczos(A, b: DeviceVector, c: DeviceVector, k: int, allow_breakdown=False, At=None, V=None, U=None):
+    """V, beta1, T, U, gamma1, Tt = nonhermitian_lanczos(A, b, c, k; allow_breakdown) (src/krylov_processes.jl:133-222)."""
+    ctx, n, keep = b.ctx, len(b), []
+    if At is None:
+        if not isinstance(A, CsrMatrix):
+            raise TypeError("nonhermitian_lanczos: a callable A needs the adjoint callable At")
+        At = A.transpose()
+    V, U = _basis(ctx, n, k + 1, V), _basis(ctx, n, k + 1, U)
+    beta, gamma, nt, nh = C.c_double(), C.c_double(), np.zeros(3 * k - 1), np.zeros(3 * k - 1)
+    _ck(lib().khip_nonhermitian_lanczos(ctx._h, _op_mn(ctx, A, n, n, keep), _op_mn(ctx, At, n, n, keep), n, b.ptr, c.ptr, k,
+                                        int(allow_breakdown), V.ptr, V.ld, U.ptr, U.ld, C.byref(beta), C.byref(gamma),
+                                        nt.ctypes.data_as(c_double_p), nh.ctypes.data_as(c_double_p)))
+    return V, beta.value, _tridiag_from_nzval(k, nt), U, gamma.value, _tridiag_from_nzval(k, nh)
+
+
+def saunders_simon_yip(A, b: DeviceVector, c: DeviceVector, k: int, allow_breakdown=False, At=None, V=None, U=None):
+    """V, beta1, T, U, gamma1, Tt = saunders_simon_yip(A, b, c, k; allow_breakdown) (src/krylov_processes.jl:431-524).
+    A is m x n, b has length m, c has length n."""
+    ctx, m, n, keep = b.ctx, len(b), len(c), []
+    if At is None:
+        if not isinstance(A, CsrMatrix):
+            raise TypeError("saunders_simon_yip: a callable A needs the adjoint callable At")
+        At = A.transpose()
+    V, U = _basis(ctx, m, k + 1, V), _basis(ctx, n, k + 1, U)
+    beta, gamma, nt, nh = C.c_double(), C.c_double(), np.zeros(3 * k - 1), np.zeros(3 * k - 1)
+    _ck(lib().khip_saunders_simon_yip(ctx._h, _op_mn(ctx, A, n, m, keep), _op_mn(ctx, At, m, n, keep), m, n, b.ptr, c.ptr, k,
+                                      int(allow_breakdown), V.ptr, V.ld, U.ptr, U.ld, C.byref(beta), C.byref(gamma),
+                                      nt.ctypes.data_as(c_double_p), nh.ctypes.data_as(c_double_p)))
+    return V, beta.value, _tridiag_from_nzval(k, nt), U, gamma.value, _tridiag_from_nzval(k, nh)
+
+
+def montoison_orban(A, B, b: DeviceVector, c: DeviceVector, k: int, allow_breakdown=False, reorthogonalization=False,
+                    V=None, U=None):
+    """V, beta, H, U, gamma, F = montoison_orban(A, B, b, c, k; allow_breakdown, reorthogonalization)
+    (src/krylov_processes.jl:553-632).  A is m x n, B is n x m, b has length m, c has length n."""
+    ctx, m, n, keep = b.ctx, len(b), len(c), []
+    V, U = _basis(ctx, m, k + 1, V), _basis(ctx, n, k + 1, U)
+    beta, gamma = C.c_double(), C.c_double()
+    H, F = np.zeros((k + 1, k), order="F"), np.zeros((k + 1, k), order="F")
+    _ck(lib().khip_montoison_orban(ctx._h, _op_mn(ctx, A, n, m, keep), _op_mn(ctx, B, m, n, keep), m, n, b.ptr, c.ptr, k,
+                                   int(allow_breakdown), int(reorthogonalization), V.ptr, V.ld, U.ptr, U.ld,
+                                   C.byref(beta), C.byref(gamma), H.ctypes.data_as(c_double_p), F.ctypes.data_as(c_double_p)))
+    return V, beta.value, H, U, gamma.value, F
 
 
 def _make_operator_mn(ctx, op, nin, nout, keep):

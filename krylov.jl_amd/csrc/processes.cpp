@@ -1,6 +1,8 @@
-// Krylov processes on the device: hermitian_lanczos, arnoldi, golub_kahan.
+// Krylov processes on the device: hermitian_lanczos, nonhermitian_lanczos, arnoldi, golub_kahan,
+// saunders_simon_yip, montoison_orban -- all of src/krylov_processes.jl for Float64.
 //
-// Reference: src/krylov_processes.jl:28-102 (hermitian_lanczos), :250-296 (arnoldi), :323-398 (golub_kahan).
+// Reference: src/krylov_processes.jl:28-102 (hermitian_lanczos), :133-222 (nonhermitian_lanczos), :250-296 (arnoldi),
+// :323-398 (golub_kahan), :431-524 (saunders_simon_yip), :553-632 (montoison_orban).
 // Same order of kmul! / kdotr / kaxpy! / knorm / kdivcopy! as the reference, on the same device primitives the
 // solvers use: the orthogonalisation runs through the MGS cascade (khip_mgs) whose coefficients stay on the
 // device until the one host read a step needs (the breakdown test of :92 / :288 is a host branch in the reference
@@ -162,6 +164,161 @@ int khip_golub_kahan(khip_ctx *ctx, const khip_operator *A, const khip_operator 
     nz[pa + 1] = beta_next;                                      // :397-398
     nz[pa + 2] = alpha_next;
     pa += 2;
+  }
+  return KHIP_OK;
+}
+
+int khip_nonhermitian_lanczos(khip_ctx *ctx, const khip_operator *A, const khip_operator *At, int64_t n, const double *b,
+                              const double *c, int k, int allow_breakdown, double *V, int64_t ldv, double *U, int64_t ldu,
+                              double *beta1_host, double *gamma1_host, double *T_nzval_host, double *Tt_nzval_host) {
+  KHIP_REQUIRE(ctx && A && At && b && c && beta1_host && gamma1_host && T_nzval_host && Tt_nzval_host && n >= 0 && k >= 1,
+               "nonhermitian_lanczos: bad argument");
+  KHIP_REQUIRE(basis_ok(V, n, ldv) && basis_ok(U, n, ldu),
+               "nonhermitian_lanczos: V and U must be 16-byte aligned with even leading dimensions >= n");
+  double *nt = T_nzval_host, *nh = Tt_nzval_host;
+  memset(nt, 0, sizeof(double) * (size_t)(3 * k - 1));
+  memset(nh, 0, sizeof(double) * (size_t)(3 * k - 1));
+  *beta1_host = 0.0;
+  *gamma1_host = 0.0;
+  int pa = 0;
+  for (int i = 0; i < k; ++i) {
+    double *vi = V + (int64_t)i * ldv, *ui = U + (int64_t)i * ldu;
+    double *q = V + (int64_t)(i + 1) * ldv, *p = U + (int64_t)(i + 1) * ldu;
+    if (i == 0) {                                                // :173-187
+      double cb = 0.0;
+      KHIP_TRY(khip_dot(ctx, n, c, b, &cb));
+      if (cb == 0.0) {
+        if (!allow_breakdown) { set_error("Exact breakdown β₁γ₁ == 0."); return KHIP_ERR_NUMERIC; }
+        // the reference zero-fills v2 / u2 here and leaves v1 / u1 as allocated (undef); zeros make that deterministic
+        KHIP_TRY(khip_fill(ctx, n, vi, 0.0));
+        KHIP_TRY(khip_fill(ctx, n, ui, 0.0));
+      } else {
+        const double beta1 = std::sqrt(std::fabs(cb));
+        const double gamma1 = cb / beta1;
+        KHIP_TRY(khip_divcopy(ctx, n, vi, b, beta1));
+        KHIP_TRY(khip_divcopy(ctx, n, ui, c, gamma1));
+        *beta1_host = beta1;
+        *gamma1_host = gamma1;
+      }
+    }
+    KHIP_TRY(apply(ctx, A, vi, q));                              // :188
+    KHIP_TRY(apply(ctx, At, ui, p));                             // :189
+    if (i >= 1) {                                                // :190-197
+      const double beta_i = nt[pa - 2], gamma_i = nt[pa - 1];
+      KHIP_TRY(khip_axpy(ctx, n, -gamma_i, V + (int64_t)(i - 1) * ldv, q));
+      KHIP_TRY(khip_axpy(ctx, n, -beta_i, U + (int64_t)(i - 1) * ldu, p));
+    }
+    double alpha = 0.0, pq = 0.0;
+    KHIP_TRY(khip_dot(ctx, n, ui, q, &alpha));                   // :198
+    nt[pa] = alpha;
+    nh[pa] = alpha;
+    KHIP_TRY(khip_axpy(ctx, n, -alpha, vi, q));                  // :201
+    KHIP_TRY(khip_axpy(ctx, n, -alpha, ui, p));                  // :202
+    KHIP_TRY(khip_dot(ctx, n, p, q, &pq));                       // :203
+    double beta_next = 0.0, gamma_next = 0.0;
+    if (pq == 0.0) {                                             // :204-209
+      if (!allow_breakdown) { set_error("Exact breakdown βᵢ₊₁γᵢ₊₁ == 0 at iteration i = %d.", i + 1); return KHIP_ERR_NUMERIC; }
+      KHIP_TRY(khip_fill(ctx, n, q, 0.0));
+      KHIP_TRY(khip_fill(ctx, n, p, 0.0));
+    } else {                                                     // :210-215
+      beta_next = std::sqrt(std::fabs(pq));
+      gamma_next = pq / beta_next;
+      KHIP_TRY(khip_divcopy(ctx, n, q, q, beta_next));
+      KHIP_TRY(khip_divcopy(ctx, n, p, p, gamma_next));
+    }
+    nt[pa + 1] = beta_next;                                      // :216-221
+    nh[pa + 1] = gamma_next;
+    if (i + 1 <= k - 1) {
+      nt[pa + 2] = gamma_next;
+      nh[pa + 2] = beta_next;
+    }
+    pa += 3;
+  }
+  return KHIP_OK;
+}
+
+int khip_saunders_simon_yip(khip_ctx *ctx, const khip_operator *A, const khip_operator *At, int64_t m, int64_t n,
+                            const double *b, const double *c, int k, int allow_breakdown, double *V, int64_t ldv,
+                            double *U, int64_t ldu, double *beta1_host, double *gamma1_host, double *T_nzval_host,
+                            double *Tt_nzval_host) {
+  KHIP_REQUIRE(ctx && A && At && b && c && beta1_host && gamma1_host && T_nzval_host && Tt_nzval_host && m >= 0 && n >= 0 &&
+                   k >= 1, "saunders_simon_yip: bad argument");
+  KHIP_REQUIRE(basis_ok(V, m, ldv) && basis_ok(U, n, ldu),
+               "saunders_simon_yip: V and U must be 16-byte aligned with even leading dimensions >= m and >= n");
+  double *nt = T_nzval_host, *nh = Tt_nzval_host;
+  memset(nt, 0, sizeof(double) * (size_t)(3 * k - 1));
+  memset(nh, 0, sizeof(double) * (size_t)(3 * k - 1));
+  int pa = 0;
+  for (int i = 0; i < k; ++i) {
+    double *vi = V + (int64_t)i * ldv, *ui = U + (int64_t)i * ldu;
+    double *q = V + (int64_t)(i + 1) * ldv, *p = U + (int64_t)(i + 1) * ldu;
+    if (i == 0) {                                                // :470-485
+      KHIP_TRY(first_vector(ctx, m, b, vi, allow_breakdown, "β₁", beta1_host));
+      KHIP_TRY(first_vector(ctx, n, c, ui, allow_breakdown, "γ₁ᴴ", gamma1_host));
+    }
+    KHIP_TRY(apply(ctx, A, ui, q));                              // :486
+    KHIP_TRY(apply(ctx, At, vi, p));                             // :487
+    if (i >= 1) {                                                // :488-495
+      const double beta_i = nt[pa - 2], gamma_i = nt[pa - 1];
+      KHIP_TRY(khip_axpy(ctx, m, -gamma_i, V + (int64_t)(i - 1) * ldv, q));
+      KHIP_TRY(khip_axpy(ctx, n, -beta_i, U + (int64_t)(i - 1) * ldu, p));
+    }
+    double alpha = 0.0, beta_next = 0.0, sq = 0.0;
+    const double *one[1] = {vi};
+    KHIP_TRY(khip_mgs(ctx, m, 1, one, q, &alpha, &beta_next, 0));            // :496, :499, :501 in one cascade
+    nt[pa] = alpha;
+    nh[pa] = alpha;
+    KHIP_TRY(khip_axpy_sqnorm(ctx, n, -alpha, ui, p, &sq));                  // :500 and :508 in one pass
+    const double gamma_next = std::sqrt(sq);
+    KHIP_TRY(normalise(ctx, m, q, beta_next, allow_breakdown, "βᵢ₊₁", i + 1));   // :502-507
+    KHIP_TRY(normalise(ctx, n, p, gamma_next, allow_breakdown, "γᵢ₊₁", i + 1));  // :509-514
+    nt[pa + 1] = beta_next;                                      // :515-520
+    nh[pa + 1] = gamma_next;
+    if (i + 1 <= k - 1) {
+      nt[pa + 2] = gamma_next;
+      nh[pa + 2] = beta_next;
+    }
+    pa += 3;
+  }
+  return KHIP_OK;
+}
+
+int khip_montoison_orban(khip_ctx *ctx, const khip_operator *A, const khip_operator *B, int64_t m, int64_t n,
+                         const double *b, const double *c, int k, int allow_breakdown, int reorthogonalization,
+                         double *V, int64_t ldv, double *U, int64_t ldu, double *beta_host, double *gamma_host,
+                         double *H_host, double *F_host) {
+  KHIP_REQUIRE(ctx && A && B && b && c && beta_host && gamma_host && H_host && F_host && m >= 0 && n >= 0 && k >= 1,
+               "montoison_orban: bad argument");
+  KHIP_REQUIRE(basis_ok(V, m, ldv) && basis_ok(U, n, ldu),
+               "montoison_orban: V and U must be 16-byte aligned with even leading dimensions >= m and >= n");
+  const int ldh = k + 1;
+  memset(H_host, 0, sizeof(double) * (size_t)ldh * k);
+  memset(F_host, 0, sizeof(double) * (size_t)ldh * k);
+  std::vector<const double *> vc((size_t)k + 1), uc((size_t)k + 1);
+  for (int j = 0; j <= k; ++j) { vc[j] = V + (int64_t)j * ldv; uc[j] = U + (int64_t)j * ldu; }
+  for (int j = 0; j < k; ++j) {
+    double *vj = V + (int64_t)j * ldv, *uj = U + (int64_t)j * ldu;
+    double *q = V + (int64_t)(j + 1) * ldv, *p = U + (int64_t)(j + 1) * ldu;
+    if (j == 0) {                                                // :571-586
+      KHIP_TRY(first_vector(ctx, m, b, vj, allow_breakdown, "β", beta_host));
+      KHIP_TRY(first_vector(ctx, n, c, uj, allow_breakdown, "γ", gamma_host));
+    }
+    KHIP_TRY(apply(ctx, A, uj, q));                              // :587
+    KHIP_TRY(apply(ctx, B, vj, p));                              // :588
+    double *h = H_host + (size_t)j * ldh, *f = F_host + (size_t)j * ldh;
+    double hn = 0.0, fn = 0.0;
+    // the reference interleaves the two Gram-Schmidt sweeps (:589-607); they touch disjoint vectors, so each runs
+    // as its own cascade with the same values in the same order
+    KHIP_TRY(khip_mgs(ctx, m, j + 1, vc.data(), q, h, reorthogonalization ? nullptr : &hn, 0));
+    KHIP_TRY(khip_mgs(ctx, n, j + 1, uc.data(), p, f, reorthogonalization ? nullptr : &fn, 0));
+    if (reorthogonalization) {
+      KHIP_TRY(khip_mgs(ctx, m, j + 1, vc.data(), q, h, &hn, 1));
+      KHIP_TRY(khip_mgs(ctx, n, j + 1, uc.data(), p, f, &fn, 1));
+    }
+    h[j + 1] = hn;                                               // :608
+    KHIP_TRY(normalise(ctx, m, q, hn, allow_breakdown, "Hᵢ₊₁.ᵢ", j + 1));   // :609-614
+    f[j + 1] = fn;                                               // :615
+    KHIP_TRY(normalise(ctx, n, p, fn, allow_breakdown, "Fᵢ₊₁.ᵢ", j + 1));   // :616-621
   }
   return KHIP_OK;
 }

@@ -1,12 +1,13 @@
-"""CPU restatement of the reference's Krylov processes (src/krylov_processes.jl).
+"""CPU restatement of the reference's six Krylov processes (src/krylov_processes.jl), Float64.
 
 TEST INFRASTRUCTURE ONLY -- importable from tests/ (and nothing under krylov.jl_amd/).  Each function follows the
 reference loop line by line on the oracle's k* primitives (oracle/krylov_oracle.c: ko_dot, ko_nrm2, ko_axpy;
 kdivcopy! is numpy's true division).  Operators are callables `y = A(x)` on host vectors.
 
 Pinned (tests/test_oracle.py::test_processes_*) by the assertions of the reference's own test file
-test/test_processes.jl:31-117,196-218 (orthonormality of the leading columns, beta v1 = b, A V_k = V_{k+1} T / H,
-A V_k = U B, A' U = V L', exact-breakdown errors with the reference's messages) on the reference's sizes
+test/test_processes.jl:31-190,194-234 (orthonormality of the leading columns, beta v1 = b, A V_k = V_{k+1} T / H,
+A V_k = U B, A' U = V L', the Paige-permuted block relations, exact-breakdown errors with the reference's
+messages on its own breakdown matrices `ssy_mo_breakdown*`, test/test_utils.jl:396-420) on the reference's sizes
 (n = 500, m = 250, k = 20); not pinned against Julia output (no Julia in this image).
 """
 from __future__ import annotations
@@ -163,3 +164,129 @@ def golub_kahan(A, At, b, n, k, allow_breakdown=False):
         nz[pa + 2] = alpha_next
         pa += 2
     return V, U, beta1, nz
+
+
+def nonhermitian_lanczos(A, At, b, c, k, allow_breakdown=False):
+    """src/krylov_processes.jl:133-222 (Float64: conj is the identity).  Returns V, beta1, nzval_T, U, gamma1, nzval_Tt."""
+    n = b.size
+    V = np.zeros((n, k + 1), order="F")
+    U = np.zeros((n, k + 1), order="F")
+    nt, nh = np.zeros(3 * k - 1), np.zeros(3 * k - 1)
+    beta1 = gamma1 = 0.0
+    pa = 0
+    for i in range(k):
+        vi, ui, q, p = V[:, i], U[:, i], V[:, i + 1], U[:, i + 1]
+        if i == 0:                                                          # :173-187
+            cb = _o.dot(c, b)
+            if cb == 0.0:
+                if not allow_breakdown:
+                    raise Breakdown("Exact breakdown β₁γ₁ == 0.")
+                q[:] = 0.0                                                  # v1 / u1 stay as allocated (zeros here)
+                p[:] = 0.0
+            else:
+                beta1 = np.sqrt(abs(cb))
+                gamma1 = cb / beta1
+                vi[:] = b / beta1
+                ui[:] = c / gamma1
+        q[:] = A(np.ascontiguousarray(vi))                                  # :188
+        p[:] = At(np.ascontiguousarray(ui))                                 # :189
+        if i >= 1:                                                          # :190-197
+            beta_i, gamma_i = nt[pa - 2], nt[pa - 1]
+            _o.axpy(-gamma_i, V[:, i - 1], q)
+            _o.axpy(-beta_i, U[:, i - 1], p)
+        alpha = _o.dot(ui, q)                                               # :198
+        nt[pa] = alpha
+        nh[pa] = alpha
+        _o.axpy(-alpha, vi, q)                                              # :201
+        _o.axpy(-alpha, ui, p)                                              # :202
+        pq = _o.dot(p, q)                                                   # :203
+        if pq == 0.0:                                                       # :204-209
+            if not allow_breakdown:
+                raise Breakdown(f"Exact breakdown βᵢ₊₁γᵢ₊₁ == 0 at iteration i = {i + 1}.")
+            beta_next = gamma_next = 0.0
+            q[:] = 0.0
+            p[:] = 0.0
+        else:                                                               # :210-215
+            beta_next = np.sqrt(abs(pq))
+            gamma_next = pq / beta_next
+            q[:] = q / beta_next
+            p[:] = p / gamma_next
+        nt[pa + 1] = beta_next                                              # :216-221
+        nh[pa + 1] = gamma_next
+        if i + 1 <= k - 1:
+            nt[pa + 2] = gamma_next
+            nh[pa + 2] = beta_next
+        pa += 3
+    return V, beta1, nt, U, gamma1, nh
+
+
+def saunders_simon_yip(A, At, b, c, k, allow_breakdown=False):
+    """src/krylov_processes.jl:431-524.  A: R^n -> R^m.  Returns V (m x (k+1)), beta1, nzval_T, U (n x (k+1)), gamma1, nzval_Tt."""
+    m, n = b.size, c.size
+    V = np.zeros((m, k + 1), order="F")
+    U = np.zeros((n, k + 1), order="F")
+    nt, nh = np.zeros(3 * k - 1), np.zeros(3 * k - 1)
+    beta1 = gamma1 = 0.0
+    pa = 0
+    for i in range(k):
+        vi, ui, q, p = V[:, i], U[:, i], V[:, i + 1], U[:, i + 1]
+        if i == 0:                                                          # :470-485
+            beta1 = _first(vi, b, allow_breakdown, "β₁")
+            gamma1 = _first(ui, c, allow_breakdown, "γ₁ᴴ")
+        q[:] = A(np.ascontiguousarray(ui))                                  # :486
+        p[:] = At(np.ascontiguousarray(vi))                                 # :487
+        if i >= 1:                                                          # :488-495
+            beta_i, gamma_i = nt[pa - 2], nt[pa - 1]
+            _o.axpy(-gamma_i, V[:, i - 1], q)
+            _o.axpy(-beta_i, U[:, i - 1], p)
+        alpha = _o.dot(vi, q)                                               # :496
+        nt[pa] = alpha
+        nh[pa] = alpha
+        _o.axpy(-alpha, vi, q)                                              # :499
+        _o.axpy(-alpha, ui, p)                                              # :500
+        beta_next = _o.nrm2(q)                                              # :501
+        _normalise(q, beta_next, allow_breakdown, "βᵢ₊₁", i + 1)
+        gamma_next = _o.nrm2(p)                                             # :508
+        _normalise(p, gamma_next, allow_breakdown, "γᵢ₊₁", i + 1)
+        nt[pa + 1] = beta_next                                              # :515-520
+        nh[pa + 1] = gamma_next
+        if i + 1 <= k - 1:
+            nt[pa + 2] = gamma_next
+            nh[pa + 2] = beta_next
+        pa += 3
+    return V, beta1, nt, U, gamma1, nh
+
+
+def montoison_orban(A, B, b, c, k, allow_breakdown=False, reorthogonalization=False):
+    """src/krylov_processes.jl:553-632.  A: R^n -> R^m, B: R^m -> R^n.  Returns V, beta, H, U, gamma, F."""
+    m, n = b.size, c.size
+    V = np.zeros((m, k + 1), order="F")
+    U = np.zeros((n, k + 1), order="F")
+    H = np.zeros((k + 1, k), order="F")
+    F = np.zeros((k + 1, k), order="F")
+    beta = gamma = 0.0
+    for j in range(k):
+        vj, uj, q, p = V[:, j], U[:, j], V[:, j + 1], U[:, j + 1]
+        if j == 0:                                                          # :571-586
+            beta = _first(vj, b, allow_breakdown, "β")
+            gamma = _first(uj, c, allow_breakdown, "γ")
+        q[:] = A(np.ascontiguousarray(uj))                                  # :587
+        p[:] = B(np.ascontiguousarray(vj))                                  # :588
+        for i in range(j + 1):                                              # :589-596
+            H[i, j] = _o.dot(V[:, i], q)
+            _o.axpy(-H[i, j], V[:, i], q)
+            F[i, j] = _o.dot(U[:, i], p)
+            _o.axpy(-F[i, j], U[:, i], p)
+        if reorthogonalization:                                             # :597-607
+            for i in range(j + 1):
+                ht = _o.dot(V[:, i], q)
+                _o.axpy(-ht, V[:, i], q)
+                H[i, j] += ht
+                ft = _o.dot(U[:, i], p)
+                _o.axpy(-ft, U[:, i], p)
+                F[i, j] += ft
+        H[j + 1, j] = _o.nrm2(q)                                            # :608
+        _normalise(q, H[j + 1, j], allow_breakdown, "Hᵢ₊₁.ᵢ", j + 1)
+        F[j + 1, j] = _o.nrm2(p)                                            # :615
+        _normalise(p, F[j + 1, j], allow_breakdown, "Fᵢ₊₁.ᵢ", j + 1)
+    return V, beta, H, U, gamma, F

@@ -1,6 +1,8 @@
-"""GPU parity of the Krylov processes (khip_hermitian_lanczos / khip_arnoldi / khip_golub_kahan)
+"""GPU parity of the six Krylov processes (khip_hermitian_lanczos / khip_nonhermitian_lanczos / khip_arnoldi /
+khip_golub_kahan / khip_saunders_simon_yip / khip_montoison_orban)
 against the CPU oracle (oracle/oracle_processes.py) through the C ABI, plus the reference's own assertions
-(test/test_processes.jl:31-117,194-218) evaluated on the device results.
+(test/test_processes.jl:31-190,194-234, shared with the oracle pins through tests/process_checks.py) evaluated on
+the device results.
 
 Tolerances (fp64): the processes are short recurrences whose rounding differences grow with the step count, so the
 parity bound is stated per quantity for k = 20 steps:
@@ -175,3 +177,116 @@ def test_process_argument_checks(K, ctx):
     assert bad == -1
     bad = K.lib().khip_arnoldi(ctx._h, op, 2, b.ptr, 0, 0, 0, V.ptr, V.ld, C.byref(beta), H.ctypes.data_as(K.c_double_p))
     assert bad == -1
+
+
+# ---------------------------------------------------------------------------------- two-sided processes
+
+def _rand_sparse(m, n, seed, density=0.05, shift=0.0):
+    import scipy.sparse as sp
+    S = sp.random(m, n, density=density, random_state=seed, format="csr")
+    if shift:
+        S = S + shift * sp.eye(m, n, format="csr")
+    S = S.tocsr()
+    S.sort_indices()
+    return S
+
+
+def _T(S):
+    St = S.T.tocsr()
+    St.sort_indices()
+    return St
+
+
+def test_nonhermitian_lanczos_matches_oracle(K, ctx, oracle, parity_log):
+    import oracle_processes as P
+    import process_checks as pc
+    n, k = 500, 20
+    S = _rand_sparse(n, n, 21, shift=4.0)
+    rng = np.random.default_rng(8)
+    b, c = rng.random(n), rng.random(n)
+    Vr, b1r, ntr, Ur, g1r, nhr = P.nonhermitian_lanczos(_serial_matvec(S), _serial_matvec(_T(S)), b, c, k)
+    V, b1, T, U, g1, Tt = K.nonhermitian_lanczos(_upload(K, ctx, S), ctx.array(b), ctx.array(c), k)
+    Vh, Uh = V.to_host(), U.to_host()
+    pc.check_nonhermitian_lanczos(S.toarray(), b, c, k, Vh, b1, T.toarray(), Uh, g1, Tt.toarray())   # test/test_processes.jl:59-65
+    dcoef = float(max(np.max(np.abs(T.data - ntr)), np.max(np.abs(Tt.data - nhr))) / np.max(np.abs(ntr)))
+    dbasis = float(max(np.max(np.abs(Vh - Vr)), np.max(np.abs(Uh - Ur))))
+    parity_log(test="nonhermitian_lanczos", n=n, k=k, coef_rel=dcoef, basis_abs=dbasis)
+    assert abs(b1 - b1r) <= 4 * EPS * b1r and abs(g1 - g1r) <= 4 * EPS * abs(g1r)
+    assert dcoef <= COEF_RTOL and dbasis <= BASIS_TOL
+
+
+def test_saunders_simon_yip_matches_oracle(K, ctx, oracle, parity_log):
+    import oracle_processes as P
+    import process_checks as pc
+    m, n, k = 250, 500, 20
+    S = _rand_sparse(m, n, 22)
+    rng = np.random.default_rng(9)
+    b, c = rng.random(m), rng.random(n)
+    Vr, b1r, ntr, Ur, g1r, nhr = P.saunders_simon_yip(_serial_matvec(S), _serial_matvec(_T(S)), b, c, k)
+    V, b1, T, U, g1, Tt = K.saunders_simon_yip(_upload(K, ctx, S), ctx.array(b), ctx.array(c), k)
+    Vh, Uh = V.to_host(), U.to_host()
+    assert V.shape == (m, k + 1) and U.shape == (n, k + 1)
+    pc.check_saunders_simon_yip(S.toarray(), b, c, k, Vh, b1, T.toarray(), Uh, g1, Tt.toarray())     # test/test_processes.jl:126-142
+    dcoef = float(max(np.max(np.abs(T.data - ntr)), np.max(np.abs(Tt.data - nhr))) / np.max(np.abs(ntr)))
+    dbasis = float(max(np.max(np.abs(Vh - Vr)), np.max(np.abs(Uh - Ur))))
+    parity_log(test="saunders_simon_yip", m=m, n=n, k=k, coef_rel=dcoef, basis_abs=dbasis)
+    assert abs(b1 - b1r) <= 4 * EPS * b1r and abs(g1 - g1r) <= 4 * EPS * g1r
+    assert dcoef <= COEF_RTOL and dbasis <= BASIS_TOL
+
+
+@pytest.mark.parametrize("reorth", [False, True])
+def test_montoison_orban_matches_oracle(K, ctx, oracle, parity_log, reorth):
+    import oracle_processes as P
+    import process_checks as pc
+    m, n, k = 250, 500, 20
+    SA, SB = _rand_sparse(m, n, 23), _rand_sparse(n, m, 24)
+    rng = np.random.default_rng(10)
+    b, c = rng.random(m), rng.random(n)
+    Vr, br, Hr, Ur, gr, Fr = P.montoison_orban(_serial_matvec(SA), _serial_matvec(SB), b, c, k, reorthogonalization=reorth)
+    V, beta, H, U, gamma, F = K.montoison_orban(_upload(K, ctx, SA), _upload(K, ctx, SB), ctx.array(b), ctx.array(c), k,
+                                                reorthogonalization=reorth)
+    Vh, Uh = V.to_host(), U.to_host()
+    pc.check_montoison_orban(SA.toarray(), SB.toarray(), b, c, k, Vh, beta, H, Uh, gamma, F)         # test/test_processes.jl:155-171
+    dcoef = float(max(np.max(np.abs(H - Hr)) / np.max(np.abs(Hr)), np.max(np.abs(F - Fr)) / np.max(np.abs(Fr))))
+    dbasis = float(max(np.max(np.abs(Vh - Vr)), np.max(np.abs(Uh - Ur))))
+    parity_log(test="montoison_orban", m=m, n=n, k=k, reorth=reorth, coef_rel=dcoef, basis_abs=dbasis)
+    assert abs(beta - br) <= 4 * EPS * br and abs(gamma - gr) <= 4 * EPS * gr
+    assert dcoef <= COEF_RTOL and dbasis <= BASIS_TOL
+
+
+def test_two_sided_exact_breakdowns(K, ctx):
+    """test/test_processes.jl:205-234: A0 = I and the reference's ssy_mo_breakdown{,2,3} matrices
+    (test/test_utils.jl:396-420) -- same error text at the same iteration."""
+    import process_checks as pc
+    import scipy.sparse as sp
+
+    def dev(M):
+        return _upload(K, ctx, sp.csr_matrix(M))
+
+    def raises(msg, fn, *a, **kw):
+        with pytest.raises(K.KhipError) as e:
+            fn(*a, **kw)
+        assert str(e.value).endswith(msg), str(e.value)
+
+    A0, b0, c0 = dev(np.eye(2)), ctx.zeros(2), ctx.array(np.ones(2))
+    (M1, b1, c1), (M2, b2, c2), (M3, b3, c3) = pc.ssy_mo_breakdown(), pc.ssy_mo_breakdown2(), pc.ssy_mo_breakdown3()
+    A1, A2, A3 = dev(M1), dev(M2), dev(M3)
+    A1t, A2t, A3t = dev(M1.T), dev(M2.T), dev(M3.T)
+    d = ctx.array
+    raises("Exact breakdown β₁γ₁ == 0.", K.nonhermitian_lanczos, A0, b0, c0, 2)
+    V, beta, T, U, gamma, Tt = K.nonhermitian_lanczos(A0, b0, c0, 2, allow_breakdown=True)
+    assert beta == 0.0 and gamma == 0.0 and not V.to_host().any() and not U.to_host().any() and not T.toarray().any()
+    raises("Exact breakdown β₁ == 0.", K.saunders_simon_yip, A0, b0, c0, 2)
+    K.saunders_simon_yip(A0, b0, c0, 2, allow_breakdown=True)
+    raises("Exact breakdown γ₁ᴴ == 0.", K.saunders_simon_yip, A0, c0, b0, 2)
+    K.saunders_simon_yip(A0, c0, b0, 2, allow_breakdown=True)
+    raises("Exact breakdown βᵢ₊₁ == 0 at iteration i = 1.", K.saunders_simon_yip, A1, d(b1), d(c1), 1)
+    raises("Exact breakdown βᵢ₊₁ == 0 at iteration i = 2.", K.saunders_simon_yip, A2, d(b2), d(c2), 2)
+    raises("Exact breakdown γᵢ₊₁ == 0 at iteration i = 2.", K.saunders_simon_yip, A3, d(b3), d(c3), 2)
+    raises("Exact breakdown β == 0.", K.montoison_orban, A0, A0, b0, c0, 2)
+    K.montoison_orban(A0, A0, b0, c0, 2, allow_breakdown=True)
+    raises("Exact breakdown γ == 0.", K.montoison_orban, A0, A0, c0, b0, 2)
+    K.montoison_orban(A0, A0, c0, b0, 2, allow_breakdown=True)
+    raises("Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 1.", K.montoison_orban, A1, A1t, d(b1), d(c1), 1)
+    raises("Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 2.", K.montoison_orban, A2, A2t, d(b2), d(c2), 2)
+    raises("Exact breakdown Fᵢ₊₁.ᵢ == 0 at iteration i = 2.", K.montoison_orban, A3, A3t, d(b3), d(c3), 2)

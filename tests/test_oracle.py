@@ -511,3 +511,62 @@ def test_processes_exact_breakdown_messages(oracle):
         P.hermitian_lanczos(A0, np.array([1.0, 0.0]), 2)
     with pytest.raises(P.Breakdown, match="Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 1."):
         P.arnoldi(A0, np.array([1.0, 0.0]), 2)
+
+
+def _tri(P, k, nz):
+    import scipy.sparse as sp
+    colptr, rowval = P.tridiag_pattern(k)
+    return sp.csc_matrix((nz, rowval, colptr), shape=(k + 1, k)).toarray()
+
+
+def test_processes_two_sided_reference_assertions(oracle):
+    """test/test_processes.jl:53-74 (non-Hermitian Lanczos), :120-152 (Saunders-Simon-Yip), :147-190 (Montoison-Orban)."""
+    import oracle_processes as P
+    import process_checks as pc
+    m, n, k = 250, 500, 20
+    rng = np.random.default_rng(4)
+    A = rng.random((n, n)); b = rng.random(n); c = rng.random(n)
+    V, b1, nt, U, g1, nh = P.nonhermitian_lanczos(lambda x: A @ x, lambda y: A.T @ y, b, c, k)
+    pc.check_nonhermitian_lanczos(A, b, c, k, V, b1, _tri(P, k, nt), U, g1, _tri(P, k, nh))
+
+    A = rng.random((m, n)); b = rng.random(m); c = rng.random(n)
+    V, b1, nt, U, g1, nh = P.saunders_simon_yip(lambda x: A @ x, lambda y: A.T @ y, b, c, k)
+    pc.check_saunders_simon_yip(A, b, c, k, V, b1, _tri(P, k, nt), U, g1, _tri(P, k, nh))
+
+    B = rng.random((n, m))
+    for reorth in (False, True):
+        V, beta, H, U, gamma, F = P.montoison_orban(lambda x: A @ x, lambda y: B @ y, b, c, k, reorthogonalization=reorth)
+        pc.check_montoison_orban(A, B, b, c, k, V, beta, H, U, gamma, F)
+
+
+def test_processes_two_sided_breakdowns(oracle):
+    """test/test_processes.jl:205-234 on A0 = I and the reference's ssy_mo_breakdown{,2,3} matrices."""
+    import oracle_processes as P
+    import process_checks as pc
+    op = lambda M: (lambda x: M @ x)
+    A0, b0, c0 = np.eye(2), np.zeros(2), np.ones(2)
+    A1, b1, c1 = pc.ssy_mo_breakdown()
+    A2, b2, c2 = pc.ssy_mo_breakdown2()
+    A3, b3, c3 = pc.ssy_mo_breakdown3()
+
+    def raises(msg, fn, *a, **kw):
+        with pytest.raises(P.Breakdown) as e:
+            fn(*a, **kw)
+        assert str(e.value) == msg
+
+    raises("Exact breakdown β₁γ₁ == 0.", P.nonhermitian_lanczos, op(A0), op(A0.T), b0, c0, 2)
+    P.nonhermitian_lanczos(op(A0), op(A0.T), b0, c0, 2, allow_breakdown=True)
+    raises("Exact breakdown β₁ == 0.", P.saunders_simon_yip, op(A0), op(A0.T), b0, c0, 2)
+    P.saunders_simon_yip(op(A0), op(A0.T), b0, c0, 2, allow_breakdown=True)
+    raises("Exact breakdown γ₁ᴴ == 0.", P.saunders_simon_yip, op(A0), op(A0.T), c0, b0, 2)
+    P.saunders_simon_yip(op(A0), op(A0.T), c0, b0, 2, allow_breakdown=True)
+    raises("Exact breakdown βᵢ₊₁ == 0 at iteration i = 1.", P.saunders_simon_yip, op(A1), op(A1.T), b1, c1, 1)
+    raises("Exact breakdown βᵢ₊₁ == 0 at iteration i = 2.", P.saunders_simon_yip, op(A2), op(A2.T), b2, c2, 2)
+    raises("Exact breakdown γᵢ₊₁ == 0 at iteration i = 2.", P.saunders_simon_yip, op(A3), op(A3.T), b3, c3, 2)
+    raises("Exact breakdown β == 0.", P.montoison_orban, op(A0), op(A0.T), b0, c0, 2)
+    P.montoison_orban(op(A0), op(A0.T), b0, c0, 2, allow_breakdown=True)
+    raises("Exact breakdown γ == 0.", P.montoison_orban, op(A0), op(A0.T), c0, b0, 2)
+    P.montoison_orban(op(A0), op(A0.T), c0, b0, 2, allow_breakdown=True)
+    raises("Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 1.", P.montoison_orban, op(A1), op(A1.T), b1, c1, 1)
+    raises("Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 2.", P.montoison_orban, op(A2), op(A2.T), b2, c2, 2)
+    raises("Exact breakdown Fᵢ₊₁.ᵢ == 0 at iteration i = 2.", P.montoison_orban, op(A3), op(A3.T), b3, c3, 2)
