@@ -1,5 +1,7 @@
 // csr_aux.hip -- SpMM for row-major panels, CSR set-up helpers (row statistics, index shift, halo
 // gather / remap kernels) and the device-side generators of the benchmark operators.
+#include <type_traits>
+
 #include "spmv_common.hpp"
 
 namespace khip {
@@ -108,6 +110,291 @@ __global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
   }
 }
 
+// Panel-row window in LDS (default for even p on operators with the locality): spmm2_kernel is bound by the gather
+// rate of the vector L1 -- 27 gathers of one 128-byte panel row per matrix row for the 27-point operator,
+// ~19 B/clk/CU -- although consecutive matrix rows of a banded operator reach mostly the SAME panel rows (32 rows of
+// the 27-point stencil touch 9 x 34 distinct ones, not 27 x 32).  Once per handle and lane count L, spmm_window_build
+// (below) finds, for every group of RPB = 256 / L consecutive rows, the list of distinct columns and stores it with a
+// 16-bit slot number per nonzero (+2 B/nonzero and 4 B per list entry of HBM).  The kernel then
+//   1. copies the distinct panel rows of its group ONCE from global memory into LDS (list order = column order, so the
+//      copy runs over contiguous memory) together with the group's (val, slot) entries (fully coalesced),
+//   2. runs the row products out of LDS: per nonzero two broadcast reads (val, slot), one 16-byte panel-row read, the
+//      rounded multiply and the rounded add of spmm2_kernel, in stored order.
+// A group whose rows reach more panel rows or hold more nonzeros than the window takes is flagged at build time and
+// goes down the direct-gather path.  Same operations in the same order => Y is bit-identical to spmm2_kernel /
+// spmm_kernel / p SpMVs.
+//
+// What shaped the kernel (216^3, 27 points, p = 16; tools/spmm_window_check.py, rocprofv3 SQ counters):
+//  * one-shot workgroups: 2.5 ms (direct gathers 3.05 ms) -- ~16 waves per CU, the LDS limit, cannot hide the three
+//    dependent latencies row pointer / list -> panel row -> product;
+//  * persistent workgroups with the next groups prefetched into registers: no gain until the prefetch stages were
+//    STRAIGHT-LINE, LOAD-ONLY code -- any use of a loaded value (a sign extension, a flag test) or any branch between
+//    issue and use makes the compiler emit s_waitcnt vmcnt(0), i.e. wait for everything just issued; __syncthreads()
+//    does the same through its fence, hence lds_barrier();
+//  * after that the kernel was bound by INSTRUCTION ISSUE (~1000 instructions per wave and group, VALU 76 % busy):
+//    64-bit address arithmetic (v_mul_lo_u32, v_mad_u64_u32, owned/ghost selects) and per-entry lane broadcasts.
+//    Hence shifts instead of multiplies when p = 2 L, a DIST template, scalar loads for the per-group words, and
+//    (val, slot) in LDS where a broadcast read replaces three cross-lane moves.
+constexpr int kWinPanelBytes = 44 * 1024;          // LDS for the panel rows
+
+template <int L>
+struct WinShape {
+  static constexpr int RPB = kBlock / L;                       // matrix rows per workgroup
+  static constexpr int CAP = kWinPanelBytes / (16 * L);        // distinct panel rows the window holds
+  static constexpr int STRIDE = (CAP + RPB - 1) / RPB * RPB;   // list entries per row group = panel rows of the LDS window
+  static constexpr int NU = STRIDE / RPB;                      // list entries per lane
+  static constexpr int ENTRIES = RPB * 32;                     // (val, slot) entries of a row group staged in LDS
+  static constexpr int NE = ENTRIES / kBlock;                  // ... per lane
+  static constexpr int HT = CAP <= 256 ? 512 : (CAP <= 512 ? 1024 : (CAP <= 1024 ? 2048 : 4096));   // >= CAP + kBlock, power of 2
+  static constexpr size_t kLds = (size_t)STRIDE * L * 16 + (size_t)(ENTRIES + 8) * 8 + (size_t)(ENTRIES + 8) * 2;
+};
+
+struct WinArgs {
+  const int32_t *list;       // [groups][STRIDE]: the distinct columns of a row group (ascending-ish), padded with 0
+  const uint16_t *slot;      // per nonzero: position of its column in the group's list
+  const int32_t *flag;       // per row group: 1 = direct-gather group
+  int64_t groups;
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup fence + s_barrier and the fence
+// drains vmcnt as well, i.e. it would wait for the prefetches of the next groups at every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NU, int NE>
+struct WinSet {                // what a lane holds of one row group in flight
+  int key[NU];                 // stage A: its list entries,
+  int32_t s, e;                //          the extent of its row (raw loaded words: no arithmetic before the next iteration),
+  int32_t gs, flag;            //          the group's first nonzero and its direct flag (uniform: scalar loads)
+  dbl2 v[NU];                  // stage B: its 16-byte pieces of the panel rows
+  double ev[NE];               //          and its share of the group's (val, slot) entries
+  unsigned short es[NE];
+};
+
+template <int L, bool DIST, bool POW2>        // POW2: p == 2 L, a panel row is 16 L bytes and its offset a shift
+__global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs w, int p) {
+  using W = WinShape<L>;
+  constexpr int NU = W::NU, NE = W::NE;
+  using Set = WinSet<NU, NE>;
+  extern __shared__ dbl2 win_xs[];                                           // [STRIDE][L] panel rows
+  double *win_val = reinterpret_cast<double *>(win_xs + W::STRIDE * L);      // [ENTRIES + 8]
+  unsigned short *win_slot = reinterpret_cast<unsigned short *>(win_val + W::ENTRIES + 8);
+  const int tid = threadIdx.x, sub = tid / L, c = tid % L;
+  const bool col_ok = 2 * c + 1 < p;
+  const int piece = col_ok ? 2 * c : 0;
+  const int64_t G = gridDim.x;
+  const int nnz_last = (int)(a.nnz_bound - 1);
+  if (tid < 8) { win_val[W::ENTRIES + tid] = 0.0; win_slot[W::ENTRIES + tid] = 0; }   // spare entries the tail batch may read
+
+  // Stages A and B are straight-line code: loads only, no use of a loaded value, no branch.  Indices past the end are
+  // clamped and the results ignored.
+  auto stage_a = [&](int64_t g, Set &z) {
+    const int64_t gg = g < w.groups ? g : w.groups - 1;
+    const int32_t *lst = w.list + gg * (int64_t)W::STRIDE;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) z.key[j] = lst[sub + j * W::RPB];
+    const int64_t row = a.row_lo + gg * W::RPB + sub;
+    const int64_t rr = row < a.row_hi ? row : a.row_hi - 1;
+    z.s = a.rowptr[rr];
+    z.e = a.rowptr[rr + 1];
+    z.gs = a.rowptr[a.row_lo + gg * W::RPB];
+    z.flag = w.flag[gg];
+  };
+  auto stage_b = [&](Set &z) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      unsigned q = (unsigned)(z.gs + tid + k * kBlock);
+      q = q < (unsigned)nnz_last ? q : (unsigned)nnz_last;
+      z.ev[k] = a.val[q];
+      z.es[k] = w.slot[q];
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const unsigned key = (unsigned)z.key[j];
+      const double *src = a.x;
+      uint64_t r = key;
+      if (DIST) {
+        const bool own = (int64_t)key < a.n_owned;
+        src = own ? a.x : a.ghost;
+        r = own ? r : r - (uint64_t)a.n_owned;
+      }
+      uint64_t off;
+      if (POW2) {
+        constexpr int SH = L == 2 ? 5 : (L == 4 ? 6 : (L == 8 ? 7 : (L == 16 ? 8 : 9)));      // log2(16 L)
+        off = r << SH;
+      } else {
+        off = r * (uint64_t)(unsigned)(p * 8);
+      }
+      z.v[j] = *reinterpret_cast<const dbl2 *>(reinterpret_cast<const char *>(src) + off + piece * 8);
+    }
+  };
+  // stage C of group g out of `cur`, while B runs for g + G into `nxt` and A for g + 2 G reuses the key registers of `cur`.
+  // The two sets swap roles every iteration (the loop below is unrolled by two): a register copy of a set would wait
+  // for the loads that are still filling it.
+  auto iteration = [&](int64_t g, Set &cur, Set &nxt) {
+    const int64_t row = a.row_lo + g * W::RPB + sub;
+    const bool row_ok = row < a.row_hi;
+    const int sC = cur.s, eC = row_ok ? cur.e : cur.s;
+    const int gsC = __builtin_amdgcn_readfirstlane(cur.gs);
+    const bool directC = __builtin_amdgcn_readfirstlane(cur.flag) != 0;
+    if (!directC) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j) win_xs[(sub + j * W::RPB) * L + c] = cur.v[j];
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        win_val[tid + k * kBlock] = cur.ev[k];
+        win_slot[tid + k * kBlock] = cur.es[k];
+      }
+    }
+    lds_barrier();
+    stage_b(nxt);
+    stage_a(g + 2 * G, cur);
+    if (directC) {
+      if (row_ok) {
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int64_t base = sC; base < eC; base += L) {
+          const int cnt = (int)((eC - base) < L ? (eC - base) : L);
+          const bool mine = c < cnt;
+          const double myv = mine ? a.val[base + c] : 0.0;
+          const int32_t myc = mine ? a.col[base + c] : 0;
+          dbl2 xg[L];
+#pragma unroll
+          for (int t = 0; t < L; ++t) {
+            const int32_t cc = __shfl(myc, t, L);
+            xg[t] = dbl2{0.0, 0.0};
+            const bool own = cc < a.n_owned;
+            const double *src = own ? a.x : a.ghost;
+            const int64_t r = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
+            if (t < cnt && col_ok) xg[t] = *reinterpret_cast<const dbl2 *>(src + r * p + 2 * c);
+          }
+#pragma unroll
+          for (int t = 0; t < L; ++t) {
+            const double vv = __shfl(myv, t, L);
+            if (t < cnt) {
+              const double p0 = vv * xg[t].x, p1 = vv * xg[t].y;
+              acc0 = acc0 + p0;
+              acc1 = acc1 + p1;
+            }
+          }
+        }
+        if (col_ok) *reinterpret_cast<dbl2 *>(a.y + row * p + 2 * c) = dbl2{acc0, acc1};
+      }
+    } else {
+      // every lane of a row reads the row's (val, slot) stream at the same LDS address (a broadcast), then its own
+      // 16 bytes of the panel row.  Batches of 8 entries: all reads of a batch are issued before its first product.
+      const int len = eC - sC;
+      const double *lv = win_val + (sC - gsC);
+      const unsigned short *lsl = win_slot + (sC - gsC);
+      const dbl2 *xc = win_xs + c;
+      double acc0 = 0.0, acc1 = 0.0;
+      const int len0 = __builtin_amdgcn_readfirstlane(len);
+      if (__ballot(len != len0) == 0) {
+        // the wave's rows are equally long (interior of a stencil): scalar loop bounds, no masks
+        int t0 = 0;
+        for (; t0 + 8 <= len0; t0 += 8) {
+          double vv[8];
+          int sl[8];
+          dbl2 xv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { vv[k] = lv[t0 + k]; sl[k] = lsl[t0 + k]; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xv[k] = xc[sl[k] * L];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const double p0 = vv[k] * xv[k].x, p1 = vv[k] * xv[k].y;
+            acc0 = acc0 + p0;
+            acc1 = acc1 + p1;
+          }
+        }
+        if (t0 < len0) {
+          // tail: the reads run past the row (into the next rows' entries or the 8 spare ones: valid slots all),
+          // the products stop at the uniform bound
+          const int n = len0 - t0;
+          double vv[8];
+          int sl[8];
+          dbl2 xv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { vv[k] = lv[t0 + k]; sl[k] = lsl[t0 + k]; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xv[k] = xc[sl[k] * L];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (k < n) {
+              const double p0 = vv[k] * xv[k].x, p1 = vv[k] * xv[k].y;
+              acc0 = acc0 + p0;
+              acc1 = acc1 + p1;
+            }
+          }
+        }
+      } else {
+        for (int t0 = 0; __any(t0 < len); t0 += 8) {
+          double vv[8];
+          int sl[8];
+          dbl2 xv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k < len ? t0 + k : 0;       // past the end of the row: its first entry, not used
+            vv[k] = lv[t];
+            sl[k] = lsl[t];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xv[k] = xc[sl[k] * L];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            if (t0 + k < len) {
+              const double p0 = vv[k] * xv[k].x, p1 = vv[k] * xv[k].y;
+              acc0 = acc0 + p0;
+              acc1 = acc1 + p1;
+            }
+          }
+        }
+      }
+      if (row_ok && col_ok) *reinterpret_cast<dbl2 *>(a.y + row * p + 2 * c) = dbl2{acc0, acc1};
+    }
+    lds_barrier();
+  };
+
+  Set P, Q;
+  int64_t g = blockIdx.x;
+  stage_a(g, P);
+  stage_b(P);
+  stage_a(g + G, Q);
+  for (;;) {
+    if (g >= w.groups) break;
+    iteration(g, P, Q);
+    g += G;
+    if (g >= w.groups) break;
+    iteration(g, Q, P);
+    g += G;
+  }
+}
+
+int spmm_window_build(khip_ctx *ctx, khip_csr *A, int L);   // below
+
+template <int L>
+static void launch_window(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p) {
+  using W = WinShape<L>;
+  const int64_t groups = (A->m + W::RPB - 1) / W::RPB;
+  WinArgs w{A->win_list, A->win_slot, A->win_flag, groups};
+  const size_t lds = W::kLds;
+  int per_cu = (int)((size_t)(160 * 1024) / lds);                                 // LDS-limited residency ...
+  if (per_cu > 2) per_cu = 2;                                                     // ... and two waves per SIMD by registers
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = (int64_t)ctx->num_cu * per_cu * 3;         // 3 x the resident workgroups: the queue evens out the tail (measured 2 %)
+  if (ctx->tune.spmm_window_grid > 0) grid = ctx->tune.spmm_window_grid;
+  if (grid > groups) grid = groups;
+  const bool dist = a.ghost != a.x, pow2 = p == 2 * L;
+  const dim3 gd((unsigned)grid), bd(kBlock);
+  if (lds > 64 * 1024) {                 // beyond the default dynamic-LDS limit: raise it for the instantiation about to run
+    const void *fn = dist ? (pow2 ? (const void *)spmm_window_kernel<L, true, true> : (const void *)spmm_window_kernel<L, true, false>)
+                          : (pow2 ? (const void *)spmm_window_kernel<L, false, true> : (const void *)spmm_window_kernel<L, false, false>);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (dist && pow2) hipLaunchKernelGGL((spmm_window_kernel<L, true, true>), gd, bd, lds, ctx->stream, a, w, p);
+  else if (dist) hipLaunchKernelGGL((spmm_window_kernel<L, true, false>), gd, bd, lds, ctx->stream, a, w, p);
+  else if (pow2) hipLaunchKernelGGL((spmm_window_kernel<L, false, true>), gd, bd, lds, ctx->stream, a, w, p);
+  else hipLaunchKernelGGL((spmm_window_kernel<L, false, false>), gd, bd, lds, ctx->stream, a, w, p);
+}
+
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {
   if (p < 1 || p > 64) { set_error("spmm: 1 <= p <= 64 required (got %d)", p); return KHIP_ERR_INVALID; }
   SpmvArgs a;
@@ -118,7 +405,8 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
     KHIP_TRY(comm_halo_exchange_end(ctx, A));
     if (A->n_ghost > 0) { a.ghost = A->ghost_w; a.n_owned = A->m; }
   }
-  a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.fake_gather = 0; a.tiles_per_block = 1; a.nnz_bound = A->nnz + kPad;
+  a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.fake_gather = 0; a.tiles_per_block = 1;
+  a.nnz_bound = A->nnz + kPad;
   int P = 4;
   while (P < p) P <<= 1;
   const int rpb = kBlock / P;
@@ -150,6 +438,21 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
     int64_t want2 = (A->m + rpb2 - 1) / rpb2;
     const int grid2 = (int)(want2 < gcap ? (want2 > 0 ? want2 : 1) : gcap);
     a.sweep_s = 0;
+    if (ctx->tune.spmm_window && want2 <= gcap && A->m > 0) {      // panel-row window in LDS: one row group per workgroup
+      khip_csr *Aw = const_cast<khip_csr *>(A);
+      if (Aw->win_L != L && Aw->win_L != -L) KHIP_TRY(spmm_window_build(ctx, Aw, L));
+      if (Aw->win_L == L) {
+        switch (L) {
+          case 2: launch_window<2>(ctx, A, a, p); break;
+          case 4: launch_window<4>(ctx, A, a, p); break;
+          case 8: launch_window<8>(ctx, A, a, p); break;
+          case 16: launch_window<16>(ctx, A, a, p); break;
+          default: launch_window<32>(ctx, A, a, p); break;
+        }
+        KHIP_CHECK_HIP(hipGetLastError());
+        return KHIP_OK;
+      }
+    }
     switch (L) {
       case 2: hipLaunchKernelGGL((spmm2_kernel<2>), dim3(grid2), dim3(kBlock), 0, ctx->stream, a, p); break;
       case 4: hipLaunchKernelGGL((spmm2_kernel<4>), dim3(grid2), dim3(kBlock), 0, ctx->stream, a, p); break;
@@ -635,6 +938,154 @@ int csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr *T) {
     if (e != hipSuccess) { set_error("csr_transpose: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
   }
   return csr_finalize(ctx, T);
+}
+
+// ---------------------------------------------------------------- SpMM window metadata ----------
+// One workgroup per group of RPB consecutive rows: the distinct columns of the group through an LDS hash set
+// (identity hash + linear probing, so neighbouring columns stay neighbours), numbered in slot order by a prefix sum
+// => the list of a banded operator comes out in (nearly) ascending column order and the kernel's copy of the panel rows
+// runs over contiguous memory.  FILL = false counts (cnt[g] = -1 when the group does not fit), FILL = true writes the
+// list at base[g] and the 16-bit slot of every nonzero.
+constexpr int kWinEmpty = -1;
+
+template <int L, bool FILL>
+__global__ __launch_bounds__(kBlock) void spmm_window_build_kernel(const int32_t *rowptr, const int32_t *col, int64_t m,
+                                                                    int32_t *cnt, int stride, int32_t *list, uint16_t *slot,
+                                                                    unsigned long long *stat) {
+  using W = WinShape<L>;
+  constexpr int PER = W::HT / kBlock;            // consecutive hash slots per thread in the numbering pass
+  __shared__ int keys[W::HT];
+  __shared__ unsigned short ids[W::HT];
+  __shared__ int part[kBlock];
+  __shared__ int count, overflow;
+  const int tid = threadIdx.x, sub = tid / L, c = tid % L;
+  const int64_t row = (int64_t)blockIdx.x * W::RPB + sub;
+  if (FILL && cnt[blockIdx.x] < 0) return;       // direct group: its list stays zero
+
+  for (int h = tid; h < W::HT; h += kBlock) keys[h] = kWinEmpty;
+  if (tid == 0) { count = 0; overflow = 0; }
+  __syncthreads();
+  int64_t s = 0, e = 0;
+  if (row < m) { s = rowptr[row]; e = rowptr[row + 1]; }
+  for (int64_t q = s + c; q < e; q += L) {
+    if (__atomic_load_n(&overflow, __ATOMIC_RELAXED)) break;
+    const int key = col[q];
+    unsigned h = (unsigned)key & (W::HT - 1);
+    for (;;) {
+      const int k = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
+      if (k == key) break;
+      if (k == kWinEmpty) {
+        const int old = atomicCAS(&keys[h], kWinEmpty, key);
+        if (old == kWinEmpty) {
+          if (atomicAdd(&count, 1) >= W::CAP) __atomic_store_n(&overflow, 1, __ATOMIC_RELAXED);
+          break;
+        }
+        if (old == key) break;
+      }
+      h = (h + 1) & (W::HT - 1);
+    }
+  }
+  __syncthreads();
+  if (!FILL) {
+    if (tid == 0) {
+      const int64_t r0 = (int64_t)blockIdx.x * W::RPB, r1 = r0 + W::RPB < m ? r0 + W::RPB : m;
+      const bool direct = overflow != 0 || rowptr[r1] - rowptr[r0] > W::ENTRIES;
+      cnt[blockIdx.x] = direct ? -1 : count;
+      if (direct) atomicAdd(&stat[0], 1ull);
+      else { atomicMax(&stat[1], (unsigned long long)count); atomicAdd(&stat[2], (unsigned long long)count); }
+    }
+    return;
+  }
+  // numbering in slot order: thread t owns slots [t PER, (t + 1) PER)
+  int mine = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) mine += keys[tid * PER + j] != kWinEmpty;
+  part[tid] = mine;
+  __syncthreads();
+  int before = 0;
+  for (int t = 0; t < tid; ++t) before += part[t];
+  int32_t *lst = list + (int64_t)blockIdx.x * stride;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int k = keys[tid * PER + j];
+    if (k != kWinEmpty) {
+      ids[tid * PER + j] = (unsigned short)before;
+      lst[before] = k;
+      ++before;
+    }
+  }
+  __syncthreads();
+  for (int64_t q = s + c; q < e; q += L) {
+    const int key = col[q];
+    unsigned h = (unsigned)key & (W::HT - 1);
+    while (keys[h] != key) h = (h + 1) & (W::HT - 1);
+    slot[q] = ids[h];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void window_flag_kernel(const int32_t *cnt, int64_t groups, int32_t *flag) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g < groups) flag[g] = cnt[g] < 0 ? 1 : 0;
+}
+
+void csr_free_window(khip_csr *A) {
+  (void)hipFree(A->win_list); (void)hipFree(A->win_slot); (void)hipFree(A->win_flag);
+  A->win_list = nullptr; A->win_slot = nullptr; A->win_flag = nullptr;
+  A->win_L = 0;
+}
+
+template <int L>
+static int window_build_t(khip_ctx *ctx, khip_csr *A) {
+  using W = WinShape<L>;
+  const int64_t groups = (A->m + W::RPB - 1) / W::RPB;
+  int32_t *cnt = nullptr;
+  unsigned long long *stat = nullptr;            // [0] groups on the direct path, [1] largest list, [2] sum of the lists
+  struct Scratch { int32_t *&c; unsigned long long *&s; ~Scratch() { (void)hipFree(c); (void)hipFree(s); } } scratch{cnt, stat};
+  KHIP_CHECK_HIP(hipMalloc(&cnt, sizeof(int32_t) * (size_t)groups));
+  KHIP_CHECK_HIP(hipMalloc(&stat, 3 * sizeof(unsigned long long)));
+  KHIP_CHECK_HIP(hipMemsetAsync(stat, 0, 3 * sizeof(unsigned long long), ctx->stream));
+  hipLaunchKernelGGL((spmm_window_build_kernel<L, false>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col,
+                     A->m, cnt, 0, nullptr, nullptr, stat);
+  KHIP_CHECK_HIP(hipGetLastError());
+  unsigned long long st[3] = {0, 0, 0};
+  KHIP_CHECK_HIP(hipMemcpyAsync(st, stat, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  // worth it only when most groups fit and the rows really share panel rows (>= 1.5 references per distinct column)
+  if (2 * (long long)st[0] > groups || st[2] == 0 || 2 * (unsigned long long)A->nnz < 3 * st[2]) { A->win_L = -L; return KHIP_OK; }
+  const int stride = W::STRIDE;
+  KHIP_CHECK_HIP(hipMalloc(&A->win_list, sizeof(int32_t) * (size_t)groups * stride));
+  KHIP_CHECK_HIP(hipMalloc(&A->win_slot, sizeof(uint16_t) * (size_t)(A->nnz + kPad)));
+  KHIP_CHECK_HIP(hipMalloc(&A->win_flag, sizeof(int32_t) * (size_t)groups));
+  KHIP_CHECK_HIP(hipMemsetAsync(A->win_list, 0, sizeof(int32_t) * (size_t)groups * stride, ctx->stream));       // padding: column 0
+  KHIP_CHECK_HIP(hipMemsetAsync(A->win_slot, 0, sizeof(uint16_t) * (size_t)(A->nnz + kPad), ctx->stream));
+  hipLaunchKernelGGL(window_flag_kernel, dim3((unsigned)((groups + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, cnt, groups,
+                     A->win_flag);
+  hipLaunchKernelGGL((spmm_window_build_kernel<L, true>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col,
+                     A->m, cnt, stride, A->win_list, A->win_slot, nullptr);
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  A->win_L = L;
+  return KHIP_OK;
+}
+
+// Builds (or rebuilds for another lane count) the window metadata of A.  On return A->win_L == L (usable) or -L (the
+// operator lacks the locality, or memory is short: the caller keeps the direct-gather kernel and does not ask again).
+int spmm_window_build(khip_ctx *ctx, khip_csr *A, int L) {
+  csr_free_window(A);
+  int rc;
+  switch (L) {
+    case 2: rc = window_build_t<2>(ctx, A); break;
+    case 4: rc = window_build_t<4>(ctx, A); break;
+    case 8: rc = window_build_t<8>(ctx, A); break;
+    case 16: rc = window_build_t<16>(ctx, A); break;
+    default: rc = window_build_t<32>(ctx, A); break;
+  }
+  if (rc != KHIP_OK || A->win_L != L) {          // not usable: release whatever was allocated, remember the answer
+    (void)hipGetLastError();
+    csr_free_window(A);
+    A->win_L = -L;
+  }
+  return KHIP_OK;
 }
 
 }  // namespace khip

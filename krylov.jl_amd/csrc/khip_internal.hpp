@@ -74,6 +74,8 @@ struct Tuning {
   int hist_window = 1 << 14;   // device-resident loops: residual-history entries kept on the device between drains
   int red_u = 0;            // reductions: 16-byte accesses per lane (0 auto: 4 for long vectors, else 1)
   int spmm_wide = 1;        // SpMM: two panel columns per lane (16-byte gathers) when p is even
+  int spmm_window_grid = 0; // workgroups of the persistent window kernel (0 = CUs x LDS-limited residency)
+  int spmm_window = 1;      // SpMM: stage the distinct panel rows of a row group in LDS (csr_aux.hip, spmm_window_kernel)
   int spmm_sweep = 0;       // SpMM: plane-sweep tile order when the band is wider than the L2 can hold (csr_aux.hip)
   int spmm_sweep_s = 0;     // tiles per plane (0 = from the handle's band width)
   int spmm_sweep_w = 64;    // tiles per XCD column
@@ -151,6 +153,11 @@ struct khip_csr {
   double *tmpl_val = nullptr;          // [T][K]
   int32_t *tmpl_cnt = nullptr;         // [T]
   int tmpl_T = 0, tmpl_K = 0;
+  // optional SpMM panel-row window (csr_aux.hip, built on the first SpMM that can use it)
+  int win_L = 0;                       // lanes per row the metadata was built for; -L = tried, not usable; 0 = not tried
+  int32_t *win_list = nullptr;         // [groups][STRIDE(L)] distinct columns of a row group, padded with 0
+  int32_t *win_flag = nullptr;         // per row group: 1 = direct-gather group (too many panel rows or nonzeros for the window)
+  uint16_t *win_slot = nullptr;        // per nonzero: position of its column in the group's list
 };
 
 namespace khip {
@@ -225,6 +232,7 @@ int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 
 // template.hip
 void csr_free_templates(khip_csr *A);
+void csr_free_window(khip_csr *A);
 
 // api.cpp: the MGS cascade of khip_mgs in two halves (enqueue: launches only; the k coefficients and ||q||^2 end up in
 // results[slot .. slot + k], all-reduced on the device when there are several ranks)

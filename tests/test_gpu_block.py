@@ -160,3 +160,79 @@ def test_block_gmres_preconditioners(K, ctx, oracle):
     # operator given as a callback instead of a CSR handle
     X, st, _ = K.block_gmres(lambda Xp, Yp: K.spmm_(dA, Xp, Yp), B, memory=8, ctx=ctx)
     assert st.solved and np.abs(X - Xt).max() <= 1e-5
+
+
+# ---- SpMM with the panel-row window in LDS (csr_aux.hip, spmm_window_kernel) ------------------------------------
+
+def _spmm_both(K, ctx, dA, X, p):
+    """Y with the window kernel (default) and with the direct-gather kernel, as host arrays."""
+    dX = K.Panel.from_host(ctx, X)
+    out = []
+    for window in (1, 0):
+        ctx.set_option("spmm_window", window)
+        dY = K.Panel(ctx, dA.m, p)
+        K.spmm_(dA, dX, dY)
+        out.append(dY.to_host())
+    ctx.set_option("spmm_window", 1)
+    return out
+
+
+@pytest.mark.parametrize("p", [2, 4, 6, 8, 12, 16, 24, 32])
+def test_spmm_window_bit_identical_to_columnwise_spmv(K, ctx, oracle, p):
+    """27-point operator (the rows of a group share panel rows: window path) -- Y == the direct-gather kernel == p SpMVs."""
+    A = oracle.stencil27_unsym(14)
+    X = np.random.default_rng(p).standard_normal((A.n, p))
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (A.n, A.n))
+    Yw, Yd = _spmm_both(K, ctx, dA, X, p)
+    ref = np.stack([A.matvec(np.ascontiguousarray(X[:, j])) for j in range(p)], axis=1)
+    assert np.array_equal(Yw, Yd) and np.array_equal(Yw, ref)
+
+
+def test_spmm_window_mixed_groups_and_fallbacks(K, ctx, oracle):
+    """(a) a banded operator with a few dense rows: their groups exceed the window and take the direct path inside the
+    window kernel; (b) a scattered operator: no locality, the handle keeps the direct-gather kernel; (c) rectangular;
+    (d) rows of very different length in one wave (non-uniform path) incl. empty rows."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    n, p = 6000, 16
+
+    def check(S, tag):
+        S = S.tocsr()
+        S.sort_indices()
+        dA = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data.copy(), S.shape)
+        X = rng.standard_normal((S.shape[1], p))
+        Yw, Yd = _spmm_both(K, ctx, dA, X, p)
+        ref = np.zeros((S.shape[0], p))
+        for i in range(S.shape[0]):                      # serial row loops, column by column = the order of the kernels
+            for q in range(S.indptr[i], S.indptr[i + 1]):
+                ref[i] = ref[i] + S.data[q] * X[S.indices[q]]
+        assert np.array_equal(Yw, Yd), tag
+        assert np.array_equal(Yw, ref), tag
+
+    band = sp.diags([rng.standard_normal(n - abs(k)) for k in range(-6, 7)], list(range(-6, 7)), format="lil")
+    for r in (100, 101, 3333):                           # dense rows: > window capacity in panel rows and in nonzeros
+        band[r, :] = rng.standard_normal(n) * (rng.random(n) < 0.3)
+    check(band, "band + dense rows")
+    check(sp.random(n, n, density=0.004, random_state=7) + sp.eye(n), "scattered")
+    check(sp.diags([np.ones(900), 2 * np.ones(900), 3 * np.ones(900)], [0, 40, 1], shape=(900, 1400)), "rectangular")
+    ragged = sp.lil_matrix((n, n))
+    for i in range(n):
+        k = (i * 7) % 23                                 # 0..22 entries, changing from row to row
+        cols = np.unique(np.clip(i + np.arange(k) - k // 2, 0, n - 1))
+        if cols.size:
+            ragged[i, cols] = rng.standard_normal(cols.size)
+    check(ragged, "ragged rows")
+
+
+def test_block_gmres_same_history_with_and_without_window(K, ctx, oracle):
+    A = oracle.stencil27_unsym(12)
+    S = A.to_scipy()
+    B, _ = _rhs(S, A.n, 8)
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (A.n, A.n))
+    res = []
+    for window in (1, 0):
+        ctx.set_option("spmm_window", window)
+        X, st, _ = K.block_gmres(dA, B, memory=6, ctx=ctx, history=True, restart=True, itmax=30)
+        res.append((X, st.niter, np.array(st.residuals)))
+    ctx.set_option("spmm_window", 1)
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][0], res[1][0])
