@@ -192,6 +192,13 @@ int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const d
 /* Q <- beta*Q + alpha * V * Psi  (Psi p-by-p column-major HOST) */
 int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const double *V,
                        const double *Psi_host, double beta, double *Q);
+/* Block Gram-Schmidt sweep of Q against the k panels V[0..k) (device pointers in a HOST array) in the reference's
+ * order (src/block_gmres.jl:244-247): for i: Psi_i = V_i^T Q ; Q <- Q - V_i Psi_i.  Psi_host receives the k blocks
+ * (p x p column-major each, block i at Psi_host + i p p); accumulate != 0 adds them instead (the reorthogonalisation
+ * pass :250-256).  On one GPU Psi_{i+1} is formed by the kernel that applies Psi_i (four panel passes per step
+ * instead of five, one host synchronisation per sweep); same bits as the khip_panel_gemm_tn / _nn sequence. */
+int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, double *Q, double *Psi_host,
+                   int accumulate);
 /* reduced QR of the panel: Q overwritten by an orthonormal basis, R_host (p-by-p col-major,
  * upper triangular, positive... sign convention of Householder: see DESIGN.md) */
 int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host);

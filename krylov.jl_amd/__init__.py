@@ -136,6 +136,7 @@ SIGNATURES = {
     "khip_panel_to_colmajor": (_int, [_vp, _i64, _int, _vp, _vp]),
     "khip_panel_gemm_tn": (_int, [_vp, _i64, _int, _vp, _vp, c_double_p]),
     "khip_panel_gemm_nn": (_int, [_vp, _i64, _int, _dbl, _vp, c_double_p, _dbl, _vp]),
+    "khip_panel_mgs": (_int, [_vp, _i64, _int, _int, c_void_pp, _vp, c_double_p, _int]),
     "khip_panel_qr": (_int, [_vp, _i64, _int, _vp, c_double_p]),
     "khip_panel_norm": (_int, [_vp, _i64, _int, _vp, c_double_p]),
     "khip_comm_unique_id": (_int, [_vp]),
@@ -1197,6 +1198,17 @@ def panel_gemm_nn_(alpha, V: Panel, Psi, beta, Q: Panel) -> Panel:
     Pf = np.asfortranarray(Psi, dtype=np.float64)
     _ck(lib().khip_panel_gemm_nn(V.ctx._h, V.n, V.p, alpha, V.buf.ptr, Pf.ctypes.data_as(c_double_p), beta, Q.buf.ptr))
     return Q
+
+
+def panel_mgs_(V, Q: Panel, accumulate_into=None):
+    """Block Gram-Schmidt sweep of Q against the panels V[0..k) (src/block_gmres.jl:244-247) -> list of k p x p blocks."""
+    k, p = len(V), Q.p
+    ptrs = (C.c_void_p * max(k, 1))(*[v.buf.ptr for v in V])
+    out = np.zeros((k, p * p)) if accumulate_into is None else np.ascontiguousarray(
+        np.stack([np.asarray(b, dtype=np.float64).ravel(order="F") for b in accumulate_into]))
+    _ck(lib().khip_panel_mgs(Q.ctx._h, Q.n, p, k, ptrs, Q.buf.ptr, out.ctypes.data_as(c_double_p),
+                             0 if accumulate_into is None else 1))
+    return [out[i].reshape(p, p, order="F").copy() for i in range(k)]
 
 
 def panel_qr_(Q: Panel) -> np.ndarray:

@@ -289,7 +289,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   double *dX = ws->dX, *X = ws->X, *W = ws->W, *Bp = ws->Bp;
   std::vector<double *> &V = ws->V;
   auto &Z = ws->Z; auto &R = ws->R; auto &H = ws->H; auto &tau = ws->tau;
-  std::vector<double> C(pp), D(2 * pp), Psi(pp);
+  std::vector<double> C(pp), D(2 * pp), sweep;
   const bool warm_start = ws->warm_start;
   ws->box.reset();
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
@@ -361,15 +361,18 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
       if (!NisI) KB(apply_block_op(ctx, N, V[inner_iter - 1], Pk, p));             // :241  P <- N V_k
       KB(apply_block_op(ctx, A, Pk, W, p));                                        // :242  W <- A N V_k
       if (!MisI) KB(apply_block_op(ctx, M, W, Q, p));                              // :243  Q <- M A N V_k
-      for (int i = 0; i < inner_iter; ++i) {                                       // :244-247
-        KB(khip_panel_gemm_tn(ctx, n, p, V[i], Q, R[nr + i].data()));              // Psi = V_i^T Q
-        KB(khip_panel_gemm_nn(ctx, n, p, -1.0, V[i], R[nr + i].data(), 1.0, Q));   // Q -= V_i Psi
-      }
-      if (reorth) {                                                                // :250-256
-        for (int i = 0; i < inner_iter; ++i) {
-          KB(khip_panel_gemm_tn(ctx, n, p, V[i], Q, Psi.data()));
-          KB(khip_panel_gemm_nn(ctx, n, p, -1.0, V[i], Psi.data(), 1.0, Q));
-          for (size_t l = 0; l < pp; ++l) R[nr + i][l] += Psi[l];
+      // :244-247 (Psi_i = V_i^T Q ; Q -= V_i Psi_i for i = 1..k) and the reorthogonalisation pass :250-256, each as
+      // one sweep whose blocks stay on the device between the steps
+      {
+        std::vector<const double *> Vp((size_t)inner_iter);
+        for (int i = 0; i < inner_iter; ++i) Vp[i] = V[i];
+        sweep.assign((size_t)inner_iter * pp, 0.0);
+        KB(khip_panel_mgs(ctx, n, p, inner_iter, Vp.data(), Q, sweep.data(), 0));
+        for (int i = 0; i < inner_iter; ++i) std::copy(sweep.begin() + (size_t)i * pp, sweep.begin() + (size_t)(i + 1) * pp, R[nr + i].begin());
+        if (reorth) {
+          KB(khip_panel_mgs(ctx, n, p, inner_iter, Vp.data(), Q, sweep.data(), 0));
+          for (int i = 0; i < inner_iter; ++i)
+            for (size_t l = 0; l < pp; ++l) R[nr + i][l] += sweep[(size_t)i * pp + l];
         }
       }
 

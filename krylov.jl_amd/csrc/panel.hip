@@ -11,10 +11,13 @@
 // Q - V Psi reads two and writes one.  The MFMA only keeps the FP64 pipe from co-limiting:
 //   Psi = V^T Q : D(16x16) += A(16x4) B(4x16) with A[i][k] = V[r0+k][i], B[k][j] = Q[r0+k][j]
 //                 => lane l feeds V[r0*p + l] and Q[r0*p + l] (p = 16): one MFMA per 4 rows.
+//   (the two are also fused into one pass per Gram-Schmidt step: panel_nn_tn_kernel / khip_panel_mgs)
 //   Q += a V Psi: D(16 rows x 16 cols) += A(16 rows x 4) B(4 x 16): A[i][k] = V[r0+i][4kk+k],
 //                 B[k][j] = Psi[4kk+k][j] held in registers; C/D lane layout of the f64 MFMA:
 //                 col = lane & 15, row = (lane >> 4) + 4 * reg  (cdna_hip_programming.md section 3).
 // p up to 32 is handled with 2 x 2 tiles of 16 columns; p that is not a multiple of 16 zero-fills.
+#include <vector>
+
 #include "device_reduce.hpp"
 
 namespace khip {
@@ -184,6 +187,101 @@ __global__ __launch_bounds__(kBlock) void panel_gemm_nn_kernel(int64_t n_pad, in
     }
 }
 
+// ---------------------------------------------------------------- Q -= V_i Psi_i fused with Psi_{i+1} = V_{i+1}^T Q ----
+// One step of the block Gram-Schmidt sweep (src/block_gmres.jl:244-247) in one pass: the D tile of the first product
+// -- lane (i, k), register g = Q_new[r0 + k + 4g][16b + i] -- is exactly the B operand the second product needs for
+// its k-step u = g, so the updated rows never leave the registers between the two.  A wave covers the same
+// kRowsPerWaveTN rows, in the same order, as a wave of panel_gemm_tn_kernel and the update is the expression of
+// panel_gemm_nn_kernel: Q and Psi_{i+1} are bit-identical to the two separate kernels; four panel passes instead of five.
+template <int NT, int UNT>
+__global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int p, double alpha, const double *Vi,
+                                                             const double *Psi_dev, double beta, const double *Vn, double *Q,
+                                                             double *partials) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t row_begin = wid * kRowsPerWaveTN;
+  const int i = lane & 15, k = lane >> 4;
+  constexpr int KK = NT * 4;
+  dbl4 tn[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) tn[a][b] = dbl4{0.0, 0.0, 0.0, 0.0};
+  if (row_begin < n_pad) {
+    const int64_t row_end = (row_begin + kRowsPerWaveTN < n_pad) ? row_begin + kRowsPerWaveTN : n_pad;
+    double bf[KK][NT];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        const int prow = 4 * kk + k, pcol = 16 * b + i;
+        bf[kk][b] = (prow < p && pcol < p) ? Psi_dev[(size_t)pcol * p + prow] : 0.0;
+      }
+    for (int64_t r = row_begin; r < row_end; r += 16 * UNT) {
+      double af[UNT][KK], va[UNT][4][NT];
+      dbl4 cin[UNT][NT];
+#pragma unroll
+      for (int t = 0; t < UNT; ++t) {
+        const int64_t r0 = r + 16 * t;
+        const bool tok = r0 < row_end;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          const int vcol = 4 * kk + k;
+          af[t][kk] = (tok && vcol < p) ? Vi[(r0 + i) * p + vcol] : 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = 16 * b + i;
+            cin[t][b][g] = (tok && beta != 0.0 && col < p) ? Q[(r0 + k + 4 * g) * p + col] : 0.0;
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int a = 0; a < NT; ++a) {
+            const int col = 16 * a + i;
+            va[t][u][a] = (tok && col < p) ? Vn[(r0 + 4 * u + k) * p + col] : 0.0;
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < UNT; ++t) {
+        const int64_t r0 = r + 16 * t;
+        if (r0 >= row_end) break;
+        dbl4 acc[NT], wnew[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[b] = dbl4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+          for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t][kk], bf[kk][b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = 16 * b + i;
+            wnew[b][g] = col < p ? fma(alpha, acc[b][g], beta * cin[t][b][g]) : 0.0;
+            if (col < p) Q[(r0 + k + 4 * g) * p + col] = wnew[b][g];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+              tn[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[t][u][a], wnew[b][u], tn[a][b], 0, 0, 0);
+      }
+    }
+  }
+  double *out = partials + (size_t)wid * (NT * NT * 256);
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) out[(a * NT + b) * 256 + g * 64 + lane] = tn[a][b][g];
+}
+
 }  // namespace khip
 
 using namespace khip;
@@ -261,35 +359,108 @@ int khip_panel_to_colmajor(khip_ctx *ctx, int64_t n, int p, const double *P, dou
   return KHIP_OK;
 }
 
-int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const double *Q, double *Psi_host) {
-  KHIP_REQUIRE(ctx && V && Q && Psi_host && p >= 1 && p <= 32, "panel_gemm_tn: bad argument (1 <= p <= 32)");
-  const int64_t np = pad16(n);
-  const int NT = p <= 16 ? 1 : 2;
+// Launch geometry of the V^T Q kernels and the reduction tree that turns their per-wave tiles into Psi (p x p,
+// column-major) at psi_out on the device.  `first` launches the kernel that fills the ping region.
+struct TnPlan {
+  int NT;
+  int64_t nwaves;
+  unsigned blocks;
+  size_t tile_elems;
+};
+static TnPlan tn_plan(int64_t np, int p) {
+  TnPlan t;
+  t.NT = p <= 16 ? 1 : 2;
   const int64_t nwaves_used = (np + kRowsPerWaveTN - 1) / kRowsPerWaveTN;
   const int64_t nblocks = (nwaves_used + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t nwaves = (nblocks > 0 ? nblocks : 1) * kWavesPerBlock;
-  const size_t tile_elems = (size_t)NT * NT * 256;
-  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)nwaves * tile_elems));
-  const unsigned g = (unsigned)(nblocks > 0 ? nblocks : 1);
-  double *ping = g_ps.partials, *pong = g_ps.partials + (size_t)nwaves * tile_elems;
-  if (NT == 1) hipLaunchKernelGGL((panel_gemm_tn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, V, Q, ping);
-  else hipLaunchKernelGGL((panel_gemm_tn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, V, Q, ping);
-  int64_t count = nwaves;
+  t.blocks = (unsigned)(nblocks > 0 ? nblocks : 1);
+  t.nwaves = (int64_t)t.blocks * kWavesPerBlock;
+  t.tile_elems = (size_t)t.NT * t.NT * 256;
+  return t;
+}
+static void tn_reduce(khip_ctx *ctx, const TnPlan &t, int p, double *psi_out) {
+  double *ping = g_ps.partials, *pong = g_ps.partials + (size_t)t.nwaves * t.tile_elems;
+  int64_t count = t.nwaves;
   while (true) {
     const int64_t groups = (count + kTnFan - 1) / kTnFan;
-    double *psi_out = groups == 1 ? g_ps.psi_dev : nullptr;
-    if (NT == 1) hipLaunchKernelGGL((panel_tn_reduce_kernel<1>), dim3((unsigned)groups, 1), dim3(kBlock), 0, ctx->stream, count, p, ping, pong, psi_out);
-    else hipLaunchKernelGGL((panel_tn_reduce_kernel<2>), dim3((unsigned)groups, 4), dim3(kBlock), 0, ctx->stream, count, p, ping, pong, psi_out);
+    double *out = groups == 1 ? psi_out : nullptr;
+    if (t.NT == 1) hipLaunchKernelGGL((panel_tn_reduce_kernel<1>), dim3((unsigned)groups, 1), dim3(kBlock), 0, ctx->stream, count, p, ping, pong, out);
+    else hipLaunchKernelGGL((panel_tn_reduce_kernel<2>), dim3((unsigned)groups, 4), dim3(kBlock), 0, ctx->stream, count, p, ping, pong, out);
     if (groups == 1) break;
     count = groups;
-    double *t = ping; ping = pong; pong = t;
+    double *tmp = ping; ping = pong; pong = tmp;
   }
+}
+// Psi = V^T Q into psi_out (device), no host synchronisation
+static int tn_enqueue(khip_ctx *ctx, int64_t np, int p, const double *V, const double *Q, double *psi_out) {
+  const TnPlan t = tn_plan(np, p);
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.nwaves * t.tile_elems));
+  if (t.NT == 1) hipLaunchKernelGGL((panel_gemm_tn_kernel<1>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, V, Q, g_ps.partials);
+  else hipLaunchKernelGGL((panel_gemm_tn_kernel<2>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, V, Q, g_ps.partials);
+  tn_reduce(ctx, t, p, psi_out);
   KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const double *Q, double *Psi_host) {
+  KHIP_REQUIRE(ctx && V && Q && Psi_host && p >= 1 && p <= 32, "panel_gemm_tn: bad argument (1 <= p <= 32)");
+  KHIP_TRY(ensure_panel_scratch(ctx, 1));
+  KHIP_TRY(tn_enqueue(ctx, pad16(n), p, V, Q, g_ps.psi_dev));
   KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned, g_ps.psi_dev, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   memcpy(Psi_host, g_ps.psi_pinned, sizeof(double) * (size_t)p * p);
   // row-partitioned panels: the block is the sum of the ranks' partial blocks (2 KB at p = 16), added in rank order
   return comm_allreduce_sum_host(ctx, Psi_host, p * p);
+}
+
+// Block Gram-Schmidt sweep of Q against the k panels V[0..k) in the reference's order (src/block_gmres.jl:244-247):
+//   for i: Psi_i = V_i^T Q ; Q <- Q - V_i Psi_i.
+// Single GPU: every Psi_i stays on the device (Psi_{i+1} comes out of the fused kernel that applies Psi_i), the host
+// reads all k blocks after ONE synchronisation.  Row-partitioned panels need the rank sum of every Psi_i before it is
+// applied, which goes through the host: the two-kernel sequence per step.  Either way the same bits.
+int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, double *Q, double *Psi_host,
+                   int accumulate) {
+  KHIP_REQUIRE(ctx && Q && p >= 1 && p <= 32 && k >= 0 && (k == 0 || (V_host && Psi_host)), "panel_mgs: bad argument (1 <= p <= 32)");
+  const size_t pp = (size_t)p * p;
+  const bool fuse = ctx->tune.panel_fuse != 0 && comm_nranks(ctx) == 1 && k >= 1 && k < kPsiSlots;
+  if (!fuse) {
+    std::vector<double> psi(pp);
+    for (int i = 0; i < k; ++i) {
+      KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, V_host[i], Q, psi.data()));
+      KHIP_TRY(khip_panel_gemm_nn(ctx, n, p, -1.0, V_host[i], psi.data(), 1.0, Q));
+      for (size_t l = 0; l < pp; ++l) Psi_host[(size_t)i * pp + l] = accumulate ? Psi_host[(size_t)i * pp + l] + psi[l] : psi[l];
+    }
+    return KHIP_OK;
+  }
+  const int64_t np = pad16(n);
+  const TnPlan t = tn_plan(np, p);
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.nwaves * t.tile_elems));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // the Psi staging ring is ours from slot 1 on
+  g_ps.next_slot = 1;
+  const int64_t tiles = np / 16;
+  const unsigned g_nn = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  KHIP_TRY(tn_enqueue(ctx, np, p, V_host[0], Q, g_ps.psi_dev + 1024));
+  for (int i = 0; i < k; ++i) {
+    double *psi_i = g_ps.psi_dev + (size_t)(i + 1) * 1024;
+    if (i + 1 < k) {
+      double *psi_n = g_ps.psi_dev + (size_t)(i + 2) * 1024;
+      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
+      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
+      tn_reduce(ctx, t, p, psi_n);
+    } else if (tiles > 0) {
+      if (p <= 16) hipLaunchKernelGGL((panel_gemm_nn_kernel<1>), dim3(g_nn), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, Q);
+      else hipLaunchKernelGGL((panel_gemm_nn_kernel<2>), dim3(g_nn), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, Q);
+    }
+  }
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned + 1024, g_ps.psi_dev + 1024, sizeof(double) * 1024 * (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < k; ++i) {
+    const double *src = g_ps.psi_pinned + (size_t)(i + 1) * 1024;
+    double *dst = Psi_host + (size_t)i * pp;
+    for (size_t l = 0; l < pp; ++l) dst[l] = accumulate ? dst[l] + src[l] : src[l];
+  }
+  g_ps.next_slot = k + 1;
+  return KHIP_OK;
 }
 
 int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const double *V, const double *Psi_host, double beta,

@@ -236,3 +236,51 @@ def test_block_gmres_same_history_with_and_without_window(K, ctx, oracle):
         res.append((X, st.niter, np.array(st.residuals)))
     ctx.set_option("spmm_window", 1)
     assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][0], res[1][0])
+
+
+# ---- block Gram-Schmidt sweep with the fused apply-and-project kernel (panel.hip, panel_nn_tn_kernel) -----------
+
+@pytest.mark.parametrize("n,p,k", [(1000, 16, 1), (1000, 16, 4), (4099, 16, 3), (777, 8, 5), (5000, 32, 3), (300, 5, 2), (257, 24, 2)])
+def test_panel_mgs_fused_bit_identical_to_two_kernel_sequence(K, ctx, n, p, k):
+    """khip_panel_mgs (src/block_gmres.jl:244-247 and the reorthogonalisation pass :250-256): Q and every Psi block
+    from the fused sweep equal the khip_panel_gemm_tn / khip_panel_gemm_nn sequence bit for bit."""
+    rng = np.random.default_rng(n + p + k)
+    Vall = np.linalg.qr(rng.standard_normal((n, p * k)))[0]
+    Vh = [np.ascontiguousarray(Vall[:, i * p:(i + 1) * p]) for i in range(k)]
+    Qh = rng.standard_normal((n, p))
+    res = []
+    for fuse in (1, 0):
+        ctx.set_option("panel_fuse", fuse)
+        V = [K.Panel.from_host(ctx, v) for v in Vh]
+        Q = K.Panel.from_host(ctx, Qh)
+        blocks = K.panel_mgs_(V, Q)
+        again = K.panel_mgs_(V, Q, accumulate_into=blocks)
+        res.append((Q.to_host(), np.array(blocks), np.array(again)))
+    ctx.set_option("panel_fuse", 1)
+    # the explicit primitive sequence
+    V = [K.Panel.from_host(ctx, v) for v in Vh]
+    Q = K.Panel.from_host(ctx, Qh)
+    prim = []
+    for i in range(k):
+        psi = K.panel_gemm_tn(V[i], Q)
+        K.panel_gemm_nn_(-1.0, V[i], psi, 1.0, Q)
+        prim.append(psi)
+    assert all(np.array_equal(a, b) for a, b in zip(res[0], res[1]))
+    assert np.array_equal(res[0][1], np.array(prim))
+    assert max(np.abs(v.T @ res[0][0]).max() for v in Vh) < 1e-13          # two sweeps: orthogonal to working precision
+    assert np.allclose(np.array(prim), np.array([v.T @ Qh for v in Vh]), atol=1e-12)
+
+
+@pytest.mark.parametrize("kw", [dict(restart=True), dict(reorthogonalization=True), dict()])
+def test_block_gmres_same_with_and_without_fused_sweep(K, ctx, oracle, kw):
+    A = oracle.stencil27_unsym(10)
+    B, _ = _rhs(A.to_scipy(), A.n, 4)
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (A.n, A.n))
+    res = []
+    for fuse in (1, 0):
+        ctx.set_option("panel_fuse", fuse)
+        X, st, _ = K.block_gmres(dA, B, memory=6, ctx=ctx, history=True, itmax=25, **kw)
+        res.append((X, st.niter, st.status, np.array(st.residuals)))
+    ctx.set_option("panel_fuse", 1)
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][0], res[1][0])
