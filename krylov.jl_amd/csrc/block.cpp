@@ -142,8 +142,10 @@ extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double 
   // ~eps^-1/2, after which the two ordinary rounds converge.  Everything touching the n x p panel stays on the
   // device; only p x p matrices visit the host, as in the reference (src/block_gmres.jl:250-283).
   bool shifted_done = false;
+  bool have_G = false;                    // G of this round came out of the kernel that applied the previous R^-1
   for (int pass = 0; pass < 2; ++pass) {
-    KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, Q, Q, G.data()));
+    if (!have_G) KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, Q, Q, G.data()));
+    have_G = false;
     bool ok = chol_upper(p, G.data(), R.data());
     if (ok && pass == 0 && !shifted_done) {
       double dmax = 0, dmin = std::numeric_limits<double>::infinity();
@@ -171,7 +173,13 @@ extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double 
       pass = -1;                                                          // two ordinary rounds follow
     }
     inv_upper(p, R.data(), Ri.data());
-    KHIP_TRY(khip_panel_gemm_nn(ctx, n, p, 1.0, Q, Ri.data(), 0.0, Q));   // in place: Q <- Q R^-1
+    if (pass == 0 && ctx->tune.panel_fuse != 0) {
+      // first ordinary round: Q <- Q R^-1 and the Gram matrix of the second round in one pass (same bits)
+      KHIP_TRY(panel_scale_gram(ctx, n, p, Q, Ri.data(), G.data()));
+      have_G = true;
+    } else {
+      KHIP_TRY(khip_panel_gemm_nn(ctx, n, p, 1.0, Q, Ri.data(), 0.0, Q));   // in place: Q <- Q R^-1
+    }
     matmul_pp(p, R.data(), Racc.data(), tmp.data());                      // Racc <- R * Racc
     Racc = tmp;
   }

@@ -193,7 +193,9 @@ __global__ __launch_bounds__(kBlock) void panel_gemm_nn_kernel(int64_t n_pad, in
 // its k-step u = g, so the updated rows never leave the registers between the two.  A wave covers the same
 // kRowsPerWaveTN rows, in the same order, as a wave of panel_gemm_tn_kernel and the update is the expression of
 // panel_gemm_nn_kernel: Q and Psi_{i+1} are bit-identical to the two separate kernels; four panel passes instead of five.
-template <int NT, int UNT>
+// SELF: the second product is the Gram matrix of the updated panel itself (Vn unused): round 1 of the CholeskyQR
+// (Q <- Q R^-1) fused with G = Q^T Q of round 2.
+template <int NT, int UNT, bool SELF>
 __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int p, double alpha, const double *Vi,
                                                              const double *Psi_dev, double beta, const double *Vn, double *Q,
                                                              double *partials) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
 #pragma unroll
           for (int a = 0; a < NT; ++a) {
             const int col = 16 * a + i;
-            va[t][u][a] = (tok && col < p) ? Vn[(r0 + 4 * u + k) * p + col] : 0.0;
+            va[t][u][a] = (!SELF && tok && col < p) ? Vn[(r0 + 4 * u + k) * p + col] : 0.0;
           }
       }
 #pragma unroll
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
           for (int a = 0; a < NT; ++a)
 #pragma unroll
             for (int b = 0; b < NT; ++b)
-              tn[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[t][u][a], wnew[b][u], tn[a][b], 0, 0, 0);
+              tn[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(SELF ? wnew[a][u] : va[t][u][a], wnew[b][u], tn[a][b], 0, 0, 0);
       }
     }
   }
@@ -412,6 +414,33 @@ int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const d
   return comm_allreduce_sum_host(ctx, Psi_host, p * p);
 }
 
+}  // extern "C"
+// Q <- Q Ri in place and G = Q_new^T Q_new in the same pass (khip_panel_qr: the scaling of round 1 with the Gram matrix
+// of round 2); bit-identical to khip_panel_gemm_nn followed by khip_panel_gemm_tn(Q, Q).  G is rank-summed like
+// every V^T Q.
+int khip::panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const double *Ri_host, double *G_host) {
+  const int64_t np = pad16(n);
+  const TnPlan t = tn_plan(np, p);
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.nwaves * t.tile_elems));
+  if (g_ps.next_slot == kPsiSlots || g_ps.next_slot == 0) {
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    g_ps.next_slot = 1;
+  }
+  const int slot = g_ps.next_slot++;
+  double *psi_h = g_ps.psi_pinned + (size_t)slot * 1024, *psi_d = g_ps.psi_dev + (size_t)slot * 1024;
+  memcpy(psi_h, Ri_host, sizeof(double) * (size_t)p * p);
+  KHIP_CHECK_HIP(hipMemcpyAsync(psi_d, psi_h, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, ctx->stream));
+  if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials);
+  else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials);
+  tn_reduce(ctx, t, p, g_ps.psi_dev);
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned, g_ps.psi_dev, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(G_host, g_ps.psi_pinned, sizeof(double) * (size_t)p * p);
+  return comm_allreduce_sum_host(ctx, G_host, p * p);
+}
+extern "C" {
+
 // Block Gram-Schmidt sweep of Q against the k panels V[0..k) in the reference's order (src/block_gmres.jl:244-247):
 //   for i: Psi_i = V_i^T Q ; Q <- Q - V_i Psi_i.
 // Single GPU: every Psi_i stays on the device (Psi_{i+1} comes out of the fused kernel that applies Psi_i), the host
@@ -443,8 +472,8 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
     double *psi_i = g_ps.psi_dev + (size_t)(i + 1) * 1024;
     if (i + 1 < k) {
       double *psi_n = g_ps.psi_dev + (size_t)(i + 2) * 1024;
-      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
-      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
+      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
+      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
       tn_reduce(ctx, t, p, psi_n);
     } else if (tiles > 0) {
       if (p <= 16) hipLaunchKernelGGL((panel_gemm_nn_kernel<1>), dim3(g_nn), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, Q);

@@ -284,3 +284,23 @@ def test_block_gmres_same_with_and_without_fused_sweep(K, ctx, oracle, kw):
     ctx.set_option("panel_fuse", 1)
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
     assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][0], res[1][0])
+
+
+@pytest.mark.parametrize("n,p,cond", [(1000, 16, 1e2), (4099, 16, 1e10), (300, 5, 10.0), (5000, 32, 1e3)])
+def test_panel_qr_same_with_and_without_fused_round(K, ctx, n, p, cond):
+    """CholeskyQR2: the in-place scaling of round 1 fused with the Gram matrix of round 2 (panel_scale_gram) gives the
+    same Q and R as the separate kernels, also after a shifted first pass (cond 1e10)."""
+    rng = np.random.default_rng(n + p)
+    U = np.linalg.qr(rng.standard_normal((n, p)))[0]
+    W = np.linalg.qr(rng.standard_normal((p, p)))[0]
+    A = U @ np.diag(np.logspace(0, -np.log10(cond), p)) @ W.T
+    res = []
+    for fuse in (1, 0):
+        ctx.set_option("panel_fuse", fuse)
+        Q = K.Panel.from_host(ctx, A)
+        R = K.panel_qr_(Q)
+        res.append((Q.to_host(), R))
+    ctx.set_option("panel_fuse", 1)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    Qh, R = res[0]
+    assert np.allclose(Qh @ R, A, atol=1e-12 * np.abs(A).max() * cond ** 0 + 1e-13) and np.allclose(Qh.T @ Qh, np.eye(p), atol=1e-10)
