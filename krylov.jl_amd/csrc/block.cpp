@@ -336,20 +336,24 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
 
   while (!(solved || tired || user_requested_exit || overtimed)) {
     int nr = 0;
-    for (int i = 0; i < mem; ++i) KB(khip_fill(ctx, len, V[i], 0.0));              // :195-197
+    // :195-197 zero-fills the mem basis panels here.  Every panel is written (copy of R0 / of the orthonormalised Q)
+    // before anything reads it and this ABI has no accessor for V, so the fill is unobservable and its mem panel
+    // writes (6.5 GB per restart at cfg 5) are skipped.
     for (auto &blk : R) std::fill(blk.begin(), blk.end(), 0.0);
     for (auto &blk : Z) std::fill(blk.begin(), blk.end(), 0.0);
 
     if (restart) {
       KB(khip_fill(ctx, len, Xr, 0.0));
       if (npass >= 1) {
-        KB(apply_block_op(ctx, A, X, W, p));
-        KB(khip_axpby(ctx, len, 1.0, Bp, -1.0, W));
-        if (!MisI) KB(apply_block_op(ctx, M, W, R0, p));
+        // the residual block of a restart goes straight into V[1] (the copy of :211 is the only reader of R0)
+        double *Wr = MisI ? V[0] : W;
+        KB(apply_block_op(ctx, A, X, Wr, p));
+        KB(khip_axpby(ctx, len, 1.0, Bp, -1.0, Wr));
+        if (!MisI) KB(apply_block_op(ctx, M, W, V[0], p));
       }
     }
 
-    KB(khip_copy(ctx, len, V[0], R0));                                             // :211
+    if (!(restart && npass >= 1)) KB(khip_copy(ctx, len, V[0], R0));               // :211
     KB(khip_panel_qr(ctx, n, p, V[0], Z[0].data()));                               // :212 householder!(V[1], Z[1], ..)
 
     npass = npass + 1;
@@ -367,7 +371,11 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
 
       double *Pk = NisI ? V[inner_iter - 1] : ws->Pn;
       if (!NisI) KB(apply_block_op(ctx, N, V[inner_iter - 1], Pk, p));             // :241  P <- N V_k
-      KB(apply_block_op(ctx, A, Pk, W, p));                                        // :242  W <- A N V_k
+      // Q of this iteration lives in the next basis panel when that exists: the copy of :307 disappears
+      double *const Qsave = Q;
+      if ((int)V.size() > inner_iter) Q = V[inner_iter];
+      double *Wk = MisI ? Q : W;
+      KB(apply_block_op(ctx, A, Pk, Wk, p));                                       // :242  W <- A N V_k
       if (!MisI) KB(apply_block_op(ctx, M, W, Q, p));                              // :243  Q <- M A N V_k
       // :244-247 (Psi_i = V_i^T Q ; Q -= V_i Psi_i for i = 1..k) and the reorthogonalisation pass :250-256, each as
       // one sweep whose blocks stay on the device between the steps
@@ -448,10 +456,11 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
           }
           while ((int)Z.size() <= inner_iter) Z.emplace_back(pp, 0.0);
         }
-        KB(khip_copy(ctx, len, V[inner_iter], Q));                                 // :307
+        if (Q != V[inner_iter]) KB(khip_copy(ctx, len, V[inner_iter], Q));         // :307
         for (int j = 0; j < p; ++j)
           for (int l = 0; l < p; ++l) Z[inner_iter][(size_t)j * p + l] = D[(size_t)j * 2 * p + p + l];
       }
+      Q = Qsave;
     }
 
     // block back-substitution (:313-321), Y aliases Z
