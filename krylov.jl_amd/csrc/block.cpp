@@ -490,7 +490,15 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
       }
     }
 
-    for (int i = 0; i < inner_iter; ++i) KB(khip_panel_gemm_nn(ctx, n, p, 1.0, V[i], Y[i].data(), 1.0, Xr));   // :324-326
+    {                                                                              // :324-326, the k products in one pass
+      std::vector<const double *> Vp((size_t)inner_iter);
+      std::vector<double> Yall((size_t)inner_iter * pp);
+      for (int i = 0; i < inner_iter; ++i) {
+        Vp[i] = V[i];
+        std::copy(Y[i].begin(), Y[i].begin() + pp, Yall.begin() + (size_t)i * pp);
+      }
+      KB(panel_multi_nn(ctx, n, p, inner_iter, Vp.data(), Yall.data(), 1.0, Xr));
+    }
     if (!NisI) {                                                                   // :327-330
       KB(khip_copy(ctx, len, ws->Pn, Xr));
       KB(apply_block_op(ctx, N, ws->Pn, Xr, p));

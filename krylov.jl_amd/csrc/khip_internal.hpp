@@ -234,6 +234,8 @@ int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 // template.hip
 void csr_free_templates(khip_csr *A);
 void csr_free_window(khip_csr *A);
+int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,
+                   double *X);   // panel.hip
 int panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const double *Ri_host, double *G_host);   // panel.hip
 
 // api.cpp: the MGS cascade of khip_mgs in two halves (enqueue: launches only; the k coefficients and ||q||^2 end up in

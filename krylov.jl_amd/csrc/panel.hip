@@ -284,6 +284,68 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
       for (int g = 0; g < 4; ++g) out[(a * NT + b) * 256 + g * 64 + lane] = tn[a][b][g];
 }
 
+// ---------------------------------------------------------------- X = beta X + sum_i V_i Y_i ----
+// The solution update of block_gmres! (src/block_gmres.jl:324-326: k products mul!(X, V_i, Y_i, 1, 1)) in one pass over X:
+// per 16-row tile the k products are applied in the order i = 0..k-1 with the expression of panel_gemm_nn_kernel
+// (x <- fma(1, acc_i, 1 * x); the first one with the caller's beta), so X is bit-identical to the k separate calls;
+// k + 2 panel passes instead of 3 k.
+constexpr int kMultiNN = 32;
+struct MultiNNArgs { const double *v[kMultiNN]; };
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void panel_multi_nn_kernel(int64_t n_pad, int p, int k, MultiNNArgs V, const double *Y_dev,
+                                                                double beta, double *X) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int64_t r0 = tile * 16;
+  if (r0 >= n_pad) return;
+  const int i = lane & 15, kq = lane >> 4;
+  constexpr int KK = NT * 4;
+  dbl4 x[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 16 * b + i;
+      x[b][g] = (beta != 0.0 && col < p) ? X[(r0 + kq + 4 * g) * p + col] : 0.0;
+    }
+  double bcur = beta;
+  for (int j = 0; j < k; ++j) {
+    const double *Vj = V.v[j];
+    const double *Yj = Y_dev + (size_t)j * 1024;
+    double af[KK], bf[KK][NT];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const int vcol = 4 * kk + kq;
+      af[kk] = (vcol < p) ? Vj[(r0 + i) * p + vcol] : 0.0;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        const int prow = 4 * kk + kq, pcol = 16 * b + i;
+        bf[kk][b] = (prow < p && pcol < p) ? Yj[(size_t)pcol * p + prow] : 0.0;
+      }
+    }
+    dbl4 acc[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[b] = dbl4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk][b], acc[b], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) x[b][g] = fma(1.0, acc[b][g], bcur * x[b][g]);
+    bcur = 1.0;
+  }
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = 16 * b + i;
+      if (col < p) X[(r0 + kq + 4 * g) * p + col] = x[b][g];
+    }
+}
+
 }  // namespace khip
 
 using namespace khip;
@@ -438,6 +500,34 @@ int khip::panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const dou
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   memcpy(G_host, g_ps.psi_pinned, sizeof(double) * (size_t)p * p);
   return comm_allreduce_sum_host(ctx, G_host, p * p);
+}
+extern "C" {
+
+}  // extern "C"
+// X <- beta X + sum_i V_i Y_i (Y_host: k blocks of p x p, column-major), products applied in the order i = 0..k-1:
+// the k calls khip_panel_gemm_nn(1, V_i, Y_i, beta_i, X) with beta_0 = beta, beta_i = 1 of src/block_gmres.jl:324-326.
+int khip::panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host,
+                         double beta, double *X) {
+  const size_t pp = (size_t)p * p;
+  if (ctx->tune.panel_fuse == 0 || k < 1 || k > kMultiNN || k + 1 >= kPsiSlots) {
+    for (int i = 0; i < k; ++i) KHIP_TRY(khip_panel_gemm_nn(ctx, n, p, 1.0, V_host[i], Y_host + (size_t)i * pp, i == 0 ? beta : 1.0, X));
+    return KHIP_OK;
+  }
+  const int64_t np = pad16(n);
+  KHIP_TRY(ensure_panel_scratch(ctx, 1));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // the Psi staging ring is ours from slot 1 on
+  MultiNNArgs a;
+  for (int i = 0; i < kMultiNN; ++i) a.v[i] = i < k ? V_host[i] : nullptr;
+  for (int i = 0; i < k; ++i) memcpy(g_ps.psi_pinned + (size_t)(i + 1) * 1024, Y_host + (size_t)i * pp, sizeof(double) * pp);
+  KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_dev + 1024, g_ps.psi_pinned + 1024, sizeof(double) * 1024 * (size_t)k, hipMemcpyHostToDevice, ctx->stream));
+  g_ps.next_slot = k + 1;
+  const int64_t tiles = np / 16;
+  if (tiles == 0) return KHIP_OK;
+  const unsigned g = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (p <= 16) hipLaunchKernelGGL((panel_multi_nn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, beta, X);
+  else hipLaunchKernelGGL((panel_multi_nn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, beta, X);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
 }
 extern "C" {
 
