@@ -107,7 +107,13 @@ int khip_gen_stencil(khip_ctx *ctx, int kind, int n1, int n2, int n3, int64_t ro
  * src/gmres.jl:159,222,257, src/bicgstab.jl:160,221,228.  For a distributed handle x and y are
  * the owned slices; the halo exchange happens inside. */
 int khip_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y);
-/* Y <- A X for row-major n-by-p panels (ld = p).  ref: mul!(W, A, P) src/block_gmres.jl:242. */
+/* Y <- A X for row-major n-by-p panels (ld = p).  ref: mul!(W, A, P) src/block_gmres.jl:242.
+ * The first product with an even p on an operator whose neighbouring rows share columns (banded / stencil) builds,
+ * once per handle and range of p, a list of the distinct columns of every group of 256 / ceil_pow2(p / 2) rows and a
+ * 16-bit slot per nonzero (~2 B per nonzero + 4 B per list entry of device memory, about the time of five products);
+ * later products copy each distinct panel row once into LDS instead of gathering it per nonzero.  Y is bit-identical
+ * either way (ctx option "spmm_window" = 0 keeps the direct gathers).  Like every call on a handle, this is confined
+ * to the context's thread. */
 int khip_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
 /* algorithmic HBM bytes of one khip_spmv on this handle: 12 nnz + 4 (m+1) + 8 n + 8 m */
 int khip_spmv_bytes(const khip_csr *A, int64_t *bytes);
