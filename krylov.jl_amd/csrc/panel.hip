@@ -540,7 +540,7 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
                    int accumulate) {
   KHIP_REQUIRE(ctx && Q && p >= 1 && p <= 32 && k >= 0 && (k == 0 || (V_host && Psi_host)), "panel_mgs: bad argument (1 <= p <= 32)");
   const size_t pp = (size_t)p * p;
-  const bool fuse = ctx->tune.panel_fuse != 0 && comm_nranks(ctx) == 1 && k >= 1 && k + 1 < kPsiSlots;   // slots 1 .. k + 1 of the ring
+  const bool fuse = ctx->tune.panel_fuse != 0 && comm_nranks(ctx) == 1 && k >= 1 && k + 1 < kPsiSlots;   // Psi_i lives in slot i + 1 of the ring (one spare)
   if (!fuse) {
     std::vector<double> psi(pp);
     for (int i = 0; i < k; ++i) {
