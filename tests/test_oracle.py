@@ -570,3 +570,25 @@ def test_processes_two_sided_breakdowns(oracle):
     raises("Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 1.", P.montoison_orban, op(A1), op(A1.T), b1, c1, 1)
     raises("Exact breakdown Hᵢ₊₁.ᵢ == 0 at iteration i = 2.", P.montoison_orban, op(A2), op(A2.T), b2, c2, 2)
     raises("Exact breakdown Fᵢ₊₁.ᵢ == 0 at iteration i = 2.", P.montoison_orban, op(A3), op(A3.T), b3, c3, 2)
+
+
+def test_processes_single_step_shapes(oracle):
+    """k = 1: the smallest T (2 entries), L (3 entries) and H (2 x 1) of the reference's storage, and the defining
+    relations on them."""
+    import oracle_processes as P
+    rng = np.random.default_rng(6)
+    n = 40
+    A = rng.random((n, n)); S = A + A.T; b = rng.random(n); c = rng.random(n)
+    V, beta, nz = P.hermitian_lanczos(lambda x: S @ x, b, 1)
+    assert nz.shape == (2,) and V.shape == (n, 2)
+    assert np.allclose(S @ V[:, 0], nz[0] * V[:, 0] + nz[1] * V[:, 1])
+    V, beta, H = P.arnoldi(lambda x: A @ x, b, 1)
+    assert H.shape == (2, 1) and np.allclose(A @ V[:, 0], V @ H[:, 0])
+    V, U, beta, nz = P.golub_kahan(lambda x: A @ x, lambda y: A.T @ y, b, n, 1)
+    assert nz.shape == (3,)                                  # alpha1, beta2, alpha2
+    assert np.allclose(A @ V[:, 0], nz[0] * U[:, 0] + nz[1] * U[:, 1])
+    assert np.allclose(A.T @ U[:, 1], nz[1] * V[:, 0] + nz[2] * V[:, 1])
+    V, b1, nt, U, g1, nh = P.nonhermitian_lanczos(lambda x: A @ x, lambda y: A.T @ y, b, c, 1)
+    assert nt.shape == (2,) and nh.shape == (2,) and nt[0] == nh[0]
+    assert np.allclose(A @ V[:, 0], nt[0] * V[:, 0] + nt[1] * V[:, 1])
+    assert np.allclose(A.T @ U[:, 0], nh[0] * U[:, 0] + nh[1] * U[:, 1])
