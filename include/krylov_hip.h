@@ -95,6 +95,13 @@ int khip_csr_compress(khip_ctx *ctx, khip_csr *A, int *templates);
 /* bytes one SpMV of this handle moves in its CURRENT representation (khip_spmv_bytes: always the CSR formula) */
 int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes);
 int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
+/* How the staged SpMV reads the column indices of this handle (csrc/colcode.hip): *bits = 32 (the int32 CSR columns),
+ * or 8 / 16 when the operator's entries lie on at most 256 / 2048 distinct diagonals (column - row) and the handle keeps,
+ * next to its CSR arrays, one / two bytes per entry (the rank of the entry's diagonal in a sorted table; col = row +
+ * table[code], exact).  The coded stream is built by the first khip_spmv that can use it; *diagonals = table size
+ * (0 before that, or when the operator has too many).  y is bit-identical either way; ctx option "spmv_codes" = 0
+ * keeps the int32 stream.  ref: the product is kmul!(y, A, x), src/krylov_utils.jl:305. */
+int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
 /* device-side generators of the benchmark operators (rows [row0, row0+m) of the global matrix,
  * global columns; ref: test/get_div_grad.jl:8-25, test/test_utils.jl:160-169).
  * kind: 0 = get_div_grad(n1,n2,n3) 7-pt Poisson, 1 = kron_unsymmetric(n1), 2 = 27-pt cfg-5 operator.
@@ -220,6 +227,12 @@ int khip_comm_init(khip_ctx *ctx, int rank, int nranks, const void *id128_host);
  * the RCCL backend for everything built on top; used to test the distributed path on a single GPU. */
 int khip_comm_init_local(khip_ctx *ctx, int rank, int nranks, int hub_id);
 int khip_comm_rank(khip_ctx *ctx, int *rank, int *nranks);
+/* What the communicator attached to ctx looks like: *rccl_ranks = ncclCommCount of the RCCL communicator (0 for the
+ * in-process backend or without a communicator), *local_backend = 1 for khip_comm_init_local, *halo_comm_separate = 1
+ * when the halo exchange runs on its own communicator split off the first (csrc/comm.cpp: dot all-gathers on the
+ * context's stream and communicator, halo Send/Recv on the second stream and communicator).  Any pointer may be null.
+ * ref: the reference's MPI recipe docs/src/custom_workspaces.md:477-586. */
+int khip_comm_info(khip_ctx *ctx, int *rank, int *nranks, int *rccl_ranks, int *local_backend, int *halo_comm_separate);
 int khip_comm_barrier(khip_ctx *ctx);
 
 /* Host-only helpers of the partition / halo logic (no GPU needed; used by khip_csr_create_dist and

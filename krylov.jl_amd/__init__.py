@@ -87,6 +87,7 @@ SIGNATURES = {
     "khip_spmv": (_int, [_vp, _vp, _vp, _vp]),
     "khip_spmm": (_int, [_vp, _vp, _vp, _vp, _int]),
     "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
+    "khip_csr_code_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "khip_profile_spmv": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),
     "khip_dot": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
     "khip_nrm2": (_int, [_vp, _i64, _vp, c_double_p]),
@@ -144,6 +145,7 @@ SIGNATURES = {
     "khip_comm_init_local": (_int, [_vp, _int, _int, _int]),
     "khip_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "khip_comm_barrier": (_int, [_vp]),
+    "khip_comm_info": (_int, [_vp] + [C.POINTER(_int)] * 5),
     "khip_default_options": (COptions, []),
     "khip_cg_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
     "khip_cg_workspace_destroy": (_int, [_vp]),
@@ -286,6 +288,11 @@ class Context:
         """In-process communicator: the ranks are contexts of this process, one host thread each."""
         _ck(lib().khip_comm_init_local(self._h, rank, nranks, hub_id))
         self.rank, self.nranks = rank, nranks
+
+    def comm_info(self) -> dict:
+        v = [C.c_int() for _ in range(5)]
+        _ck(lib().khip_comm_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("rank", "nranks", "rccl_ranks", "local_backend", "halo_comm_separate"), (x.value for x in v)))
 
     def barrier(self):
         _ck(lib().khip_comm_barrier(self._h))
@@ -596,6 +603,14 @@ class CsrMatrix:
         b = C.c_int64()
         _ck(lib().khip_spmv_bytes_stored(self._h, C.byref(b)))
         return b.value
+
+    @property
+    def code_info(self):
+        """(bits, diagonals) of the column stream the staged SpMV reads: (32, 0) = plain int32 columns, (8 | 16, T) =
+        dictionary-coded diagonals (csrc/colcode.hip), built by the first product that can use it."""
+        b, t = C.c_int(), C.c_int()
+        _ck(lib().khip_csr_code_info(self._h, C.byref(b), C.byref(t)))
+        return b.value, t.value
 
     def transpose(self) -> "CsrMatrix":
         """A' as its own handle: `At.matvec(x, y)` is `mul!(y, A', x)` (docs/src/matrix_free.md:36-42)."""

@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I/opt/rocm/include"
 mkdir -p "$HERE/build"
 objs=""
-for f in blas1.hip spmv.hip csr_aux.hip panel.hip ilu.hip template.hip comm.cpp api.cpp solvers.cpp block.cpp processes.cpp; do
+for f in blas1.hip spmv.hip csr_aux.hip panel.hip ilu.hip template.hip colcode.hip comm.cpp api.cpp solvers.cpp block.cpp processes.cpp; do
   [ -f "$SRC/$f" ] || continue
   o="$HERE/build/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h*' -newer "$o" | head -1)" ]; then

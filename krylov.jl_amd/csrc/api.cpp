@@ -95,7 +95,7 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
       {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"spmm_window", &t.spmm_window}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
+      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"spmm_window", &t.spmm_window}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;
@@ -267,6 +267,7 @@ int khip_csr_destroy(khip_csr *A) {
   (void)hipFree(A->ghost_w); (void)hipFree(A->sendbuf_w);
   csr_free_templates(A);
   csr_free_window(A);
+  csr_free_codes(A);
   delete A;
   return KHIP_OK;
 }
@@ -276,6 +277,13 @@ int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz) {
   if (m) *m = A->m;
   if (n) *n = A->n;
   if (nnz) *nnz = A->nnz;
+  return KHIP_OK;
+}
+
+int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals) {
+  KHIP_REQUIRE(A, "csr_code_info: null handle");
+  if (bits) *bits = A->code_state == 1 ? A->code_bits : 32;
+  if (diagonals) *diagonals = A->code_state == 1 ? A->code_T : 0;
   return KHIP_OK;
 }
 
@@ -346,6 +354,8 @@ int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes) {
   KHIP_REQUIRE(A && bytes, "spmv_bytes_stored: null argument");
   const int64_t ncols_read = A->dist ? A->m + A->n_ghost : A->n;
   if (A->tmpl_id) *bytes = 2 * A->m + 8 * ncols_read + 8 * A->m;        // template id + x + y
+  else if (A->code_state == 1)                                          // coded columns (colcode.hip): 1 or 2 B per entry
+    *bytes = (8 + A->code_bits / 8) * A->nnz + 4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
   else *bytes = 12 * A->nnz + 4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
   return KHIP_OK;
 }

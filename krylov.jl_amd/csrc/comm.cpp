@@ -45,6 +45,9 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  // optional (absent in very old builds): rank count as the library sees it, and a second communicator for the halo
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr;
 };
 
 static Rccl g_rccl;
@@ -74,6 +77,8 @@ static int load_rccl() {
   KHIP_SYM(GroupEnd, "ncclGroupEnd")
   KHIP_SYM(GetErrorString, "ncclGetErrorString")
 #undef KHIP_SYM
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+  g_rccl.CommSplit = reinterpret_cast<decltype(g_rccl.CommSplit)>(dlsym(h, "ncclCommSplit"));
   g_rccl.handle = h;
   return KHIP_OK;
 }
@@ -118,9 +123,18 @@ struct LocalHub {
 static std::mutex g_hub_mu;
 static std::map<int, LocalHub *> g_hubs;
 
+// Stream / communicator discipline.  Every rank issues its RCCL calls from ONE host thread in
+// program order, so the order of operations per communicator is the same on all ranks.  Two communicators:
+//   comm       all-gathers of the (hi, lo) dot partials and the setup-time all-gathers, always on ctx->stream;
+//   halo_comm  the grouped ncclSend / ncclRecv of the halo exchange (and the all-gather of x in gather mode), on
+//              ctx->comm_stream when the exchange overlaps the interior rows.
+// halo_comm is split off comm (ncclCommSplit, same ranks).  If the library cannot split, halo_comm == comm and the
+// exchange is issued on ctx->stream as well (no overlap): one communicator is then only ever used from one stream.
 struct Comm {
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  ncclComm_t halo_comm = nullptr;  // == comm when the split is unavailable
+  int rccl_ranks = 0;              // ncclCommCount(comm): what the library itself believes (0 = local backend)
   LocalHub *hub = nullptr;         // non-null => local backend
   dd *gather_dev = nullptr;       // [nranks][kMaxRedOut]
   dd *gather_pinned = nullptr;
@@ -321,7 +335,7 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
     }
     return KHIP_OK;
   }
-  hipStream_t cs = ctx->tune.overlap_halo ? ctx->comm_stream : ctx->stream;
+  hipStream_t cs = (ctx->tune.overlap_halo && c->halo_comm != c->comm) ? ctx->comm_stream : ctx->stream;
   if (cs != ctx->stream) {
     ctx->ev_cur = (ctx->ev_cur + 1) % khip_ctx::kEvRing;           // begin/end pairs alternate strictly
     KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a[ctx->ev_cur], ctx->stream));
@@ -332,8 +346,8 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
     if (r == c->rank) continue;
     const int64_t ns = A->send_off[r + 1] - A->send_off[r];
     const int64_t nr = A->recv_off[r + 1] - A->recv_off[r];
-    if (ns > 0) KHIP_CHECK_NCCL(g_rccl.Send(sendbuf + A->send_off[r] * w, (size_t)ns * w, ncclFloat64, r, c->comm, cs));
-    if (nr > 0) KHIP_CHECK_NCCL(g_rccl.Recv(ghost + A->recv_off[r] * w, (size_t)nr * w, ncclFloat64, r, c->comm, cs));
+    if (ns > 0) KHIP_CHECK_NCCL(g_rccl.Send(sendbuf + A->send_off[r] * w, (size_t)ns * w, ncclFloat64, r, c->halo_comm, cs));
+    if (nr > 0) KHIP_CHECK_NCCL(g_rccl.Recv(ghost + A->recv_off[r] * w, (size_t)nr * w, ncclFloat64, r, c->halo_comm, cs));
   }
   KHIP_CHECK_NCCL(g_rccl.GroupEnd());
   if (cs != ctx->stream) KHIP_CHECK_HIP(hipEventRecord(ctx->ev_b[ctx->ev_cur], cs));
@@ -348,7 +362,7 @@ int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A) {
     c->hub->barrier();                                          // ... and so are theirs out of mine
     return KHIP_OK;
   }
-  if (ctx->tune.overlap_halo) KHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_b[ctx->ev_cur], 0));
+  if (ctx->tune.overlap_halo && c->halo_comm != c->comm) KHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_b[ctx->ev_cur], 0));
   return KHIP_OK;
 }
 
@@ -455,10 +469,31 @@ int khip_comm_init(khip_ctx *ctx, int rank, int nranks, const void *id128_host) 
     delete c;
     return KHIP_ERR_COMM;
   }
+  c->halo_comm = c->comm;
+  if (g_rccl.CommSplit && nranks > 1) {
+    ncclComm_t h2 = nullptr;
+    if (g_rccl.CommSplit(c->comm, 0, rank, &h2, nullptr) == ncclSuccess && h2) c->halo_comm = h2;
+  }
+  c->rccl_ranks = nranks;
+  if (g_rccl.CommCount) {
+    int cnt = 0;
+    if (g_rccl.CommCount(c->comm, &cnt) == ncclSuccess) c->rccl_ranks = cnt;
+  }
   KHIP_CHECK_HIP(hipMalloc(&c->gather_dev, sizeof(dd) * (size_t)kMaxRedOut * nranks));
   KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->gather_pinned), sizeof(dd) * (size_t)kMaxRedOut * nranks,
                                hipHostMallocDefault));
   ctx->comm = c;
+  return KHIP_OK;
+}
+
+int khip_comm_info(khip_ctx *ctx, int *rank, int *nranks, int *rccl_ranks, int *local_backend, int *halo_comm_separate) {
+  KHIP_REQUIRE(ctx, "comm_info: null context");
+  const Comm *c = ctx->comm;
+  if (rank) *rank = c ? c->rank : 0;
+  if (nranks) *nranks = c ? c->nranks : 1;
+  if (rccl_ranks) *rccl_ranks = c ? c->rccl_ranks : 0;
+  if (local_backend) *local_backend = (c && c->hub) ? 1 : 0;
+  if (halo_comm_separate) *halo_comm_separate = (c && !c->hub && c->halo_comm != c->comm) ? 1 : 0;
   return KHIP_OK;
 }
 
@@ -512,6 +547,7 @@ int khip_comm_barrier(khip_ctx *ctx) {
 int khip_comm_destroy_internal(khip_ctx *ctx) {
   Comm *c = ctx->comm;
   if (!c) return KHIP_OK;
+  if (c->halo_comm && c->halo_comm != c->comm && !c->hub) g_rccl.CommDestroy(c->halo_comm);
   if (c->comm && !c->hub) g_rccl.CommDestroy(c->comm);
   if (c->gather_dev) (void)hipFree(c->gather_dev);
   if (c->gather_pinned) (void)hipHostFree(c->gather_pinned);

@@ -639,6 +639,7 @@ __global__ __launch_bounds__(kBlock) void col_remap_kernel(int32_t *col, int64_t
 }
 
 int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost) {
+  csr_free_codes(A);        // the coded column stream (colcode.hip) is rebuilt from the renumbered columns
   if (A->nnz == 0) return KHIP_OK;
   int64_t want = (A->nnz + kBlock - 1) / kBlock;
   int grid = (int)(want < 4096 ? want : 4096);

@@ -66,6 +66,7 @@ struct Tuning {
   int spmv_cap = 0;         // staged kernel LDS window in entries (0 = sized to the widest row block)
   int spmv_lds_pad = 0;     // experiment: extra dynamic LDS bytes per workgroup (lowers occupancy)
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
+  int spmv_codes = 1;       // staged kernel: stream dictionary-coded columns (1 or 2 B per entry) when the operator has <= 2048 diagonals; 0 = plain int32 columns; 16 = force 2-byte codes
   int spmv_lanes = 0;       // vector kernel lanes per row (0 = auto)
   int spmv_persist = 0;     // 1 = persistent grid (<= 8 workgroups per CU) instead of one row block per workgroup
   int compensated = 1;      // Dot2 (TwoSum/TwoProd) reductions
@@ -159,6 +160,12 @@ struct khip_csr {
   int32_t *win_list = nullptr;         // [groups][STRIDE(L)] distinct columns of a row group, padded with 0
   int32_t *win_flag = nullptr;         // per row group: 1 = direct-gather group (too many panel rows or nonzeros for the window)
   uint16_t *win_slot = nullptr;        // per nonzero: position of its column in the group's list
+  // optional dictionary-coded column stream of the staged SpMV (colcode.hip, built on the first product that can use it)
+  int code_state = 0;                  // 0 = not tried, 1 = built, -1 = tried, not usable (too many distinct diagonals)
+  int code_bits = 0;                   // 8 or 16
+  int code_T = 0;                      // distinct (column - row) offsets
+  void *code = nullptr;                // uint8_t / uint16_t [nnz + pad]
+  int32_t *code_tab = nullptr;         // [code_T], ascending
 };
 
 namespace khip {
@@ -234,6 +241,8 @@ int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 // template.hip
 void csr_free_templates(khip_csr *A);
 void csr_free_window(khip_csr *A);
+void csr_free_codes(khip_csr *A);                  // colcode.hip
+int csr_build_codes(khip_ctx *ctx, khip_csr *A);   // colcode.hip: sets A->code_state to 1 or -1
 int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,
                    double *X);   // panel.hip
 int panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const double *Ri_host, double *G_host);   // panel.hip

@@ -40,6 +40,11 @@ struct SpmvArgs {
   const long long *stop_seq;   // device-resident loop control (solver_device.hpp); null outside such loops
   long long seq;
   int fake_gather;       // experiment: coalesced x reads instead of x[col] (WRONG results)
+  // dictionary-coded column indices (colcode.hip): col = row + code_tab[code[k]]
+  const void *code;          // uint8_t[nnz + pad] or uint16_t[nnz + pad]
+  const int32_t *code_tab;   // sorted distinct (column - row) offsets, code_T entries
+  int code_T;
+  int stage_rows;            // coded kernel: rows per block (256, 128, 64 or 32)
 };
 
 template <bool NT, typename T>

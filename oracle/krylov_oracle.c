@@ -281,6 +281,11 @@ void ko_csr_matvec_omp(const double *x, double *y, void *csr) { ko_spmv_omp((con
 void ko_csr_block_matvec(const double *X, double *Y, int p, void *csr) {
   ko_spmm((const ko_csr *)csr, X, Y, p);
 }
+/* same values (rows are independent), rows spread over the OpenMP threads: used for the full-size goldens */
+void ko_csr_block_matvec_omp(const double *X, double *Y, int p, void *csr) {
+  const ko_csr *A = (const ko_csr *)csr;
+  for (int j = 0; j < p; j++) ko_spmv_omp(A, X + (size_t)j * A->n, Y + (size_t)j * A->n);
+}
 
 /* ===================================================================== *
  *  BLAS-1 shim
@@ -1065,6 +1070,8 @@ static void dlarfg(int n, double *alpha, double *x, double *tau) {
 /* DLARF side='L': C(m x n) <- (I - tau v v^T) C, v has implicit v[0] = 1 */
 static void dlarf_left(int m, int n, const double *v, double tau, double *C, int ldc) {
   if (tau == 0.0) return;
+  /* columns of C are independent */
+#pragma omp parallel for schedule(dynamic, 1) if (m > 100000)
   for (int j = 0; j < n; j++) {
     double *cj = C + (size_t)j * ldc;
     double w = cj[0];
@@ -1162,6 +1169,8 @@ void ko_block_gmres_warm_start(ko_block_gmres_workspace *ws, const double *X0) {
 
 /* C(p x q) = A(n x p)^T * B(n x q) */
 static void gemm_tn(int64_t n, int p, int q, const double *A, const double *B, double *C) {
+  /* every (i, j) entry is its own sequential extended-precision dot: the thread count cannot change a value */
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) if (n > 100000)
   for (int j = 0; j < q; j++)
     for (int i = 0; i < p; i++) {
       long double acc = 0.0L;
@@ -1173,6 +1182,8 @@ static void gemm_tn(int64_t n, int p, int q, const double *A, const double *B, d
 /* C(n x q) = alpha * A(n x p) * B(p x q) + beta * C */
 static void gemm_nn(int64_t n, int p, int q, double alpha, const double *A, const double *B,
                     double beta, double *C) {
+  /* columns of C are independent */
+#pragma omp parallel for schedule(dynamic, 1) if (n > 100000)
   for (int j = 0; j < q; j++) {
     double *c = C + (size_t)j * n;
     if (beta != 1.0) for (int64_t l = 0; l < n; l++) c[l] = beta * c[l];

@@ -64,6 +64,7 @@ void ko_spmm(const ko_csr *A, const double *X, double *Y, int p); /* column-majo
 void ko_csr_matvec(const double *x, double *y, void *csr);        /* ko_matvec adaptor  */
 void ko_csr_matvec_omp(const double *x, double *y, void *csr);
 void ko_csr_block_matvec(const double *X, double *Y, int p, void *csr);
+void ko_csr_block_matvec_omp(const double *X, double *Y, int p, void *csr);   /* same values, row-parallel */
 
 /* ---- ILU(0) / IC(0) preconditioner -------------------------
  * The reference gets these from the vendor library (ic02 / ilu02 of CUSPARSE resp. rocSPARSE,

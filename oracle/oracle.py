@@ -153,6 +153,7 @@ def lib():
     L.csr_matvec = C.cast(L.ko_csr_matvec, MATVEC)
     L.csr_matvec_omp = C.cast(L.ko_csr_matvec_omp, MATVEC)
     L.csr_block_matvec = C.cast(L.ko_csr_block_matvec, BLOCK_MATVEC)
+    L.csr_block_matvec_omp = C.cast(L.ko_csr_block_matvec_omp, BLOCK_MATVEC)
     _lib = L
     return L
 
@@ -161,6 +162,11 @@ def _dp(a: np.ndarray):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] or a.flags["F_CONTIGUOUS"]
     return a.ctypes.data_as(c_double_p)
 
+
+# True: CsrMatrix operators are applied with the row-parallel OpenMP loops (ko_spmv_omp).  Rows are independent, so
+# every y value is the one the serial loop produces; only the full-size goldens (tests/golden/make_scale_golden.py)
+# switch this on.  dot / axpy / QR arithmetic is unaffected.
+PARALLEL_MATVEC = False
 
 NULL_MATVEC = C.cast(None, MATVEC)
 NULL_BLOCK_MATVEC = C.cast(None, BLOCK_MATVEC)
@@ -322,8 +328,7 @@ class _PyOps:
                 y[:] = f(x)
             return MATVEC(cb)
         if isinstance(A, CsrMatrix):
-            self.A, self.ud, self.keep = lib().csr_matvec, A.ptr(), A
-            assert M is None and N is None or True
+            self.A, self.ud, self.keep = (lib().csr_matvec_omp if PARALLEL_MATVEC else lib().csr_matvec), A.ptr(), A
         else:
             self.A, self.ud, self.keep = mk(A), None, None
         # when A is a CsrMatrix the userdata is the csr; python M/N ignore userdata
@@ -399,7 +404,7 @@ def block_gmres(A, B, X0=None, memory=5, M=None, N=None, **kw):
             Y[:, :] = f(X)
         return BLOCK_MATVEC(cb)
     if isinstance(A, CsrMatrix):
-        fa, ud = L.csr_block_matvec, A.ptr()
+        fa, ud = (L.csr_block_matvec_omp if PARALLEL_MATVEC else L.csr_block_matvec), A.ptr()
     else:
         fa, ud = mk(A), None
     fm, fn = mk(M), mk(N)

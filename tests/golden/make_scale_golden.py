@@ -1,0 +1,98 @@
+"""Oracle residual histories AT THE BASELINE SIZES -> tests/golden/oracle_cfg{2,3,5}.json.
+
+  cfg 2: cg! on get_div_grad(512,512,512), b = ones, atol = rtol = 0, 100 iterations        (src/cg.jl:195-268)
+  cfg 3: gmres!(memory = 30, restart = true) on kron_unsymmetric(256), b = A*ones, 45 inner
+         iterations = one full cycle, the restart, and half of the second cycle            (src/gmres.jl:237-330)
+  cfg 5: block_gmres!(memory = 5, restart = true) on the 27-point 216^3 operator, p = 16,
+         B = A*X_true, 7 iterations = one cycle, the restart, two more                     (src/block_gmres.jl:236-310)
+
+Everything is the oracle's own arithmetic (oracle/krylov_oracle.c: serial extended-precision dots, fma axpys,
+unblocked Householder QR).  The operator products run row-parallel (ko_spmv_omp): rows are independent, so each y value
+is the serial loop's; likewise the p x p entries of the oracle's panel products and the columns its reflectors update
+are independent, so the thread count changes no value.  These are golden vectors OF THE ORACLE: "parity unpinned" with
+respect to Krylov.jl itself (no Julia in the image), exactly like tests/golden/oracle_histories.json.
+
+Run (needs ~20 GB of RAM for cfg 2, a few minutes on 8 cores):  python tests/golden/make_scale_golden.py [2] [3] [5]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import oracle as ok  # noqa: E402
+
+ok.PARALLEL_MATVEC = True
+ok.lib().ko_set_threads(len(os.sched_getaffinity(0)))
+which = [int(a) for a in sys.argv[1:]] or [2, 3, 5]
+SAMPLE = 16          # solution entries kept as a second, x-level check
+
+
+def sample_idx(n):
+    return [int(i) for i in np.linspace(0, n - 1, SAMPLE).astype(np.int64)]
+
+
+def cfg5_xtrue(n, p):
+    """The well-conditioned trigonometric family of tests/test_gpu_block.py::_rhs."""
+    t = (np.arange(n) + 1.0) / n
+    return np.stack([np.cos(j * np.pi * t) + 0.1 * j for j in range(p)], axis=1)
+
+
+def dump(name, d):
+    path = os.path.join(HERE, name)
+    json.dump(d, open(path, "w"), indent=1)
+    print("wrote", path, flush=True)
+
+
+if 2 in which:
+    t0 = time.time()
+    n1, iters = 512, 100
+    A = ok.poisson3d(n1)
+    b = np.ones(A.n)
+    res = ok.cg(A, b, atol=0.0, rtol=0.0, itmax=iters, history=True)
+    assert res.niter == iters, (res.niter, res.status)
+    idx = sample_idx(A.n)
+    dump("oracle_cfg2_cg512.json", dict(
+        generator="tests/golden/make_scale_golden.py", oracle="oracle/krylov_oracle.c ko_cg (src/cg.jl:120-291)",
+        config="BASELINE cfg 2: cg! on get_div_grad(512,512,512), b = ones, x0 = 0, atol = rtol = 0",
+        n=A.n, nnz=A.nnz, niter=res.niter, status=res.status,
+        residuals=[float(v) for v in res.residuals], x_index=idx, x_sample=[float(res.x[i]) for i in idx],
+        seconds=time.time() - t0))
+    del A, b, res
+
+if 3 in which:
+    t0 = time.time()
+    n1, mem, iters = 256, 30, 45
+    A = ok.kron_unsymmetric(n1)
+    b = A.matvec(np.ones(A.n))
+    res = ok.gmres(A, b, memory=mem, restart=True, atol=0.0, rtol=0.0, itmax=iters, history=True)
+    assert res.niter == iters, (res.niter, res.status)
+    idx = sample_idx(A.n)
+    dump("oracle_cfg3_gmres256.json", dict(
+        generator="tests/golden/make_scale_golden.py", oracle="oracle/krylov_oracle.c ko_gmres (src/gmres.jl:121-384)",
+        config="BASELINE cfg 3: gmres!(memory = 30, restart = true) on kron_unsymmetric(256), b = A*ones, atol = rtol = 0",
+        n=A.n, nnz=A.nnz, memory=mem, niter=res.niter, status=res.status,
+        residuals=[float(v) for v in res.residuals], x_index=idx, x_sample=[float(res.x[i]) for i in idx],
+        seconds=time.time() - t0))
+    del A, b, res
+
+if 5 in which:
+    t0 = time.time()
+    n1, p, mem, iters = 216, 16, 5, 7
+    A = ok.stencil27_unsym(n1)
+    Xt = cfg5_xtrue(A.n, p)
+    B = np.stack([A.matvec(np.ascontiguousarray(Xt[:, j])) for j in range(p)], axis=1)
+    res = ok.block_gmres(A, B, memory=mem, restart=True, atol=0.0, rtol=0.0, itmax=iters, history=True)
+    assert res.niter == iters, (res.niter, res.status)
+    idx = sample_idx(A.n)
+    dump("oracle_cfg5_block216.json", dict(
+        generator="tests/golden/make_scale_golden.py",
+        oracle="oracle/krylov_oracle.c ko_block_gmres (src/block_gmres.jl:110-358)",
+        config="BASELINE cfg 5: block_gmres!(memory = 5, restart = true), p = 16, 27-point 216^3 operator "
+               "(ko_csr_stencil27_unsym), B = A*X_true with X_true[i, j] = cos(j pi (i+1)/n) + 0.1 j, atol = rtol = 0",
+        n=A.n, nnz=A.nnz, p=p, memory=mem, niter=res.niter, status=res.status,
+        residuals=[float(v) for v in res.residuals], x_index=idx,
+        x_sample=[[float(v) for v in res.x[i]] for i in idx], seconds=time.time() - t0))

@@ -566,3 +566,83 @@ def test_spmv_fuzz_all_kernels_bit_exact(K, ctx, oracle):
     finally:
         for k, v in defaults.items():
             ctx.set_option(k, v)
+
+
+@pytest.mark.parametrize("kind,n1,bits,diags", [("poisson", 20, 8, 7), ("kron_unsymmetric", 12, 8, 7), ("stencil27", 9, 8, 27)])
+def test_spmv_coded_columns_bit_exact(K, ctx, oracle, kind, n1, bits, diags):
+    """The staged kernel's dictionary-coded column stream (csrc/colcode.hip: one byte per entry = the rank of the
+    entry's diagonal) gives the y of the int32 stream and of the oracle's serial loop bit for bit, with and without the
+    fused dots; forced two-byte codes and the switch `spmv_codes = 0` too."""
+    gen = {"poisson": oracle.poisson3d, "kron_unsymmetric": oracle.kron_unsymmetric, "stencil27": oracle.stencil27_unsym}[kind]
+    A = gen(n1)
+    rng = np.random.default_rng(77)
+    x = _vec(rng, A.n)
+    y_ref = A.matvec(x)
+    dx = ctx.array(x)
+    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel")}
+    try:
+        ctx.set_option("spmv_kernel", 4)            # the 27-point operator would take the ordered kernel by default
+        for mode, want_bits in ((1, bits), (16, 16), (0, 32)):
+            ctx.set_option("spmv_codes", mode)
+            dA = K.CsrMatrix.stencil(ctx, kind, n1)
+            assert dA.code_info == (32, 0)                              # nothing is built before the first product
+            dy = ctx.zeros(A.n)
+            dA.matvec(dx, dy)
+            assert dA.code_info == ((want_bits, diags) if mode else (32, 0))
+            assert np.array_equal(dy.to_host(), y_ref), (kind, mode)
+            dy2 = ctx.zeros(A.n)
+            d = K.spmv_dot(dA, dx, dy2)
+            assert np.array_equal(dy2.to_host(), y_ref)
+            d_cpu = oracle.dot(x, y_ref)
+            assert abs(d - d_cpu) <= 2 * EPS * abs(d_cpu) + 1e-16 * float(np.abs(x * y_ref).sum())
+            stored = dA.spmv_bytes_stored
+            want = (8 + (want_bits // 8)) * A.nnz + 4 * (A.n + 1) + 16 * A.n
+            assert stored == want and dA.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+
+
+def test_spmv_coded_columns_general_matrices(K, ctx):
+    """Matrices whose entries lie on few / many / too many diagonals: 8-bit codes, 16-bit codes, and the int32 stream
+    (more than 2048 distinct column - row offsets); empty rows, a rectangular operator, rows wider than one LDS window.
+    y equals the serial loop bit for bit in every case."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(99)
+
+    def banded(m, n, offs, drop=0.2):
+        rows, cols = [], []
+        for i in range(m):
+            for d in offs:
+                j = i + d
+                if 0 <= j < n and rng.random() > drop:
+                    rows.append(i); cols.append(j)
+        vals = rng.standard_normal(len(rows))
+        S = sp.csr_matrix((vals, (rows, cols)), shape=(m, n)); S.sort_indices()
+        return S
+    cases = [
+        (banded(3000, 3000, [-700, -3, -1, 0, 1, 2, 900]), 8),
+        (banded(2000, 2600, list(range(-150, 151, 1))[::50] + [400, 599]), 8),           # rectangular
+        (banded(1500, 1500, sorted(set(int(v) for v in rng.integers(-1400, 1400, size=300))), drop=0.98), 16),
+        (sp.random(4000, 4000, density=0.0015, random_state=5, format="csr"), 32),        # ~4000+ distinct offsets
+    ]
+    saved = ctx.get_option("spmv_kernel")
+    try:
+        ctx.set_option("spmv_kernel", 4)
+        for S, want_bits in cases:
+            S.sort_indices()
+            m, n = S.shape
+            dA = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data, (m, n))
+            x = rng.standard_normal(n)
+            y_ref = np.zeros(m)
+            for i in range(m):
+                acc = 0.0
+                for q in range(S.indptr[i], S.indptr[i + 1]):
+                    acc = acc + S.data[q] * x[S.indices[q]]
+                y_ref[i] = acc
+            dy = ctx.zeros(m)
+            dA.matvec(ctx.array(x), dy)
+            assert dA.code_info[0] == want_bits, (S.shape, dA.code_info)
+            assert np.array_equal(dy.to_host(), y_ref), (S.shape, dA.code_info)
+    finally:
+        ctx.set_option("spmv_kernel", saved)
