@@ -410,6 +410,185 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
   }
 }
 
+// ---------------------------------------------------------------- staged rows, software-pipelined ----
+// The staged kernels above run one dependent chain per workgroup -- row pointers -> window (val + columns) -> x gathers
+// -> y -- and only the middle link carries the bulk of the bytes: with 8 workgroups per CU about 40 % of them have their
+// window in flight at any time, ~50 KB per CU, and by Little's law that, not HBM, sets the rate (5.2-5.5 TB/s of real
+// traffic while the streaming BLAS-1 kernels reach 6.2-6.7).  This kernel gives every workgroup a run of `tiles_per_block`
+// CONSECUTIVE row blocks and keeps three of them in different stages at once:
+//     iteration t:   walk block t out of LDS (LDS reads, x gathers issued)
+//                    -> issue the window loads of block t+1 into registers   (its row pointers arrived an iteration ago)
+//                    -> issue the row-pointer loads of block t+2
+//                    -> wait for the gathers only (counted vmcnt: vector loads return in order and the gathers are the
+//                       OLDEST outstanding ones), finish the rows, store y
+// so a workgroup has a window in flight practically all the time.  Everything is vector memory (the block-uniform row
+// pointers too: scalar loads return out of order and would turn every LDS wait into a wait for them), the loop body is
+// straight-line, lanes without a k-th entry are predicated by selects (they gather x[0]), and barriers order LDS only
+// (s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads() would drain the prefetches).  Arithmetic per row is unchanged --
+// stored order, one rounded multiply and one rounded add per entry -- so y is bit-identical to the other kernels.
+// CODE = uint8_t / uint16_t: dictionary-coded columns (colcode.hip); CODE = int32_t: the plain CSR column stream.
+// Requires every row block to fit one window (rows * max_row_nnz + 3 <= 2048) and nnz > 0; launch_spmv checks.
+template <> struct code_load<int32_t> {    // 4 columns = four dwords
+  typedef u32x4 vec;
+  static __device__ __forceinline__ vec ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct RowPtrSet { int s, e, a, b; };      // block start / end (uniform), this lane's row start / end
+
+template <typename CODE, bool DOT, bool COMP, bool DIST>
+__global__ __launch_bounds__(kBlock) void spmv_pipe_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
+  typedef typename code_load<CODE>::vec cvec;
+  constexpr bool CODED = sizeof(CODE) < 4;
+  constexpr int UK = 8;
+  const int ROWS = a.stage_rows;
+  const int CAP = a.stage_cap;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_stage[];
+  double *s_val = reinterpret_cast<double *>(s_stage);
+  CODE *s_code = reinterpret_cast<CODE *>(s_stage + (size_t)CAP * sizeof(double));
+  int32_t *s_tab = reinterpret_cast<int32_t *>(s_stage + (size_t)CAP * (sizeof(double) + sizeof(CODE)));
+  const int tid = threadIdx.x;
+  const CODE *code = CODED ? reinterpret_cast<const CODE *>(a.code) : reinterpret_cast<const CODE *>(a.col);
+  const int64_t nrows = a.row_hi - a.row_lo;
+  const int64_t nrb = (nrows + ROWS - 1) / ROWS;
+  const int tpb = a.tiles_per_block > 0 ? a.tiles_per_block : 1;
+  const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap, a.sweep_s, a.sweep_w);
+  const int64_t rb_begin = (int64_t)cid * tpb;
+  const int64_t rb_end = (rb_begin + tpb < nrb) ? rb_begin + tpb : nrb;
+  const int kmax = a.max_row;
+  dd dacc[2];
+  dacc[0] = dd{0.0, 0.0};
+  dacc[1] = dd{0.0, 0.0};
+  if (CODED)
+    for (int i = tid; i < a.code_T; i += kBlock) s_tab[i] = a.code_tab[i];
+
+  // row pointers of block rb; blocks past the run are empty (all four words equal) and cost one cached line
+  auto load_rp = [&](int64_t rb) -> RowPtrSet {
+    int64_t r0 = a.row_lo + rb * ROWS;
+    if (rb >= rb_end || r0 > a.row_hi) r0 = a.row_hi;
+    const int64_t rend = (r0 + ROWS < a.row_hi) ? r0 + ROWS : a.row_hi;
+    const int64_t ia = (r0 + tid < rend) ? r0 + tid : rend;
+    const int64_t ib = (r0 + tid + 1 < rend) ? r0 + tid + 1 : rend;
+    RowPtrSet p;
+    p.s = a.rowptr[r0];
+    p.e = a.rowptr[rend];
+    p.a = a.rowptr[ia];
+    p.b = a.rowptr[ib];
+    return p;
+  };
+  u32x4 v[4];
+  cvec c[2];
+  auto issue_window = [&](const RowPtrSet &p) {
+    const int s = __builtin_amdgcn_readfirstlane(p.s), e = __builtin_amdgcn_readfirstlane(p.e);
+    const int c0 = s & ~3;
+    const int lim4 = (e - c0 + 3) & ~3;
+    const __amdgpu_buffer_rsrc_t rv =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(a.val + c0), 0, lim4 * 8, kBufRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<CODE *>(code + c0), 0, lim4 * (int)sizeof(CODE), kBufRsrcWord3);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = q * (4 * kBlock) + 4 * tid;
+      v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 0);
+      v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 0);
+      c[q] = code_load<CODE>::ld(rc, o * (int)sizeof(CODE));
+    }
+  };
+
+  RowPtrSet p0 = load_rp(rb_begin);
+  issue_window(p0);
+  RowPtrSet p1 = load_rp(rb_begin + 1);
+
+  for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
+    // window of block rb: registers -> LDS (waits for its loads; the row pointers issued behind them stay in flight)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = q * (4 * kBlock) + 4 * tid;
+      if (o < CAP) {
+        *reinterpret_cast<u32x4 *>(s_val + o) = v[2 * q];
+        *reinterpret_cast<u32x4 *>(s_val + o + 2) = v[2 * q + 1];
+        *reinterpret_cast<cvec *>(s_code + o) = c[q];
+      }
+    }
+    lds_only_barrier();
+    const int64_t r0 = a.row_lo + rb * ROWS;
+    const int64_t rend = (r0 + ROWS < a.row_hi) ? r0 + ROWS : a.row_hi;
+    const bool live = r0 + tid < rend;
+    const int32_t row = (int32_t)(r0 + tid);
+    const int base = p0.a - (p0.s & ~3);
+    const int cnt = p0.b - p0.a;
+    double acc = 0.0;
+    int k0 = 0;
+    for (; k0 + UK < kmax; k0 += UK) {          // rows longer than UK entries: all batches but the last, plain
+      int32_t cc[UK];
+      double vv[UK], xx[UK];
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        const int j = (k0 + u < cnt) ? base + k0 + u : 0;
+        cc[u] = (int32_t)s_code[j];
+        vv[u] = s_val[j];
+      }
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        const int32_t col = CODED ? row + s_tab[cc[u]] : cc[u];
+        xx[u] = gather_x<DIST>(a, (k0 + u < cnt) ? col : 0);
+      }
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        const double prod = vv[u] * xx[u];
+        const double next = acc + prod;
+        acc = (k0 + u < cnt) ? next : acc;
+      }
+    }
+    {   // last batch, with the prefetches between the issue of its gathers and their use
+      int32_t cc[UK];
+      double vv[UK], xx[UK];
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        const int j = (k0 + u < cnt) ? base + k0 + u : 0;
+        cc[u] = (int32_t)s_code[j];
+        vv[u] = s_val[j];
+      }
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        const int32_t col = CODED ? row + s_tab[cc[u]] : cc[u];
+        xx[u] = gather_x<DIST>(a, (k0 + u < cnt) ? col : 0);
+      }
+      double wv = 0.0;
+      if (DOT) wv = a.dotw[live ? r0 + tid : rend - 1];
+      __builtin_amdgcn_sched_barrier(0);
+      issue_window(p1);                          // block rb + 1 (v, c are free: they went to LDS before the barrier)
+      const RowPtrSet p2 = load_rp(rb + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UK; ++u) {
+        const double prod = vv[u] * xx[u];
+        const double next = acc + prod;
+        acc = (k0 + u < cnt) ? next : acc;
+      }
+      if (live) {
+        if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+        if (DOT) {
+          acc_prod<COMP>(dacc[0], wv, acc);
+          if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
+          else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);
+        }
+      }
+      p0 = p1;
+      p1 = p2;
+    }
+    lds_only_barrier();                          // every lane is done with the LDS window
+  }
+  if (DOT) {
+    if (a.dot_sq) wave_publish<2>(dacc, ra);
+    else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
+  }
+}
+
 // ---------------------------------------------------------------- row templates ----------
 // Compressed handles (template.hip): a row is a 16-bit id into a table of (column - row, value) sequences
 // held in LDS.  One lane per row; lanes of a wave mostly share the template (LDS broadcast), and at step k
@@ -603,6 +782,17 @@ static void launch_code_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra,
 #undef KHIP_L
 }
 
+template <typename CODE>
+static void launch_pipe_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
+                            bool dist) {
+  const size_t lds = (size_t)ctx->tune.spmv_lds_pad + (8u + sizeof(CODE)) * (size_t)a.stage_cap +
+                     (sizeof(CODE) < 4 ? 4u * (size_t)a.code_T : 0u);
+#define KHIP_L(DOT, COMP, DIST) \
+  hipLaunchKernelGGL((spmv_pipe_kernel<CODE, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
 template <int L, int RPG, bool NT>
 static void launch_ordered_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                                bool dist) {
@@ -690,7 +880,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.dot_sq = dot_sq;
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
-  a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256;
+  a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256; a.max_row = 0;
   a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;
   const bool dot = dot_slot >= 0, comp = ctx->tune.compensated != 0, dist = A->dist;
   const bool persist = ctx->tune.spmv_persist != 0;
@@ -762,16 +952,31 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
 #define KHIP_STG(R) do { if (nt) launch_stage_cfg<R, true>(ctx, a, ra, grid, dot, comp, dist); \
                          else launch_stage_cfg<R, false>(ctx, a, ra, grid, dot, comp, dist); } while (0)
-    if (ctx->tune.spmv_codes && !nt && !a.fake_gather) {
-      // coded column stream (colcode.hip): built once per handle, at the first product that gets here
-      khip_csr *Am = const_cast<khip_csr *>(A);
-      if (Am->code_state == 0) KHIP_TRY(csr_build_codes(ctx, Am));
-      if (Am->code_state == 1) {
-        a.code = Am->code; a.code_tab = Am->code_tab; a.code_T = Am->code_T; a.stage_rows = rows;
-        if (Am->code_bits == 8) launch_code_cfg<uint8_t>(ctx, a, ra, grid, dot, comp, dist);
-        else launch_code_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
-        rows = 0;      // launched
-      }
+    khip_csr *Am = const_cast<khip_csr *>(A);
+    const bool try_codes = ctx->tune.spmv_codes && !nt && !a.fake_gather;
+    // coded column stream (colcode.hip): built once per handle, at the first product that gets here
+    if (try_codes && Am->code_state == 0) KHIP_TRY(csr_build_codes(ctx, Am));
+    const bool coded = try_codes && Am->code_state == 1;
+    if (coded) { a.code = Am->code; a.code_tab = Am->code_tab; a.code_T = Am->code_T; }
+    a.stage_rows = rows;
+    a.max_row = (int)A->max_row_nnz;
+    // software-pipelined form: needs one window per row block
+    const bool pipe = ctx->tune.spmv_pipe > 0 && !nt && !a.fake_gather && A->nnz > 0 && A->max_row_nnz >= 1 &&
+                      (int64_t)rows * A->max_row_nnz + 3 <= 2048 && ctx->tune.spmv_cap == 0;
+    if (pipe) {
+      a.tiles_per_block = ctx->tune.spmv_pipe;
+      grid = pick_grid(ctx, (nrb4 + a.tiles_per_block - 1) / a.tiles_per_block, false);
+      if ((int64_t)grid * a.tiles_per_block < nrb4) a.tiles_per_block = (int)((nrb4 + grid - 1) / grid);
+      if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
+      ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
+      if (!coded) launch_pipe_cfg<int32_t>(ctx, a, ra, grid, dot, comp, dist);
+      else if (Am->code_bits == 8) launch_pipe_cfg<uint8_t>(ctx, a, ra, grid, dot, comp, dist);
+      else launch_pipe_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
+      rows = 0;      // launched
+    } else if (coded) {
+      if (Am->code_bits == 8) launch_code_cfg<uint8_t>(ctx, a, ra, grid, dot, comp, dist);
+      else launch_code_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
+      rows = 0;      // launched
     }
     switch (rows) {
       case 0: break;

@@ -44,7 +44,8 @@ struct SpmvArgs {
   const void *code;          // uint8_t[nnz + pad] or uint16_t[nnz + pad]
   const int32_t *code_tab;   // sorted distinct (column - row) offsets, code_T entries
   int code_T;
-  int stage_rows;            // coded kernel: rows per block (256, 128, 64 or 32)
+  int stage_rows;            // coded / pipelined kernels: rows per block (256, 128, 64 or 32)
+  int max_row;               // pipelined kernel: longest row of the operator (uniform trip count of the row walk)
 };
 
 template <bool NT, typename T>

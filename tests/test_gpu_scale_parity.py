@@ -7,10 +7,11 @@ Stated tolerances (fp64):
   * cfg 2, cg!: every residual norm within 1e-12 relative of the oracle's over 100 iterations (the north star's figure),
     for the reference's primitive sequence (fused = 0) and for the fused / device-resident paths; solution samples
     within 1e-12 of max|x|.
-  * cfg 3, gmres!(30, restart): |dr_k| <= 1e-10 r_k + 100 eps r_0 (the restart recomputes b - A x: cancellation
-    amplifies one-ulp differences of x by r_0 / r_k), iteration count and status equal.
-  * cfg 5, block_gmres!(5, restart), p = 16: |dr_k| <= 1e-8 r_k + 1e-10 r_0 -- the bound tests/test_gpu_block.py states
-    for restarted block solves; measured values are logged to gpurun_out/parity_log.jsonl.
+  * cfg 3, gmres!(30, restart), 45 iterations (one cycle, the restart, half a cycle): every residual norm within 1e-12
+    relative (measured 3.4e-14), iteration count and status equal, solution samples within 1e-12 of max|x|.
+  * cfg 5, block_gmres!(5, restart), p = 16, 7 iterations: every residual norm within 1e-12 relative (measured 3.0e-14),
+    solution samples within 1e-10 of max|X| (measured 5e-12).
+  Measured values are logged to gpurun_out/parity_log.jsonl (committed per round under profiles/).
 """
 import json
 import os
@@ -77,14 +78,14 @@ def test_gmres_cfg3_cycle_matches_oracle(K, ctx, parity_log, fused):
     assert st.niter == g["niter"] and st.status == g["status"]
     h = st.residuals
     assert len(h) == len(href)
-    units = float(np.max(np.abs(h - href) / (1e-10 * href + 100 * EPS * href[0])))
+    units = _rel(h, href) / 1e-12
     xs = ws.x.to_host()
     xg = np.array(g["x_sample"])
     xdev = float(np.max(np.abs(xs[g["x_index"]] - xg)) / np.max(np.abs(xg)))
     parity_log(test="gmres_cfg3_vs_oracle", fused=bool(fused), iterations=st.niter, hist_max_rel=_rel(h, href),
                hist_tol_units=units, x_sample_rel=xdev)
     assert units <= 1.0, units
-    assert xdev <= 1e-10, xdev
+    assert xdev <= 1e-12, xdev
 
 
 def test_block_gmres_cfg5_matches_oracle(K, ctx, parity_log):
@@ -108,11 +109,11 @@ def test_block_gmres_cfg5_matches_oracle(K, ctx, parity_log):
     assert st.niter == g["niter"] and st.status == g["status"]
     h = st.residuals
     assert len(h) == len(href)
-    units = float(np.max(np.abs(h - href) / (1e-8 * href + 1e-10 * href[0])))
+    units = _rel(h, href) / 1e-12
     X = ws.X
     xg = np.array(g["x_sample"])
     xdev = float(np.max(np.abs(X[g["x_index"], :] - xg)) / np.max(np.abs(xg)))
     parity_log(test="block_gmres_cfg5_vs_oracle", iterations=st.niter, hist_max_rel=_rel(h, href), hist_tol_units=units,
                x_sample_rel=xdev)
     assert units <= 1.0, units
-    assert xdev <= 1e-8, xdev
+    assert xdev <= 1e-10, xdev
