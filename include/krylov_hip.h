@@ -212,9 +212,13 @@ int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const doub
  * instead of five, one host synchronisation per sweep); same bits as the khip_panel_gemm_tn / _nn sequence. */
 int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, double *Q, double *Psi_host,
                    int accumulate);
-/* reduced QR of the panel: Q overwritten by an orthonormal basis, R_host (p-by-p col-major,
- * upper triangular, positive... sign convention of Householder: see DESIGN.md) */
+/* Reduced QR of the panel as householder!(Q, R, tau) = kgeqrf! + korgqr! leaves it (src/block_krylov_utils.jl:201-208,
+ * :230-236, :254-262): Q overwritten by the orthonormal factor, R_host (p-by-p column-major, upper triangular) and
+ * tau_host (p, may be null) with LAPACK's sign convention (R_jj = -sign(alpha_j) |x_j|, tau_j in [1, 2]).  Computed on the
+ * device by CholeskyQR2 (shifted CholeskyQR3 for ill-conditioned blocks); the signs and tau come from the top p-by-p block
+ * of Q (csrc/block.cpp).  ctx option "panel_signs" = 0 leaves the positive diagonal of the Cholesky factor. */
 int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host);
+int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host, double *tau_host);
 int khip_panel_norm(khip_ctx *ctx, int64_t n, int p, const double *Q, double *result_host);
 
 /* ------------------------------------------------ multi-GPU ------------------- */

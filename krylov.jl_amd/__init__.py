@@ -139,6 +139,7 @@ SIGNATURES = {
     "khip_panel_gemm_nn": (_int, [_vp, _i64, _int, _dbl, _vp, c_double_p, _dbl, _vp]),
     "khip_panel_mgs": (_int, [_vp, _i64, _int, _int, c_void_pp, _vp, c_double_p, _int]),
     "khip_panel_qr": (_int, [_vp, _i64, _int, _vp, c_double_p]),
+    "khip_panel_qr_tau": (_int, [_vp, _i64, _int, _vp, c_double_p, c_double_p]),
     "khip_panel_norm": (_int, [_vp, _i64, _int, _vp, c_double_p]),
     "khip_comm_unique_id": (_int, [_vp]),
     "khip_comm_init": (_int, [_vp, _int, _int, _vp]),
@@ -1231,6 +1232,14 @@ def panel_qr_(Q: Panel) -> np.ndarray:
     R = np.zeros((Q.p, Q.p), order="F")
     _ck(lib().khip_panel_qr(Q.ctx._h, Q.n, Q.p, Q.buf.ptr, R.ctypes.data_as(c_double_p)))
     return R
+
+
+def panel_qr_tau_(Q: Panel):
+    """householder!(Q, R, tau): Q, R and tau as kgeqrf! + korgqr! leave them (LAPACK signs); returns (R, tau)."""
+    R = np.zeros((Q.p, Q.p), order="F")
+    tau = np.zeros(Q.p)
+    _ck(lib().khip_panel_qr_tau(Q.ctx._h, Q.n, Q.p, Q.buf.ptr, R.ctypes.data_as(c_double_p), tau.ctypes.data_as(c_double_p)))
+    return R, tau
 
 
 def panel_norm(Q: Panel) -> float:

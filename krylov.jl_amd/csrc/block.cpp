@@ -8,10 +8,14 @@
 // Panel QR: the reference calls householder!(Q, C, tau) = geqrf + orgqr on the n x p block
 // (src/block_krylov_utils.jl:201-208): p BLAS-2 passes over the panel.  Here: CholeskyQR2 --
 // G = Q^T Q (one MFMA pass), R = chol(G), Q <- Q R^-1 (one pass), repeated once -- 4 passes, all
-// at HBM speed.  Q spans the same space and R = R2 R1 has a positive diagonal (LAPACK's has
-// Householder signs): block-GMRES residual norms ||C||_F and the iterates X are invariant under
-// that column-sign change, so parity with the reference holds on residual norms / solutions, not on
-// the individual Psi blocks (SURVEY.md section 7 "hard parts").  An ill-conditioned block (cond(Q)^2 > 1/eps)
+// at HBM speed.  Cholesky leaves R = R2 R1 with a positive diagonal; LAPACK's R has Householder signs.  The factors
+// differ by a diagonal S of +-1 (Q_h = Q S, R_h = S R), and S is recovered WITHOUT touching the panel again: Householder
+// QR of an orthonormal Q is an LU factorisation without pivoting of Q - [S; 0] whose pivots -- hence the signs
+// S_j = -sign(pivot_j) and the scalars tau_j = 1 + |pivot_j| -- only involve the TOP p x p block of Q (Ballard, Demmel,
+// Grigori, Jacquelin, Nguyen, Solomonik: "Reconstructing Householder vectors from TSQR", IPDPS 2014).  That block is
+// fetched (2 KB) before the last in-place scaling Q <- Q R^-1, S is folded into R^-1, and the panel comes out as
+// geqrf + orgqr would leave it: same Q, same R, same tau (up to rounding), so the Psi / C / H blocks of block_gmres! are
+// the reference's, not merely equivalent ones.  An ill-conditioned block (cond(Q)^2 > 1/eps)
 // first takes a SHIFTED Cholesky pass (shifted CholeskyQR3) -- still entirely on the device (an exactly
 // rank-deficient block, which the reference does not support either, docs/src/interfaces/reference.md:236,
 // comes out like LAPACK's: A = QR with a tiny diagonal entry).  Only p x p matrices are ever handled on the host.
@@ -118,6 +122,28 @@ void matmul_pp(int p, const double *A, const double *B, double *C) {   // C = A 
     }
 }
 
+// Signs and tau of LAPACK's Householder QR from the top p x p block Q1 (row-major, row i at Q1 + i p) of a panel with
+// orthonormal columns: LU without pivoting of Q1 - S, the sign of each pivot chosen as DLARFG chooses beta
+// (beta = -sign(alpha) |x|, sign(+0) = +).  Overwrites Q1.
+void householder_signs(int p, int64_t n, double *Q1, double *S, double *tau) {
+  for (int j = 0; j < p; ++j) {
+    const double a = Q1[(size_t)j * p + j];
+    if ((int64_t)j >= n - 1) {                         // DLARFG on a single entry: H = I, tau = 0, the entry keeps its sign
+      S[j] = std::signbit(a) ? -1.0 : 1.0;
+      tau[j] = 0.0;
+      continue;
+    }
+    S[j] = std::signbit(a) ? 1.0 : -1.0;
+    tau[j] = 1.0 + std::fabs(a);
+    const double piv = a - S[j];                       // |piv| >= 1
+    Q1[(size_t)j * p + j] = piv;
+    for (int i = j + 1; i < p; ++i) {
+      const double l = Q1[(size_t)i * p + j] / piv;
+      for (int k = j + 1; k < p; ++k) Q1[(size_t)i * p + k] -= l * Q1[(size_t)j * p + k];
+    }
+  }
+}
+
 struct StatsBoxB {
   khip_stats st;
   std::vector<double> residuals;
@@ -131,8 +157,13 @@ struct StatsBoxB {
 }  // namespace
 
 extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host) {
+  return khip_panel_qr_tau(ctx, n, p, Q, R_host, nullptr);
+}
+
+extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host, double *tau_host) {
   KHIP_REQUIRE(ctx && Q && R_host && p >= 1 && p <= 32, "panel_qr: bad argument (1 <= p <= 32)");
   const size_t pp = (size_t)p * p;
+  std::vector<double> S((size_t)p, 1.0), tauv((size_t)p, 0.0);
   std::vector<double> G(pp), R(pp), Ri(pp), Racc(pp, 0.0), tmp(pp);
   for (int i = 0; i < p; ++i) Racc[(size_t)i * p + i] = 1.0;             // accumulated R = R_k ... R_1 (R_0)
   // CholeskyQR2: two rounds of G = Q'Q (FP64 MFMA), host Cholesky of the p x p Gram matrix, Q <- Q R^-1 in place.
@@ -173,6 +204,34 @@ extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double 
       pass = -1;                                                          // two ordinary rounds follow
     }
     inv_upper(p, R.data(), Ri.data());
+    if (pass == 1 && ctx->tune.panel_signs != 0) {
+      // last scaling: LAPACK's column signs from the top block of the result, Q1 = (top block of Q) R^-1, folded into R^-1.
+      // Row-partitioned panels: the top block is rank 0's; the other ranks contribute zeros to the rank sum.
+      std::vector<double> top(pp, 0.0), Q1(pp, 0.0);
+      const int64_t have = n < p ? n : p;              // local rows of the top block
+      int64_t n_global_rows = n;
+      if (comm_nranks(ctx) > 1) {
+        double v = (double)n;
+        KHIP_TRY(comm_allreduce_sum_host(ctx, &v, 1));
+        n_global_rows = (int64_t)v;
+      }
+      const bool mine = comm_nranks(ctx) == 1 || comm_rank_of(ctx) == 0;
+      if (mine && have > 0) {
+        KHIP_CHECK_HIP(hipMemcpyAsync(top.data(), Q, sizeof(double) * (size_t)have * p, hipMemcpyDeviceToHost, ctx->stream));
+        KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      if (comm_nranks(ctx) > 1) KHIP_TRY(comm_allreduce_sum_host(ctx, top.data(), (int)pp));
+      for (int i = 0; i < p; ++i)
+        for (int j = 0; j < p; ++j) {
+          double acc = 0.0;
+          for (int l = 0; l <= j; ++l) acc += top[(size_t)i * p + l] * Ri[(size_t)j * p + l];   // Ri upper, column-major
+          Q1[(size_t)i * p + j] = acc;
+        }
+      householder_signs(p, n_global_rows, Q1.data(), S.data(), tauv.data());
+      for (int j = 0; j < p; ++j)
+        if (S[j] < 0)
+          for (int i = 0; i < p; ++i) Ri[(size_t)j * p + i] = -Ri[(size_t)j * p + i];
+    }
     if (pass == 0 && ctx->tune.panel_fuse != 0) {
       // first ordinary round: Q <- Q R^-1 and the Gram matrix of the second round in one pass (same bits)
       KHIP_TRY(panel_scale_gram(ctx, n, p, Q, Ri.data(), G.data()));
@@ -185,7 +244,11 @@ extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double 
   }
   memcpy(R_host, Racc.data(), sizeof(double) * pp);
   for (int j = 0; j < p; ++j)
-    for (int i = j + 1; i < p; ++i) R_host[(size_t)j * p + i] = 0;
+    for (int i = 0; i < p; ++i) {
+      if (i > j) R_host[(size_t)j * p + i] = 0;
+      else if (S[i] < 0) R_host[(size_t)j * p + i] = -R_host[(size_t)j * p + i];      // R_h = S R
+    }
+  if (tau_host) memcpy(tau_host, tauv.data(), sizeof(double) * (size_t)p);
   return KHIP_OK;
 }
 

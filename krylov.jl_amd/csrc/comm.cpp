@@ -143,6 +143,7 @@ struct Comm {
 };
 
 int comm_nranks(const khip_ctx *ctx) { return ctx->comm ? ctx->comm->nranks : 1; }
+int comm_rank_of(const khip_ctx *ctx) { return ctx->comm ? ctx->comm->rank : 0; }
 
 // --------------------------------------------------------------------------- host plan
 // Pure host logic, exported for the CPU (gloo) tests: given every rank's sorted list of needed

@@ -75,6 +75,7 @@ struct Tuning {
   int mgs_keep = -1;        // MGS cascade: keep q and the freshly dotted basis vector cacheable for the next step (-1 auto: when they fit the Infinity Cache; 0 off; 1 on; 2 nothing streamed)
   int hist_window = 1 << 14;   // device-resident loops: residual-history entries kept on the device between drains
   int red_u = 0;            // reductions: 16-byte accesses per lane (0 auto: 4 for long vectors, else 1)
+  int panel_signs = 1;      // panel QR: LAPACK's Householder signs / tau from the top p x p block (block.cpp); 0 = positive diagonal of R
   int panel_fuse = 1;       // block Gram-Schmidt: apply Psi_i and form Psi_{i+1} in one pass (panel.hip, single rank)
   int spmm_wide = 1;        // SpMM: two panel columns per lane (16-byte gathers) when p is even
   int spmm_window_grid = 0; // workgroups of the persistent window kernel (0 = CUs x LDS-limited residency)
@@ -261,6 +262,7 @@ void panel_scratch_destroy(khip_ctx *ctx);
 
 // comm.cpp
 int comm_nranks(const khip_ctx *ctx);
+int comm_rank_of(const khip_ctx *ctx);
 int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host);
 // all-reduce results_dd[slot..slot+count) into results[slot..] ON THE DEVICE (no host sync with RCCL), then run ctx->ctl's epilogue
 int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count);

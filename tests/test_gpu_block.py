@@ -1,9 +1,8 @@
 """GPU parity of the panel kernels (MFMA f64) and block_gmres_ against numpy / the CPU oracle.
 
-The panel QR on the device is CholeskyQR2 (positive diagonal R) while the reference / oracle use
-Householder (LAPACK signs): Q R, span(Q) and ||R||_F agree, individual factors differ by column
-signs.  block-GMRES parity is therefore stated on what is invariant: iteration counts, residual
-norm histories and the solution.  Tolerance on the history: |dr_k| <= 1e-8 r_k + floor * r_0 with floor = 100 eps
+The panel QR on the device is CholeskyQR2 with LAPACK's Householder signs and tau recovered from the top p x p block
+(csrc/block.cpp): Q, R and tau are compared with LAPACK's geqrf / orgqr directly, no sign fix-up.  block-GMRES parity is
+stated on iteration counts, residual norm histories and the solution.  Tolerance on the history: |dr_k| <= 1e-8 r_k + floor * r_0 with floor = 100 eps
 without restart (measured: 1e-13 relative) and floor = 1e-10 with restart: the restart recomputes B - A X,
 and X carries the cond(R_k)-amplified difference between the two panel-QR variants (measured 1.3e-11 r_0)."""
 import numpy as np
@@ -36,20 +35,33 @@ def test_panel_layout_and_products(K, ctx, n, p):
     assert np.allclose(K.panel_gemm_tn(dE, dQ), (2.0 * V @ M)[:p, :][: min(n, p)].T.T if False else E.T @ (2.0 * V @ M), atol=1e-12)
 
 
-@pytest.mark.parametrize("n,p", [(64, 4), (1000, 16), (20000, 16), (3000, 7), (4096, 32)])
+@pytest.mark.parametrize("n,p", [(64, 4), (1000, 16), (20000, 16), (3000, 7), (4096, 32), (16, 16), (33, 1)])
 def test_panel_qr(K, ctx, n, p):
+    """householder!(Q, R, tau) (src/block_krylov_utils.jl:201-208): Q, R and tau equal LAPACK's geqrf + orgqr -- compared
+    WITHOUT any sign normalisation."""
+    import scipy.linalg as sl
     rng = np.random.default_rng(7 * n + p)
     A = rng.standard_normal((n, p)) @ (np.eye(p) + 0.3 * rng.standard_normal((p, p)))
     dQ = K.Panel.from_host(ctx, A)
-    R = K.panel_qr_(dQ)
+    R, tau = K.panel_qr_tau_(dQ)
     Qh = dQ.to_host()
-    assert np.allclose(np.tril(R, -1), 0) and np.all(np.diag(R) > 0)
+    assert np.allclose(np.tril(R, -1), 0)
     assert np.allclose(Qh.T @ Qh, np.eye(p), atol=1e-13)
     assert np.allclose(Qh @ R, A, atol=1e-12 * np.abs(A).max() * p)
-    # same factorisation as LAPACK up to column signs
-    Ql, Rl = np.linalg.qr(A)
-    S = np.sign(np.diag(Rl))
-    assert np.allclose(Qh, Ql * S, atol=1e-10) and np.allclose(R, (Rl.T * S).T, atol=1e-10 * np.abs(Rl).max())
+    (_, tau_l), _ = sl.qr(A, mode="raw")
+    Ql, Rl = sl.qr(A, mode="economic")
+    assert np.array_equal(np.sign(np.diag(R)), np.sign(np.diag(Rl)))
+    assert np.allclose(Qh, Ql, atol=1e-10) and np.allclose(R, Rl, atol=1e-10 * np.abs(Rl).max())
+    assert np.allclose(tau, tau_l, atol=1e-10) and np.all(((tau >= 1.0) & (tau <= 2.0)) | (tau == 0.0))   # tau = 0: last column of a square block
+    # the positive-diagonal factor stays available
+    ctx.set_option("panel_signs", 0)
+    try:
+        dQ2 = K.Panel.from_host(ctx, A)
+        R2 = K.panel_qr_(dQ2)
+        S = np.sign(np.diag(Rl))
+        assert np.all(np.diag(R2) > 0) and np.allclose(dQ2.to_host(), Ql * S, atol=1e-10)
+    finally:
+        ctx.set_option("panel_signs", 1)
 
 
 @pytest.mark.parametrize("eps_col", [1e-6, 1e-9, 1e-12])
@@ -62,7 +74,7 @@ def test_panel_qr_ill_conditioned_takes_the_shifted_pass(K, ctx, eps_col):
     dQ = K.Panel.from_host(ctx, A)
     R = K.panel_qr_(dQ)
     Qh = dQ.to_host()
-    assert np.allclose(np.tril(R, -1), 0) and np.all(np.diag(R) > 0)
+    assert np.allclose(np.tril(R, -1), 0) and np.all(np.diag(R) != 0)
     assert np.allclose(Qh.T @ Qh, np.eye(6), atol=1e-10)
     assert np.allclose(Qh @ R, A, atol=1e-10)
 
@@ -306,3 +318,44 @@ def test_panel_qr_same_with_and_without_fused_round(K, ctx, n, p, cond):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     Qh, R = res[0]
     assert np.allclose(Qh @ R, A, atol=1e-12 * np.abs(A).max() * cond ** 0 + 1e-13) and np.allclose(Qh.T @ Qh, np.eye(p), atol=1e-10)
+
+
+def test_block_arnoldi_step_blocks_equal_the_oracles(K, ctx, oracle):
+    """One block-Arnoldi step of block_gmres! issued primitive by primitive (src/block_gmres.jl:211-212, :242-247, :259):
+    the basis panels AND the small blocks -- Z_1 (R factor of the residual block), Psi_1 = V_1' W, C (R factor of the
+    orthogonalised W) -- equal the ones the oracle's Householder path (ko_householder = geqrf + orgqr) produces, entry by
+    entry and with the same signs: the device QR is not merely an equivalent factorisation."""
+    import ctypes as C
+    A = oracle.kron_unsymmetric(9)
+    n, p = A.n, 16
+    S = A.to_scipy()
+    B, _ = _rhs(S, n, p)
+    L = oracle.lib()
+    dp = C.POINTER(C.c_double)
+
+    def householder(M):
+        Q = np.asfortranarray(M.copy())
+        R = np.zeros((p, p), order="F")
+        tau = np.zeros(p)
+        L.ko_householder(n, p, Q.ctypes.data_as(dp), R.ctypes.data_as(dp), tau.ctypes.data_as(dp), 0)
+        return Q, R, tau
+    V1, Z1, tau1 = householder(B)
+    W = np.stack([A.matvec(np.ascontiguousarray(V1[:, j])) for j in range(p)], axis=1)
+    Psi = V1.T @ W
+    W2 = W - V1 @ Psi
+    Q2, Cb, tau2 = householder(W2)
+
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (n, n))
+    dV = K.Panel.from_host(ctx, B)
+    Z1g, tau1g = K.panel_qr_tau_(dV)
+    dW = K.Panel(ctx, n, p)
+    K.spmm_(dA, dV, dW)
+    Psig = K.panel_gemm_tn(dV, dW)
+    K.panel_gemm_nn_(-1.0, dV, Psig, 1.0, dW)
+    Cg, tau2g = K.panel_qr_tau_(dW)
+
+    def close(X, Y, tol):
+        return float(np.max(np.abs(X - Y))) <= tol * max(1.0, float(np.max(np.abs(Y))))
+    assert close(dV.to_host(), V1, 1e-11) and close(Z1g, Z1, 1e-11) and close(tau1g, tau1, 1e-11)
+    assert close(Psig, Psi, 1e-10)
+    assert close(dW.to_host(), Q2, 1e-9) and close(Cg, Cb, 1e-9) and close(tau2g, tau2, 1e-9)
