@@ -24,7 +24,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EPS = np.finfo(float).eps
 HIST_RTOL = 1e-10
 HIST_FLOOR = 100 * EPS
-HIST_RTOL_BICGSTAB = 1e-7   # BiCGSTAB's alpha/omega are ratios of cancelling dots: measured 2e-9 after 40 iterations
+
+
+def _bicgstab_rtol(n1):
+    """Tolerance of the GPU-vs-oracle BiCGSTAB history, DERIVED, not fitted: both are double-precision runs of one
+    recurrence whose exact (binary128) history is in tests/golden/quad_histories.json together with the CPU oracle's own
+    distance d to it (1.1e-11 at 8^3, 1.5e-8 at 16^3: alpha and omega are ratios of cancelling dots).  The HIP path is held
+    to 8 d of the exact history (tests/test_gpu_quad_reference.py), so the two can differ by at most (1 + 8) d."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "quad_histories.json")))
+    d = {c["n1"]: c["oracle_double_max_rel_dev"] for c in g["cases"] if c["solver"] == "bicgstab"}
+    return 9.0 * d[n1] + 1e-13
 
 
 def _upload(K, ctx, A):
@@ -368,7 +377,7 @@ def test_bicgstab_matches_oracle(K, ctx, oracle, parity_log, n1, fused):
     dev = _hist_dev(st.residuals, ref.residuals)
     parity_log(test="bicgstab_kron", n1=n1, fused=fused, niter=st.niter, hist_tol_units=dev,
                hist_max_rel=_hist_rel(st.residuals, ref.residuals))
-    assert _hist_rel(st.residuals, ref.residuals) <= HIST_RTOL_BICGSTAB
+    assert _hist_rel(st.residuals, ref.residuals) <= _bicgstab_rtol(n1)          # 9.5e-11 at 8^3, 1.4e-7 at 16^3
     S = A.to_scipy()
     assert np.linalg.norm(bh - S @ x.to_host()) / np.linalg.norm(bh) <= 1e-6       # test/test_bicgstab.jl:39-45
     assert ws.nbytes == 6 * 8 * A.n                                                # storage 6n
@@ -394,7 +403,7 @@ def test_bicgstab_device_resident_loop_equals_host_loop(K, ctx, oracle):
         assert np.array_equal(x2.to_host(), x1.to_host()), kw
     ref = oracle.bicgstab(A, bh, history=True)
     x2, st2, _ = K.bicgstab(dA, b, fused=2, history=True)
-    assert st2.niter == ref.niter and np.max(np.abs(st2.residuals - ref.residuals) / ref.residuals) <= HIST_RTOL_BICGSTAB
+    assert st2.niter == ref.niter and np.max(np.abs(st2.residuals - ref.residuals) / ref.residuals) <= 1e-9   # random b, 10^3: measured 1e-11
     ctx.set_option("hist_window", 8)
     try:
         x3, st3, _ = K.bicgstab(dA, b, fused=2, history=True, rtol=1e-13, atol=0.0)

@@ -592,3 +592,30 @@ def test_processes_single_step_shapes(oracle):
     assert nt.shape == (2,) and nh.shape == (2,) and nt[0] == nh[0]
     assert np.allclose(A @ V[:, 0], nt[0] * V[:, 0] + nt[1] * V[:, 1])
     assert np.allclose(A.T @ U[:, 0], nh[0] * U[:, 0] + nh[1] * U[:, 1])
+
+
+def test_binary128_reference_distances_are_reproducible(oracle):
+    """tests/golden/quad_histories.json stores, per case, the binary128 history of the oracle's recurrence and the distance
+    of the double-precision oracle to it.  Re-derive that distance for the small cases with the oracle as built here:
+    the stored numbers are properties of the algorithm + IEEE double, not of a particular run."""
+    ok = oracle
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "quad_histories.json")))
+    seen = 0
+    for c in g["cases"]:
+        if c["n1"] > 16 or c["solver"] == "block_gmres":
+            continue
+        A = getattr(ok, c["matrix"])(c["n1"])
+        b = np.ones(A.n) if c["rhs"] == "ones" else A.matvec(np.ones(A.n))
+        kw = dict(restart=bool(c.get("restart", False)), reorthogonalization=bool(c.get("reorthogonalization", False)))
+        if c["solver"] == "cg":
+            ref = ok.cg(A, b, history=True)
+        elif c["solver"] == "bicgstab":
+            ref = ok.bicgstab(A, b, history=True)
+        else:
+            ref = ok.gmres(A, b, memory=c["memory"], history=True, **kw)
+        hq = np.array(c["residuals"])
+        assert ref.niter == c["niter"] and ref.status == c["status"]
+        dev = float(np.max(np.abs(ref.residuals - hq) / hq))
+        assert abs(dev - c["oracle_double_max_rel_dev"]) <= 1e-3 * c["oracle_double_max_rel_dev"] + 1e-18, c["name"]
+        seen += 1
+    assert seen >= 6
