@@ -43,6 +43,7 @@ CASES = [
     dict(name="cg_poisson16", solver="cg", matrix="poisson3d", n1=16, rhs="ones"),
     dict(name="cg_poisson32", solver="cg", matrix="poisson3d", n1=32, rhs="ones"),
     dict(name="bicgstab_kron8", solver="bicgstab", matrix="kron_unsymmetric", n1=8, rhs="A*ones"),
+    dict(name="bicgstab_kron12", solver="bicgstab", matrix="kron_unsymmetric", n1=12, rhs="A*ones"),
     dict(name="bicgstab_kron16", solver="bicgstab", matrix="kron_unsymmetric", n1=16, rhs="A*ones"),
     dict(name="gmres_kron8", solver="gmres", matrix="kron_unsymmetric", n1=8, rhs="A*ones", memory=10),
     dict(name="gmres_kron16", solver="gmres", matrix="kron_unsymmetric", n1=16, rhs="A*ones", memory=10),
