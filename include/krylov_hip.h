@@ -125,6 +125,14 @@ int khip_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int 
 /* algorithmic HBM bytes of one khip_spmv on this handle: 12 nnz + 4 (m+1) + 8 n + 8 m */
 int khip_spmv_bytes(const khip_csr *A, int64_t *bytes);
 
+/* Test-only exports of the scalar helpers of the solver loops, so that the reference's exact known answers
+ * (test/test_aux.jl:3-117) are checked against the copies the product runs: sym_givens (src/krylov_utils.jl:21-51),
+ * roots_quadratic (:110-152), to_boundary with M = I (:375-402; x, d device vectors, the dots run on the device). */
+int khip_test_sym_givens(double a, double b, double *c, double *s, double *rho);
+int khip_test_roots_quadratic(double q2, double q1, double q0, int nitref, double *root1, double *root2);
+int khip_test_to_boundary(khip_ctx *ctx, int64_t n, const double *x, const double *d, double radius, int flip,
+                          double *sigma1, double *sigma2);
+
 /* Profiling hook used by bench.py's roofline leg: with khip_ctx_set_option(ctx, "profile_spmv", 1)
  * every SpMV kernel launch is bracketed by HIP events on the context's stream; this call
  * synchronises, returns the number of launches recorded since the last call and their summed
@@ -364,6 +372,10 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
                            const khip_operator *N, const double *B_colmajor, const khip_options *opts);
 int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor);
 const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws);
+/* storage test (test/test_allocations.jl:734-761): bytes of the workspace with n x p blocks at their logical size;
+ * *extra_bytes (may be null) = what this implementation holds beyond the reference's formula (the row-major panel copy
+ * of B and the p x p staging blocks of the fused sweeps) */
+size_t            khip_block_gmres_workspace_bytes(khip_block_gmres_workspace *ws, size_t *extra_bytes);
 
 /* ---- Krylov processes (src/krylov_processes.jl) --------------------------------------------------------------
  * The bases are dense COLUMN-MAJOR device arrays as in the reference (`M(undef, n, k+1)`): column j starts at

@@ -172,6 +172,10 @@ SIGNATURES = {
     "khip_bicgstab_solution": (_vp, [_vp]),
     "khip_bicgstab_stats": (C.POINTER(CStats), [_vp]),
     "khip_bicgstab_workspace_bytes": (_sz, [_vp]),
+    "khip_block_gmres_workspace_bytes": (_sz, [_vp, C.POINTER(C.c_size_t)]),
+    "khip_test_sym_givens": (_int, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
+    "khip_test_roots_quadratic": (_int, [C.c_double, C.c_double, C.c_double, _int, c_double_p, c_double_p]),
+    "khip_test_to_boundary": (_int, [_vp, _i64, _vp, _vp, C.c_double, _int, c_double_p, c_double_p]),
     "khip_block_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, _int, c_void_pp]),
     "khip_block_gmres_workspace_destroy": (_int, [_vp]),
     "khip_block_gmres_warm_start": (_int, [_vp, _vp]),
@@ -1277,7 +1281,14 @@ class BlockGmresWorkspace(_Workspace):
 
     @property
     def nbytes(self):
-        raise NotImplementedError
+        """Workspace bytes as test/test_allocations.jl:734-761 counts them (includes `nbytes_extra`)."""
+        return lib().khip_block_gmres_workspace_bytes(self._h, None)
+
+    @property
+    def nbytes_extra(self):
+        e = C.c_size_t()
+        lib().khip_block_gmres_workspace_bytes(self._h, C.byref(e))
+        return e.value
 
 
 def _make_block_operator(ctx, op, n, p, keep):

@@ -262,6 +262,9 @@ struct khip_block_gmres_workspace {
   double *Bp = nullptr;                                        // panel copy of B
   std::vector<double *> V;
   std::vector<std::vector<double>> Z, R, H, tau;               // host p x p, p x p, 2p x p, p
+  std::vector<double> C, D;                                    // host p x p, 2p x p (src/block_krylov_workspaces.jl:126-127)
+  std::vector<double> sweep, Yall, tmp;                        // staging of the fused sweeps: mem p x p each (grown with the basis), p x p
+  std::vector<const double *> Vp;
   bool warm_start = false;
   StatsBoxB box;
 };
@@ -302,6 +305,12 @@ int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p
   ws->R.assign((size_t)memory * (memory + 1) / 2, std::vector<double>(pp, 0.0));
   ws->H.assign(memory, std::vector<double>(2 * pp, 0.0));
   ws->tau.assign(memory, std::vector<double>(p, 0.0));
+  ws->C.assign(pp, 0.0);
+  ws->D.assign(2 * pp, 0.0);
+  ws->sweep.assign((size_t)memory * pp, 0.0);
+  ws->Yall.assign((size_t)memory * pp, 0.0);
+  ws->tmp.assign(pp, 0.0);
+  ws->Vp.assign((size_t)memory, nullptr);
   *out = ws;
   return KHIP_OK;
 }
@@ -315,6 +324,23 @@ int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws) {
 }
 
 const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+
+// Storage as test/test_allocations.jl:734-761 counts it (n x p blocks at their logical size, without the <= 15 padding
+// rows of a panel): X, W, V[1..mem] (+ dX / P / Q when allocated) on the device, C, D, tau, Z, R, H on the host -- plus what
+// this implementation adds: the row-major panel copy of B (the boundary takes the reference's column-major B) and the
+// staging of the fused sweeps (2 mem + 1 blocks of p x p).  *extra_bytes (may be null) receives that addition.
+size_t khip_block_gmres_workspace_bytes(khip_block_gmres_workspace *ws, size_t *extra_bytes) {
+  if (!ws) return 0;
+  const size_t block = sizeof(double) * (size_t)ws->n * ws->p;
+  size_t panels = ws->V.size();
+  for (double *v : {ws->dX, ws->X, ws->W, ws->Pn, ws->Qm}) panels += v ? 1 : 0;
+  size_t host = ws->C.size() + ws->D.size();
+  for (auto *grp : {&ws->Z, &ws->R, &ws->H, &ws->tau})
+    for (const auto &blk : *grp) host += blk.size();
+  const size_t extra = (ws->Bp ? block : 0) + sizeof(double) * (ws->sweep.size() + ws->Yall.size() + ws->tmp.size());
+  if (extra_bytes) *extra_bytes = extra;
+  return panels * block + sizeof(double) * host + extra;
+}
 
 int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor) {
   KHIP_REQUIRE(ws && X_colmajor, "block_gmres_get_X: null argument");
@@ -360,7 +386,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   double *dX = ws->dX, *X = ws->X, *W = ws->W, *Bp = ws->Bp;
   std::vector<double *> &V = ws->V;
   auto &Z = ws->Z; auto &R = ws->R; auto &H = ws->H; auto &tau = ws->tau;
-  std::vector<double> C(pp), D(2 * pp), sweep;
+  std::vector<double> &C = ws->C, &D = ws->D, &sweep = ws->sweep;      // in-place solve: no allocation per call (test/test_allocations.jl:752)
   const bool warm_start = ws->warm_start;
   ws->box.reset();
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
@@ -443,9 +469,11 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
       // :244-247 (Psi_i = V_i^T Q ; Q -= V_i Psi_i for i = 1..k) and the reorthogonalisation pass :250-256, each as
       // one sweep whose blocks stay on the device between the steps
       {
-        std::vector<const double *> Vp((size_t)inner_iter);
+        std::vector<const double *> &Vp = ws->Vp;
+        if (Vp.size() < (size_t)inner_iter) Vp.resize((size_t)inner_iter);                // only when the basis grew (restart = false)
         for (int i = 0; i < inner_iter; ++i) Vp[i] = V[i];
-        sweep.assign((size_t)inner_iter * pp, 0.0);
+        if (sweep.size() < (size_t)inner_iter * pp) sweep.resize((size_t)inner_iter * pp);
+        std::fill(sweep.begin(), sweep.begin() + (size_t)inner_iter * pp, 0.0);
         KB(khip_panel_mgs(ctx, n, p, inner_iter, Vp.data(), Q, sweep.data(), 0));
         for (int i = 0; i < inner_iter; ++i) std::copy(sweep.begin() + (size_t)i * pp, sweep.begin() + (size_t)(i + 1) * pp, R[nr + i].begin());
         if (reorth) {
@@ -508,7 +536,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
       } else {
         inner_tired = inner_iter >= inner_itmax;
       }
-      overtimed = (now_s() - t0) > timemax;
+      overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
 
       if (!(solved || inner_tired || user_requested_exit || overtimed)) {
         if (!restart && (inner_iter >= mem)) {                                     // :300-305
@@ -528,7 +556,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
 
     // block back-substitution (:313-321), Y aliases Z
     auto &Y = Z;
-    std::vector<double> tmp(pp);
+    std::vector<double> &tmp = ws->tmp;
     for (int i = inner_iter; i >= 1; --i) {
       int pos = nr + i - inner_iter;
       for (int j = inner_iter; j >= i + 1; --j) {
@@ -554,8 +582,10 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
     }
 
     {                                                                              // :324-326, the k products in one pass
-      std::vector<const double *> Vp((size_t)inner_iter);
-      std::vector<double> Yall((size_t)inner_iter * pp);
+      std::vector<const double *> &Vp = ws->Vp;
+      std::vector<double> &Yall = ws->Yall;
+      if (Vp.size() < (size_t)inner_iter) Vp.resize((size_t)inner_iter);
+      if (Yall.size() < (size_t)inner_iter * pp) Yall.resize((size_t)inner_iter * pp);
       for (int i = 0; i < inner_iter; ++i) {
         Vp[i] = V[i];
         std::copy(Y[i].begin(), Y[i].begin() + pp, Yall.begin() + (size_t)i * pp);
@@ -571,7 +601,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
     inner_itmax = inner_itmax - inner_iter;
     iter = iter + inner_iter;
     tired = iter >= itmax;
-    overtimed = (now_s() - t0) > timemax;
+    overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
   if (tired) status = "maximum number of iterations exceeded";

@@ -271,6 +271,18 @@ int comm_allreduce_sum_host(khip_ctx *ctx, double *vals, int count);
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A);
 int comm_build_plan(khip_ctx *ctx, khip_csr *A);
 
+// "time limit exceeded" decided COLLECTIVELY: every stopping test of the solver loops comes from all-reduced scalars and
+// is therefore identical on all ranks -- except the wall clock.  A rank that alone ran out of time would leave its peers
+// blocked in the next all-gather / Send / Recv, so with a communicator attached the flag is summed over the ranks (any
+// rank over the limit stops all of them, at the same iteration).  Costs a host all-gather per test, hence only when the
+// caller set a finite timemax.  All ranks reach every call site together (same control flow), as the collective needs.
+inline bool time_limit_reached(khip_ctx *ctx, double elapsed_s, double timemax) {
+  if (!(timemax < 1e300)) return false;                 // no limit (the default): no collective either
+  double over = elapsed_s > timemax ? 1.0 : 0.0;
+  if (comm_nranks(ctx) > 1 && comm_allreduce_sum_host(ctx, &over, 1) != KHIP_OK) return true;   // a broken communicator ends the solve
+  return over > 0.0;
+}
+
 // rows of the GLOBAL operator (= n on one GPU): a distributed handle knows it, otherwise the local counts are summed
 inline int64_t global_rows(khip_ctx *ctx, const khip_operator *A, int64_t n_local) {
   if (A && A->csr && !A->apply && A->csr->dist) return A->csr->n_global;

@@ -117,12 +117,11 @@ int cg_device_loop(khip_cg_workspace *ws, const khip_csr *A, double gamma, doubl
                    double t0, double timemax, CgDevState *out, bool *overtimed) {
   khip_ctx *ctx = ws->ctx;
   const int64_t n = ws->n;
-  if (!ws->dev_state) {
-    KHIP_CHECK_HIP(hipMalloc(&ws->dev_state, sizeof(CgDevState)));
-    KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->snap), 2 * sizeof(CgDevState), hipHostMallocDefault));
-    KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindowMax));
-    for (auto &e : ws->snap_ev) KHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
+  // every resource is guarded on its own: hist_dev and the events are shared with the single-reduction loop below
+  if (!ws->dev_state) KHIP_CHECK_HIP(hipMalloc(&ws->dev_state, sizeof(CgDevState)));
+  if (!ws->snap) KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->snap), 2 * sizeof(CgDevState), hipHostMallocDefault));
+  if (!ws->hist_dev) KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindowMax));
+  for (auto &e : ws->snap_ev) if (!e) KHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   long long kHistWindow = ctx->tune.hist_window;
   if (kHistWindow < kDevChunk) kHistWindow = kDevChunk;
   if (kHistWindow > kHistWindowMax) kHistWindow = kHistWindowMax;
@@ -186,7 +185,7 @@ int cg_device_loop(khip_cg_workspace *ws, const khip_csr *A, double gamma, doubl
       if (ws->snap[b ^ 1].stop_seq != kSeqNever) stopped = true;
     }
     if (enq >= itmax) stopped = true;
-    if (!stopped && (now_s() - t0) > timemax) { *overtimed = true; stopped = true; }
+    if (!stopped && time_limit_reached(ctx, now_s() - t0, timemax)) { *overtimed = true; stopped = true; }
   }
   ctx->ctl = SeqCtl{};
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -268,7 +267,7 @@ int cg_single_reduction_loop(khip_cg_workspace *ws, const khip_csr *A, double ga
       if (ws->cgcg_snap[b ^ 1].stop_seq != kSeqNever) stopped = true;
     }
     if (enq >= itmax) stopped = true;
-    if (!stopped && (now_s() - t0) > timemax) { *overtimed = true; stopped = true; }
+    if (!stopped && time_limit_reached(ctx, now_s() - t0, timemax)) { *overtimed = true; stopped = true; }
   }
   ctx->ctl = SeqCtl{};
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -341,8 +340,7 @@ size_t khip_cg_workspace_bytes(khip_cg_workspace *ws) {
 }
 
 // to_boundary with M === I (src/krylov_utils.jl:375-402) + roots_quadratic (:110-152)
-static int roots_quadratic(double q2, double q1, double q0, double *r1, double *r2) {
-  const int nitref = 1;
+static int roots_quadratic(double q2, double q1, double q0, double *r1, double *r2, int nitref = 1) {
   double root1, root2;
   if (q2 == 0.0) {
     double root;
@@ -380,6 +378,45 @@ static int roots_quadratic(double q2, double q1, double q0, double *r1, double *
   return 0;
 }
 
+}  // extern "C"
+
+// to_boundary(n, x, d, z, radius; flip, xNorm2, dNorm2) with M === I (src/krylov_utils.jl:375-402): the two sigma with
+// ||x + sigma d|| = radius.  The dots run on the device (kdotr); a zero xNorm2 / dNorm2 argument means "compute it".
+// Returns 0, or a negative code with the reference's error text in *err.
+static int to_boundary_dev(khip_ctx *ctx, int64_t n, const double *x, const double *d, double radius, bool flip, double xNorm2,
+                           double dNorm2, double *s1, double *s2, const char **err) {
+  if (!(radius > 0)) { *err = "radius must be positive"; return -1; }
+  double rxd;
+  KHIP_TRY(khip_dot(ctx, n, x, d, &rxd));
+  if (dNorm2 == 0.0) KHIP_TRY(khip_dot(ctx, n, d, d, &dNorm2));
+  if (xNorm2 == 0.0) KHIP_TRY(khip_dot(ctx, n, x, x, &xNorm2));
+  if (dNorm2 == 0.0) { *err = "zero direction"; return -2; }
+  if (flip) rxd = -rxd;
+  const double radius2 = radius * radius;
+  if (!(xNorm2 <= radius2)) { *err = "outside of the trust region"; return -3; }
+  if (roots_quadratic(dNorm2, 2 * rxd, xNorm2 - radius2, s1, s2)) { *err = "The quadratic `q` doesn't have real roots."; return -4; }
+  return 0;
+}
+
+extern "C" {
+
+// Test-only exports of the scalar helpers the solver loops use (tests/test_abi.py, tests/test_gpu_solvers.py hold the
+// reference's exact known answers, test/test_aux.jl:3-117, against THESE copies, not only against the oracle's).
+int khip_test_sym_givens(double a, double b, double *c, double *s, double *rho);      // defined next to sym_givens below
+int khip_test_roots_quadratic(double q2, double q1, double q0, int nitref, double *root1, double *root2) {
+  KHIP_REQUIRE(root1 && root2, "test_roots_quadratic: null argument");
+  if (roots_quadratic(q2, q1, q0, root1, root2, nitref)) { set_error("The quadratic `q` doesn't have real roots."); return KHIP_ERR_NUMERIC; }
+  return KHIP_OK;
+}
+int khip_test_to_boundary(khip_ctx *ctx, int64_t n, const double *x, const double *d, double radius, int flip, double *sigma1,
+                          double *sigma2) {
+  KHIP_REQUIRE(ctx && x && d && sigma1 && sigma2, "test_to_boundary: null argument");
+  const char *err = "";
+  const int rc = to_boundary_dev(ctx, n, x, d, radius, flip != 0, 0.0, 0.0, sigma1, sigma2, &err);
+  if (rc < 0) { set_error("%s", err); return KHIP_ERR_NUMERIC; }
+  return rc;
+}
+
 int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_operator *M, const double *b,
                   const khip_options *opts_in) {
   KHIP_REQUIRE(ws && A && b, "cg_solve: null argument");
@@ -395,6 +432,8 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
   const bool fused = o.fused != 0;
 
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (o.variant != 0 && o.variant != 1)
+    return ws->box.fail(KHIP_ERR_INVALID, "cg: options.variant must be 0 (cg! recurrence) or 1 (single-reduction CG)");
   if (A->csr && !A->apply) {
     int64_t am, an;
     khip_csr_shape(A->csr, &am, &an, nullptr);
@@ -474,7 +513,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
       solved = fin.solved != 0;
       inconsistent = false;
       tired = iter >= itmax;
-      if (fin.breakdown && !solved) zero_curvature = true;                          // reported with the reference's status string
+      if (fin.breakdown && !solved) { zero_curvature = true; inconsistent = true; }   // as the cg! path reports it (:203-205, linesearch = false)
     }
   }
   const bool device_loop = o.variant == 0 && o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback;
@@ -518,16 +557,12 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     double sigma;
     if (radius == 0) {
       sigma = alpha;
-    } else {                                                                       // to_boundary(n, x, p, z, radius, dNorm2=pNorm²)
-      double rxd, xNorm2;
-      K(khip_dot(ctx, n, x, p, &rxd));
-      K(khip_dot(ctx, n, x, x, &xNorm2));
-      const double radius2 = radius * radius;
-      if (pNorm2 == 0.0) return ws->box.fail(KHIP_ERR_NUMERIC, "zero direction");
-      if (!(xNorm2 <= radius2)) return ws->box.fail(KHIP_ERR_NUMERIC, "outside of the trust region");
+    } else {                                                                       // to_boundary(n, x, p, z, radius, dNorm2=pNorm²) :216
       double s1, s2;
-      if (roots_quadratic(pNorm2, 2 * rxd, xNorm2 - radius2, &s1, &s2))
-        return ws->box.fail(KHIP_ERR_NUMERIC, "The quadratic `q` doesn't have real roots.");
+      const char *err = "";
+      const int rcb = to_boundary_dev(ctx, n, x, p, radius, false, 0.0, pNorm2, &s1, &s2, &err);
+      if (rcb < 0) return ws->box.fail(KHIP_ERR_NUMERIC, err);
+      if (rcb > 0) return ws->box.fail_rc(rcb);
       sigma = s1 > s2 ? s1 : s2;
     }
     if ((radius > 0) && ((pAp <= 0) || (alpha > sigma))) {                         // :229-237
@@ -576,7 +611,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     iter = iter + 1;
     tired = iter >= itmax;
     if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;    // :264
-    overtimed = (now_s() - t0) > timemax;
+    overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
   if (solved && on_boundary) status = "on trust-region boundary";
@@ -612,6 +647,7 @@ struct khip_gmres_workspace {
   std::vector<double *> slabs;   // owned allocations backing V
   std::vector<int> slab_count;
   std::vector<double> c, s, z, R;
+  std::vector<double> look;      // mem + 1 doubles: landing buffer of the look-ahead fetch (k coefficients + ||q||^2); no per-iteration allocation
   int inner_iter = 0;
   bool warm_start = false;
   StatsBox box;
@@ -652,6 +688,12 @@ static void sym_givens(double a, double b, double &c, double &s, double &rho) {
 
 extern "C" {
 
+int khip_test_sym_givens(double a, double b, double *c, double *s, double *rho) {
+  KHIP_REQUIRE(c && s && rho, "test_sym_givens: null argument");
+  sym_givens(a, b, *c, *s, *rho);
+  return KHIP_OK;
+}
+
 int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory, khip_gmres_workspace **out) {
   KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "gmres_workspace_create: bad argument");
   if (memory <= 0) memory = 20;
@@ -665,6 +707,7 @@ int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory,
   if (rc) { khip_gmres_workspace_destroy(ws); return rc; }
   ws->c.assign(memory, 0.0); ws->s.assign(memory, 0.0); ws->z.assign(memory, 0.0);
   ws->R.assign((size_t)memory * (memory + 1) / 2, 0.0);
+  ws->look.assign((size_t)memory + 1, 0.0);
   *out = ws;
   return KHIP_OK;
 }
@@ -692,7 +735,7 @@ size_t khip_gmres_workspace_bytes(khip_gmres_workspace *ws) {
   size_t cnt = ws->V.size();
   for (double *v : {ws->dx, ws->x, ws->w, ws->p, ws->q}) cnt += v ? 1 : 0;
   return cnt * sizeof(double) * (size_t)ws->n +
-         sizeof(double) * (ws->c.size() + ws->s.size() + ws->z.size() + ws->R.size());
+         sizeof(double) * (ws->c.size() + ws->s.size() + ws->z.size() + ws->R.size() + ws->look.size());
 }
 
 int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
@@ -825,8 +868,9 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
           K(apply_op(ctx, A, V[inner_iter], w));                                                // the next :257
           spec_done = true;
         }
-        std::vector<double> tmp((size_t)inner_iter + 1);
-        K(results_copy_end(ctx, inner_iter + 1, tmp.data()));
+        if (ws->look.size() < (size_t)inner_iter + 1) ws->look.resize((size_t)inner_iter + 1);   // only when the basis grew (restart = false)
+        double *tmp = ws->look.data();
+        K(results_copy_end(ctx, inner_iter + 1, tmp));
         for (int i = 0; i < inner_iter; ++i) R[nr + i] = tmp[i];
         Hbis = std::sqrt(tmp[inner_iter]);
       } else if (fused) {
@@ -875,7 +919,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
       } else {
         inner_tired = inner_iter >= inner_itmax;
       }
-      overtimed = (now_s() - t0) > timemax;
+      overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
 
       if (!(solved || inner_tired || breakdown || user_requested_exit || overtimed)) {
         if (!restart && (inner_iter >= mem)) {                                     // :319-324
@@ -919,7 +963,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
     inner_itmax = inner_itmax - inner_iter;
     iter = iter + inner_iter;
     tired = iter >= itmax;
-    overtimed = (now_s() - t0) > timemax;
+    overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
   if (tired) status = "maximum number of iterations exceeded";
@@ -1044,7 +1088,7 @@ int bicgstab_device_loop(khip_bicgstab_workspace *ws, const khip_csr *A, const d
       if (ws->snap[b ^ 1].stop_seq != kSeqNever) stopped = true;
     }
     if (enq >= itmax) stopped = true;
-    if (!stopped && (now_s() - t0) > timemax) { *overtimed = true; stopped = true; }
+    if (!stopped && time_limit_reached(ctx, now_s() - t0, timemax)) { *overtimed = true; stopped = true; }
   }
   ctx->ctl = SeqCtl{};
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1212,7 +1256,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
       solved = (rNorm <= eps_tol) || rdm;
       tired = iter >= itmax;
       breakdown = (alpha == 0 || std::isnan(alpha));
-      overtimed = (now_s() - t0) > timemax;
+      overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
       continue;
     }
 
@@ -1263,7 +1307,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
     solved = resid_decrease_lim || resid_decrease_mach;
     tired = iter >= itmax;
     breakdown = (alpha == 0 || std::isnan(alpha));
-    overtimed = (now_s() - t0) > timemax;
+    overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
   if (tired) status = "maximum number of iterations exceeded";

@@ -1,6 +1,7 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
 include/krylov_hip.h declares, fails loudly without a GPU, and the host-only partition / halo-plan
 helpers are correct.  No kernel is launched here."""
+import ctypes as C
 import os
 import re
 
@@ -126,3 +127,63 @@ def test_halo_plan_random_matrix(K):
         np.add.at(yl, np.repeat(np.arange(m), np.diff(blk.indptr)), blk.data * xe[loc])
         y[starts[g]:starts[g + 1]] = yl
     assert np.allclose(y, S @ x, atol=1e-13)
+
+
+# ---- the PRODUCT's scalar helpers against the reference's exact known answers (test/test_aux.jl:3-79) --------------
+# (host code of libkrylov_hip.so, reached through test-only exports: no GPU needed, no oracle involved)
+
+def _sym_givens(L, a, b):
+    c, s, r = C.c_double(), C.c_double(), C.c_double()
+    assert L.khip_test_sym_givens(a, b, C.byref(c), C.byref(s), C.byref(r)) == 0
+    return c.value, s.value, r.value
+
+
+def _roots(L, q2, q1, q0, nitref=1):
+    r1, r2 = C.c_double(), C.c_double()
+    rc = L.khip_test_roots_quadratic(q2, q1, q0, nitref, C.byref(r1), C.byref(r2))
+    if rc != 0:
+        raise ValueError(L.khip_last_error().decode())
+    return r1.value, r2.value
+
+
+def test_product_sym_givens_known_answers():
+    """test/test_aux.jl:3-34 against csrc/solvers.cpp's sym_givens (the copy gmres! runs)."""
+    import krylov_jl_amd as K
+    L = K.lib()
+    g = lambda a, b: _sym_givens(L, a, b)
+    assert g(0.0, 0.0) == (1.0, 0.0, 0.0)
+    a = 3.14
+    assert g(a, 0.0) == (1.0, 0.0, a)
+    assert g(-a, 0.0) == (-1.0, 0.0, a)
+    assert g(0.0, a) == (0.0, 1.0, a)
+    assert g(0.0, -a) == (0.0, -1.0, a)
+    for (x, y) in [(3.0, 4.0), (-4.0, 3.0), (1e-3, -7.0), (5.0, -1e-9), (-2.0, -2.0)]:
+        c, s, r = g(x, y)
+        assert abs(c * x + s * y - r) <= 1e-15 * abs(r)          # [c s; s -c] [x; y] = [r; 0]
+        assert abs(s * x - c * y) <= 1e-15 * abs(r)
+        assert abs(c * c + s * s - 1) <= 4e-16
+
+
+def test_product_roots_quadratic_known_answers():
+    """test/test_aux.jl:36-79 against csrc/solvers.cpp's roots_quadratic (the copy cg!'s trust region runs)."""
+    import math
+    import pytest
+    import krylov_jl_amd as K
+    L = K.lib()
+    rq = lambda *a, **k: _roots(L, *a, **k)
+    assert rq(0.0, 0.0, 0.0) == (0.0, 0.0)
+    with pytest.raises(ValueError):
+        rq(0.0, 0.0, 1.0)
+    assert rq(0.0, 3.14, -1.0) == (1.0 / 3.14, 1.0 / 3.14)
+    with pytest.raises(ValueError):
+        rq(1.0, 0.0, 1.0)
+    assert rq(1.0, 0.0, 0.0) == (0.0, 0.0)
+    r = rq(1.0, 3.0, 2.0)
+    assert math.isclose(r[0], -2.0) and math.isclose(r[1], -1.0)
+    with pytest.raises(ValueError):
+        rq(1.0e8, 1.0, 1.0)
+    assert rq(-1.0e-8, 1.0e5, 1.0, nitref=0) == (1.0e13, 0.0)              # ill-conditioned quadratic
+    assert rq(-1.0e-8, 1.0e5, 1.0, nitref=1) == (1.0e13, -1.0e-05)         # "iterative refinement is crucial!"
+    for nit in (0, 1):
+        r = rq(-1.0e-7, 1.0, 1.0, nitref=nit)
+        assert math.isclose(r[0], 1.0e7, rel_tol=1e-6) and math.isclose(r[1], -1.0, rel_tol=1e-6)

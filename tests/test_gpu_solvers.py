@@ -502,3 +502,76 @@ def test_no_device_memory_leak_over_object_lifecycles(K, oracle):
     free1, _ = ctx.mem_info()
     ctx.close()
     assert free0 - free1 <= 8 << 20, (free0, free1)      # allow allocator granularity, not a per-cycle leak
+
+
+# ------------------------------------------------------------------ product helpers and storage formulas
+
+def test_product_to_boundary_known_answers(K, ctx):
+    """test/test_aux.jl:81-95 against the to_boundary the trust-region cg! runs (csrc/solvers.cpp; dots on the device)."""
+    import ctypes as C
+    n = 5
+    x = np.ones(n)
+    d = np.ones(n)
+    d[0:n:2] = -1
+
+    def tb(xv, dv, radius, flip=False):
+        s1, s2 = C.c_double(), C.c_double()
+        dx, dd = ctx.array(xv), ctx.array(dv)
+        rc = K.lib().khip_test_to_boundary(ctx._h, n, dx.ptr, dd.ptr, radius, int(flip), C.byref(s1), C.byref(s2))
+        if rc != 0:
+            raise ValueError(K.lib().khip_last_error().decode())
+        return s1.value, s2.value
+    for bad in (-1.0, 0.5):                                  # "radius must be positive", "outside of the trust region"
+        with pytest.raises(ValueError):
+            tb(x, d, bad)
+    with pytest.raises(ValueError):                          # "zero direction"
+        tb(x, np.zeros(n), 1.0)
+    r = tb(x, d, 5.0)
+    assert math.isclose(max(r), 2.209975124224178, rel_tol=1e-14)
+    assert math.isclose(min(r), -1.8099751242241782, rel_tol=1e-14)
+    r = tb(x, d, 5.0, flip=True)
+    assert math.isclose(max(r), 1.8099751242241782, rel_tol=1e-14)
+    assert math.isclose(min(r), -2.209975124224178, rel_tol=1e-14)
+
+
+@pytest.mark.parametrize("mem", [5, 30])
+def test_gmres_storage_formula(K, ctx, oracle, mem):
+    """test/test_allocations.jl:251-270: GMRES needs 2 n-vectors (x, w), mem n-vectors (V), 3 mem-vectors (c, s, z) and a
+    packed triangle of mem (mem + 1) / 2 -- exactly that, plus the (mem + 1)-entry landing buffer of the look-ahead fetch;
+    a solve allocates nothing more (restart = true), Δx / p / q appear only with warm start / preconditioners."""
+    A = oracle.kron_unsymmetric(8)
+    n = A.n
+    dA = _upload(K, ctx, A)
+    b = ctx.array(A.matvec(np.ones(n)))
+    ws = K.GmresWorkspace(ctx, n, n, memory=mem)
+    formula = 8 * (2 * n + n * mem + 2 * mem + mem * (mem + 1) // 2) + 8 * mem
+    assert ws.nbytes == formula + 8 * (mem + 1)
+    K.gmres_(ws, dA, b, restart=True)
+    assert ws.stats.solved and ws.nbytes == formula + 8 * (mem + 1) + 8 * n      # + Δx: allocate_if(restart, ...), src/gmres.jl:141
+    K.gmres_(ws, dA, b, restart=True)
+    assert ws.nbytes == formula + 8 * (mem + 1) + 8 * n                           # the in-place solve allocates nothing
+    K.gmres_(ws, dA, b, restart=True, N=lambda v, o: K.kcopy_(n, o, v))
+    assert ws.nbytes == formula + 8 * (mem + 1) + 2 * 8 * n                       # + p (right preconditioner), src/gmres.jl:143
+
+
+def test_block_gmres_storage_formula(K, ctx, oracle):
+    """test/test_allocations.jl:734-761: 2 (n p) blocks X, W; C (p p); D (2p p); mem tau (p), V (n p), Z (p p), H (2p p);
+    mem (mem + 1) / 2 R (p p).  This implementation holds in addition the row-major panel copy of B and 2 mem + 1 staging
+    blocks (p p) of the fused sweeps, reported separately; a restarted solve adds ΔX (n p) once, nothing per call."""
+    A = oracle.kron_unsymmetric(8)
+    n, p, mem = A.n, 4, 6
+    dA = _upload(K, ctx, A)
+    S = A.to_scipy()
+    t = (np.arange(n) + 1.0) / n
+    B = S @ np.stack([t ** j for j in range(p)], axis=1)
+    ws = K.BlockGmresWorkspace(ctx, n, n, p, memory=mem)
+    formula = 8 * (2 * n * p + p * p + 2 * p * p + mem * p + mem * n * p + mem * p * p + (mem * (mem + 1) // 2) * p * p + mem * 2 * p * p)
+    extra = 8 * n * p + 8 * (2 * mem + 1) * p * p
+    assert ws.nbytes_extra == extra and ws.nbytes == formula + extra
+    Bd = ctx.array(np.asfortranarray(B).ravel(order="F"))
+    K.block_gmres_(ws, dA, Bd, itmax=mem)                                          # as the reference's test: itmax = mem, no basis growth
+    assert ws.stats.niter == mem and ws.nbytes == formula + extra                  # the in-place solve allocated nothing
+    K.block_gmres_(ws, dA, Bd, restart=True)
+    assert ws.nbytes == formula + extra + 8 * n * p                                # + ΔX, src/block_gmres.jl:145
+    K.block_gmres_(ws, dA, Bd, restart=True)
+    assert ws.nbytes == formula + extra + 8 * n * p
