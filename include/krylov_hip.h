@@ -46,6 +46,7 @@ void        khip_version(int *major, int *minor);
 
 /* ---------------------------------------------------------------- context ---- */
 /* stream: a hipStream_t to borrow (e.g. the caller's current stream) or NULL to create one. */
+int   khip_device_count(int *count);            /* HIP devices visible to this process (0 without a GPU; never fails) */
 int   khip_ctx_create(int device, void *stream, khip_ctx **out);
 int   khip_ctx_destroy(khip_ctx *ctx);
 int   khip_ctx_sync(khip_ctx *ctx);
@@ -102,6 +103,13 @@ int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
  * (0 before that, or when the operator has too many).  y is bit-identical either way; ctx option "spmv_codes" = 0
  * keeps the int32 stream.  ref: the product is kmul!(y, A, x), src/krylov_utils.jl:305. */
 int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
+/* How a distributed handle fetches the remote part of x before a product (csrc/comm.cpp; the reference's MPI recipe,
+ * docs/src/custom_workspaces.md:517-521 and :583-586): *gather_mode = 0: only the entries this rank's columns reference
+ * travel (grouped Send/Recv with the owning ranks; *n_ghost entries received, *n_send sent per product); 1: every rank's
+ * slice is all-gathered (*n_ghost = ranks x largest slice, *n_send = own slice).  Chosen at khip_csr_create_dist by the
+ * ctx options "halo_mode" (0 = per operator: gather when some rank would fetch more than "halo_gather_pct" % of its own
+ * row count, 1 = always the neighbour exchange, 2 = always the all-gather).  y is bit-identical in both modes. */
+int khip_csr_halo_info(const khip_csr *A, int *gather_mode, int64_t *n_ghost, int64_t *n_send);
 /* device-side generators of the benchmark operators (rows [row0, row0+m) of the global matrix,
  * global columns; ref: test/get_div_grad.jl:8-25, test/test_utils.jl:160-169).
  * kind: 0 = get_div_grad(n1,n2,n3) 7-pt Poisson, 1 = kron_unsymmetric(n1), 2 = 27-pt cfg-5 operator.

@@ -88,6 +88,7 @@ SIGNATURES = {
     "khip_spmm": (_int, [_vp, _vp, _vp, _vp, _int]),
     "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
     "khip_csr_code_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "khip_csr_halo_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "khip_profile_spmv": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),
     "khip_dot": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
     "khip_nrm2": (_int, [_vp, _i64, _vp, c_double_p]),
@@ -146,6 +147,7 @@ SIGNATURES = {
     "khip_comm_init_local": (_int, [_vp, _int, _int, _int]),
     "khip_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "khip_comm_barrier": (_int, [_vp]),
+    "khip_device_count": (_int, [C.POINTER(_int)]),
     "khip_comm_info": (_int, [_vp] + [C.POINTER(_int)] * 5),
     "khip_default_options": (COptions, []),
     "khip_cg_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
@@ -226,6 +228,12 @@ def _ck(rc):
 
 def gpu_available() -> bool:
     return os.path.exists("/dev/kfd")
+
+
+def device_count() -> int:
+    n = C.c_int()
+    lib().khip_device_count(C.byref(n))
+    return n.value
 
 
 # --------------------------------------------------------------------------- context / vectors
@@ -616,6 +624,13 @@ class CsrMatrix:
         b, t = C.c_int(), C.c_int()
         _ck(lib().khip_csr_code_info(self._h, C.byref(b), C.byref(t)))
         return b.value, t.value
+
+    @property
+    def halo_info(self):
+        """(gather_mode, n_ghost, n_send) of a distributed handle: how the remote part of x is fetched before a product."""
+        g, ng, ns = C.c_int(), C.c_int64(), C.c_int64()
+        _ck(lib().khip_csr_halo_info(self._h, C.byref(g), C.byref(ng), C.byref(ns)))
+        return g.value, ng.value, ns.value
 
     def transpose(self) -> "CsrMatrix":
         """A' as its own handle: `At.matvec(x, y)` is `mul!(y, A', x)` (docs/src/matrix_free.md:36-42)."""

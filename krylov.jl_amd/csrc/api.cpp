@@ -20,6 +20,14 @@ void khip_version(int *major, int *minor) {
 }
 
 // ------------------------------------------------------------------ context ----
+int khip_device_count(int *count) {
+  KHIP_REQUIRE(count, "device_count: null output");
+  int ndev = 0;
+  const hipError_t e = hipGetDeviceCount(&ndev);
+  *count = e == hipSuccess ? ndev : 0;
+  return KHIP_OK;
+}
+
 int khip_ctx_create(int device, void *stream, khip_ctx **out) {
   KHIP_REQUIRE(out, "ctx_create: null output");
   int ndev = 0;
@@ -95,7 +103,7 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
       {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"spmm_window", &t.spmm_window}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
+      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;
@@ -277,6 +285,14 @@ int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz) {
   if (m) *m = A->m;
   if (n) *n = A->n;
   if (nnz) *nnz = A->nnz;
+  return KHIP_OK;
+}
+
+int khip_csr_halo_info(const khip_csr *A, int *gather_mode, int64_t *n_ghost, int64_t *n_send) {
+  KHIP_REQUIRE(A, "csr_halo_info: null handle");
+  if (gather_mode) *gather_mode = A->gather ? 1 : 0;
+  if (n_ghost) *n_ghost = A->n_ghost;
+  if (n_send) *n_send = A->gather ? A->m : A->n_send;
   return KHIP_OK;
 }
 

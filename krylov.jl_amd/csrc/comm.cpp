@@ -208,56 +208,107 @@ static int allgather_host(khip_ctx *ctx, const void *in, void *out, size_t bytes
   return KHIP_OK;
 }
 
+// Everything that can fail on ONE rank only (staging overflow, an inconsistent partition, the host plan) is carried as
+// a status word through the next setup all-gather, so that all ranks leave together with the same error instead of one
+// rank returning while its peers block in the collective.  (A failing HIP call is not recoverable either way.)
+struct DevScratch {                        // frees setup-time device buffers on every path out
+  std::vector<void *> ptrs;
+  ~DevScratch() { for (void *p : ptrs) (void)hipFree(p); }
+  template <typename T> int alloc(T **out, size_t count) {
+    KHIP_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(out), sizeof(T) * (count ? count : 1)));
+    ptrs.push_back(*out);
+    return KHIP_OK;
+  }
+};
+
+enum PlanStatus : int64_t { PLAN_OK = 0, PLAN_WANT_GATHER = 1, PLAN_FAILED = 2 };
+
 int comm_build_plan(khip_ctx *ctx, khip_csr *A) {
   Comm *c = ctx->comm;
   if (!c) { set_error("distributed operator needs khip_comm_init first"); return KHIP_ERR_INVALID; }
   const int G = c->nranks;
-  // 1. off-rank columns of my rows (device filter -> host sort/unique)
+  DevScratch scratch;
+  // 1. off-rank columns of my rows (device filter -> host sort/unique).  The staging buffer counts REFERENCES; a shard
+  //    whose references do not fit is not an error: it asks for gather mode, which needs no list at all.
   std::vector<int32_t> ghost;
+  int64_t status = PLAN_OK;
   {
     int64_t cap = A->nnz < (64ll << 20) ? A->nnz : (64ll << 20);
     if (cap < 1) cap = 1;
     int32_t *d_list = nullptr;
     unsigned long long *d_cnt = nullptr;
-    KHIP_CHECK_HIP(hipMalloc(&d_list, sizeof(int32_t) * (size_t)cap));
-    KHIP_CHECK_HIP(hipMalloc(&d_cnt, sizeof(unsigned long long)));
+    KHIP_TRY(scratch.alloc(&d_list, (size_t)cap));
+    KHIP_TRY(scratch.alloc(&d_cnt, 1));
     KHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), ctx->stream));
     KHIP_TRY(launch_collect_offrank(ctx, A, A->row0, A->row0 + A->m, d_list, d_cnt, cap));
     unsigned long long cnt = 0;
     KHIP_CHECK_HIP(hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     if ((int64_t)cnt > cap) {
-      (void)hipFree(d_list); (void)hipFree(d_cnt);
-      set_error("halo plan: %llu off-rank references exceed the %lld-entry staging buffer", cnt, (long long)cap);
-      return KHIP_ERR_UNSUPPORTED;
+      status = PLAN_WANT_GATHER;
+    } else {
+      ghost.resize((size_t)cnt);
+      if (cnt) KHIP_CHECK_HIP(hipMemcpy(ghost.data(), d_list, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+      std::sort(ghost.begin(), ghost.end());
+      ghost.erase(std::unique(ghost.begin(), ghost.end()), ghost.end());
     }
-    ghost.resize((size_t)cnt);
-    if (cnt) KHIP_CHECK_HIP(hipMemcpy(ghost.data(), d_list, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost));
-    KHIP_CHECK_HIP(hipFree(d_list));
-    KHIP_CHECK_HIP(hipFree(d_cnt));
-    std::sort(ghost.begin(), ghost.end());
-    ghost.erase(std::unique(ghost.begin(), ghost.end()), ghost.end());
   }
-  // 2. partition + list sizes of every rank
-  int64_t mine[3] = {A->row0, A->m, (int64_t)ghost.size()};
-  std::vector<int64_t> all(3 * (size_t)G);
+  // 2. partition, list sizes and status of every rank
+  int64_t mine[4] = {A->row0, A->m, (int64_t)ghost.size(), status};
+  std::vector<int64_t> all(4 * (size_t)G);
   KHIP_TRY(allgather_host(ctx, mine, all.data(), sizeof(mine)));
   std::vector<int64_t> row_starts(G + 1), ghost_off(G + 1, 0);
-  int64_t maxcnt = 1;
+  int64_t maxcnt = 1, maxm = 1;
+  bool bad_partition = false, want_gather = ctx->tune.halo_mode == 2;
   for (int r = 0; r < G; ++r) {
-    row_starts[r] = all[3 * r];
-    if (r > 0 && all[3 * (r - 1)] + all[3 * (r - 1) + 1] != all[3 * r]) {
-      set_error("row partition is not contiguous at rank %d", r);
-      return KHIP_ERR_INVALID;
-    }
-    ghost_off[r + 1] = ghost_off[r] + all[3 * r + 2];
-    maxcnt = std::max(maxcnt, all[3 * r + 2]);
+    row_starts[r] = all[4 * r];
+    if (r > 0 && all[4 * (r - 1)] + all[4 * (r - 1) + 1] != all[4 * r]) bad_partition = true;
+    ghost_off[r + 1] = ghost_off[r] + all[4 * r + 2];
+    maxcnt = std::max(maxcnt, all[4 * r + 2]);
+    maxm = std::max(maxm, all[4 * r + 1]);
+    if (all[4 * r + 3] == PLAN_WANT_GATHER) want_gather = true;
+    if (ctx->tune.halo_mode == 0 && all[4 * r + 2] * 100 > all[4 * r + 1] * (int64_t)ctx->tune.halo_gather_pct && all[4 * r + 2] > 0)
+      want_gather = true;                      // this rank would fetch more than halo_gather_pct % of its own size
   }
-  row_starts[G] = all[3 * (G - 1)] + all[3 * (G - 1) + 1];
-  if (row_starts[0] != 0 || row_starts[G] != A->n_global) {
-    set_error("row partition [%lld, %lld) does not cover n_global = %lld", (long long)row_starts[0],
+  row_starts[G] = all[4 * (G - 1)] + all[4 * (G - 1) + 1];
+  if (bad_partition || row_starts[0] != 0 || row_starts[G] != A->n_global) {     // same data on every rank: all fail together
+    set_error("row partition [%lld, %lld) is not contiguous or does not cover n_global = %lld", (long long)row_starts[0],
               (long long)row_starts[G], (long long)A->n_global);
     return KHIP_ERR_INVALID;
+  }
+  if (ctx->tune.halo_mode == 1 && want_gather) {
+    // forced neighbour exchange although a rank's references overflowed the staging buffer: nothing to build a list from
+    bool overflow = false;
+    for (int r = 0; r < G; ++r) overflow |= all[4 * r + 3] == PLAN_WANT_GATHER;
+    if (overflow) { set_error("halo plan: off-rank references exceed the staging buffer; use halo_mode 0 or 2 (all-gather of x)"); return KHIP_ERR_UNSUPPORTED; }
+    want_gather = false;
+  }
+  A->gather = false;
+  if (want_gather && G > 1) {
+    // ---- gather mode: x is all-gathered before every product (the general fallback of SURVEY 8e / the reference's
+    //      recipe docs/src/custom_workspaces.md:583-586); ghost region = receive buffer, stride maxm per rank
+    if (A->m + (int64_t)G * maxm >= (1ll << 31)) { set_error("gather mode: %d x %lld columns exceed int32 indexing", G, (long long)maxm); return KHIP_ERR_UNSUPPORTED; }
+    int64_t *d_starts = nullptr;
+    KHIP_TRY(scratch.alloc(&d_starts, (size_t)G + 1));
+    KHIP_CHECK_HIP(hipMemcpyAsync(d_starts, row_starts.data(), sizeof(int64_t) * (size_t)(G + 1), hipMemcpyHostToDevice, ctx->stream));
+    KHIP_TRY(launch_col_remap_gather(ctx, A, d_starts, G, maxm));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    A->gather = true;
+    A->gather_maxm = maxm;
+    A->gather_rows.assign((size_t)G, 0);
+    for (int r = 0; r < G; ++r) A->gather_rows[(size_t)r] = all[4 * r + 1];
+    A->n_ghost = (int64_t)G * maxm;
+    A->n_send = maxm;                                  // staging for a short last slice (m < maxm)
+    A->recv_off.assign(G + 1, 0); A->send_off.assign(G + 1, 0);
+    KHIP_CHECK_HIP(hipMalloc(&A->ghost, sizeof(double) * (size_t)A->n_ghost));
+    KHIP_CHECK_HIP(hipMalloc(&A->sendbuf, sizeof(double) * (size_t)maxm));
+    KHIP_CHECK_HIP(hipMemsetAsync(A->ghost, 0, sizeof(double) * (size_t)A->n_ghost, ctx->stream));
+    KHIP_CHECK_HIP(hipMemsetAsync(A->sendbuf, 0, sizeof(double) * (size_t)maxm, ctx->stream));
+    int64_t lo_hi[2];
+    KHIP_TRY(launch_row_ghost_range(ctx, A, lo_hi));
+    A->interior_lo = lo_hi[0];
+    A->interior_hi = lo_hi[1];
+    return KHIP_OK;
   }
   // 3. every rank's ghost list (padded allgather)
   std::vector<int32_t> padded((size_t)maxcnt, 0), gathered((size_t)maxcnt * G);
@@ -267,22 +318,23 @@ int comm_build_plan(khip_ctx *ctx, khip_csr *A) {
   for (int r = 0; r < G; ++r)
     std::copy(gathered.begin() + (size_t)r * maxcnt, gathered.begin() + (size_t)r * maxcnt + (ghost_off[r + 1] - ghost_off[r]),
               ghost_all.begin() + ghost_off[r]);
-  // 4. plan
+  // 4. plan (a function of the gathered lists; a failure here is nevertheless agreed on collectively)
   std::vector<int32_t> send_idx;
   int rc = build_halo_plan_host(c->rank, G, row_starts.data(), ghost_all.data(), ghost_off.data(), A->recv_off,
                                 A->send_off, send_idx);
-  if (rc != KHIP_OK) { set_error("halo plan construction failed"); return rc; }
+  double failed = rc != KHIP_OK ? 1.0 : 0.0;
+  KHIP_TRY(comm_allreduce_sum_host(ctx, &failed, 1));
+  if (failed > 0) { set_error("halo plan construction failed on %d rank(s)", (int)failed); return rc != KHIP_OK ? rc : KHIP_ERR_INVALID; }
   A->n_ghost = (int64_t)ghost.size();
   A->n_send = (int64_t)send_idx.size();
   // 5. device state
   int32_t *d_ghost_sorted = nullptr;
-  KHIP_CHECK_HIP(hipMalloc(&d_ghost_sorted, sizeof(int32_t) * (size_t)std::max<int64_t>(A->n_ghost, 1)));
+  KHIP_TRY(scratch.alloc(&d_ghost_sorted, (size_t)std::max<int64_t>(A->n_ghost, 1)));
   if (A->n_ghost)
     KHIP_CHECK_HIP(hipMemcpyAsync(d_ghost_sorted, ghost.data(), sizeof(int32_t) * (size_t)A->n_ghost,
                                   hipMemcpyHostToDevice, ctx->stream));
   KHIP_TRY(launch_col_remap(ctx, A, d_ghost_sorted, A->n_ghost));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  KHIP_CHECK_HIP(hipFree(d_ghost_sorted));
   KHIP_CHECK_HIP(hipMalloc(&A->ghost, sizeof(double) * (size_t)std::max<int64_t>(A->n_ghost, 1)));
   KHIP_CHECK_HIP(hipMalloc(&A->sendbuf, sizeof(double) * (size_t)std::max<int64_t>(A->n_send, 1)));
   KHIP_CHECK_HIP(hipMalloc(&A->send_idx, sizeof(int32_t) * (size_t)std::max<int64_t>(A->n_send, 1)));
@@ -320,6 +372,38 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
     sendbuf = A->sendbuf_w; ghost = A->ghost_w;
   }
   const size_t w = (size_t)width;
+  if (A->gather) {
+    // all-gather of x (row-major panel: of X): every rank contributes its slice, padded to the stride maxm
+    const int64_t maxm = A->gather_maxm;
+    const double *src = x;
+    if (A->m < maxm) {                                            // short slice: stage it (the pad is never referenced)
+      KHIP_CHECK_HIP(hipMemcpyAsync(sendbuf, x, sizeof(double) * (size_t)A->m * w, hipMemcpyDeviceToDevice, ctx->stream));
+      src = sendbuf;
+    }
+    if (c->hub) {
+      LocalHub *h = c->hub;
+      KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      h->sendbuf[c->rank] = src;
+      h->barrier();
+      for (int r = 0; r < c->nranks; ++r) {
+        if (r == c->rank) continue;
+        const int64_t nr = A->gather_rows[(size_t)r];
+        if (nr > 0)
+          KHIP_CHECK_HIP(hipMemcpyAsync(ghost + (size_t)r * maxm * w, h->sendbuf[r], sizeof(double) * (size_t)nr * w,
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      return KHIP_OK;
+    }
+    hipStream_t gs = (ctx->tune.overlap_halo && c->halo_comm != c->comm) ? ctx->comm_stream : ctx->stream;
+    if (gs != ctx->stream) {
+      ctx->ev_cur = (ctx->ev_cur + 1) % khip_ctx::kEvRing;
+      KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a[ctx->ev_cur], ctx->stream));
+      KHIP_CHECK_HIP(hipStreamWaitEvent(gs, ctx->ev_a[ctx->ev_cur], 0));
+    }
+    KHIP_CHECK_NCCL(g_rccl.AllGather(src, ghost, (size_t)maxm * w, ncclFloat64, c->halo_comm, gs));
+    if (gs != ctx->stream) KHIP_CHECK_HIP(hipEventRecord(ctx->ev_b[ctx->ev_cur], gs));
+    return KHIP_OK;
+  }
   KHIP_TRY(launch_gather(ctx, A->n_send, A->send_idx, x, sendbuf, width));
   if (c->hub) {
     LocalHub *h = c->hub;

@@ -649,6 +649,36 @@ int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev
   return KHIP_OK;
 }
 
+// Gather mode (all-gather of x before the product, comm.cpp): the ghost region is the all-gather's receive buffer, rank r's
+// slice at [r * maxm, r * maxm + m_r).  Owned columns -> [0, m), a column owned by rank r at offset o -> m + r * maxm + o.
+__global__ __launch_bounds__(kBlock) void col_remap_gather_kernel(int32_t *col, int64_t nnz, int64_t row0, int64_t m,
+                                                                   const int64_t *row_starts, int nranks, int64_t maxm) {
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nnz; j += (int64_t)gridDim.x * kBlock) {
+    const int64_t c = col[j];
+    if (c >= row0 && c < row0 + m) {
+      col[j] = (int32_t)(c - row0);
+    } else {
+      int lo = 0, hi = nranks;            // owner: last r with row_starts[r] <= c
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (row_starts[mid] <= c) lo = mid; else hi = mid;
+      }
+      col[j] = (int32_t)(m + (int64_t)lo * maxm + (c - row_starts[lo]));
+    }
+  }
+}
+
+int launch_col_remap_gather(khip_ctx *ctx, khip_csr *A, const int64_t *row_starts_dev, int nranks, int64_t maxm) {
+  csr_free_codes(A);
+  if (A->nnz == 0) return KHIP_OK;
+  int64_t want = (A->nnz + kBlock - 1) / kBlock;
+  int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(col_remap_gather_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->col, A->nnz, A->row0, A->m,
+                     row_starts_dev, nranks, maxm);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 // rows whose (remapped) columns reach into the ghost region: largest such row in the lower half,
 // smallest in the upper half -> [lo, hi) is guaranteed interior.
 __global__ __launch_bounds__(kBlock) void ghost_range_kernel(const int32_t *rowptr, const int32_t *col, int64_t m,

@@ -84,6 +84,8 @@ struct Tuning {
   int spmm_sweep_s = 0;     // tiles per plane (0 = from the handle's band width)
   int spmm_sweep_w = 64;    // tiles per XCD column
   int overlap_halo = 1;     // overlap halo exchange with interior rows
+  int halo_mode = 0;        // distributed operators: 1 = exchange only the needed remote x entries (neighbour Send/Recv), 2 = all-gather x before every product, 0 = choose per operator (gather when a rank needs more than halo_gather_pct % of its own row count from its peers)
+  int halo_gather_pct = 50; // see halo_mode
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
 
@@ -150,6 +152,10 @@ struct khip_csr {
   int halo_w_cap = 0;
   int64_t n_send = 0;
   std::vector<int64_t> send_off, recv_off;   // per-peer offsets (size nranks+1)
+  // gather mode (comm.cpp): x is all-gathered before the product instead of exchanging the needed entries only
+  bool gather = false;
+  int64_t gather_maxm = 0;                   // slice stride of the receive buffer (largest local row count)
+  std::vector<int64_t> gather_rows;          // local row count of every rank
   int64_t interior_lo = 0, interior_hi = 0;  // rows [lo,hi) reference no ghost column
   // optional row-template compression (template.hip): one 16-bit template id per row + a small table
   uint16_t *tmpl_id = nullptr;
@@ -234,6 +240,7 @@ int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays a
 int csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr *T);   // T = A' (fresh handle, deterministic entry order)
 int launch_gather(khip_ctx *ctx, int64_t n, const int32_t *idx, const double *x, double *out, int width = 1);
 int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost);
+int launch_col_remap_gather(khip_ctx *ctx, khip_csr *A, const int64_t *row_starts_dev, int nranks, int64_t maxm);
 int launch_collect_offrank(khip_ctx *ctx, const khip_csr *A, int64_t row0, int64_t row1, int32_t *out_dev,
                            unsigned long long *count_dev, int64_t cap);
 int launch_row_ghost_range(khip_ctx *ctx, const khip_csr *A, int64_t *lo_hi_host);

@@ -249,3 +249,57 @@ def test_distributed_spmm_window_local_ranks(K, oracle):
     for rank, (Yw, Yd) in enumerate(_run_ranks(K, world, 515151, body)):
         r0, r1 = starts[rank], starts[rank + 1]
         assert np.array_equal(Yw, Yd) and np.array_equal(Yw, ref[r0:r1])
+
+
+@pytest.mark.parametrize("world,n1", [(2, 12), (3, 10), (4, 13)])
+def test_gather_mode_equals_neighbour_exchange_local_ranks(K, oracle, world, n1):
+    """The two ways a distributed handle fetches the remote part of x (csrc/comm.cpp, docs/src/custom_workspaces.md:517-521
+    and :583-586): neighbour exchange of the referenced entries (halo_mode = 1) and all-gather of x (halo_mode = 2, the
+    general fallback BASELINE's north star names).  Same y bit for bit, same CG history, same SpMM; unequal slices
+    (13^3 rows over 4 ranks) exercise the padded stride of the gather buffer; halo_mode = 0 picks the gather as soon as a
+    rank would fetch more than halo_gather_pct % of its own size."""
+    A_cpu = oracle.kron_unsymmetric(n1)
+    n = A_cpu.n
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(n)
+    y_ref = A_cpu.matvec(x)
+    p = 4
+    Xh = rng.standard_normal((n, p))
+    Y_ref = np.stack([A_cpu.matvec(np.ascontiguousarray(Xh[:, j])) for j in range(p)], axis=1)
+    bh = A_cpu.matvec(np.ones(n))
+    ref = oracle.bicgstab(A_cpu, bh, history=True)
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        out = {}
+        for mode in (1, 2):
+            c.set_option("halo_mode", mode)
+            A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+            out[f"info{mode}"] = A.halo_info
+            out[f"y{mode}"] = A.matvec(c.array(x[r0:r1])).to_host()
+            Y = K.Panel(c, r1 - r0, p)
+            K.spmm_(A, K.Panel.from_host(c, Xh[r0:r1]), Y)
+            out[f"Y{mode}"] = Y.to_host()
+            _, st, _ = K.bicgstab(A, c.array(bh[r0:r1]), history=True)
+            out[f"h{mode}"] = (st.niter, st.residuals.copy())
+        c.set_option("halo_mode", 0)
+        c.set_option("halo_gather_pct", 1)                    # any ghost plane is more than 1 % of a slab here
+        A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+        out["auto_low"] = A.halo_info[0]
+        c.set_option("halo_gather_pct", 100000)
+        A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+        out["auto_high"] = A.halo_info[0]
+        return out
+
+    res = _run_ranks(K, world, 31000 + world * 100 + n1, body)
+    maxm = max(starts[r + 1] - starts[r] for r in range(world))
+    for rank, out in enumerate(res):
+        r0, r1 = starts[rank], starts[rank + 1]
+        assert out["info1"][0] == 0 and out["info2"] == (1, world * maxm, r1 - r0)
+        for mode in (1, 2):
+            assert np.array_equal(out[f"y{mode}"], y_ref[r0:r1]), (rank, mode)
+            assert np.array_equal(out[f"Y{mode}"], Y_ref[r0:r1]), (rank, mode)
+            assert out[f"h{mode}"][0] == ref.niter
+        assert np.array_equal(out["h1"][1], out["h2"][1])
+        assert out["auto_low"] == 1 and out["auto_high"] == 0
