@@ -197,7 +197,14 @@ static int csr_upload(khip_ctx *ctx, khip_csr *A, const void *rowptr, int rowptr
     if (on_device) KHIP_CHECK_HIP(hipMemcpy(tmp64.data(), rowptr, sizeof(int64_t) * (size_t)(m + 1), hipMemcpyDeviceToHost));
     else memcpy(tmp64.data(), rowptr, sizeof(int64_t) * (size_t)(m + 1));
     std::vector<int32_t> tmp32((size_t)(m + 1));
-    for (int64_t i = 0; i <= m; ++i) tmp32[(size_t)i] = (int32_t)tmp64[(size_t)i];
+    for (int64_t i = 0; i <= m; ++i) {
+      const int64_t v = tmp64[(size_t)i];
+      if (v < INT32_MIN || v > INT32_MAX) {
+        set_error("csr_create: row pointer %lld at row %lld does not fit the shard's int32 indexing", (long long)v, (long long)i);
+        return KHIP_ERR_INVALID;
+      }
+      tmp32[(size_t)i] = (int32_t)v;
+    }
     KHIP_CHECK_HIP(hipMemcpy(A->rowptr, tmp32.data(), sizeof(int32_t) * (size_t)(m + 1), hipMemcpyHostToDevice));
   }
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));

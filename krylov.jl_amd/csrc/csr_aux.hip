@@ -536,10 +536,56 @@ __global__ __launch_bounds__(kBlock) void blockptr_kernel(const int32_t *rowptr,
   }
 }
 
+// Structural validation of user arrays (they are trusted by every kernel afterwards: window loads through buffer
+// descriptors, x gathers, the ghost remap): row pointers start at 0, never decrease, end at nnz; columns lie in [0, n).
+// bad[0] = smallest offending row (m + 1 = none), bad[1] = kind (1 row pointer, 2 column).
+__global__ __launch_bounds__(kBlock) void csr_validate_kernel(const int32_t *rowptr, const int32_t *col, int64_t m, int64_t n,
+                                                               int64_t nnz, unsigned long long *bad) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t s = rowptr[i], e = rowptr[i + 1];
+    bool ok = s >= 0 && e >= s && e <= nnz && (i > 0 || s == 0) && (i < m - 1 || e == nnz);
+    int kind = ok ? 0 : 1;
+    if (ok)
+      for (int64_t q = s; q < e; ++q) {
+        const int32_t c = col[q];
+        if (c < 0 || (int64_t)c >= n) { kind = 2; break; }
+      }
+    if (kind) {
+      const unsigned long long old = atomicMin(&bad[0], (unsigned long long)i);
+      if ((unsigned long long)i < old) bad[1] = (unsigned long long)kind;
+    }
+  }
+}
+
 int csr_finalize(khip_ctx *ctx, khip_csr *A) {
   A->mean_row_nnz = A->m > 0 ? (double)A->nnz / (double)A->m : 0.0;
   A->max_row_nnz = 0;
-  if (A->m == 0) return KHIP_OK;
+  if (A->m == 0) {
+    if (A->nnz != 0) { set_error("csr: %lld nonzeros in an operator without rows", (long long)A->nnz); return KHIP_ERR_INVALID; }
+    return KHIP_OK;
+  }
+  {
+    unsigned long long *d_bad = nullptr;
+    KHIP_CHECK_HIP(hipMalloc(&d_bad, 2 * sizeof(unsigned long long)));
+    unsigned long long h_bad[2] = {(unsigned long long)A->m + 1, 0ull};
+    hipError_t e = hipMemcpyAsync(d_bad, h_bad, sizeof(h_bad), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      int64_t wantv = (A->m + kBlock - 1) / kBlock;
+      hipLaunchKernelGGL(csr_validate_kernel, dim3((unsigned)(wantv < 65536 ? wantv : 65536)), dim3(kBlock), 0, ctx->stream,
+                         A->rowptr, A->col, A->m, A->n, A->nnz, d_bad);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_bad, d_bad, sizeof(h_bad), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) { set_error("csr validation: %s", hipGetErrorString(e)); return KHIP_ERR_HIP; }
+    if (h_bad[0] <= (unsigned long long)A->m) {
+      set_error(h_bad[1] == 2 ? "csr: row %llu has a column index outside [0, %lld) (wrong index_base?)"
+                              : "csr: row pointers are not a monotone sequence from 0 to nnz at row %llu (n = %lld; wrong index_base?)",
+                h_bad[0], (long long)A->n);
+      return KHIP_ERR_INVALID;
+    }
+  }
   {
     const int64_t nb = (A->m + 255) / 256;
     KHIP_CHECK_HIP(hipMalloc(&A->blockptr, sizeof(int32_t) * (size_t)(nb + 1)));

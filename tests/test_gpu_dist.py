@@ -303,3 +303,31 @@ def test_gather_mode_equals_neighbour_exchange_local_ranks(K, oracle, world, n1)
             assert out[f"h{mode}"][0] == ref.niter
         assert np.array_equal(out["h1"][1], out["h2"][1])
         assert out["auto_low"] == 1 and out["auto_high"] == 0
+
+
+def test_time_limit_is_agreed_on_by_all_ranks(K, oracle):
+    """the wall clock is the one stopping test that is not derived from all-reduced scalars.  With a
+    communicator attached it is decided collectively, so every rank leaves the loop at the same iteration with the same
+    status -- for the host loops (fused 0 / 1), the device-resident loop (fused = 2), gmres! and bicgstab!."""
+    world, n1 = 2, 16
+    n = n1 ** 3
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = K.CsrMatrix.stencil(c, "poisson", n1, rows=(r0, r1), distributed=True)
+        b = c.empty(r1 - r0)
+        K.kfill_(b, 1.0)
+        out = []
+        for fused in (2, 1, 0):
+            _, st, _ = K.cg(A, b, atol=0.0, rtol=0.0, itmax=10 ** 6, timemax=1e-5, fused=fused)
+            out.append((st.niter, st.status))
+        _, st, _ = K.gmres(A, b, atol=0.0, rtol=0.0, itmax=10 ** 6, timemax=1e-5, memory=5, restart=True)
+        out.append((st.niter, st.status))
+        _, st, _ = K.bicgstab(A, b, atol=0.0, rtol=0.0, itmax=10 ** 6, timemax=1e-5)
+        out.append((st.niter, st.status))
+        return out
+
+    res = _run_ranks(K, world, 60606, body)
+    assert res[0] == res[1]
+    assert all(status == "time limit exceeded" and niter < 1000 for niter, status in res[0])

@@ -646,3 +646,24 @@ def test_spmv_coded_columns_general_matrices(K, ctx):
             assert np.array_equal(dy.to_host(), y_ref), (S.shape, dA.code_info)
     finally:
         ctx.set_option("spmv_kernel", saved)
+
+
+def test_csr_create_rejects_malformed_arrays(K, ctx):
+    """khip_csr_create validates what every kernel afterwards trusts: monotone row pointers from 0 to nnz,
+    columns inside [0, n), 1-based arrays passed as 0-based, 64-bit row pointers that do not fit a shard."""
+    import ctypes as C
+    rp = np.array([0, 2, 3, 5], dtype=np.int64)
+    cl = np.array([0, 1, 1, 0, 2], dtype=np.int32)
+    vl = np.ones(5)
+    K.CsrMatrix.from_host(ctx, rp, cl, vl, (3, 3))                                   # well-formed
+    for bad_rp, bad_cl, why in [
+            (np.array([0, 3, 2, 5], dtype=np.int64), cl, "row pointers"),            # decreasing
+            (np.array([1, 2, 3, 5], dtype=np.int64), cl, "row pointers"),            # does not start at 0
+            (np.array([0, 2, 3, 4], dtype=np.int64), cl, "row pointers"),            # does not end at nnz
+            (rp, np.array([0, 1, 1, 0, 3], dtype=np.int32), "column index"),         # column == n
+            (rp, np.array([0, -1, 1, 0, 2], dtype=np.int32), "column index"),        # negative column
+            (rp + 1, cl + 1, "row pointers"),                                        # 1-based arrays declared 0-based
+            (np.array([0, 2, 3, 2 ** 40], dtype=np.int64), cl, "int32")]:
+        with pytest.raises(K.KhipError) as ei:
+            K.CsrMatrix.from_host(ctx, bad_rp, bad_cl, vl, (3, 3))
+        assert why in str(ei.value), (why, str(ei.value))
