@@ -99,3 +99,16 @@ def test_capi_device_mode():
     out = _run("hip_capi_device")
     assert out.returncode == 0 and "0 failure(s)" in out.stdout, out.stdout + out.stderr[-800:]
     assert "FAIL" not in out.stdout
+
+
+def test_block_gmres_primitive_sequence_equals_the_solver():
+    """tests/c/block_primitive_sequence.c: block_gmres! replayed ONE C-ABI call per reference line (src/block_gmres.jl:155-330)
+    -- khip_spmm, khip_panel_gemm_tn / _nn, khip_panel_qr_tau, host kormqr on the 2p x p blocks: what a Julia HIPMatrix
+    would issue -- against khip_block_gmres_solve: same iteration count, history and solution, with and
+    without restart.  Built by __graft_entry__.build()."""
+    exe = os.path.join(ROOT, "tests", "c", "block_primitive_sequence")
+    if not os.path.exists(exe):
+        pytest.skip("tests/c/block_primitive_sequence not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "0 failure(s)" in out.stdout, out.stdout + out.stderr[-800:]
+    assert out.stdout.count("PASS") == 2 and "FAIL" not in out.stdout
