@@ -1,6 +1,8 @@
 // csr_aux.hip -- SpMM for row-major panels, CSR set-up helpers (row statistics, index shift, halo
 // gather / remap kernels) and the device-side generators of the benchmark operators.
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "spmv_common.hpp"
 
@@ -135,7 +137,16 @@ __global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
 //    64-bit address arithmetic (v_mul_lo_u32, v_mad_u64_u32, owned/ghost selects) and per-entry lane broadcasts.
 //    Hence shifts instead of multiplies when p = 2 L, a DIST template, scalar loads for the per-group words, and
 //    (val, slot) in LDS where a broadcast read replaces three cross-lane moves.
-constexpr int kWinPanelBytes = 44 * 1024;          // LDS for the panel rows
+// LDS for the panel rows and workgroups per CU the kernel is compiled for.  44 KB / 2 is the measured optimum: 40 KB / 3
+// (three waves per SIMD, 168 VGPRs with 4 spilled) is 4 % faster at p = 16 but 2-3x slower at p = 8 and 4, whose
+// instantiations spill heavily under the tighter register budget (profiles/r02_spmm_experiments.log).
+#ifndef KHIP_WIN_KB
+#define KHIP_WIN_KB 44
+#endif
+#ifndef KHIP_WIN_WGS
+#define KHIP_WIN_WGS 2
+#endif
+constexpr int kWinPanelBytes = KHIP_WIN_KB * 1024;
 
 template <int L>
 struct WinShape {
@@ -154,6 +165,10 @@ struct WinArgs {
   const uint16_t *slot;      // per nonzero: position of its column in the group's list
   const int32_t *flag;       // per row group: 1 = direct-gather group
   int64_t groups;
+  // plane sweep of the row groups (sweep_S > 0): XCD x = blockIdx % 8 walks columns of sweep_W consecutive groups through
+  // all sweep_K planes of sweep_S groups, so that the panel rows of plane k are in that XCD's L2 when the groups of the
+  // planes k - 1, k, k + 1 ask for them (the 192 workgroups of an XCD span three planes of one column at any time).
+  int sweep_S, sweep_W, sweep_K, sweep_cols;   // sweep_cols = columns per XCD (the plane is padded to 8 W sweep_cols groups)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup fence + s_barrier and the fence
@@ -181,13 +196,28 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
   const int tid = threadIdx.x, sub = tid / L, c = tid % L;
   const bool col_ok = 2 * c + 1 < p;
   const int piece = col_ok ? 2 * c : 0;
-  const int64_t G = gridDim.x;
   const int nnz_last = (int)(a.nnz_bound - 1);
   if (tid < 8) { win_val[W::ENTRIES + tid] = 0.0; win_slot[W::ENTRIES + tid] = 0; }   // spare entries the tail batch may read
+  // virtual index l of this workgroup's t-th group -> group number (w.groups = "no group": a padding slot of the sweep)
+  const bool sweep = w.sweep_S > 0;
+  const int xcd = (int)(blockIdx.x & 7);
+  const int64_t lstep = sweep ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
+  const int64_t lend = sweep ? (int64_t)w.sweep_cols * w.sweep_K * w.sweep_W : w.groups;
+  auto phys = [&](int64_t l) -> int64_t {
+    if (!sweep) return l < w.groups ? l : w.groups;
+    if (l >= lend) return w.groups;
+    const int64_t per = (int64_t)w.sweep_K * w.sweep_W;
+    const int64_t tt = l / per, rem = l - tt * per;
+    const int64_t k = rem / w.sweep_W, ww = rem - k * w.sweep_W;
+    const int64_t pos = (tt * 8 + xcd) * w.sweep_W + ww;              // position inside the plane
+    const int64_t g = k * w.sweep_S + pos;
+    return (pos < w.sweep_S && g < w.groups) ? g : w.groups;
+  };
 
   // Stages A and B are straight-line code: loads only, no use of a loaded value, no branch.  Indices past the end are
   // clamped and the results ignored.
-  auto stage_a = [&](int64_t g, Set &z) {
+  auto stage_a = [&](int64_t l, Set &z) {
+    const int64_t g = phys(l);
     const int64_t gg = g < w.groups ? g : w.groups - 1;
     const int32_t *lst = w.list + gg * (int64_t)W::STRIDE;
 #pragma unroll
@@ -230,7 +260,8 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
   // stage C of group g out of `cur`, while B runs for g + G into `nxt` and A for g + 2 G reuses the key registers of `cur`.
   // The two sets swap roles every iteration (the loop below is unrolled by two): a register copy of a set would wait
   // for the loads that are still filling it.
-  auto iteration = [&](int64_t g, Set &cur, Set &nxt) {
+  auto iteration = [&](int64_t l, Set &cur, Set &nxt) {
+    const int64_t g = phys(l);
     const int64_t row = a.row_lo + g * W::RPB + sub;
     const bool row_ok = row < a.row_hi;
     const int sC = cur.s, eC = row_ok ? cur.e : cur.s;
@@ -247,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
     }
     lds_barrier();
     stage_b(nxt);
-    stage_a(g + 2 * G, cur);
+    stage_a(l + 2 * lstep, cur);
     if (directC) {
       if (row_ok) {
         double acc0 = 0.0, acc1 = 0.0;
@@ -354,17 +385,17 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
   };
 
   Set P, Q;
-  int64_t g = blockIdx.x;
-  stage_a(g, P);
+  int64_t l = sweep ? (int64_t)(blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  stage_a(l, P);
   stage_b(P);
-  stage_a(g + G, Q);
+  stage_a(l + lstep, Q);
   for (;;) {
-    if (g >= w.groups) break;
-    iteration(g, P, Q);
-    g += G;
-    if (g >= w.groups) break;
-    iteration(g, Q, P);
-    g += G;
+    if (l >= lend) break;
+    iteration(l, P, Q);
+    l += lstep;
+    if (l >= lend) break;
+    iteration(l, Q, P);
+    l += lstep;
   }
 }
 
@@ -374,14 +405,28 @@ template <int L>
 static void launch_window(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p) {
   using W = WinShape<L>;
   const int64_t groups = (A->m + W::RPB - 1) / W::RPB;
-  WinArgs w{A->win_list, A->win_slot, A->win_flag, groups};
+  WinArgs w{A->win_list, A->win_slot, A->win_flag, groups, 0, 0, 0, 0};
   const size_t lds = W::kLds;
   int per_cu = (int)((size_t)(160 * 1024) / lds);                                 // LDS-limited residency ...
-  if (per_cu > 2) per_cu = 2;                                                     // ... and two waves per SIMD by registers
+  if (per_cu > KHIP_WIN_WGS) per_cu = KHIP_WIN_WGS;                               // ... and the register budget the kernel is compiled for
   if (per_cu < 1) per_cu = 1;
   int64_t grid = (int64_t)ctx->num_cu * per_cu * 3;         // 3 x the resident workgroups: the queue evens out the tail (measured 2 %)
   if (ctx->tune.spmm_window_grid > 0) grid = ctx->tune.spmm_window_grid;
   if (grid > groups) grid = groups;
+  if (ctx->tune.spmm_win_sweep != 0 && grid >= 64) {
+    // plane sweep: S = groups per grid plane, from the plane distance of the operator (rows); worthwhile when the panel rows
+    // a row reaches (2 planes apart) exceed what an XCD's L2 keeps (4 MiB)
+    const int64_t plane_rows = A->plane_rows > 0 ? A->plane_rows : A->band;
+    const int64_t S = ctx->tune.spmm_sweep_s > 0 ? ctx->tune.spmm_sweep_s : (plane_rows + W::RPB / 2) / W::RPB;
+    int Wc = ctx->tune.spmm_sweep_w > 0 ? ctx->tune.spmm_sweep_w : 64;
+    const size_t reach = (size_t)plane_rows * 2 * (size_t)p * sizeof(double);
+    if (S >= 8 * (int64_t)Wc && S < groups && (ctx->tune.spmm_sweep_s > 0 || reach > ((size_t)2 << 20))) {
+      grid &= ~(int64_t)7;                                                        // whole workgroups per XCD
+      w.sweep_S = (int)S; w.sweep_W = Wc;
+      w.sweep_K = (int)((groups + S - 1) / S);
+      w.sweep_cols = (int)((S + 8 * (int64_t)Wc - 1) / (8 * (int64_t)Wc));
+    }
+  }
   const bool dist = a.ghost != a.x, pow2 = p == 2 * L;
   const dim3 gd((unsigned)grid), bd(kBlock);
   if (lds > 64 * 1024) {                 // beyond the default dynamic-LDS limit: raise it for the instantiation about to run
@@ -610,6 +655,31 @@ int csr_finalize(khip_ctx *ctx, khip_csr *A) {
   KHIP_CHECK_HIP(hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->band = h;
+  // Plane distance of a 3-D operator, for the plane-sweep orders: a longest row near the middle is looked at on the host;
+  // its positive offsets fall into clusters (a new one starts where an offset more than doubles): 1 | n1 | n1^2 for the
+  // 7-point operator, 1 | n1-1..n1+1 | n1^2-n1-1..n1^2+n1+1 for the 27-point one.  plane_rows = centre of the last cluster.
+  A->plane_rows = 0;
+  if (A->m >= 128 && A->max_row_nnz >= 2 && A->max_row_nnz <= 256) {
+    const int64_t r0 = A->m / 2;
+    const int span = 64;
+    std::vector<int32_t> rp((size_t)span + 1);
+    KHIP_CHECK_HIP(hipMemcpy(rp.data(), A->rowptr + r0, sizeof(int32_t) * (size_t)(span + 1), hipMemcpyDeviceToHost));
+    int best = 0;
+    for (int i = 1; i < span; ++i) if (rp[(size_t)i + 1] - rp[(size_t)i] > rp[(size_t)best + 1] - rp[(size_t)best]) best = i;
+    const int len = rp[(size_t)best + 1] - rp[(size_t)best];
+    if (len >= 2) {
+      std::vector<int32_t> cols((size_t)len);
+      KHIP_CHECK_HIP(hipMemcpy(cols.data(), A->col + rp[(size_t)best], sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost));
+      std::vector<int64_t> pos;
+      for (int32_t cidx : cols) if ((int64_t)cidx > r0 + best) pos.push_back((int64_t)cidx - (r0 + best));
+      std::sort(pos.begin(), pos.end());
+      if (!pos.empty()) {
+        size_t start = 0;
+        for (size_t i = 1; i < pos.size(); ++i) if (pos[i] > 2 * pos[i - 1] + 2) start = i;
+        A->plane_rows = (pos[start] + pos.back()) / 2;
+      }
+    }
+  }
   return KHIP_OK;
 }
 

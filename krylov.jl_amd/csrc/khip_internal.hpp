@@ -80,7 +80,8 @@ struct Tuning {
   int spmm_wide = 1;        // SpMM: two panel columns per lane (16-byte gathers) when p is even
   int spmm_window_grid = 0; // workgroups of the persistent window kernel (0 = CUs x LDS-limited residency)
   int spmm_window = 1;      // SpMM: stage the distinct panel rows of a row group in LDS (csr_aux.hip, spmm_window_kernel)
-  int spmm_sweep = 0;       // SpMM: plane-sweep tile order when the band is wider than the L2 can hold (csr_aux.hip)
+  int spmm_sweep = 0;       // SpMM direct kernel: plane-sweep tile order when the band is wider than the L2 can hold (csr_aux.hip; measured no faster)
+  int spmm_win_sweep = 0;   // SpMM window kernel: plane-sweep order of the row groups (each XCD walks columns of spmm_sweep_w groups through all planes); measured 15 % slower although it removes the re-fetches (profiles/r02_spmm_experiments.log)
   int spmm_sweep_s = 0;     // tiles per plane (0 = from the handle's band width)
   int spmm_sweep_w = 64;    // tiles per XCD column
   int overlap_halo = 1;     // overlap halo exchange with interior rows
@@ -140,6 +141,7 @@ struct khip_csr {
   double *val = nullptr;               // device, nnz (+pad)
   int64_t max_row_nnz = 0;
   int64_t band = 0;                    // max |column - row| (local indices)
+  int64_t plane_rows = 0;              // estimated distance (rows) between the outermost coupling planes of a 3-D operator (0 = unknown; csr_finalize)
   double mean_row_nnz = 0;
   // distributed state (null / zero when single GPU)
   bool dist = false;
