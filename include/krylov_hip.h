@@ -228,6 +228,12 @@ int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const doub
  * instead of five, one host synchronisation per sweep); same bits as the khip_panel_gemm_tn / _nn sequence. */
 int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, double *Q, double *Psi_host,
                    int accumulate);
+/* X <- beta X + sum_{i < k} V_i Y_i, the products applied in the order i = 0 .. k-1: the k calls mul!(Xr, V[i], Y[i], 1, 1) of
+ * the solution update src/block_gmres.jl:324-326 in one pass over X (k + 2 panel passes instead of 3 k).  V_host: k device
+ * panel pointers in a HOST array; Y_host: k blocks of p x p, column-major, HOST.  Bit-identical to the k khip_panel_gemm_nn
+ * calls.  ctx option "panel_multi_tiles" (default 2; 0 = one tile per wave, factors re-read per tile). */
+int khip_panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,
+                        double *X);
 /* Reduced QR of the panel as householder!(Q, R, tau) = kgeqrf! + korgqr! leaves it (src/block_krylov_utils.jl:201-208,
  * :230-236, :254-262): Q overwritten by the orthonormal factor, R_host (p-by-p column-major, upper triangular) and
  * tau_host (p, may be null) with LAPACK's sign convention (R_jj = -sign(alpha_j) |x_j|, tau_j in [1, 2]).  Computed on the

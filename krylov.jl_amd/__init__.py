@@ -141,6 +141,7 @@ SIGNATURES = {
     "khip_panel_mgs": (_int, [_vp, _i64, _int, _int, c_void_pp, _vp, c_double_p, _int]),
     "khip_panel_qr": (_int, [_vp, _i64, _int, _vp, c_double_p]),
     "khip_panel_qr_tau": (_int, [_vp, _i64, _int, _vp, c_double_p, c_double_p]),
+    "khip_panel_multi_nn": (_int, [_vp, _i64, _int, _int, C.POINTER(_vp), c_double_p, _dbl, _vp]),
     "khip_panel_norm": (_int, [_vp, _i64, _int, _vp, c_double_p]),
     "khip_comm_unique_id": (_int, [_vp]),
     "khip_comm_init": (_int, [_vp, _int, _int, _vp]),
@@ -1251,6 +1252,15 @@ def panel_qr_(Q: Panel) -> np.ndarray:
     R = np.zeros((Q.p, Q.p), order="F")
     _ck(lib().khip_panel_qr(Q.ctx._h, Q.n, Q.p, Q.buf.ptr, R.ctypes.data_as(c_double_p)))
     return R
+
+
+def panel_multi_nn_(Vs, Ys, beta: float, X: Panel) -> Panel:
+    """X <- beta X + sum_i V_i Y_i in the order i = 0..k-1 (src/block_gmres.jl:324-326 in one pass); Ys: k host p x p blocks."""
+    k = len(Vs)
+    ptrs = (C.c_void_p * max(k, 1))(*[v.buf.ptr for v in Vs])
+    Y = np.ascontiguousarray(np.concatenate([np.asfortranarray(y, dtype=np.float64).ravel(order="F") for y in Ys])) if k else np.zeros(1)
+    _ck(lib().khip_panel_multi_nn(X.ctx._h, X.n, X.p, k, ptrs, Y.ctypes.data_as(c_double_p), float(beta), X.buf.ptr))
+    return X
 
 
 def panel_qr_tau_(Q: Panel):

@@ -346,12 +346,105 @@ __global__ __launch_bounds__(kBlock) void panel_multi_nn_kernel(int64_t n_pad, i
     }
 }
 
+// Same update with the k factor blocks held in LDS and T consecutive 16-row tiles per wave.  The kernel above re-reads the
+// 4 B-operand values of every factor from global memory for every tile: 8 k + 8 vector-memory instructions per 2 (k + 2) KB
+// of panel traffic, and on this chip a wave's vector-memory instruction costs ~17 cycles of the CU's texture path whatever
+// its width (tools/l2bench.hip: 8 B per lane reach half the bytes per clock of 16 B per lane) -- the kernel ran at 3.3 TB/s.
+// Here every workgroup copies the factors once (transposed, so that the B-operand reads are lane-contiguous = free of bank
+// conflicts) and each wave walks T tiles: 4 k + 8 instructions per tile.  Same A / B operand values into the same MFMA
+// chain in the same order => X bit-identical to panel_multi_nn_kernel and to the k khip_panel_gemm_nn calls.
+// With k = 1 and a general alpha it is also Q <- beta Q + alpha V Psi (panel_gemm_nn_kernel's expression; V may alias X:
+// the A fragments of a tile are loaded before its first store).
+template <int NT>
+__global__ __launch_bounds__(kBlock) void panel_multi_nn_lds_kernel(int64_t n_pad, int p, int k, MultiNNArgs V, const double *Y_dev,
+                                                                    double alpha, double beta, double *X, int T) {
+  extern __shared__ double s_Y[];                    // [k][p][p]: s_Y[j][prow][pcol] = Y_j[pcol][prow] (Y_j column-major)
+  const int pp = p * p;
+  for (int idx = threadIdx.x; idx < k * pp; idx += kBlock) {
+    const int j = idx / pp, r = idx - j * pp, prow = r / p, pcol = r - prow * p;
+    s_Y[idx] = Y_dev[(size_t)j * 1024 + (size_t)pcol * p + prow];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, kq = lane >> 4;
+  constexpr int KK = NT * 4;
+  const int64_t tile0 = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * T;
+  for (int t = 0; t < T; ++t) {
+    const int64_t r0 = (tile0 + t) * 16;
+    if (r0 >= n_pad) return;
+    dbl4 x[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = 16 * b + i;
+        x[b][g] = (beta != 0.0 && col < p) ? X[(r0 + kq + 4 * g) * p + col] : 0.0;
+      }
+    double bcur = beta;
+    for (int j = 0; j < k; ++j) {
+      const double *Vj = V.v[j];
+      const double *Yj = s_Y + (size_t)j * pp;
+      double af[KK], bf[KK][NT];
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        const int vcol = 4 * kk + kq;
+        af[kk] = (vcol < p) ? Vj[(r0 + i) * p + vcol] : 0.0;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          const int prow = 4 * kk + kq, pcol = 16 * b + i;
+          bf[kk][b] = (prow < p && pcol < p) ? Yj[prow * p + pcol] : 0.0;
+        }
+      }
+      dbl4 acc[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[b] = dbl4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf[kk][b], acc[b], 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x[b][g] = fma(alpha, acc[b][g], bcur * x[b][g]);
+      bcur = 1.0;
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = 16 * b + i;
+        if (col < p) X[(r0 + kq + 4 * g) * p + col] = x[b][g];
+      }
+  }
+}
+
 }  // namespace khip
 
 using namespace khip;
 
 namespace {
 int64_t pad16(int64_t n) { return (n + 15) & ~(int64_t)15; }
+
+// Q <- beta Q + alpha V Psi (Psi_dev: p x p column-major in device memory): the LDS-factor kernel with k = 1 when
+// "panel_multi_tiles" > 0 (same bits, fewer vector-memory instructions), else one tile per wave with the factor re-read.
+void launch_gemm_nn(khip_ctx *ctx, int64_t np, int p, double alpha, const double *V, const double *Psi_dev, double beta, double *Q) {
+  const int64_t tiles = np / 16;
+  if (tiles == 0) return;
+  const int T = ctx->tune.panel_multi_tiles;
+  if (T > 0) {
+    MultiNNArgs a;
+    for (int i = 0; i < kMultiNN; ++i) a.v[i] = i == 0 ? V : nullptr;
+    const int64_t per_wg = (int64_t)kWavesPerBlock * T;
+    const unsigned g = (unsigned)((tiles + per_wg - 1) / per_wg);
+    const size_t lds = sizeof(double) * (size_t)p * p;
+    if (p <= 16) hipLaunchKernelGGL((panel_multi_nn_lds_kernel<1>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, 1, a, Psi_dev, alpha, beta, Q, T);
+    else hipLaunchKernelGGL((panel_multi_nn_lds_kernel<2>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, 1, a, Psi_dev, alpha, beta, Q, T);
+    return;
+  }
+  const unsigned g = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (p <= 16) hipLaunchKernelGGL((panel_gemm_nn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, Psi_dev, beta, Q);
+  else hipLaunchKernelGGL((panel_gemm_nn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, Psi_dev, beta, Q);
+}
 
 constexpr int kPsiSlots = 64;    // staging ring for the p x p factors of Q += V Psi
 struct PanelScratch {            // scratch for the V^T Q partial tiles and the Psi staging
@@ -503,6 +596,13 @@ int khip::panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const dou
 }
 extern "C" {
 
+// the solution update of block_gmres! (src/block_gmres.jl:324-326) as one call; see include/krylov_hip.h
+int khip_panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,
+                        double *X) {
+  KHIP_REQUIRE(ctx && X && p >= 1 && p <= 32 && k >= 0 && (k == 0 || (V_host && Y_host)), "panel_multi_nn: bad argument (1 <= p <= 32)");
+  return khip::panel_multi_nn(ctx, n, p, k, V_host, Y_host, beta, X);
+}
+
 }  // extern "C"
 // X <- beta X + sum_i V_i Y_i (Y_host: k blocks of p x p, column-major), products applied in the order i = 0..k-1:
 // the k calls khip_panel_gemm_nn(1, V_i, Y_i, beta_i, X) with beta_0 = beta, beta_i = 1 of src/block_gmres.jl:324-326.
@@ -523,6 +623,16 @@ int khip::panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *c
   g_ps.next_slot = k + 1;
   const int64_t tiles = np / 16;
   if (tiles == 0) return KHIP_OK;
+  const size_t lds = sizeof(double) * (size_t)k * pp;
+  const int T = ctx->tune.panel_multi_tiles;
+  if (T > 0 && lds <= 48 * 1024) {            // factors in LDS, T tiles per wave
+    const int64_t per_wg = (int64_t)kWavesPerBlock * T;
+    const unsigned g = (unsigned)((tiles + per_wg - 1) / per_wg);
+    if (p <= 16) hipLaunchKernelGGL((panel_multi_nn_lds_kernel<1>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, 1.0, beta, X, T);
+    else hipLaunchKernelGGL((panel_multi_nn_lds_kernel<2>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, 1.0, beta, X, T);
+    KHIP_CHECK_HIP(hipGetLastError());
+    return KHIP_OK;
+  }
   const unsigned g = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   if (p <= 16) hipLaunchKernelGGL((panel_multi_nn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, beta, X);
   else hipLaunchKernelGGL((panel_multi_nn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, beta, X);
@@ -556,7 +666,6 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // the Psi staging ring is ours from slot 1 on
   g_ps.next_slot = 1;
   const int64_t tiles = np / 16;
-  const unsigned g_nn = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
   KHIP_TRY(tn_enqueue(ctx, np, p, V_host[0], Q, g_ps.psi_dev + 1024));
   for (int i = 0; i < k; ++i) {
     double *psi_i = g_ps.psi_dev + (size_t)(i + 1) * 1024;
@@ -566,8 +675,7 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
       else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
       tn_reduce(ctx, t, p, psi_n);
     } else if (tiles > 0) {
-      if (p <= 16) hipLaunchKernelGGL((panel_gemm_nn_kernel<1>), dim3(g_nn), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, Q);
-      else hipLaunchKernelGGL((panel_gemm_nn_kernel<2>), dim3(g_nn), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, Q);
+      launch_gemm_nn(ctx, np, p, -1.0, V_host[i], psi_i, 1.0, Q);
     }
   }
   KHIP_CHECK_HIP(hipGetLastError());
@@ -597,11 +705,7 @@ int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const doub
   double *psi_h = g_ps.psi_pinned + (size_t)slot * 1024, *psi_d = g_ps.psi_dev + (size_t)slot * 1024;
   memcpy(psi_h, Psi_host, sizeof(double) * (size_t)p * p);
   KHIP_CHECK_HIP(hipMemcpyAsync(psi_d, psi_h, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, ctx->stream));
-  const int64_t tiles = np / 16;
-  if (tiles == 0) return KHIP_OK;
-  const unsigned g = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (p <= 16) hipLaunchKernelGGL((panel_gemm_nn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, psi_d, beta, Q);
-  else hipLaunchKernelGGL((panel_gemm_nn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, psi_d, beta, Q);
+  launch_gemm_nn(ctx, np, p, alpha, V, psi_d, beta, Q);
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }

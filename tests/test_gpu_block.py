@@ -359,3 +359,35 @@ def test_block_arnoldi_step_blocks_equal_the_oracles(K, ctx, oracle):
     assert close(dV.to_host(), V1, 1e-11) and close(Z1g, Z1, 1e-11) and close(tau1g, tau1, 1e-11)
     assert close(Psig, Psi, 1e-10)
     assert close(dW.to_host(), Q2, 1e-9) and close(Cg, Cb, 1e-9) and close(tau2g, tau2, 1e-9)
+
+
+@pytest.mark.parametrize("n,p,k", [(16, 16, 1), (1000, 16, 5), (33333, 16, 3), (5000, 4, 6), (4096, 32, 3), (3000, 7, 2), (20000, 16, 24)])
+def test_panel_multi_nn_equals_the_product_sequence(K, ctx, n, p, k):
+    """X += sum V_i Y_i (src/block_gmres.jl:324-326) in one pass: bit-identical to the k mul!(Xr, V[i], Y[i], 1, 1) calls,
+    with the factor blocks re-read per tile (panel_multi_tiles = 0) or held in LDS with 1, 4 or 8 tiles per wave."""
+    rng = np.random.default_rng(n + p + k)
+    Vh = [rng.standard_normal((n, p)) for _ in range(k)]
+    Yh = [rng.standard_normal((p, p)) for _ in range(k)]
+    X0 = rng.standard_normal((n, p))
+    Vs = [K.Panel.from_host(ctx, v) for v in Vh]
+    ref = K.Panel.from_host(ctx, X0)
+    for v, y in zip(Vs, Yh):
+        K.panel_gemm_nn_(1.0, v, y, 1.0, ref)
+    ref_h = ref.to_host()
+    saved = ctx.get_option("panel_multi_tiles")
+    try:
+        for tiles in (0, 1, 4, 8):
+            ctx.set_option("panel_multi_tiles", tiles)
+            X = K.Panel.from_host(ctx, X0)
+            K.panel_multi_nn_(Vs, Yh, 1.0, X)
+            assert np.array_equal(X.to_host(), ref_h), (n, p, k, tiles)
+        # beta = 0 ignores the old X (the first product of a restart-free solve)
+        X = K.Panel.from_host(ctx, np.full((n, p), np.nan))
+        K.panel_multi_nn_(Vs, Yh, 0.0, X)
+        ref0 = K.Panel.from_host(ctx, X0)
+        K.panel_gemm_nn_(1.0, Vs[0], Yh[0], 0.0, ref0)
+        for v, y in zip(Vs[1:], Yh[1:]):
+            K.panel_gemm_nn_(1.0, v, y, 1.0, ref0)
+        assert np.array_equal(X.to_host(), ref0.to_host())
+    finally:
+        ctx.set_option("panel_multi_tiles", saved)
