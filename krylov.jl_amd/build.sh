@@ -4,14 +4,15 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/csrc"
-OUT="$HERE/libkrylov_hip.so"
+OUT="${KHIP_OUT:-$HERE/libkrylov_hip.so}"          # KHIP_OUT / KHIP_BUILD_DIR / KHIP_EXTRA_FLAGS: instrumented variants (tools/spmm_trace.py)
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I/opt/rocm/include"
-mkdir -p "$HERE/build"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I/opt/rocm/include $KHIP_EXTRA_FLAGS"
+BUILD="${KHIP_BUILD_DIR:-$HERE/build}"
+mkdir -p "$BUILD"
 objs=""
 for f in blas1.hip spmv.hip csr_aux.hip panel.hip ilu.hip template.hip colcode.hip comm.cpp api.cpp solvers.cpp block.cpp processes.cpp; do
   [ -f "$SRC/$f" ] || continue
-  o="$HERE/build/${f%.*}.o"
+  o="$BUILD/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h*' -newer "$o" | head -1)" ]; then
     echo "hipcc $f"
     $HIPCC $FLAGS -x hip -c "$SRC/$f" -o "$o" &
@@ -23,6 +24,9 @@ $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs -ldl
 echo "built $OUT"
 # libkrylov_hip_capi.so: the reference's C / Fortran interface on top (needs ITS header, which is not redistributed)
 KH="${KRYLOV_H_DIR:-/root/reference/interfaces/include}"
+if [ -n "$KHIP_OUT" ]; then
+  exit 0                                  # instrumented variant: the C-interface shim is not rebuilt
+fi
 if [ -f "$KH/krylov.h" ]; then
   g++ -O2 -fPIC -shared -std=c++17 -I"$KH" -I"$HERE/../include" -o "$HERE/libkrylov_hip_capi.so" "$SRC/capi_compat.cpp" \
       -L"$HERE" -lkrylov_hip -Wl,-rpath,'$ORIGIN'

@@ -175,6 +175,23 @@ struct WinArgs {
 // drains vmcnt as well, i.e. it would wait for the prefetches of the next groups at every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Phase stamps of one wave (tools/spmm_trace.py builds a variant of the library with -DKHIP_WIN_TRACE; compiled out otherwise):
+// wave 0 of workgroup 5 writes the shader clock at the phase boundaries of its iterations 8..23.  What it showed
+// (profiles/r02_spmm_trace.log, 216^3 x 16): of ~8500 cycles per row group, ~1200 go into writing the window to LDS,
+// ~2400 into ISSUING the 34 prefetch loads (the CU's texture path takes ~17 cycles per wave instruction and 8 waves issue
+// at once), ~3200 into the products -- 27 entry steps x ~115 cycles, which is what 8 waves x (8 B val + 2 B slot + 16 B
+// panel piece per lane) cost the one LDS of the CU: the product phase is LDS-bandwidth bound, not latency bound (hiding the
+// (val, slot) read latency behind the products changed nothing).
+#ifdef KHIP_WIN_TRACE
+__device__ unsigned long long g_win_trace[16 * 8];
+#define KHIP_STAMP(slot)                                                                                   \
+  do {                                                                                                     \
+    if (trace_on && trace_it >= 8 && trace_it < 24) g_win_trace[(trace_it - 8) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define KHIP_STAMP(slot) do { } while (0)
+#endif
+
 template <int NU, int NE>
 struct WinSet {                // what a lane holds of one row group in flight
   int key[NU];                 // stage A: its list entries,
@@ -260,7 +277,12 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
   // stage C of group g out of `cur`, while B runs for g + G into `nxt` and A for g + 2 G reuses the key registers of `cur`.
   // The two sets swap roles every iteration (the loop below is unrolled by two): a register copy of a set would wait
   // for the loads that are still filling it.
+#ifdef KHIP_WIN_TRACE
+  const bool trace_on = blockIdx.x == 5 && tid == 0;
+  int trace_it = 0;
+#endif
   auto iteration = [&](int64_t l, Set &cur, Set &nxt) {
+    KHIP_STAMP(0);
     const int64_t g = phys(l);
     const int64_t row = a.row_lo + g * W::RPB + sub;
     const bool row_ok = row < a.row_hi;
@@ -276,9 +298,12 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
         win_slot[tid + k * kBlock] = cur.es[k];
       }
     }
+    KHIP_STAMP(1);
     lds_barrier();
+    KHIP_STAMP(2);
     stage_b(nxt);
     stage_a(l + 2 * lstep, cur);
+    KHIP_STAMP(3);
     if (directC) {
       if (row_ok) {
         double acc0 = 0.0, acc1 = 0.0;
@@ -379,9 +404,15 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
           }
         }
       }
+      KHIP_STAMP(4);
       if (row_ok && col_ok) *reinterpret_cast<dbl2 *>(a.y + row * p + 2 * c) = dbl2{acc0, acc1};
     }
+    KHIP_STAMP(5);
     lds_barrier();
+    KHIP_STAMP(6);
+#ifdef KHIP_WIN_TRACE
+    ++trace_it;
+#endif
   };
 
   Set P, Q;
@@ -398,6 +429,14 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
     l += lstep;
   }
 }
+
+#ifdef KHIP_WIN_TRACE
+}  // namespace khip
+extern "C" int khip_debug_win_trace(unsigned long long *out128) {
+  return hipMemcpyFromSymbol(out128, HIP_SYMBOL(khip::g_win_trace), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+}
+namespace khip {
+#endif
 
 int spmm_window_build(khip_ctx *ctx, khip_csr *A, int L);   // below
 
