@@ -619,3 +619,38 @@ def test_binary128_reference_distances_are_reproducible(oracle):
         assert abs(dev - c["oracle_double_max_rel_dev"]) <= 1e-3 * c["oracle_double_max_rel_dev"] + 1e-18, c["name"]
         seen += 1
     assert seen >= 6
+
+
+def test_parallel_matvec_changes_no_value(oracle):
+    """tests/golden/make_scale_golden.py runs the oracle with its operator products (and the independent entries of its panel
+    products) spread over the host cores.  Rows are independent: histories and solutions must equal the serial run bit for bit."""
+    ok = oracle
+    A = ok.poisson3d(12)
+    b = np.ones(A.n)
+    B = ok.kron_unsymmetric(8)
+    bb = B.matvec(np.ones(B.n))
+    t = (np.arange(B.n) + 1.0) / B.n
+    Bk = B.to_scipy() @ np.stack([t ** j for j in range(4)], axis=1)
+    serial = (ok.cg(A, b, history=True), ok.gmres(B, bb, memory=10, restart=True, history=True),
+              ok.block_gmres(B, Bk, memory=6, restart=True, history=True))
+    ok.PARALLEL_MATVEC = True
+    ok.lib().ko_set_threads(4)
+    try:
+        par = (ok.cg(A, b, history=True), ok.gmres(B, bb, memory=10, restart=True, history=True),
+               ok.block_gmres(B, Bk, memory=6, restart=True, history=True))
+    finally:
+        ok.PARALLEL_MATVEC = False
+        ok.lib().ko_set_threads(1)
+    for s_, p_ in zip(serial, par):
+        assert s_.niter == p_.niter and np.array_equal(s_.residuals, p_.residuals) and np.array_equal(s_.x, p_.x)
+
+
+def test_scale_goldens_are_well_formed():
+    """The BASELINE-size oracle histories the GPU parity tests and bench.py compare with."""
+    for name, n, niter in (("oracle_cfg2_cg512.json", 512 ** 3, 100), ("oracle_cfg3_gmres256.json", 256 ** 3, 45),
+                           ("oracle_cfg5_block216.json", 216 ** 3, 7)):
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+        assert g["n"] == n and g["niter"] == niter and len(g["residuals"]) == niter + 1
+        assert all(np.isfinite(g["residuals"])) and len(g["x_sample"]) == len(g["x_index"]) == 16
+    g2 = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg2_cg512.json")))
+    assert g2["residuals"][0] == math.sqrt(512 ** 3) and g2["nnz"] == 7 * 512 ** 3 - 6 * 512 ** 2      # ||ones||, SURVEY 8
