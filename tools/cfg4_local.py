@@ -15,6 +15,7 @@ import krylov_jl_amd as K
 n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+halo_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 0 per operator, 1 neighbour exchange, 2 all-gather of x
 n = n1 ** 3
 starts = K.row_partition(n, world)
 out, errs = [None] * world, []
@@ -23,6 +24,7 @@ def run(rank):
     try:
         c = K.Context(0)
         c.comm_init_local(rank, world, 4040)
+        c.set_option("halo_mode", halo_mode)
         r0, r1 = starts[rank], starts[rank + 1]
         t0 = time.time()
         A = K.CsrMatrix.stencil(c, "poisson", n1, rows=(r0, r1), distributed=True)
@@ -39,7 +41,7 @@ def run(rank):
         A.matvec(ws.x, r)
         K.kaxpby_(m, 1.0, ones, -1.0, r)
         true_res = K.knorm(m, r)
-        out[rank] = dict(nnz=A.nnz, rows=m, sum_A1=s, bnorm=bn, hist=hist, true_res=true_res, setup_s=time.time() - t0)
+        out[rank] = dict(halo=A.halo_info, code=A.code_info, nnz=A.nnz, rows=m, sum_A1=s, bnorm=bn, hist=hist, true_res=true_res, setup_s=time.time() - t0)
         c.barrier()
         c.close()
     except Exception as e:      # noqa: BLE001
@@ -61,6 +63,13 @@ res = {
     "recurrence_vs_true_residual_rel": abs(o["true_res"] - float(o["hist"][-1])) / float(o["hist"][0]),
     "wall_s": round(time.time() - t0, 1),
 }
+res["halo_info_rank0"] = list(o["halo"]); res["code_info_rank0"] = list(o["code"])
+oracle_golden = os.path.join(ROOT, "tests", "golden", "oracle_cfg2_cg512.json")
+if n1 == 512 and os.path.exists(oracle_golden):   # the CPU oracle's history (tests/golden/make_scale_golden.py)
+    g = json.load(open(oracle_golden))["residuals"]
+    k = min(len(g), len(o["hist"]))
+    res["iterations_compared_with_oracle"] = k - 1
+    res["max_rel_dev_vs_cpu_oracle"] = max(abs(float(o["hist"][i]) - g[i]) / g[i] for i in range(k))
 golden = os.path.join(ROOT, "tests", "golden", "cg512_residuals.json")
 if n1 == 512 and os.path.exists(golden):          # the 1-GPU history bench.py's `parity` uses
     g = json.load(open(golden))["residuals"]
