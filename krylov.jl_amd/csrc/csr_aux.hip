@@ -80,7 +80,24 @@ __global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
   constexpr int RPB = kBlock / L;
   const int sub = threadIdx.x / L, c = threadIdx.x % L;
   const bool col_ok = 2 * c + 1 < p;
-  for (int64_t row = a.row_lo + (int64_t)blockIdx.x * RPB + sub; row < a.row_hi; row += (int64_t)gridDim.x * RPB) {
+  int64_t first_tile = blockIdx.x, tile_stride = gridDim.x;
+  if (a.sweep_s > 0) {                               // plane sweep of the tiles, as in spmm_kernel
+    const int S = a.sweep_s, W = a.sweep_w;
+    const int64_t ntiles = (a.row_hi - a.row_lo + RPB - 1) / RPB;
+    const int64_t K = (ntiles + S - 1) / S;
+    const int64_t b = blockIdx.x;
+    const int pxcd = (int)(b & 7);
+    const int64_t l = b >> 3, per = K * W;
+    const int64_t tt = l / per, rem = l - tt * per;
+    const int64_t k = rem / W;
+    const int w = (int)(rem - k * W);
+    const int64_t ti = (tt * 8 + pxcd) * W + w;
+    if (ti >= S) return;
+    first_tile = k * S + ti;
+    if (first_tile >= ntiles) return;
+    tile_stride = ntiles;
+  }
+  for (int64_t row = a.row_lo + first_tile * RPB + sub; row < a.row_hi; row += tile_stride * RPB) {
     const int64_t s = a.rowptr[row], e = a.rowptr[row + 1];
     double acc0 = 0.0, acc1 = 0.0;
     for (int64_t base = s; base < e; base += L) {
@@ -520,8 +537,18 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
     while (2 * L < p) L <<= 1;                       // L lanes cover 2 L >= p columns
     const int rpb2 = kBlock / L;
     int64_t want2 = (A->m + rpb2 - 1) / rpb2;
-    const int grid2 = (int)(want2 < gcap ? (want2 > 0 ? want2 : 1) : gcap);
+    int grid2 = (int)(want2 < gcap ? (want2 > 0 ? want2 : 1) : gcap);
     a.sweep_s = 0;
+    if (ctx->tune.spmm_sweep != 0 && !ctx->tune.spmm_window) {      // direct 16-byte gathers in plane-sweep tile order (experiment)
+      const int W2 = ctx->tune.spmm_sweep_w > 0 ? ctx->tune.spmm_sweep_w : 64;
+      const int64_t plane_rows = A->plane_rows > 0 ? A->plane_rows : A->band;
+      const int64_t S2 = ctx->tune.spmm_sweep_s > 0 ? ctx->tune.spmm_sweep_s : (plane_rows + rpb2 / 2) / rpb2;
+      if (S2 >= 8 * (int64_t)W2) {
+        const int64_t Spad = (S2 + 8 * W2 - 1) / (8 * W2) * (8 * W2);
+        const int64_t K2 = (want2 + S2 - 1) / S2;
+        if (K2 * Spad <= gcap) { a.sweep_s = (int)S2; a.sweep_w = W2; grid2 = (int)(K2 * Spad); }
+      }
+    }
     if (ctx->tune.spmm_window && want2 <= gcap && A->m > 0) {      // panel-row window in LDS: one row group per workgroup
       khip_csr *Aw = const_cast<khip_csr *>(A);
       if (Aw->win_L != L && Aw->win_L != -L) KHIP_TRY(spmm_window_build(ctx, Aw, L));
