@@ -322,7 +322,10 @@ typedef struct {
                                * dots of an iteration are computed by ONE reduction (one all-reduce per iteration on N GPUs,
                                * 2 passes per iteration).  Different rounding: same solution to the requested tolerance, iteration
                                * counts within a few of the reference recurrence -- opt-in, own parity budget.
-                               * Needs M = I, a CSR operator, no trust region / linesearch / callback (else KHIP_ERR_UNSUPPORTED). */
+                               * Needs M = I, a CSR operator, no trust region / linesearch / callback (else KHIP_ERR_UNSUPPORTED).
+                               * gmres: 1 = CGS2, classical Gram-Schmidt applied twice instead of the modified Gram-Schmidt cascade of
+                               * src/gmres.jl:259-271: h = V_k' q as one reduction per four basis vectors, q -= V_k h in one pass, twice:
+                               * three all-reduces per inner iteration on N GPUs instead of k + 1.  Opt-in, own parity budget. */
 } khip_options;
 
 typedef struct {              /* SimpleStats, src/krylov_stats.jl:24-44 */

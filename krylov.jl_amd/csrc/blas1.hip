@@ -742,6 +742,137 @@ __global__ __launch_bounds__(kBlock) void multi_axpy_kernel(int64_t n, int k, Mu
   }
 }
 
+// ------------------------------------------------------------ block (classical) Gram-Schmidt pieces -------
+// gmres! options.variant = 1 (CGS2, solvers.cpp): h = V_k' q as ONE reduction pass per four basis vectors and
+// q -= V_k h as one pass with the coefficients read from device memory -- two all-reduces of k scalars per pass on N GPUs
+// instead of the k one-scalar all-reduces of the modified Gram-Schmidt cascade (src/gmres.jl:259-271).
+struct Dot4Ptrs { const double *x; const double *y[4]; int cnt; };
+
+template <bool COMP, int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void multi_dot4_kernel(int64_t n, Dot4Ptrs p, RedArgs ra) {
+  using T = typename VecT<VEC>::type;
+  if (seq_skip(ra.stop_seq, ra.seq)) return;
+  dd acc[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] = dd{0.0, 0.0};
+  const int64_t nvec = n / VEC;
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < nvec) {
+    const T xv = ldg<NT>(reinterpret_cast<const T *>(p.x) + j);
+    T yv[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (o < p.cnt) yv[o] = ldg<NT>(reinterpret_cast<const T *>(p.y[o]) + j);
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (o < p.cnt) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc_prod<COMP>(acc[o], vget(yv[o], e), vget(xv, e));
+      }
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    for (int o = 0; o < p.cnt; ++o) acc_prod<COMP>(acc[o], p.y[o][t], p.x[t]);
+  }
+  wave_publish<4>(acc, ra);
+}
+
+// results[slot + i] = V_i . q for i < k (k <= kResultSlots), four per launch; the caller all-reduces and reads them
+int launch_multi_dot(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, const double *q, int slot) {
+  if (k <= 0) return KHIP_OK;
+  const bool comp = ctx->tune.compensated != 0;
+  const bool nt = use_nt(ctx, n);
+  for (int base = 0; base < k; base += 4) {
+    Dot4Ptrs p;
+    p.x = q;
+    p.cnt = k - base < 4 ? k - base : 4;
+    bool v2 = n >= 2 && aligned16(q);
+    for (int o = 0; o < 4; ++o) {
+      p.y[o] = o < p.cnt ? V_host[base + o] : q;
+      if (!aligned16(p.y[o])) v2 = false;
+    }
+    const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+    KHIP_TRY(ensure_reduction_scratch(ctx, g * kWavesPerBlock, 4));
+    RedArgs ra = make_red_args(ctx, slot + base);
+#define KHIP_MD(COMP, VEC, NT) hipLaunchKernelGGL((multi_dot4_kernel<COMP, VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, p, ra)
+    if (comp) { if (v2) { if (nt) KHIP_MD(true, 2, true); else KHIP_MD(true, 2, false); } else { if (nt) KHIP_MD(true, 1, true); else KHIP_MD(true, 1, false); } }
+    else      { if (v2) { if (nt) KHIP_MD(false, 2, true); else KHIP_MD(false, 2, false); } else { if (nt) KHIP_MD(false, 1, true); else KHIP_MD(false, 1, false); } }
+#undef KHIP_MD
+    KHIP_CHECK_HIP(hipGetLastError());
+    // a finish of 4 outputs writes slot + base .. slot + base + 3; the unused ones of the last group are scratch slots
+    KHIP_TRY(launch_finish(ctx, g * kWavesPerBlock, 4, slot + base));
+  }
+  return KHIP_OK;
+}
+
+struct MultiPtrs { const double *v[kMultiMax]; };
+
+// x <- x - sum_j coef[j] V_j with the coefficients in device memory (results ring), applied in the order j = 0..k-1
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void multi_axpy_dev_kernel(int64_t n, int k, MultiPtrs mv, const double *coef, double *x) {
+  using T = typename VecT<VEC>::type;
+  const int64_t nvec = n / VEC;
+  T *X = reinterpret_cast<T *>(x);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    T xv = ldg<NT>(X + i);
+    int j = 0;
+    for (; j + 4 <= k; j += 4) {                       // four basis vectors in flight; applied in the order j, j+1, j+2, j+3
+      const T v0 = ldg<NT>(reinterpret_cast<const T *>(mv.v[j]) + i);
+      const T v1 = ldg<NT>(reinterpret_cast<const T *>(mv.v[j + 1]) + i);
+      const T v2 = ldg<NT>(reinterpret_cast<const T *>(mv.v[j + 2]) + i);
+      const T v3 = ldg<NT>(reinterpret_cast<const T *>(mv.v[j + 3]) + i);
+      const double c0 = -coef[j], c1 = -coef[j + 1], c2 = -coef[j + 2], c3 = -coef[j + 3];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        double sacc = vget(xv, e);
+        sacc = fma(c0, vget(v0, e), sacc);
+        sacc = fma(c1, vget(v1, e), sacc);
+        sacc = fma(c2, vget(v2, e), sacc);
+        sacc = fma(c3, vget(v3, e), sacc);
+        vset(xv, e, sacc);
+      }
+    }
+    for (; j < k; ++j) {
+      const double cj = -coef[j];
+      const T v0 = ldg<NT>(reinterpret_cast<const T *>(mv.v[j]) + i);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vset(xv, e, fma(cj, vget(v0, e), vget(xv, e)));
+    }
+    stg<NT>(xv, X + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    double sacc = x[t];
+    for (int j = 0; j < k; ++j) sacc = fma(-coef[j], mv.v[j][t], sacc);
+    x[t] = sacc;
+  }
+}
+
+int launch_multi_axpy_dev(khip_ctx *ctx, int64_t n, int k, const double *coef_dev, const double *const *V_host, double *x) {
+  if (n <= 0 || k <= 0) return KHIP_OK;
+  const bool nt = use_nt(ctx, n);
+  for (int base = 0; base < k; base += kMultiMax) {
+    const int kk = k - base < kMultiMax ? k - base : kMultiMax;
+    MultiPtrs mv;
+    bool v2 = n >= 2 && aligned16(x);
+    for (int j = 0; j < kMultiMax; ++j) {
+      mv.v[j] = j < kk ? V_host[base + j] : nullptr;
+      if (j < kk && !aligned16(mv.v[j])) v2 = false;
+    }
+    const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+    if (v2) {
+      if (nt) hipLaunchKernelGGL((multi_axpy_dev_kernel<2, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, mv, coef_dev + base, x);
+      else hipLaunchKernelGGL((multi_axpy_dev_kernel<2, false>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, mv, coef_dev + base, x);
+    } else {
+      if (nt) hipLaunchKernelGGL((multi_axpy_dev_kernel<1, true>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, mv, coef_dev + base, x);
+      else hipLaunchKernelGGL((multi_axpy_dev_kernel<1, false>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, kk, mv, coef_dev + base, x);
+    }
+    KHIP_CHECK_HIP(hipGetLastError());
+  }
+  return KHIP_OK;
+}
+
 int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host, const double *const *V_host,
                       double *x) {
   if (n <= 0 || k <= 0) return KHIP_OK;
@@ -804,6 +935,7 @@ int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot) {
   const unsigned g = (unsigned)(want < 1 ? 1 : (want > kFinishMaxBlocks ? kFinishMaxBlocks : want));
   if (nout == 1) hipLaunchKernelGGL((reduce_finish_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);
   else if (nout == 2) hipLaunchKernelGGL((reduce_finish_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);
+  else if (nout == 4) hipLaunchKernelGGL((reduce_finish_kernel<4>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);
   else { set_error("launch_finish: unsupported output count %d", nout); return KHIP_ERR_INVALID; }
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;

@@ -227,6 +227,9 @@ int launch_map(khip_ctx *ctx, int op, int64_t n, double a, double b, const doubl
                double *w);
 int launch_multi_axpy(khip_ctx *ctx, int64_t n, int k, const double *coef_host,
                       const double *const *V_host, double *x);
+// classical Gram-Schmidt pieces (gmres! variant 1): results[slot + i] = V_i . q (four per launch); x -= sum coef_dev[j] V_j
+int launch_multi_dot(khip_ctx *ctx, int64_t n, int k, const double *const *V_host, const double *q, int slot);
+int launch_multi_axpy_dev(khip_ctx *ctx, int64_t n, int k, const double *coef_dev, const double *const *V_host, double *x);
 // fetch `count` results starting at slot into host memory (synchronises the stream; all-reduces
 // across ranks when a communicator is attached).
 // already_global: results[slot..] were all-reduced on the device (comm_allreduce_dd_device): plain copy

@@ -751,8 +751,10 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   const bool restart = o.restart != 0, reorth = o.reorthogonalization != 0, fused = o.fused != 0;
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
 
+  if (o.variant != 0 && o.variant != 1)
+    return ws->box.fail(KHIP_ERR_INVALID, "gmres: options.variant must be 0 (gmres! recurrence, modified Gram-Schmidt) or 1 (CGS2)");
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
-  const bool look = fused && o.fused >= 2 && MisI && NisI && !reorth && !o.callback && !A->apply && A->csr;
+  const bool look = o.variant == 0 && fused && o.fused >= 2 && MisI && NisI && !reorth && !o.callback && !A->apply && A->csr;
   if (!MisI && !ws->q) K(alloc_vec(ctx, n, &ws->q));                               // src/gmres.jl:142-144
   if (!NisI && !ws->p) K(alloc_vec(ctx, n, &ws->p));
   if (restart && !ws->dx) K(alloc_vec(ctx, n, &ws->dx));
@@ -853,7 +855,30 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
       spec_done = false;
 
       double Hbis;
-      if (look && inner_iter + 1 <= kResultSlots) {
+      if (o.variant == 1) {
+        // CGS2 (classical Gram-Schmidt, applied twice; opt-in, NOT the reference's recurrence -- src/gmres.jl:259-271 is the
+        // modified form): h = V_k' q in one reduction per four basis vectors, q -= V_k h in one pass with device-resident
+        // coefficients, the same again, R_k += h + h2.  Two all-reduces of k scalars and one of ||q||^2 per inner iteration on
+        // N GPUs instead of k + 1 single-scalar ones.  Same Krylov space, different rounding: own parity budget in the tests.
+        const int k = inner_iter;
+        const int kpad = (k + 3) & ~3;
+        if (2 * kpad + 1 > kResultSlots) return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 1: too many basis vectors for the device scalar ring");
+        const int slot = take_slots(ctx, 2 * kpad + 1);
+        const bool multi = comm_nranks(ctx) > 1;
+        for (int pass = 0; pass < 2; ++pass) {
+          const int sp = slot + pass * kpad;
+          K(launch_multi_dot(ctx, n, k, V.data(), q, sp));
+          if (multi) K(comm_allreduce_dd_device(ctx, sp, k));
+          K(launch_multi_axpy_dev(ctx, n, k, ctx->results + sp, V.data(), q));
+        }
+        K(launch_nrm2sq(ctx, n, q, slot + 2 * kpad));
+        if (multi) K(comm_allreduce_dd_device(ctx, slot + 2 * kpad, 1));
+        if (ws->look.size() < (size_t)(2 * kpad + 1)) ws->look.resize((size_t)(2 * kpad + 1));
+        double *tmp = ws->look.data();
+        K(fetch_results(ctx, slot, 2 * kpad + 1, tmp, /*already_global=*/multi));
+        for (int i = 0; i < k; ++i) R[nr + i] = tmp[i] + tmp[kpad + i];
+        Hbis = std::sqrt(tmp[2 * kpad]);
+      } else if (look && inner_iter + 1 <= kResultSlots) {
         // ONE-STEP LOOK-AHEAD: the MGS cascade leaves its coefficients and ||q||^2 on the device.  Before the host
         // waits for them, the next basis vector V[k+1] = q / ||q|| (device scalar) and its product A V[k+1] are
         // enqueued, so the queue stays busy while the host applies the Givens rotations and tests convergence.

@@ -145,6 +145,11 @@ def test_distributed_gmres_bicgstab_local_ranks(K, oracle):
         A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
         b = c.array(bh[r0:r1])
         _, stg, _ = K.gmres(A, b, memory=10, restart=True, history=True)
+        _, stc, _ = K.gmres(A, b, memory=10, restart=True, history=True, variant=1)       # CGS2: three all-reduces per inner iteration
+        assert stc.solved and abs(stc.niter - stg.niter) <= 1
+        k = min(len(stc.residuals), len(stg.residuals))
+        big = stg.residuals[:k] > 1e-6 * stg.residuals[0]
+        assert np.max(np.abs(stc.residuals[:k][big] - stg.residuals[:k][big]) / stg.residuals[:k][big]) <= 1e-6
         xb1, stb, _ = K.bicgstab(A, b, history=True, fused=1)
         xb2, stb2, _ = K.bicgstab(A, b, history=True, fused=2)          # scalars and stopping tests on the device
         assert stb2.niter == stb.niter and stb2.status == stb.status
