@@ -100,8 +100,9 @@ int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
  * or 8 / 16 when the operator's entries lie on at most 256 / 2048 distinct diagonals (column - row) and the handle keeps,
  * next to its CSR arrays, one / two bytes per entry (the rank of the entry's diagonal in a sorted table; col = row +
  * table[code], exact).  The coded stream is built by the first khip_spmv that can use it; *diagonals = table size
- * (0 before that, or when the operator has too many).  y is bit-identical either way; ctx option "spmv_codes" = 0
- * keeps the int32 stream.  ref: the product is kmul!(y, A, x), src/krylov_utils.jl:305. */
+ * (0 before that, or when the operator has too many).  y is bit-identical either way; ctx option "spmv_codes": 1 (default)
+ * codes operators of at least 4 M entries (smaller ones are latency bound and keep the int32 stream), 2 codes whatever the
+ * size, 16 forces two-byte codes, 0 keeps the int32 stream (environment variable KHIP_SPMV_CODES sets the initial value).  ref: the product is kmul!(y, A, x), src/krylov_utils.jl:305. */
 int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
 /* How a distributed handle fetches the remote part of x before a product (csrc/comm.cpp; the reference's MPI recipe,
  * docs/src/custom_workspaces.md:517-521 and :583-586): *gather_mode = 0: only the entries this rank's columns reference

@@ -1,5 +1,6 @@
 // api.cpp -- extern "C" entry points: context, device buffers, CSR handles, the k* primitives.
 #include <cmath>
+#include <cstdlib>
 
 #include "khip_internal.hpp"
 
@@ -51,6 +52,7 @@ int khip_ctx_create(int device, void *stream, khip_ctx **out) {
     KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_a[i], hipEventDisableTiming));
     KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_b[i], hipEventDisableTiming));
   }
+  if (const char *e = getenv("KHIP_SPMV_CODES")) ctx->tune.spmv_codes = atoi(e);   // tests force the coded column stream on small operators too (tests/conftest.py)
   hipDeviceProp_t prop;
   KHIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

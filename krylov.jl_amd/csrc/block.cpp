@@ -381,6 +381,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   const double atol = std::isnan(o.atol) ? std::sqrt(kEps) : o.atol, rtol = std::isnan(o.rtol) ? std::sqrt(kEps) : o.rtol;
   const bool restart = o.restart != 0, reorth = o.reorthogonalization != 0;
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (o.variant != 0) return ws->box.fail(KHIP_ERR_INVALID, "block_gmres: options.variant must be 0 (there is no other recurrence)");
 
   if (restart && !ws->dX) KB(alloc_panel(ctx, np, p, &ws->dX));
   double *dX = ws->dX, *X = ws->X, *W = ws->W, *Bp = ws->Bp;

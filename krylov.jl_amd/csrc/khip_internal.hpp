@@ -67,7 +67,7 @@ struct Tuning {
   int spmv_lds_pad = 0;     // experiment: extra dynamic LDS bytes per workgroup (lowers occupancy)
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
   int spmv_pipe = 0;        // staged kernel: software-pipelined form with this many consecutive row blocks per workgroup (0 = one block per workgroup, no pipeline; measured no faster: profiles/r02b_sweep_pipe.log)
-  int spmv_codes = 1;       // staged kernel: stream dictionary-coded columns (1 or 2 B per entry) when the operator has <= 2048 diagonals; 0 = plain int32 columns; 16 = force 2-byte codes
+  int spmv_codes = 1;       // staged kernel: stream dictionary-coded columns (1 or 2 B per entry) when the operator has <= 2048 diagonals -- 1: for operators of >= 4 M entries; 2: whatever the size; 16: two-byte codes; 0: plain int32 columns
   int spmv_lanes = 0;       // vector kernel lanes per row (0 = auto)
   int spmv_persist = 0;     // 1 = persistent grid (<= 8 workgroups per CU) instead of one row block per workgroup
   int compensated = 1;      // Dot2 (TwoSum/TwoProd) reductions

@@ -1178,6 +1178,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   const double atol = tol_or_default(o.atol), rtol = tol_or_default(o.rtol);
   const bool fused = o.fused != 0;
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (o.variant != 0) return ws->box.fail(KHIP_ERR_INVALID, "bicgstab: options.variant must be 0 (there is no other recurrence)");
   if (!c) c = b;                                                                   // src/bicgstab.jl:105
 
   const bool MisI = (M == nullptr), NisI = (N == nullptr);

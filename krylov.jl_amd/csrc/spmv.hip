@@ -953,7 +953,10 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
 #define KHIP_STG(R) do { if (nt) launch_stage_cfg<R, true>(ctx, a, ra, grid, dot, comp, dist); \
                          else launch_stage_cfg<R, false>(ctx, a, ra, grid, dot, comp, dist); } while (0)
     khip_csr *Am = const_cast<khip_csr *>(A);
-    const bool try_codes = ctx->tune.spmv_codes && !nt && !a.fake_gather;
+    // spmv_codes: 1 = coded stream for operators large enough to be bandwidth bound (>= 4 M entries: below that an iteration is
+    // latency bound and the table lookup costs ~5 %, profiles/r02_bench_sizes.jsonl), 2 = whenever the operator qualifies,
+    // 16 = two-byte codes, 0 = never
+    const bool try_codes = ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && !nt && !a.fake_gather;
     // coded column stream (colcode.hip): built once per handle, at the first product that gets here
     if (try_codes && Am->code_state == 0) KHIP_TRY(csr_build_codes(ctx, Am));
     const bool coded = try_codes && Am->code_state == 1;

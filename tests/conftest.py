@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+# The staged SpMV streams dictionary-coded columns only for operators of >= 4 M entries by default (below that an
+# iteration is latency bound); the tests' operators are small, so every context of the test session (and of the processes
+# it spawns) forces the coded stream wherever an operator qualifies.  tests/test_gpu_primitives.py checks the default too.
+os.environ.setdefault("KHIP_SPMV_CODES", "2")
 
 
 def pytest_configure(config):

@@ -582,7 +582,11 @@ def test_spmv_coded_columns_bit_exact(K, ctx, oracle, kind, n1, bits, diags):
     saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel")}
     try:
         ctx.set_option("spmv_kernel", 4)            # the 27-point operator would take the ordered kernel by default
-        for mode, want_bits in ((1, bits), (16, 16), (0, 32)):
+        ctx.set_option("spmv_codes", 1)             # the default: only operators of >= 4 M entries get the coded stream
+        dS = K.CsrMatrix.stencil(ctx, kind, n1)
+        dS.matvec(dx, ctx.zeros(A.n))
+        assert dS.code_info == (32, 0)
+        for mode, want_bits in ((2, bits), (16, 16), (0, 32)):
             ctx.set_option("spmv_codes", mode)
             dA = K.CsrMatrix.stencil(ctx, kind, n1)
             assert dA.code_info == (32, 0)                              # nothing is built before the first product
