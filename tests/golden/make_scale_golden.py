@@ -12,7 +12,12 @@ is the serial loop's; likewise the p x p entries of the oracle's panel products 
 are independent, so the thread count changes no value.  These are golden vectors OF THE ORACLE: "parity unpinned" with
 respect to Krylov.jl itself (no Julia in the image), exactly like tests/golden/oracle_histories.json.
 
-Run (needs ~20 GB of RAM for cfg 2, a few minutes on 8 cores):  python tests/golden/make_scale_golden.py [2] [3] [5]
+  leg 4 (not a BASELINE config; bicgstab! is the fourth north-star solver): bicgstab! on cfg 3's operator kron_unsymmetric(256),
+         b = A*ones, 25 iterations, together with the binary128 history of the same recurrence (oracle/quad_reference.c,
+         make -C oracle quadref; ~20 minutes) and the double-precision oracle's distance to it: the tolerance of the GPU test
+         is derived from that distance                                     (src/bicgstab.jl:125-277)
+
+Run (needs ~20 GB of RAM for cfg 2, a few minutes on 8 cores):  python tests/golden/make_scale_golden.py [2] [3] [5] [4]
 """
 import json
 import os
@@ -78,6 +83,31 @@ if 3 in which:
         residuals=[float(v) for v in res.residuals], x_index=idx, x_sample=[float(res.x[i]) for i in idx],
         seconds=time.time() - t0))
     del A, b, res
+
+if 4 in which:
+    import struct
+    import subprocess
+    import tempfile
+    n1, iters = 256, 25
+    A = ok.kron_unsymmetric(n1)
+    b = A.matvec(np.ones(A.n))
+    ref = ok.bicgstab(A, b, atol=0.0, rtol=0.0, itmax=iters, history=True)
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:      # case file of oracle/quad_reference.c
+        f.write(struct.pack("8i", 2, 1, n1, 1, 0, 0, 0, iters))
+        f.write(struct.pack("2d", 0.0, 0.0))
+        f.write(b.tobytes())
+        case = f.name
+    out = json.loads(subprocess.check_output([os.path.join(HERE, "..", "..", "oracle", "_ref", "quad_reference"), case]))
+    os.unlink(case)
+    hq, hd = np.array(out["residuals"]), ref.residuals
+    idx = sample_idx(A.n)
+    dump("oracle_bicgstab256.json", dict(
+        generator="tests/golden/make_scale_golden.py (leg 4)",
+        config="bicgstab! on kron_unsymmetric(256), b = A*ones, atol = rtol = 0, 25 iterations (cfg 3's operator)",
+        n=A.n, nnz=A.nnz, niter=ref.niter, status=ref.status, residuals=[float(v) for v in hd], x_index=idx,
+        x_sample=[float(ref.x[i]) for i in idx], quad_residuals=out["residuals"],
+        oracle_double_max_rel_dev=float(np.max(np.abs(hd - hq) / hq))))
+    del A, b, ref
 
 if 5 in which:
     t0 = time.time()

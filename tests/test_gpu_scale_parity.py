@@ -117,3 +117,30 @@ def test_block_gmres_cfg5_matches_oracle(K, ctx, parity_log):
                x_sample_rel=xdev)
     assert units <= 1.0, units
     assert xdev <= 1e-10, xdev
+
+
+@pytest.mark.parametrize("fused", [2, 0])
+def test_bicgstab_256_matches_oracle_within_the_derived_tolerance(K, ctx, parity_log, fused):
+    """bicgstab! (the fourth north-star solver; no BASELINE config of its own) on cfg 3's operator at full size, 25 iterations.
+    BiCGSTAB's alpha and omega are ratios of cancelling dots: after 25 iterations at 256^3 the CPU oracle ITSELF is
+    d = 1.5e-6 away from the binary128 history of the recurrence (tests/golden/oracle_bicgstab256.json, leg 4 of
+    make_scale_golden.py).  Tolerances derived from d: HIP path within 8 d of the exact history, hence within
+    9 d of the oracle; iteration count and status equal."""
+    g = _golden("oracle_bicgstab256.json")
+    href, hq, d = np.array(g["residuals"]), np.array(g["quad_residuals"]), float(g["oracle_double_max_rel_dev"])
+    n1 = 256
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", n1)
+    assert A.nnz == g["nnz"]
+    ones = ctx.empty(n)
+    K.kfill_(ones, 1.0)
+    b = ctx.empty(n)
+    A.matvec(ones, b)
+    ws = K.BicgstabWorkspace(ctx, n, n)
+    K.bicgstab_(ws, A, b, atol=0.0, rtol=0.0, itmax=g["niter"], history=True, fused=fused)
+    st = ws.stats
+    assert st.niter == g["niter"] and st.status == g["status"] and len(st.residuals) == len(href)
+    d_gpu = _rel(st.residuals, hq)
+    parity_log(test="bicgstab_256_vs_oracle", fused=fused, iterations=st.niter, gpu_vs_quad=d_gpu, cpu_oracle_vs_quad=d,
+               gpu_vs_oracle=_rel(st.residuals, href))
+    assert d_gpu <= 8 * d and _rel(st.residuals, href) <= 9 * d
