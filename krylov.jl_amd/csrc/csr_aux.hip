@@ -157,6 +157,12 @@ __global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
 // LDS for the panel rows and workgroups per CU the kernel is compiled for.  44 KB / 2 is the measured optimum: 40 KB / 3
 // (three waves per SIMD, 168 VGPRs with 4 spilled) is 4 % faster at p = 16 but 2-3x slower at p = 8 and 4, whose
 // instantiations spill heavily under the tighter register budget (profiles/r02_spmm_experiments.log).
+#ifndef KHIP_WIN_SPREAD
+#define KHIP_WIN_SPREAD 1
+#endif
+#ifndef KHIP_WIN_PIPE
+#define KHIP_WIN_PIPE 1
+#endif
 #ifndef KHIP_WIN_KB
 #define KHIP_WIN_KB 44
 #endif
@@ -191,6 +197,41 @@ struct WinArgs {
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup fence + s_barrier and the fence
 // drains vmcnt as well, i.e. it would wait for the prefetches of the next groups at every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Value of lane K of every group of L consecutive lanes (L = 2, 4, 8), by DPP moves instead of an LDS broadcast read: an LDS
+// instruction costs the CU ~5 cycles whatever its width (tools/ldsbench.hip), and the product loop spent two of them per
+// entry (val, slot) next to the one panel-row read; fetched L entries at a time and spread over the row's lanes by one or
+// two v_mov_dpp each, (val, slot) cost 2 / L of an LDS instruction per entry.
+template <int L, int K>
+__device__ __forceinline__ int group_bcast(int v) {
+  static_assert(L == 2 || L == 4 || L == 8, "group_bcast: L = 2, 4, 8");
+  if (L == 2) {
+    constexpr int QP = K | (K << 2) | ((K + 2) << 4) | ((K + 2) << 6);                  // quad_perm [K, K, K+2, K+2]
+    return __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true);      // old = 0 + bound_ctrl: no register to initialise
+  }
+  constexpr int Q = K & 3, QP = Q | (Q << 2) | (Q << 4) | (Q << 6);                     // quad_perm [Q, Q, Q, Q]
+  int t = __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true);
+  if (L == 8)       // the other quad of the octet takes the value across row_half_mirror (lane i <- lane 7 - i)
+    t = __builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, K < 4 ? 0xA : 0x5, false);
+  return t;
+}
+template <int L, int K>
+__device__ __forceinline__ double group_bcast(double v) {
+  return __hiloint2double(group_bcast<L, K>(__double2hiint(v)), group_bcast<L, K>(__double2loint(v)));
+}
+// entries t0 .. t0 + 7 of a row's (val, slot) stream: fetched L at a time (lane c takes entry f L + c), spread by group_bcast
+template <int L, int K>
+struct BatchSpread {
+  __device__ static __forceinline__ void run(const double (&mv)[8 / L], const int (&ms)[8 / L], double (&vv)[8], int (&sl)[8]) {
+    vv[K] = group_bcast<L, K % L>(mv[K / L]);
+    sl[K] = group_bcast<L, K % L>(ms[K / L]);
+    BatchSpread<L, K + 1>::run(mv, ms, vv, sl);
+  }
+};
+template <int L>
+struct BatchSpread<L, 8> {
+  __device__ static __forceinline__ void run(const double (&)[8 / L], const int (&)[8 / L], double (&)[8], int (&)[8]) {}
+};
 
 // Phase stamps of one wave (tools/spmm_trace.py builds a variant of the library with -DKHIP_WIN_TRACE; compiled out otherwise):
 // wave 0 of workgroup 5 writes the shader clock at the phase boundaries of its iterations 8..23.  What it showed
@@ -357,20 +398,86 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
       const int len = eC - sC;
       const double *lv = win_val + (sC - gsC);
       const unsigned short *lsl = win_slot + (sC - gsC);
-      const dbl2 *xc = win_xs + c;
+      const char *xc = reinterpret_cast<const char *>(win_xs + c);
       double acc0 = 0.0, acc1 = 0.0;
+      constexpr bool SPREAD = KHIP_WIN_SPREAD != 0;        // (val, slot) fetched LS entries at a time and spread by DPP moves
+      constexpr int LS = KHIP_WIN_SPREAD == 8 && L == 8 ? 8 : (L < 4 ? L : 4);   // quads: one v_mov_dpp per word (octets: two)
+      const int cs = c & (LS - 1);
       const int len0 = __builtin_amdgcn_readfirstlane(len);
-      if (__ballot(len != len0) == 0) {
+      if (__ballot(len != len0) == 0 && SPREAD && KHIP_WIN_PIPE) {
+        // the wave's rows are equally long (interior of a stencil): scalar loop bounds, and two batches of 8 entries in flight --
+        // a wave gets an LDS read back every ~45 cycles (tools/ldsbench.hip), so the panel-row reads of batch b + 1 and the
+        // (val, slot) fetch of batch b + 2 are issued BEFORE the products of batch b.  Reads run up to 7 entries past the row
+        // (into the next rows' entries or the 8 spare ones: valid slots all); the products stop at the uniform bound.
+        constexpr int NF = 8 / LS;
+        struct Batch { double vv[8]; dbl2 xv[8]; };
+        double mv[NF];
+        int ms[NF];
+        auto fetch = [&](int t0) {
+#pragma unroll
+          for (int f = 0; f < NF; ++f) { mv[f] = lv[t0 + f * LS + cs]; ms[f] = (int)lsl[t0 + f * LS + cs] * (16 * L); }
+        };
+        auto spread_issue = [&](Batch &b) {
+          int sl[8];
+          BatchSpread<LS, 0>::run(mv, ms, b.vv, sl);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            b.xv[k] = *reinterpret_cast<const dbl2 *>(xc + sl[k]);
+          }
+        };
+        auto consume = [&](const Batch &b, int n) {
+          if (n >= 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const double p0 = b.vv[k] * b.xv[k].x, p1 = b.vv[k] * b.xv[k].y;
+              acc0 = acc0 + p0;
+              acc1 = acc1 + p1;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (k < n) {
+                const double p0 = b.vv[k] * b.xv[k].x, p1 = b.vv[k] * b.xv[k].y;
+                acc0 = acc0 + p0;
+                acc1 = acc1 + p1;
+              }
+            }
+          }
+        };
+        const int nb = (len0 + 7) >> 3;
+        if (nb > 0) {
+          Batch A, B;
+          fetch(0);
+          spread_issue(A);
+          if (nb > 1) fetch(8);
+          for (int b = 0;;) {      // A holds batch b, (mv, ms) the fetch of batch b + 1
+            if (b + 1 < nb) { spread_issue(B); if (b + 2 < nb) fetch(8 * (b + 2)); }
+            consume(A, len0 - 8 * b);
+            if (++b >= nb) break;
+            if (b + 1 < nb) { spread_issue(A); if (b + 2 < nb) fetch(8 * (b + 2)); }
+            consume(B, len0 - 8 * b);
+            if (++b >= nb) break;
+          }
+        }
+      } else if (__ballot(len != len0) == 0) {
         // the wave's rows are equally long (interior of a stencil): scalar loop bounds, no masks
         int t0 = 0;
         for (; t0 + 8 <= len0; t0 += 8) {
           double vv[8];
           int sl[8];
           dbl2 xv[8];
+          if (SPREAD) {
+            double mv[8 / LS];
+            int ms[8 / LS];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { vv[k] = lv[t0 + k]; sl[k] = lsl[t0 + k]; }
+            for (int f = 0; f < 8 / LS; ++f) { mv[f] = lv[t0 + f * LS + cs]; ms[f] = (int)lsl[t0 + f * LS + cs] * (16 * L); }
+            BatchSpread<LS, 0>::run(mv, ms, vv, sl);
+          } else {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) xv[k] = xc[sl[k] * L];
+            for (int k = 0; k < 8; ++k) { vv[k] = lv[t0 + k]; sl[k] = (int)lsl[t0 + k] * (16 * L); }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const dbl2 *>(xc + sl[k]);     // sl: byte offset of the panel row
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const double p0 = vv[k] * xv[k].x, p1 = vv[k] * xv[k].y;
@@ -385,10 +492,18 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
           double vv[8];
           int sl[8];
           dbl2 xv[8];
+          if (SPREAD) {
+            double mv[8 / LS];
+            int ms[8 / LS];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { vv[k] = lv[t0 + k]; sl[k] = lsl[t0 + k]; }
+            for (int f = 0; f < 8 / LS; ++f) { mv[f] = lv[t0 + f * LS + cs]; ms[f] = (int)lsl[t0 + f * LS + cs] * (16 * L); }
+            BatchSpread<LS, 0>::run(mv, ms, vv, sl);
+          } else {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) xv[k] = xc[sl[k] * L];
+            for (int k = 0; k < 8; ++k) { vv[k] = lv[t0 + k]; sl[k] = (int)lsl[t0 + k] * (16 * L); }
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const dbl2 *>(xc + sl[k]);     // sl: byte offset of the panel row
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             if (k < n) {
@@ -403,14 +518,26 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
           double vv[8];
           int sl[8];
           dbl2 xv[8];
+          if (SPREAD) {
+            double mv[8 / LS];
+            int ms[8 / LS];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int t = t0 + k < len ? t0 + k : 0;       // past the end of the row: its first entry, not used
-            vv[k] = lv[t];
-            sl[k] = lsl[t];
+            for (int f = 0; f < 8 / LS; ++f) {
+              const int t = t0 + f * LS + cs < len ? t0 + f * LS + cs : 0;
+              mv[f] = lv[t];
+              ms[f] = (int)lsl[t] * (16 * L);
+            }
+            BatchSpread<LS, 0>::run(mv, ms, vv, sl);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int t = t0 + k < len ? t0 + k : 0;       // past the end of the row: its first entry, not used
+              vv[k] = lv[t];
+              sl[k] = (int)lsl[t] * (16 * L);
+            }
           }
 #pragma unroll
-          for (int k = 0; k < 8; ++k) xv[k] = xc[sl[k] * L];
+          for (int k = 0; k < 8; ++k) xv[k] = *reinterpret_cast<const dbl2 *>(xc + sl[k]);     // sl: byte offset of the panel row
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             if (t0 + k < len) {
