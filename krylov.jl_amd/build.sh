@@ -10,16 +10,19 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 BUILD="${KHIP_BUILD_DIR:-$HERE/build}"
 mkdir -p "$BUILD"
 objs=""
+pids=""
 for f in blas1.hip spmv.hip csr_aux.hip panel.hip ilu.hip template.hip colcode.hip comm.cpp api.cpp solvers.cpp block.cpp processes.cpp; do
   [ -f "$SRC/$f" ] || continue
   o="$BUILD/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h*' -newer "$o" | head -1)" ]; then
     echo "hipcc $f"
+    rm -f "$o"                          # a failed compile must not leave a stale object for the link
     $HIPCC $FLAGS -x hip -c "$SRC/$f" -o "$o" &
+    pids="$pids $!"
   fi
   objs="$objs $o"
 done
-wait
+for pid in $pids; do wait $pid || { echo "build.sh: a compile failed" >&2; exit 1; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs -ldl
 echo "built $OUT"
 # libkrylov_hip_capi.so: the reference's C / Fortran interface on top (needs ITS header, which is not redistributed)
