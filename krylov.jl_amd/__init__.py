@@ -110,6 +110,7 @@ SIGNATURES = {
     "khip_ilu0_destroy": (_int, [C.POINTER(COperator)]),
     "khip_ilu0_info": (_int, [C.POINTER(COperator), C.POINTER(_i64), C.POINTER(_i64), c_void_pp]),
     "khip_ilu0_set_graph": (_int, [C.POINTER(COperator), _int]),
+    "khip_ilu0_block_info": (_int, [C.POINTER(COperator), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
     "khip_spmv_dot": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
     "khip_axpy2_dot": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
@@ -777,6 +778,13 @@ class Ilu0:
         lo, up = _i64(), _i64()
         _ck(lib().khip_ilu0_info(C.byref(self.op), C.byref(lo), C.byref(up), None))
         return lo.value, up.value
+
+    def block_info(self):
+        """(grid dims the pattern was recognised as, or (0, 0, 0): level scheduling; blocks per triangle; 1 if a bounded spin
+        of the block schedule ever gave up).  Synchronises."""
+        dims, nb, failed = (_i64 * 3)(), _i64(), _int()
+        _ck(lib().khip_ilu0_block_info(C.byref(self.op), dims, C.byref(nb), C.byref(failed)))
+        return tuple(dims), nb.value, failed.value
 
     def values(self):
         """Factor values on A's pattern (host copy)."""

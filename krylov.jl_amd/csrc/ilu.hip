@@ -147,6 +147,131 @@ __global__ __launch_bounds__(kIluBlock) void ilu_small_levels_kernel(IluView v, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Block schedule of the triangular solves (operators whose pattern is a structured grid in natural ordering).
+//
+// Level scheduling pays one kernel boundary per level -- 2 (n1 + n2 + n3 - 2) of them for a 7-point grid, ~7 us each: the
+// solves are launch-latency bound.  Here the rows are cut into BLOCKS of a few hundred rows (8 x 8 x 8 grid
+// points; 16 x 16 on a 2-D grid) whose dependencies point to blocks with smaller grid coordinates only.  One persistent
+// launch per triangle: a workgroup of ONE wave takes the next block off a ticket counter (tickets run along the block
+// wavefronts bx + by + bz, a topological order of the block graph), copies the block's packed factor entries to LDS while it
+// waits for the (at most three) blocks it depends on, fetches the y values of their faces, and then walks the block's OWN
+// levels out of LDS -- a dependent step costs an LDS round trip instead of a kernel boundary, and device-wide traffic (a
+// flag per block, y written through and read past the L2s) happens once per block, not once per level.  Every row is
+// still computed by one lane that walks its entries in stored order with a rounded multiply and a rounded subtract per
+// entry: y is bit-identical to the level-scheduled kernels and to the oracle's serial loops (ko_ilu0_solve).
+// No deadlock: a block waits only for blocks with SMALLER tickets; tickets are handed out in order to running workgroups,
+// so the smallest unfinished ticket never waits.  The spins are bounded all the same (a.fail is set instead of hanging).
+#ifndef KHIP_ILU_SPIN
+#define KHIP_ILU_SPIN (1 << 22)
+#endif
+constexpr int kBlkRows = 512;          // rows of a block at most
+constexpr int kBlkThreads = 64;        // one wave: its levels need no s_barrier between waves
+
+struct IluBlockHdr {
+  int64_t ent0;                        // first packed entry of the block
+  int32_t row0, nrows;                 // its rows: row_gid[row0 .. row0 + nrows), in local level order
+  int32_t nent;
+  int32_t lvl0, nlvl;                  // local level pointers lvl[lvl0 .. lvl0 + nlvl]
+  int32_t ext0, next;                  // rows of other blocks whose y it reads
+  int32_t dep0, ndep;                  // tickets of the blocks it waits for
+  int32_t pad;
+};
+
+struct IluBlkArgs {
+  const IluBlockHdr *hdr;
+  const int32_t *row_gid;              // [n]
+  const uint16_t *row_eptr;            // [n + nb]: per block nrows + 1 local entry offsets, at row0 + ticket
+  const uint16_t *lvl;
+  const int32_t *ext_gid, *dep;
+  const uint16_t *ent_slot;            // per packed entry: local row (< kBlkRows) or kBlkRows + index into the block's ext list
+  const double *ent_val;
+  const double *diag_val;              // upper solve: lu[diag] per row, in block order
+  int *done;                           // [nb]: epoch of the last solve that finished the block
+  unsigned *ticket;
+  int *fail;
+  int nb, max_ent, max_ext, max_lvl;
+};
+
+template <int KIND>     // 1: lower solve y = L^{-1} x, 2: upper solve y = U^{-1} y
+__global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs a, const double *x, double *y, int epoch,
+                                                                       unsigned ticket_base) {
+  extern __shared__ double ilu_sm[];
+  __shared__ int s_ticket;
+  double *yl = ilu_sm;                                      // [kBlkRows + max_ext]: y of the block's rows, then of the ext list
+  double *xv = yl + kBlkRows + a.max_ext;                   // [kBlkRows]: right-hand side
+  double *dv = xv + kBlkRows;                               // [kBlkRows]: pivots (upper solve)
+  double *ev = dv + (KIND == 2 ? kBlkRows : 0);             // [max_ent]
+  uint16_t *es = reinterpret_cast<uint16_t *>(ev + a.max_ent);   // [max_ent rounded up to 4]
+  uint16_t *ep = es + ((a.max_ent + 3) & ~3);               // [kBlkRows + 2]
+  uint16_t *lv = ep + kBlkRows + 2;                         // [max_lvl + 2]
+  const int lane = threadIdx.x;
+  for (;;) {
+    // lane 0 draws the ticket; every lane reads it back from LDS
+    if (lane == 0) s_ticket = (int)(atomicAdd(a.ticket, 1u) - ticket_base);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(s_ticket);
+    __syncthreads();
+    if (t >= a.nb) break;
+    const IluBlockHdr h = a.hdr[t];
+    // stage what does not depend on other blocks
+    for (int e = lane; e < h.nent; e += kBlkThreads) { ev[e] = a.ent_val[h.ent0 + e]; es[e] = a.ent_slot[h.ent0 + e]; }
+    for (int r = lane; r <= h.nrows; r += kBlkThreads) ep[r] = a.row_eptr[(int64_t)h.row0 + t + r];
+    for (int l = lane; l <= h.nlvl; l += kBlkThreads) lv[l] = a.lvl[h.lvl0 + l];
+    for (int r = lane; r < h.nrows; r += kBlkThreads) {
+      const int32_t gid = a.row_gid[h.row0 + r];
+      xv[r] = KIND == 1 ? x[gid] : y[gid];
+      if (KIND == 2) dv[r] = a.diag_val[h.row0 + r];
+    }
+    // the blocks this one reads from
+    for (int d = lane; d < h.ndep; d += kBlkThreads) {
+      const int *flag = a.done + a.dep[h.dep0 + d];
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > KHIP_ILU_SPIN || __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(a.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");                           // the loads below stay below the spins
+    // y of other blocks: written through and read past the L2s (agent scope), so that neither side needs a cache-wide
+    // write-back or invalidate per block
+    for (int k = lane; k < h.next; k += kBlkThreads)
+      yl[kBlkRows + k] = __hip_atomic_load(y + a.ext_gid[h.ext0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int l = 0; l < h.nlvl; ++l) {
+      const int r1 = lv[l + 1];
+      for (int r = lv[l] + lane; r < r1; r += kBlkThreads) {
+        double acc = xv[r];
+        const int e1 = ep[r + 1];
+        for (int e = ep[r]; e < e1; ++e) {
+          const double tt = ev[e] * yl[es[e]];
+          acc = acc - tt;
+        }
+        yl[r] = KIND == 2 ? acc / dv[r] : acc;
+      }
+      __syncthreads();
+    }
+    for (int r = lane; r < h.nrows; r += kBlkThreads)
+      __hip_atomic_store(y + a.row_gid[h.row0 + r], yl[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the block's y has arrived before its flag is raised
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(a.done + t, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();      // a convergent operation between this `if (lane == 0)` and the one at the top of the loop: without it
+                          // the two are threaded into a private loop of lane 0 and the other lanes re-run block t for ever
+  }
+}
+
+// ent_val[e] = lu[src[e]] (and the pivots of the upper solve) after the numeric factorisation
+__global__ __launch_bounds__(256) void ilu_pack_values_kernel(const double *lu, const int32_t *src, int64_t n, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = lu[src[i]];
+}
+
 }  // namespace khip
 
 using namespace khip;
@@ -161,6 +286,22 @@ struct khip_ilu0 {
   std::vector<int64_t> lvl_lo, lvl_up;       // level pointers into perm_lo / perm_up
   int64_t *d_lvl_lo = nullptr, *d_lvl_up = nullptr;   // device copies (for the batched small levels)
   int *bad_row = nullptr;
+  // block schedule (structured grids; see ilu_block_solve_kernel): one per triangle
+  struct Blocks {
+    int nb = 0, max_ent = 0, max_ext = 0, max_lvl = 0, grid = 0;
+    IluBlockHdr *hdr = nullptr;
+    int32_t *row_gid = nullptr, *ext_gid = nullptr, *dep = nullptr;
+    uint16_t *row_eptr = nullptr, *lvl = nullptr, *ent_slot = nullptr;
+    double *ent_val = nullptr, *diag_val = nullptr;
+    int *done = nullptr;
+    unsigned *ticket = nullptr;
+    int epoch = 0;
+    unsigned ticket_base = 0;
+    size_t lds = 0;
+  } blk_lo, blk_up;
+  int *blk_fail = nullptr;
+  int64_t grid_dims[3] = {0, 0, 0};          // detected grid (0: none, level scheduling)
+  bool use_blocks = false;
   // cached hipGraph of one application, keyed by the (x, y) pointers it was captured with
   hipGraphExec_t graph = nullptr;
   const double *gx = nullptr;
@@ -206,10 +347,26 @@ int enqueue_solve(khip_ilu0 *P, const double *x, double *y) {
   return enqueue_levels<2>(P, P->lvl_up, P->d_lvl_up, P->perm_up, x, y);
 }
 
+template <int KIND>
+int launch_blocks(khip_ilu0 *P, khip_ilu0::Blocks &B, const double *x, double *y) {
+  IluBlkArgs a{B.hdr, B.row_gid, B.row_eptr, B.lvl, B.ext_gid, B.dep, B.ent_slot, B.ent_val, B.diag_val, B.done, B.ticket,
+               P->blk_fail, B.nb, B.max_ent, B.max_ext, B.max_lvl};
+  ++B.epoch;
+  hipLaunchKernelGGL((ilu_block_solve_kernel<KIND>), dim3((unsigned)B.grid), dim3(kBlkThreads), B.lds, P->ctx->stream, a, x, y, B.epoch,
+                     B.ticket_base);
+  B.ticket_base += (unsigned)(B.nb + B.grid);          // every workgroup draws one ticket past the end
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 int ilu0_apply(void *self, const double *x, double *y) {
   khip_ilu0 *P = static_cast<khip_ilu0 *>(self);
   if (P->n == 0) return KHIP_OK;
   khip_ctx *ctx = P->ctx;
+  if (P->use_blocks && ctx->tune.ilu_blocks != 0) {
+    KHIP_TRY((launch_blocks<1>(P, P->blk_lo, x, y)));
+    return launch_blocks<2>(P, P->blk_up, x, y);
+  }
   const size_t launches = P->lvl_lo.size() + P->lvl_up.size();
   if (!P->use_graph || launches < 8) return enqueue_solve(P, x, y);
   if (!P->graph || P->gx != x || P->gy != y) {
@@ -230,9 +387,19 @@ int ilu0_apply(void *self, const double *x, double *y) {
   return KHIP_OK;
 }
 
+void blocks_free(khip_ilu0::Blocks &B) {
+  for (void *p : {(void *)B.hdr, (void *)B.row_gid, (void *)B.ext_gid, (void *)B.dep, (void *)B.row_eptr, (void *)B.lvl,
+                  (void *)B.ent_slot, (void *)B.ent_val, (void *)B.diag_val, (void *)B.done, (void *)B.ticket})
+    if (p) (void)hipFree(p);
+  B = khip_ilu0::Blocks();
+}
+
 void ilu0_free(khip_ilu0 *P) {
   if (!P) return;
   if (P->graph) (void)hipGraphExecDestroy(P->graph);
+  blocks_free(P->blk_lo);
+  blocks_free(P->blk_up);
+  if (P->blk_fail) (void)hipFree(P->blk_fail);
   for (void *p : {(void *)P->lu, (void *)P->row_lo, (void *)P->diag, (void *)P->row_hi, (void *)P->perm_lo,
                   (void *)P->perm_up, (void *)P->bad_row, (void *)P->d_lvl_lo, (void *)P->d_lvl_up})
     if (p) (void)hipFree(p);
@@ -254,6 +421,222 @@ template <typename T>
 int upload(khip_ctx *ctx, const std::vector<T> &h, T **dev) {
   KHIP_CHECK_HIP(hipMalloc(dev, sizeof(T) * std::max<size_t>(h.size(), 1)));
   if (!h.empty()) KHIP_CHECK_HIP(hipMemcpy(*dev, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+  return KHIP_OK;
+}
+
+
+// ---- block schedule: host analysis ------------------------------------------------------------------------------------
+struct HostPattern {
+  int64_t n;
+  const std::vector<int32_t> &col, &row_lo, &diag, &row_hi;
+};
+
+// Is the pattern a grid n1 x n2 x n3 in natural ordering (index = x + n1 (y + n2 z)) whose lower entries point to grid
+// points with coordinates <= and whose upper entries to coordinates >= ?  (The 7-point stencils are; the 27-point stencil is
+// not -- row (x, y, z) reaches (x + 1, y - 1, z) in its lower triangle, cubes of grid points would wait for each other.)
+// The candidates for n1 and n1 n2 are the centres of the runs of consecutive row - column offsets of a few sample rows; the
+// answer is checked on every entry.
+bool detect_grid(const HostPattern &H, int64_t dims[3]) {
+  const int64_t n = H.n;
+  if (n < 4096) return false;
+  std::vector<int64_t> offs;
+  for (int s = 0; s < 64; ++s) {
+    const int64_t i = n / 2 + (n / 3) * (s % 2) - (n / 5) * (s % 3 == 2) + 37 * s;
+    if (i < 0 || i >= n) continue;
+    for (int32_t q = H.row_lo[(size_t)i]; q < H.diag[(size_t)i]; ++q) offs.push_back(i - H.col[(size_t)q]);
+  }
+  std::sort(offs.begin(), offs.end());
+  offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+  std::vector<int64_t> centre;                       // centres of the runs of consecutive offsets
+  for (size_t a = 0; a < offs.size();) {
+    size_t b = a;
+    while (b + 1 < offs.size() && offs[b + 1] == offs[b] + 1) ++b;
+    centre.push_back((offs[a] + offs[b]) / 2);
+    a = b + 1;
+  }
+  auto valid = [&](int64_t n1, int64_t n2, int64_t n3) {
+    if (n1 < 2 || n2 < 2 || n3 < 1 || n1 * n2 * n3 != n) return false;
+    const int64_t s2 = n1 * n2;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t zi = i / s2, ri = i - zi * s2, yi = ri / n1, xi = ri - yi * n1;
+      for (int32_t q = H.row_lo[(size_t)i]; q < H.row_hi[(size_t)i]; ++q) {
+        const int64_t j = H.col[(size_t)q];
+        if (j == i) continue;
+        const int64_t zj = j / s2, rj = j - zj * s2, yj = rj / n1, xj = rj - yj * n1;
+        if (j < i ? (xj > xi || yj > yi || zj > zi) : (xj < xi || yj < yi || zj < zi)) return false;
+      }
+    }
+    return true;
+  };
+  int tried = 0;
+  for (int64_t n1 : centre) {
+    if (n1 < 2 || n % n1 != 0) continue;
+    for (int64_t s2 : centre) {                      // 3-D: a second centre that is a multiple of n1 and divides n
+      if (s2 <= n1 || s2 % n1 != 0 || n % s2 != 0) continue;
+      if (++tried > 6) return false;
+      if (valid(n1, s2 / n1, n / s2)) { dims[0] = n1; dims[1] = s2 / n1; dims[2] = n / s2; return true; }
+    }
+    if (++tried > 6) return false;
+    if (valid(n1, n / n1, 1)) { dims[0] = n1; dims[1] = n / n1; dims[2] = 1; return true; }       // 2-D
+  }
+  return false;
+}
+
+// Builds the block schedule of one triangle (lower: the entries before the diagonal, blocks in wavefront order of
+// bx + by + bz; upper: the entries after it, the mirrored order) and uploads it.  src = position in lu of every packed entry.
+int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool upper, khip_ilu0::Blocks &B,
+                 std::vector<int32_t> &src, std::vector<int32_t> &diag_src) {
+  khip_ctx *ctx = P->ctx;
+  const int64_t n = H.n, n1 = dims[0], n2 = dims[1], n3 = dims[2], s2 = n1 * n2;
+  const int T1 = n3 > 1 ? 8 : 16, T2 = T1, T3 = n3 > 1 ? 8 : 1;
+  const int64_t B1 = (n1 + T1 - 1) / T1, B2 = (n2 + T2 - 1) / T2, B3 = (n3 + T3 - 1) / T3, nb = B1 * B2 * B3;
+  if (nb > (int64_t)1 << 30) return KHIP_ERR_INVALID;
+  // ticket order: wavefronts of the block grid (mirrored for the upper solve), block id inside a wavefront
+  std::vector<int32_t> order((size_t)nb), ticket_of((size_t)nb);
+  {
+    std::vector<int64_t> cnt((size_t)(B1 + B2 + B3), 0);
+    auto wave = [&](int64_t b) {
+      const int64_t bz = b / (B1 * B2), r = b - bz * B1 * B2, by = r / B1, bx = r - by * B1;
+      return upper ? (B1 - 1 - bx) + (B2 - 1 - by) + (B3 - 1 - bz) : bx + by + bz;
+    };
+    for (int64_t b = 0; b < nb; ++b) cnt[(size_t)wave(b) + 1]++;
+    for (size_t w = 1; w < cnt.size(); ++w) cnt[w] += cnt[w - 1];
+    for (int64_t b = 0; b < nb; ++b) { const int64_t t = cnt[(size_t)wave(b)]++; order[(size_t)t] = (int32_t)b; ticket_of[(size_t)b] = (int32_t)t; }
+  }
+  auto block_of = [&](int64_t i) {
+    const int64_t z = i / s2, r = i - z * s2, y = r / n1, x = r - y * n1;
+    return ((z / T3) * B2 + y / T2) * B1 + x / T1;
+  };
+  std::vector<IluBlockHdr> hdr((size_t)nb);
+  std::vector<int32_t> row_gid; row_gid.reserve((size_t)n);
+  std::vector<uint16_t> row_eptr; row_eptr.reserve((size_t)(n + nb));
+  std::vector<uint16_t> lvl, ent_slot;
+  std::vector<int32_t> ext_gid, dep;
+  src.clear(); diag_src.clear();
+  std::vector<int32_t> lpos((size_t)n, -1), ext_mark((size_t)n, -1);
+  std::vector<int32_t> rows, llev, sorted, deps_here;
+  std::vector<int32_t> lcount;
+  int max_ent = 0, max_ext = 0, max_lvl = 0;
+  for (int64_t t = 0; t < nb; ++t) {
+    const int64_t b = order[(size_t)t];
+    const int64_t bz = b / (B1 * B2), rr = b - bz * B1 * B2, by = rr / B1, bx = rr - by * B1;
+    rows.clear();
+    for (int64_t z = bz * T3; z < std::min<int64_t>((bz + 1) * T3, n3); ++z)
+      for (int64_t y = by * T2; y < std::min<int64_t>((by + 1) * T2, n2); ++y)
+        for (int64_t x = bx * T1; x < std::min<int64_t>((bx + 1) * T1, n1); ++x) rows.push_back((int32_t)(x + n1 * (y + n2 * z)));
+    const int nr = (int)rows.size();                       // ascending row numbers
+    // local levels from the dependencies inside the block
+    llev.assign((size_t)nr, 0);
+    for (int k = 0; k < nr; ++k) lpos[(size_t)rows[(size_t)k]] = k;       // temporary: position in ascending order
+    int nl = 0;
+    for (int kk = 0; kk < nr; ++kk) {
+      const int k = upper ? nr - 1 - kk : kk;
+      const int32_t i = rows[(size_t)k];
+      int lv = 0;
+      const int32_t qa = upper ? H.diag[(size_t)i] + 1 : H.row_lo[(size_t)i], qb = upper ? H.row_hi[(size_t)i] : H.diag[(size_t)i];
+      for (int32_t q = qa; q < qb; ++q) {
+        const int32_t j = H.col[(size_t)q];
+        if (block_of(j) == b) lv = std::max(lv, llev[(size_t)lpos[(size_t)j]] + 1);
+      }
+      llev[(size_t)k] = lv;
+      nl = std::max(nl, lv + 1);
+    }
+    lcount.assign((size_t)nl + 1, 0);
+    for (int k = 0; k < nr; ++k) lcount[(size_t)llev[(size_t)k] + 1]++;
+    for (int l = 0; l < nl; ++l) lcount[(size_t)l + 1] += lcount[(size_t)l];
+    IluBlockHdr &h = hdr[(size_t)t];
+    h.row0 = (int32_t)row_gid.size(); h.nrows = nr; h.ent0 = (int64_t)src.size();
+    h.lvl0 = (int32_t)lvl.size(); h.nlvl = nl; h.ext0 = (int32_t)ext_gid.size(); h.dep0 = (int32_t)dep.size(); h.pad = 0;
+    for (int l = 0; l <= nl; ++l) lvl.push_back((uint16_t)lcount[(size_t)l]);
+    sorted.assign((size_t)nr, 0);
+    {
+      std::vector<int32_t> cur(lcount.begin(), lcount.end() - 1);
+      for (int k = 0; k < nr; ++k) sorted[(size_t)cur[(size_t)llev[(size_t)k]]++] = rows[(size_t)k];
+    }
+    for (int k = 0; k < nr; ++k) lpos[(size_t)sorted[(size_t)k]] = k;      // final: position in level order
+    deps_here.clear();
+    int ne = 0;
+    for (int k = 0; k < nr; ++k) {
+      const int32_t i = sorted[(size_t)k];
+      row_gid.push_back(i);
+      row_eptr.push_back((uint16_t)ne);
+      diag_src.push_back(H.diag[(size_t)i]);
+      const int32_t qa = upper ? H.diag[(size_t)i] + 1 : H.row_lo[(size_t)i], qb = upper ? H.row_hi[(size_t)i] : H.diag[(size_t)i];
+      for (int32_t q = qa; q < qb; ++q) {                   // stored order
+        const int32_t j = H.col[(size_t)q];
+        const int64_t bj = block_of(j);
+        int slot;
+        if (bj == b) slot = lpos[(size_t)j];
+        else {
+          if (ext_mark[(size_t)j] < 0) {
+            ext_mark[(size_t)j] = (int32_t)(ext_gid.size() - (size_t)h.ext0);
+            ext_gid.push_back(j);
+            const int32_t tj = ticket_of[(size_t)bj];
+            if (std::find(deps_here.begin(), deps_here.end(), tj) == deps_here.end()) deps_here.push_back(tj);
+          }
+          slot = kBlkRows + ext_mark[(size_t)j];
+        }
+        ent_slot.push_back((uint16_t)slot);
+        src.push_back(q);
+        ++ne;
+      }
+    }
+    row_eptr.push_back((uint16_t)ne);
+    h.nent = ne; h.next = (int32_t)(ext_gid.size() - (size_t)h.ext0); h.ndep = (int32_t)deps_here.size();
+    for (int32_t tj : deps_here) {
+      if (tj >= t) { set_error("ilu0_create: block schedule is not topological (internal)"); return KHIP_ERR_INVALID; }
+      dep.push_back(tj);
+    }
+    for (int32_t k = h.ext0; k < h.ext0 + h.next; ++k) ext_mark[(size_t)ext_gid[(size_t)k]] = -1;
+    for (int k = 0; k < nr; ++k) lpos[(size_t)sorted[(size_t)k]] = -1;
+    if (nr > kBlkRows || ne > 60000 || kBlkRows + h.next > 65535) return KHIP_ERR_INVALID;
+    max_ent = std::max(max_ent, ne); max_ext = std::max(max_ext, h.next); max_lvl = std::max(max_lvl, nl);
+  }
+  B.nb = (int)nb; B.max_ent = max_ent; B.max_ext = max_ext; B.max_lvl = max_lvl;
+  B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
+          sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + max_lvl + 2);
+  if (B.lds > (size_t)150 * 1024) return KHIP_ERR_INVALID;
+  int rc = upload(ctx, hdr, &B.hdr);
+  if (!rc) rc = upload(ctx, row_gid, &B.row_gid);
+  if (!rc) rc = upload(ctx, row_eptr, &B.row_eptr);
+  if (!rc) rc = upload(ctx, lvl, &B.lvl);
+  if (!rc) rc = upload(ctx, ext_gid, &B.ext_gid);
+  if (!rc) rc = upload(ctx, dep, &B.dep);
+  if (!rc) rc = upload(ctx, ent_slot, &B.ent_slot);
+  if (rc) return rc;
+  KHIP_CHECK_HIP(hipMalloc(&B.ent_val, sizeof(double) * std::max<size_t>(src.size(), 1)));
+  if (upper) KHIP_CHECK_HIP(hipMalloc(&B.diag_val, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  KHIP_CHECK_HIP(hipMalloc(&B.done, sizeof(int) * (size_t)nb));
+  KHIP_CHECK_HIP(hipMalloc(&B.ticket, sizeof(unsigned)));
+  KHIP_CHECK_HIP(hipMemsetAsync(B.done, 0, sizeof(int) * (size_t)nb, ctx->stream));
+  KHIP_CHECK_HIP(hipMemsetAsync(B.ticket, 0, sizeof(unsigned), ctx->stream));
+  const void *fn = upper ? (const void *)ilu_block_solve_kernel<2> : (const void *)ilu_block_solve_kernel<1>;
+  if (B.lds > 64 * 1024) KHIP_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.lds));
+  int per_cu = (int)((size_t)(160 * 1024) / std::max<size_t>(B.lds, 1));
+  per_cu = std::max(1, std::min(per_cu, 8));
+  B.grid = (int)std::min<int64_t>(nb, (int64_t)ctx->num_cu * per_cu);
+  return KHIP_OK;
+}
+
+// after the numeric factorisation: the packed factor values
+int pack_block_values(khip_ilu0 *P, khip_ilu0::Blocks &B, const std::vector<int32_t> &src, const std::vector<int32_t> &diag_src, bool upper) {
+  khip_ctx *ctx = P->ctx;
+  int32_t *d_src = nullptr;
+  struct Scratch { int32_t *&p; ~Scratch() { (void)hipFree(p); } } scratch{d_src};
+  if (!src.empty()) {
+    KHIP_TRY(upload(ctx, src, &d_src));
+    hipLaunchKernelGGL(ilu_pack_values_kernel, dim3((unsigned)((src.size() + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src,
+                       (int64_t)src.size(), B.ent_val);
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_src); d_src = nullptr;
+  }
+  if (upper && !diag_src.empty()) {
+    KHIP_TRY(upload(ctx, diag_src, &d_src));
+    hipLaunchKernelGGL(ilu_pack_values_kernel, dim3((unsigned)((diag_src.size() + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src,
+                       (int64_t)diag_src.size(), B.diag_val);
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }
 
@@ -334,6 +717,26 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
     set_error("ilu0_create: zero pivot in row %d", bad);
     return KHIP_ERR_NUMERIC;
   }
+  // ---- block schedule of the solves where the pattern is a structured grid (else: level scheduling) ----
+  if (ctx->tune.ilu_blocks != 0) {
+    const HostPattern H{n, col, row_lo, diag, row_hi};
+    if (detect_grid(H, P->grid_dims)) {
+      KHIP_CHECK_HIP(hipMalloc(&P->blk_fail, sizeof(int)));
+      KHIP_CHECK_HIP(hipMemsetAsync(P->blk_fail, 0, sizeof(int), ctx->stream));
+      std::vector<int32_t> src, dsrc;
+      int rb = build_blocks(P, H, P->grid_dims, false, P->blk_lo, src, dsrc);
+      if (rb == KHIP_OK) rb = pack_block_values(P, P->blk_lo, src, dsrc, false);
+      if (rb == KHIP_OK) rb = build_blocks(P, H, P->grid_dims, true, P->blk_up, src, dsrc);
+      if (rb == KHIP_OK) rb = pack_block_values(P, P->blk_up, src, dsrc, true);
+      if (rb == KHIP_OK) P->use_blocks = true;
+      else {                                   // not representable (or out of memory): keep the level schedule
+        (void)hipGetLastError();
+        blocks_free(P->blk_lo);
+        blocks_free(P->blk_up);
+        P->grid_dims[0] = P->grid_dims[1] = P->grid_dims[2] = 0;
+      }
+    }
+  }
   guard.p = nullptr;
   op_out->csr = nullptr;
   op_out->apply = ilu0_apply;
@@ -354,6 +757,21 @@ int khip_ilu0_info(const khip_operator *op, int64_t *levels_lower, int64_t *leve
   if (levels_lower) *levels_lower = (int64_t)P->lvl_lo.size() - 1;
   if (levels_upper) *levels_upper = (int64_t)P->lvl_up.size() - 1;
   if (lu_dev) *lu_dev = P->lu;
+  return KHIP_OK;
+}
+
+int khip_ilu0_block_info(const khip_operator *op, int64_t *dims3, int64_t *blocks, int *failed) {
+  KHIP_REQUIRE(op && op->apply == ilu0_apply && op->self, "ilu0_block_info: not an ILU(0) operator");
+  const khip_ilu0 *P = static_cast<const khip_ilu0 *>(op->self);
+  if (dims3) for (int k = 0; k < 3; ++k) dims3[k] = P->use_blocks ? P->grid_dims[k] : 0;
+  if (blocks) *blocks = P->use_blocks ? P->blk_lo.nb : 0;
+  if (failed) {
+    *failed = 0;
+    if (P->blk_fail) {
+      KHIP_CHECK_HIP(hipStreamSynchronize(P->ctx->stream));
+      KHIP_CHECK_HIP(hipMemcpy(failed, P->blk_fail, sizeof(int), hipMemcpyDeviceToHost));
+    }
+  }
   return KHIP_OK;
 }
 

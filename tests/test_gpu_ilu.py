@@ -169,3 +169,64 @@ def test_ilu0_chain_operator_uses_batched_small_levels(K, ctx, oracle):
     dt = (time.perf_counter() - t0) / 3
     assert np.array_equal(dy.to_host(), ref.solve(x))
     assert dt < 0.1, dt          # 2 n per-level launches would take ~0.2 s
+
+
+@pytest.mark.parametrize("gen,args", [("poisson3d", (16,)), ("poisson3d", (19,)), ("poisson3d", (23, 17, 12)), ("kron_unsymmetric", (17,)),
+                                       ("poisson3d", (70, 64, 1))])
+def test_ilu0_block_schedule_bit_identical(K, ctx, oracle, gen, args):
+    """Structured grids (>= 4096 rows) take the block schedule (csrc/ilu.hip: ilu_block_solve_kernel): same y, bit for bit,
+    as the level-scheduled kernels and as the oracle's serial loops -- whole and partial 8 x 8 x 8 blocks, a 2-D grid, an
+    unsymmetric pattern."""
+    A = getattr(oracle, gen)(*args)
+    ref = oracle.Ilu0(A)
+    dA = _upload(K, ctx, A)
+    P = K.Ilu0(dA)
+    dims, nb, failed = P.block_info()
+    assert dims[0] * dims[1] * dims[2] == A.n and nb > 0 and failed == 0, (dims, nb, failed)
+    if gen == "poisson3d":
+        want = tuple(args) if len(args) == 3 else (args[0],) * 3
+        assert dims == want
+    ctx.set_option("ilu_blocks", 0)
+    try:
+        Pl = K.Ilu0(dA)                      # level scheduling on the same handle
+    finally:
+        ctx.set_option("ilu_blocks", 1)
+    assert Pl.block_info()[1] == 0
+    assert np.array_equal(P.values(), ref.lu)
+    rng = np.random.default_rng(len(args) + args[0])
+    for _ in range(3):
+        x = rng.standard_normal(A.n)
+        dx, dy, dz = ctx.array(x), ctx.empty(A.n), ctx.empty(A.n)
+        P(dx, dy); Pl(dx, dz)
+        want_y = ref.solve(x)
+        assert np.array_equal(dy.to_host(), want_y)
+        assert np.array_equal(dz.to_host(), want_y)
+        P(dx, dy)                            # again: the epochs and the ticket base move on
+        assert np.array_equal(dy.to_host(), want_y)
+    assert P.block_info()[2] == 0
+
+
+def test_ilu0_block_schedule_not_taken_for_other_patterns(K, ctx, oracle):
+    """A pattern that is no grid in natural ordering (a random symmetric permutation of one) keeps level scheduling, and so
+    does the 27-point stencil: its lower triangle reaches neighbours with a LARGER x or y (row (x+1, y-1, z)), cubes of
+    grid points would wait for each other."""
+    import scipy.sparse as sp
+    A27 = oracle.stencil27_unsym(18)
+    P27 = K.Ilu0(_upload(K, ctx, A27))
+    assert P27.block_info()[:2] == ((0, 0, 0), 0)
+    x27 = np.cos(np.arange(A27.n))
+    d27 = ctx.empty(A27.n)
+    P27(ctx.array(x27), d27)
+    assert np.array_equal(d27.to_host(), oracle.Ilu0(A27).solve(x27))
+    A = oracle.poisson3d(16)
+    S = A.to_scipy().tocsr()
+    perm = np.random.default_rng(0).permutation(A.n)
+    Sp = S[perm][:, perm].tocsr(); Sp.sort_indices()
+    Ap = oracle.CsrMatrix.from_arrays(Sp.indptr.astype(np.int64), Sp.indices.astype(np.int32), Sp.data)
+    dA = _upload(K, ctx, Ap)
+    P = K.Ilu0(dA)
+    assert P.block_info()[:2] == ((0, 0, 0), 0)
+    x = np.linspace(-1, 1, A.n)
+    dy = ctx.empty(A.n)
+    P(ctx.array(x), dy)
+    assert np.array_equal(dy.to_host(), oracle.Ilu0(Ap).solve(x))
