@@ -166,8 +166,21 @@ __global__ __launch_bounds__(kIluBlock) void ilu_small_levels_kernel(IluView v, 
 #ifndef KHIP_ILU_SPIN
 #define KHIP_ILU_SPIN (1 << 22)
 #endif
+// -DKHIP_ILU_TRACE: shader-clock stamps of the phases of 64 consecutive blocks of the lower solve (tools/ilu_trace.py)
+#ifdef KHIP_ILU_TRACE
+__device__ unsigned long long g_ilu_trace[64 * 8];
+#define ILU_STAMP(slot) do { if (KIND == 1 && lane == 0 && t >= a.nb / 2 && t < a.nb / 2 + 64) g_ilu_trace[(t - a.nb / 2) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ILU_STAMP(slot) do { } while (0)
+#endif
 constexpr int kBlkRows = 512;          // rows of a block at most
 constexpr int kBlkThreads = 64;        // one wave: its levels need no s_barrier between waves
+
+// Row record of the fast path (every row of the triangle has at most 3 off-diagonal entries: the 5- and 7-point stencils):
+// 48 bytes = v0, v1, v2, pivot, {slot0, slot1, slot2, count} as 4 x u16, 8 bytes spare -- one LDS round trip of three
+// 16-byte reads brings everything of a row that does not depend on y.
+constexpr int kRecDoubles = 6;
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct IluBlockHdr {
   int64_t ent0;                        // first packed entry of the block
@@ -188,6 +201,7 @@ struct IluBlkArgs {
   const uint16_t *ent_slot;            // per packed entry: local row (< kBlkRows) or kBlkRows + index into the block's ext list
   const double *ent_val;
   const double *diag_val;              // upper solve: lu[diag] per row, in block order
+  const double *rec;                   // row records (kRecDoubles per row, block order) where every row has <= 3 entries, else null
   int *done;                           // [nb]: epoch of the last solve that finished the block
   unsigned *ticket;
   int *fail;
@@ -215,15 +229,54 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
     __syncthreads();
     if (t >= a.nb) break;
     const IluBlockHdr h = a.hdr[t];
+    ILU_STAMP(0);
+    const bool fast = a.rec != nullptr && h.pad != 0;        // row records, and no level wider than the wave
+    int my_lv = 0;                                           // fast path: lane l holds level pointer l
     // stage what does not depend on other blocks
-    for (int e = lane; e < h.nent; e += kBlkThreads) { ev[e] = a.ent_val[h.ent0 + e]; es[e] = a.ent_slot[h.ent0 + e]; }
-    for (int r = lane; r <= h.nrows; r += kBlkThreads) ep[r] = a.row_eptr[(int64_t)h.row0 + t + r];
-    for (int l = lane; l <= h.nlvl; l += kBlkThreads) lv[l] = a.lvl[h.lvl0 + l];
-    for (int r = lane; r < h.nrows; r += kBlkThreads) {
-      const int32_t gid = a.row_gid[h.row0 + r];
-      xv[r] = KIND == 1 ? x[gid] : y[gid];
-      if (KIND == 2) dv[r] = a.diag_val[h.row0 + r];
+    if (fast) {
+      // kBlkRows x 48 bytes at most, as 16-byte pieces: all loads of a batch are in flight before the first LDS store
+      const dbl2 *src = reinterpret_cast<const dbl2 *>(a.rec + (int64_t)h.row0 * kRecDoubles);
+      dbl2 *dst = reinterpret_cast<dbl2 *>(ev);
+      const int pieces = h.nrows * (kRecDoubles / 2);
+      for (int b0 = 0; b0 < pieces; b0 += 8 * kBlkThreads) {
+        dbl2 tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = b0 + u * kBlkThreads + lane;
+          tmp[u] = src[i < pieces ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = b0 + u * kBlkThreads + lane;
+          if (i < pieces) dst[i] = tmp[u];
+        }
+      }
+      my_lv = a.lvl[h.lvl0 + (lane <= h.nlvl ? lane : 0)];
+      int32_t gid[kBlkRows / kBlkThreads];
+#pragma unroll
+      for (int u = 0; u < kBlkRows / kBlkThreads; ++u) {
+        const int r = u * kBlkThreads + lane;
+        gid[u] = a.row_gid[h.row0 + (r < h.nrows ? r : 0)];
+      }
+      double xs[kBlkRows / kBlkThreads];
+#pragma unroll
+      for (int u = 0; u < kBlkRows / kBlkThreads; ++u) xs[u] = KIND == 1 ? x[gid[u]] : y[gid[u]];
+#pragma unroll
+      for (int u = 0; u < kBlkRows / kBlkThreads; ++u) {
+        const int r = u * kBlkThreads + lane;
+        if (r < h.nrows) xv[r] = xs[u];
+      }
+    } else {
+      for (int e = lane; e < h.nent; e += kBlkThreads) { ev[e] = a.ent_val[h.ent0 + e]; es[e] = a.ent_slot[h.ent0 + e]; }
+      for (int r = lane; r <= h.nrows; r += kBlkThreads) ep[r] = a.row_eptr[(int64_t)h.row0 + t + r];
+      for (int l = lane; l <= h.nlvl; l += kBlkThreads) lv[l] = a.lvl[h.lvl0 + l];
+      for (int r = lane; r < h.nrows; r += kBlkThreads) {
+        const int32_t gid = a.row_gid[h.row0 + r];
+        xv[r] = KIND == 1 ? x[gid] : y[gid];
+        if (KIND == 2) dv[r] = a.diag_val[h.row0 + r];
+      }
     }
+    ILU_STAMP(1);
     // the blocks this one reads from
     for (int d = lane; d < h.ndep; d += kBlkThreads) {
       const int *flag = a.done + a.dep[h.dep0 + d];
@@ -237,33 +290,81 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       }
     }
     __syncthreads();
+    ILU_STAMP(2);
     asm volatile("" ::: "memory");                           // the loads below stay below the spins
     // y of other blocks: written through and read past the L2s (agent scope), so that neither side needs a cache-wide
     // write-back or invalidate per block
     for (int k = lane; k < h.next; k += kBlkThreads)
       yl[kBlkRows + k] = __hip_atomic_load(y + a.ext_gid[h.ext0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    for (int l = 0; l < h.nlvl; ++l) {
-      const int r1 = lv[l + 1];
-      for (int r = lv[l] + lane; r < r1; r += kBlkThreads) {
-        double acc = xv[r];
-        const int e1 = ep[r + 1];
-        for (int e = ep[r]; e < e1; ++e) {
-          const double tt = ev[e] * yl[es[e]];
-          acc = acc - tt;
-        }
-        yl[r] = KIND == 2 ? acc / dv[r] : acc;
+    ILU_STAMP(3);
+    if (fast) {
+      // one row per lane and level; the row's record and right-hand side are read one level AHEAD (they do not depend on y),
+      // so a level costs one dependent LDS round trip: the (at most three) y values
+      const dbl2 *recs = reinterpret_cast<const dbl2 *>(ev);
+      auto row_of = [&](int l) {                                    // this lane's row of level l, or -1
+        const int r = __builtin_amdgcn_readlane(my_lv, l) + lane;
+        return r < __builtin_amdgcn_readlane(my_lv, l + 1) ? r : -1;
+      };
+      int r = row_of(0);
+      int rr = r >= 0 ? r : 0;
+      dbl2 c0 = recs[rr * 3], c1 = recs[rr * 3 + 1], c2 = recs[rr * 3 + 2];
+      double rhs = xv[rr];
+      for (int l = 0; l < h.nlvl; ++l) {
+        const int rn = l + 1 < h.nlvl ? row_of(l + 1) : -1;
+        const int rrn = rn >= 0 ? rn : 0;
+        const dbl2 n0 = recs[rrn * 3], n1 = recs[rrn * 3 + 1], n2 = recs[rrn * 3 + 2];      // next level's row
+        const double nrhs = xv[rrn];
+        const unsigned long long meta = (unsigned long long)__double_as_longlong(c2.x);
+        const int cnt = (int)(meta >> 48);
+        const double y0 = yl[meta & 0xffff], y1 = yl[(meta >> 16) & 0xffff], y2 = yl[(meta >> 32) & 0xffff];
+        double acc = rhs;
+        const double t0 = c0.x * y0, t1 = c0.y * y1, t2 = c1.x * y2;
+        acc = cnt > 0 ? acc - t0 : acc;
+        acc = cnt > 1 ? acc - t1 : acc;
+        acc = cnt > 2 ? acc - t2 : acc;
+        if (r >= 0) yl[r] = KIND == 2 ? acc / c1.y : acc;
+        __syncthreads();
+        r = rn; c0 = n0; c1 = n1; c2 = n2; rhs = nrhs;
       }
-      __syncthreads();
+    } else {
+      for (int l = 0; l < h.nlvl; ++l) {
+        const int r1 = lv[l + 1];
+        for (int r = lv[l] + lane; r < r1; r += kBlkThreads) {
+          double acc = xv[r];
+          const int e1 = ep[r + 1];
+          for (int e = ep[r]; e < e1; ++e) {
+            const double tt = ev[e] * yl[es[e]];
+            acc = acc - tt;
+          }
+          yl[r] = KIND == 2 ? acc / dv[r] : acc;
+        }
+        __syncthreads();
+      }
     }
+    ILU_STAMP(4);
     for (int r = lane; r < h.nrows; r += kBlkThreads)
       __hip_atomic_store(y + a.row_gid[h.row0 + r], yl[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the block's y has arrived before its flag is raised
+    ILU_STAMP(5);
     __syncthreads();
     if (lane == 0) __hip_atomic_store(a.done + t, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();      // a convergent operation between this `if (lane == 0)` and the one at the top of the loop: without it
                           // the two are threaded into a private loop of lane 0 and the other lanes re-run block t for ever
   }
+}
+
+// row records of the fast path: src4 = positions in lu of the row's (up to three) entries and of its pivot (-1: none),
+// meta = {slot0, slot1, slot2, count}
+__global__ __launch_bounds__(256) void ilu_pack_records_kernel(const double *lu, const int32_t *src4, const unsigned long long *meta,
+                                                               int64_t rows, double *rec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  double *o = rec + i * kRecDoubles;
+  for (int k = 0; k < 3; ++k) o[k] = src4[4 * i + k] >= 0 ? lu[src4[4 * i + k]] : 0.0;
+  o[3] = lu[src4[4 * i + 3]];
+  o[4] = __longlong_as_double((long long)meta[i]);
+  o[5] = 0.0;
 }
 
 // ent_val[e] = lu[src[e]] (and the pivots of the upper solve) after the numeric factorisation
@@ -292,7 +393,7 @@ struct khip_ilu0 {
     IluBlockHdr *hdr = nullptr;
     int32_t *row_gid = nullptr, *ext_gid = nullptr, *dep = nullptr;
     uint16_t *row_eptr = nullptr, *lvl = nullptr, *ent_slot = nullptr;
-    double *ent_val = nullptr, *diag_val = nullptr;
+    double *ent_val = nullptr, *diag_val = nullptr, *rec = nullptr;
     int *done = nullptr;
     unsigned *ticket = nullptr;
     int epoch = 0;
@@ -349,7 +450,7 @@ int enqueue_solve(khip_ilu0 *P, const double *x, double *y) {
 
 template <int KIND>
 int launch_blocks(khip_ilu0 *P, khip_ilu0::Blocks &B, const double *x, double *y) {
-  IluBlkArgs a{B.hdr, B.row_gid, B.row_eptr, B.lvl, B.ext_gid, B.dep, B.ent_slot, B.ent_val, B.diag_val, B.done, B.ticket,
+  IluBlkArgs a{B.hdr, B.row_gid, B.row_eptr, B.lvl, B.ext_gid, B.dep, B.ent_slot, B.ent_val, B.diag_val, B.rec, B.done, B.ticket,
                P->blk_fail, B.nb, B.max_ent, B.max_ext, B.max_lvl};
   ++B.epoch;
   hipLaunchKernelGGL((ilu_block_solve_kernel<KIND>), dim3((unsigned)B.grid), dim3(kBlkThreads), B.lds, P->ctx->stream, a, x, y, B.epoch,
@@ -389,7 +490,7 @@ int ilu0_apply(void *self, const double *x, double *y) {
 
 void blocks_free(khip_ilu0::Blocks &B) {
   for (void *p : {(void *)B.hdr, (void *)B.row_gid, (void *)B.ext_gid, (void *)B.dep, (void *)B.row_eptr, (void *)B.lvl,
-                  (void *)B.ent_slot, (void *)B.ent_val, (void *)B.diag_val, (void *)B.done, (void *)B.ticket})
+                  (void *)B.ent_slot, (void *)B.ent_val, (void *)B.diag_val, (void *)B.rec, (void *)B.done, (void *)B.ticket})
     if (p) (void)hipFree(p);
   B = khip_ilu0::Blocks();
 }
@@ -516,6 +617,9 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
   std::vector<int32_t> lpos((size_t)n, -1), ext_mark((size_t)n, -1);
   std::vector<int32_t> rows, llev, sorted, deps_here;
   std::vector<int32_t> lcount;
+  std::vector<int32_t> rec_src; rec_src.reserve((size_t)n * 4);      // fast path: lu positions of a row's <= 3 entries + pivot
+  std::vector<unsigned long long> rec_meta; rec_meta.reserve((size_t)n);
+  bool rec_ok = true;
   int max_ent = 0, max_ext = 0, max_lvl = 0;
   for (int64_t t = 0; t < nb; ++t) {
     const int64_t b = order[(size_t)t];
@@ -548,6 +652,8 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
     h.row0 = (int32_t)row_gid.size(); h.nrows = nr; h.ent0 = (int64_t)src.size();
     h.lvl0 = (int32_t)lvl.size(); h.nlvl = nl; h.ext0 = (int32_t)ext_gid.size(); h.dep0 = (int32_t)dep.size(); h.pad = 0;
     for (int l = 0; l <= nl; ++l) lvl.push_back((uint16_t)lcount[(size_t)l]);
+    h.pad = nl < kBlkThreads ? 1 : 0;                       // 1: no level wider than the wave, level pointers fit its lanes
+    for (int l = 0; l < nl; ++l) if (lcount[(size_t)l + 1] - lcount[(size_t)l] > kBlkThreads) h.pad = 0;
     sorted.assign((size_t)nr, 0);
     {
       std::vector<int32_t> cur(lcount.begin(), lcount.end() - 1);
@@ -561,6 +667,10 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
       row_gid.push_back(i);
       row_eptr.push_back((uint16_t)ne);
       diag_src.push_back(H.diag[(size_t)i]);
+      const size_t rec_at = rec_src.size();
+      rec_src.insert(rec_src.end(), {-1, -1, -1, H.diag[(size_t)i]});
+      unsigned long long meta = 0;
+      int in_row = 0;
       const int32_t qa = upper ? H.diag[(size_t)i] + 1 : H.row_lo[(size_t)i], qb = upper ? H.row_hi[(size_t)i] : H.diag[(size_t)i];
       for (int32_t q = qa; q < qb; ++q) {                   // stored order
         const int32_t j = H.col[(size_t)q];
@@ -579,7 +689,11 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
         ent_slot.push_back((uint16_t)slot);
         src.push_back(q);
         ++ne;
+        if (in_row < 3) { rec_src[rec_at + (size_t)in_row] = q; meta |= (unsigned long long)(unsigned)slot << (16 * in_row); }
+        ++in_row;
       }
+      if (in_row > 3) rec_ok = false;
+      rec_meta.push_back(meta | (unsigned long long)std::min(in_row, 3) << 48);
     }
     row_eptr.push_back((uint16_t)ne);
     h.nent = ne; h.next = (int32_t)(ext_gid.size() - (size_t)h.ext0); h.ndep = (int32_t)deps_here.size();
@@ -592,6 +706,7 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
     if (nr > kBlkRows || ne > 60000 || kBlkRows + h.next > 65535) return KHIP_ERR_INVALID;
     max_ent = std::max(max_ent, ne); max_ext = std::max(max_ext, h.next); max_lvl = std::max(max_lvl, nl);
   }
+  if (rec_ok) max_ent = std::max(max_ent, kBlkRows * kRecDoubles);   // the records share the LDS region of the packed entries
   B.nb = (int)nb; B.max_ent = max_ent; B.max_ext = max_ext; B.max_lvl = max_lvl;
   B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
           sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + max_lvl + 2);
@@ -606,6 +721,16 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
   if (rc) return rc;
   KHIP_CHECK_HIP(hipMalloc(&B.ent_val, sizeof(double) * std::max<size_t>(src.size(), 1)));
   if (upper) KHIP_CHECK_HIP(hipMalloc(&B.diag_val, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  if (rec_ok && n > 0) {          // row records from the factor values (the factorisation is complete)
+    int32_t *d_src4 = nullptr;
+    unsigned long long *d_meta = nullptr;
+    struct Scratch { int32_t *&a; unsigned long long *&b; ~Scratch() { (void)hipFree(a); (void)hipFree(b); } } scratch{d_src4, d_meta};
+    KHIP_TRY(upload(ctx, rec_src, &d_src4));
+    KHIP_TRY(upload(ctx, rec_meta, &d_meta));
+    KHIP_CHECK_HIP(hipMalloc(&B.rec, sizeof(double) * (size_t)n * kRecDoubles));
+    hipLaunchKernelGGL(ilu_pack_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src4, d_meta, n, B.rec);
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
   KHIP_CHECK_HIP(hipMalloc(&B.done, sizeof(int) * (size_t)nb));
   KHIP_CHECK_HIP(hipMalloc(&B.ticket, sizeof(unsigned)));
   KHIP_CHECK_HIP(hipMemsetAsync(B.done, 0, sizeof(int) * (size_t)nb, ctx->stream));
@@ -774,6 +899,12 @@ int khip_ilu0_block_info(const khip_operator *op, int64_t *dims3, int64_t *block
   }
   return KHIP_OK;
 }
+
+#ifdef KHIP_ILU_TRACE
+int khip_debug_ilu_trace(unsigned long long *out512) {
+  return hipMemcpyFromSymbol(out512, HIP_SYMBOL(khip::g_ilu_trace), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int khip_ilu0_set_graph(khip_operator *op, int enable) {
   KHIP_REQUIRE(op && op->apply == ilu0_apply && op->self, "ilu0_set_graph: not an ILU(0) operator");
