@@ -213,8 +213,8 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
                                                                        unsigned ticket_base) {
   extern __shared__ double ilu_sm[];
   __shared__ int s_ticket;
-  double *yl = ilu_sm;                                      // [kBlkRows + max_ext]: y of the block's rows, then of the ext list
-  double *xv = yl + kBlkRows + a.max_ext;                   // [kBlkRows]: right-hand side
+  double *yl = ilu_sm;                                      // [kBlkRows + max_ext + 1]: y of the block's rows, of the ext list, a spare
+  double *xv = yl + kBlkRows + a.max_ext + 1;               // [kBlkRows]: right-hand side
   double *dv = xv + kBlkRows;                               // [kBlkRows]: pivots (upper solve)
   double *ev = dv + (KIND == 2 ? kBlkRows : 0);             // [max_ent]
   uint16_t *es = reinterpret_cast<uint16_t *>(ev + a.max_ent);   // [max_ent rounded up to 4]
@@ -323,8 +323,10 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
         acc = cnt > 0 ? acc - t0 : acc;
         acc = cnt > 1 ? acc - t1 : acc;
         acc = cnt > 2 ? acc - t2 : acc;
-        if (r >= 0) yl[r] = KIND == 2 ? acc / c1.y : acc;
-        __syncthreads();
+        yl[r >= 0 ? r : kBlkRows + a.max_ext] = KIND == 2 ? acc / c1.y : acc;       // idle lanes write a spare slot: no branch
+        // no s_barrier, no s_waitcnt: the workgroup is ONE wave and the LDS executes a wave's instructions in order, so the
+        // reads of the next level see this write; only the compiler must not move them across it
+        asm volatile("" ::: "memory");
         r = rn; c0 = n0; c1 = n1; c2 = n2; rhs = nrhs;
       }
     } else {
@@ -708,7 +710,7 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
   }
   if (rec_ok) max_ent = std::max(max_ent, kBlkRows * kRecDoubles);   // the records share the LDS region of the packed entries
   B.nb = (int)nb; B.max_ent = max_ent; B.max_ext = max_ext; B.max_lvl = max_lvl;
-  B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
+  B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + 1 + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
           sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + max_lvl + 2);
   if (B.lds > (size_t)150 * 1024) return KHIP_ERR_INVALID;
   int rc = upload(ctx, hdr, &B.hdr);
