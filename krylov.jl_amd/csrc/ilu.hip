@@ -15,8 +15,10 @@
 // solves are BIT-IDENTICAL to the serial restatement the tests compare against (ko_ilu0 / ko_ilu0_solve).
 // The level analysis (setup, once per pattern) runs on the host from the downloaded index arrays;
 // the whole apply (2 x #levels launches) is captured once into a hipGraph and replayed.
-// A 7-point grid in natural ordering has n1+n2+n3-2 levels (hyperplanes): the solves are launch-latency
-// bound, not HBM bound -- see DESIGN.md for measured numbers.
+// A 7-point grid in natural ordering has n1+n2+n3-2 levels (hyperplanes): level-scheduled solves are
+// launch-latency bound, not HBM bound -- see DESIGN.md for measured numbers.  Where the pattern IS such a grid
+// (5- / 7-point stencils) the solves therefore run the BLOCK SCHEDULE further down (ilu_block_solve_kernel):
+// one persistent launch per triangle, blocks of 8 x 8 x 8 grid points solved out of LDS, per-block flags.
 //
 // Distributed handles: block-Jacobi ILU(0) of the rank's diagonal block (ghost columns are ignored), the
 // usual domain-decomposition preconditioner; it needs no communication.
