@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void spmm_window_kernel(SpmvArgs a, WinArgs
       const unsigned short *lsl = win_slot + (sC - gsC);
       const char *xc = reinterpret_cast<const char *>(win_xs + c);
       double acc0 = 0.0, acc1 = 0.0;
-      constexpr bool SPREAD = KHIP_WIN_SPREAD != 0;        // (val, slot) fetched LS entries at a time and spread by DPP moves
+      constexpr bool SPREAD = KHIP_WIN_SPREAD != 0 && L >= 4;   // (val, slot) fetched LS entries at a time and spread by DPP moves (L = 2: 3 % slower, same box)
       constexpr int LS = KHIP_WIN_SPREAD == 8 && L == 8 ? 8 : (L < 4 ? L : 4);   // quads: one v_mov_dpp per word (octets: two)
       const int cs = c & (LS - 1);
       const int len0 = __builtin_amdgcn_readfirstlane(len);
