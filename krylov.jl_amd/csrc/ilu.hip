@@ -179,7 +179,7 @@ constexpr int kBlkRows = 512;          // rows of a block at most
 constexpr int kBlkThreads = 64;        // one wave: its levels need no s_barrier between waves
 
 // Row record of the fast path (every row of the triangle has at most 3 off-diagonal entries: the 5- and 7-point stencils):
-// 48 bytes = v0, v1, v2, pivot, {slot0, slot1, slot2, count} as 4 x u16, 8 bytes spare -- one LDS round trip of three
+// 48 bytes = v0, v1, v2, pivot, {slot0, slot1, slot2, count} as 4 x u16, the row's number in y -- one LDS round trip of three
 // 16-byte reads brings everything of a row that does not depend on y.
 constexpr int kRecDoubles = 6;
 typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -325,7 +325,11 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
         acc = cnt > 0 ? acc - t0 : acc;
         acc = cnt > 1 ? acc - t1 : acc;
         acc = cnt > 2 ? acc - t2 : acc;
-        yl[r >= 0 ? r : kBlkRows + a.max_ext] = KIND == 2 ? acc / c1.y : acc;       // idle lanes write a spare slot: no branch
+        const double yv = KIND == 2 ? acc / c1.y : acc;
+        yl[r >= 0 ? r : kBlkRows + a.max_ext] = yv;             // idle lanes write a spare slot: no branch
+        // ... and through the L2 to y at once: the stores are in flight while the remaining levels run, instead of a separate
+        // pass over the block at the end whose latency sits on the critical path of the block wavefronts
+        if (r >= 0) __hip_atomic_store(y + (long long)__double_as_longlong(c2.y), yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // no s_barrier, no s_waitcnt: the workgroup is ONE wave and the LDS executes a wave's instructions in order, so the
         // reads of the next level see this write; only the compiler must not move them across it
         asm volatile("" ::: "memory");
@@ -347,8 +351,9 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       }
     }
     ILU_STAMP(4);
-    for (int r = lane; r < h.nrows; r += kBlkThreads)
-      __hip_atomic_store(y + a.row_gid[h.row0 + r], yl[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!fast)
+      for (int r = lane; r < h.nrows; r += kBlkThreads)
+        __hip_atomic_store(y + a.row_gid[h.row0 + r], yl[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the block's y has arrived before its flag is raised
     ILU_STAMP(5);
     __syncthreads();
@@ -361,14 +366,14 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
 // row records of the fast path: src4 = positions in lu of the row's (up to three) entries and of its pivot (-1: none),
 // meta = {slot0, slot1, slot2, count}
 __global__ __launch_bounds__(256) void ilu_pack_records_kernel(const double *lu, const int32_t *src4, const unsigned long long *meta,
-                                                               int64_t rows, double *rec) {
+                                                               const int32_t *row_gid, int64_t rows, double *rec) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows) return;
   double *o = rec + i * kRecDoubles;
   for (int k = 0; k < 3; ++k) o[k] = src4[4 * i + k] >= 0 ? lu[src4[4 * i + k]] : 0.0;
   o[3] = lu[src4[4 * i + 3]];
   o[4] = __longlong_as_double((long long)meta[i]);
-  o[5] = 0.0;
+  o[5] = __longlong_as_double((long long)row_gid[i]);          // the row's number in y: the level loop writes y as it goes
 }
 
 // ent_val[e] = lu[src[e]] (and the pivots of the upper solve) after the numeric factorisation
@@ -732,7 +737,7 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
     KHIP_TRY(upload(ctx, rec_src, &d_src4));
     KHIP_TRY(upload(ctx, rec_meta, &d_meta));
     KHIP_CHECK_HIP(hipMalloc(&B.rec, sizeof(double) * (size_t)n * kRecDoubles));
-    hipLaunchKernelGGL(ilu_pack_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src4, d_meta, n, B.rec);
+    hipLaunchKernelGGL(ilu_pack_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src4, d_meta, B.row_gid, n, B.rec);
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   KHIP_CHECK_HIP(hipMalloc(&B.done, sizeof(int) * (size_t)nb));
