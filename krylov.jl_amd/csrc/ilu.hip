@@ -182,6 +182,7 @@ constexpr int kBlkThreads = 64;        // one wave: its levels need no s_barrier
 // 48 bytes = v0, v1, v2, pivot, {slot0, slot1, slot2, count} as 4 x u16, the row's number in y -- one LDS round trip of three
 // 16-byte reads brings everything of a row that does not depend on y.
 constexpr int kRecDoubles = 6;
+constexpr int kRecExtCap = 1024;       // fast path: ext slots of the LDS y array; the last two are a constant 0.0 and a dump
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct IluBlockHdr {
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       // one row per lane and level; the row's record and right-hand side are read one level AHEAD (they do not depend on y),
       // so a level costs one dependent LDS round trip: the (at most three) y values
       const dbl2 *recs = reinterpret_cast<const dbl2 *>(ev);
+      if (lane == 0) yl[kBlkRows + kRecExtCap - 2] = 0.0;
       auto row_of = [&](int l) {                                    // this lane's row of level l, or -1
         const int r = __builtin_amdgcn_readlane(my_lv, l) + lane;
         return r < __builtin_amdgcn_readlane(my_lv, l + 1) ? r : -1;
@@ -318,15 +320,18 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
         const dbl2 n0 = recs[rrn * 3], n1 = recs[rrn * 3 + 1], n2 = recs[rrn * 3 + 2];      // next level's row
         const double nrhs = xv[rrn];
         const unsigned long long meta = (unsigned long long)__double_as_longlong(c2.x);
-        const int cnt = (int)(meta >> 48);
         const double y0 = yl[meta & 0xffff], y1 = yl[(meta >> 16) & 0xffff], y2 = yl[(meta >> 32) & 0xffff];
+        // absent entries are (value 0.0, slot of a constant 0.0): acc - 0.0 * 0.0 == acc bit for bit (also for -0.0 and NaN),
+        // so the three steps need no selects
         double acc = rhs;
-        const double t0 = c0.x * y0, t1 = c0.y * y1, t2 = c1.x * y2;
-        acc = cnt > 0 ? acc - t0 : acc;
-        acc = cnt > 1 ? acc - t1 : acc;
-        acc = cnt > 2 ? acc - t2 : acc;
+        const double t0 = c0.x * y0;
+        acc = acc - t0;
+        const double t1 = c0.y * y1;
+        acc = acc - t1;
+        const double t2 = c1.x * y2;
+        acc = acc - t2;
         const double yv = KIND == 2 ? acc / c1.y : acc;
-        yl[r >= 0 ? r : kBlkRows + a.max_ext] = yv;             // idle lanes write a spare slot: no branch
+        yl[r >= 0 ? r : kBlkRows + kRecExtCap - 1] = yv;        // idle lanes write the dump slot: no branch
         // ... and through the L2 to y at once: the stores are in flight while the remaining levels run, instead of a separate
         // pass over the block at the end whose latency sits on the critical path of the block wavefronts
         if (r >= 0) __hip_atomic_store(y + (long long)__double_as_longlong(c2.y), yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -702,6 +707,7 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
         ++in_row;
       }
       if (in_row > 3) rec_ok = false;
+      for (int kq = in_row; kq < 3; ++kq) meta |= (unsigned long long)(kBlkRows + kRecExtCap - 2) << (16 * kq);   // absent: the 0.0 slot
       rec_meta.push_back(meta | (unsigned long long)std::min(in_row, 3) << 48);
     }
     row_eptr.push_back((uint16_t)ne);
@@ -715,7 +721,11 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
     if (nr > kBlkRows || ne > 60000 || kBlkRows + h.next > 65535) return KHIP_ERR_INVALID;
     max_ent = std::max(max_ent, ne); max_ext = std::max(max_ext, h.next); max_lvl = std::max(max_lvl, nl);
   }
-  if (rec_ok) max_ent = std::max(max_ent, kBlkRows * kRecDoubles);   // the records share the LDS region of the packed entries
+  if (max_ext > kRecExtCap - 2) rec_ok = false;
+  if (rec_ok) {
+    max_ent = std::max(max_ent, kBlkRows * kRecDoubles);            // the records share the LDS region of the packed entries
+    max_ext = kRecExtCap;                                           // ... and the y array has its fixed 0.0 and dump slots
+  }
   B.nb = (int)nb; B.max_ent = max_ent; B.max_ext = max_ext; B.max_lvl = max_lvl;
   B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + 1 + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
           sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + max_lvl + 2);
