@@ -182,7 +182,7 @@ constexpr int kBlkThreads = 64;        // one wave: its levels need no s_barrier
 // 48 bytes = v0, v1, v2, pivot, {slot0, slot1, slot2, count} as 4 x u16, the row's number in y -- one LDS round trip of three
 // 16-byte reads brings everything of a row that does not depend on y.
 constexpr int kRecDoubles = 6;
-constexpr int kRecExtCap = 1024;       // fast path: ext slots of the LDS y array; the last two are a constant 0.0 and a dump
+constexpr int kRecExtCap = 256;        // fast path: ext slots of the LDS y array; the last two are a constant 0.0 and a dump
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct IluBlockHdr {
