@@ -101,12 +101,13 @@ def test_ilu0_errors(K, ctx, oracle):
     assert "sorted" in str(e.value)
 
 
-def test_block_jacobi_ilu0_on_distributed_handle(K, oracle):
+@pytest.mark.parametrize("n1,world", [(12, 3), (24, 2)])
+def test_block_jacobi_ilu0_on_distributed_handle(K, oracle, n1, world):
     """A distributed handle factors its owned diagonal block only (ghost columns ignored): the result equals
     ILU(0) of that block computed by the oracle, and CG with this block-Jacobi IC(0) converges on every rank
-    to the same solution as the unpreconditioned solve."""
+    to the same solution as the unpreconditioned solve.  24^3 on two ranks: slabs of 12 planes, >= 4096 rows each, so the
+    solves take the block schedule on the renumbered [owned | ghost] slab."""
     import threading
-    n1, world = 12, 3
     A_cpu = oracle.poisson3d(n1)
     n = A_cpu.n
     starts = K.row_partition(n, world)
@@ -117,10 +118,13 @@ def test_block_jacobi_ilu0_on_distributed_handle(K, oracle):
     def run(rank):
         try:
             c = K.Context(0)
-            c.comm_init_local(rank, world, 4242)
+            c.comm_init_local(rank, world, 4242 + world)
             r0, r1 = starts[rank], starts[rank + 1]
             A = K.CsrMatrix.stencil(c, "poisson", n1, rows=(r0, r1), distributed=True)
             P = K.Ilu0(A)
+            if n1 == 24:
+                dims, nb, failed = P.block_info()
+                assert dims == (24, 24, 12) and nb > 0 and failed == 0, (dims, nb, failed)
             x = np.linspace(1, 2, r1 - r0)
             y = P(c.array(x), c.empty(r1 - r0)).to_host()
             b = c.empty(r1 - r0)
