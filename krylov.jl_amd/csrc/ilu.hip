@@ -572,14 +572,30 @@ bool detect_grid(const HostPattern &H, int64_t dims[3]) {
   auto valid = [&](int64_t n1, int64_t n2, int64_t n3) {
     if (n1 < 2 || n2 < 2 || n3 < 1 || n1 * n2 * n3 != n) return false;
     const int64_t s2 = n1 * n2;
+    // j = i - d has coordinates <= those of i exactly when the mixed-radix digits (dx, dy, dz) of d fit under (x, y, z) of i
+    // (no borrow); j = i + d has coordinates >= exactly when they fit under the distance to the far faces (no carry).  The
+    // distinct offsets d are few: their digits come from a small table, the row's coordinates from a running counter --
+    // no division per entry (this check and the packing below used to take 3 s of the setup at 256^3).
+    constexpr int kMaxOffsets = 64;
+    int64_t od[kMaxOffsets], odx[kMaxOffsets], ody[kMaxOffsets], odz[kMaxOffsets];
+    int nod = 0;
+    int64_t xi = 0, yi = 0, zi = 0;
     for (int64_t i = 0; i < n; ++i) {
-      const int64_t zi = i / s2, ri = i - zi * s2, yi = ri / n1, xi = ri - yi * n1;
       for (int32_t q = H.row_lo[(size_t)i]; q < H.row_hi[(size_t)i]; ++q) {
         const int64_t j = H.col[(size_t)q];
         if (j == i) continue;
-        const int64_t zj = j / s2, rj = j - zj * s2, yj = rj / n1, xj = rj - yj * n1;
-        if (j < i ? (xj > xi || yj > yi || zj > zi) : (xj < xi || yj < yi || zj < zi)) return false;
+        const int64_t d = j < i ? i - j : j - i;
+        int k = 0;
+        while (k < nod && od[k] != d) ++k;
+        if (k == nod) {
+          if (nod == kMaxOffsets) return false;            // not a stencil
+          od[nod] = d; odz[nod] = d / s2; ody[nod] = (d - odz[nod] * s2) / n1; odx[nod] = d - odz[nod] * s2 - ody[nod] * n1;
+          ++nod;
+        }
+        if (j < i ? (odx[k] > xi || ody[k] > yi || odz[k] > zi)
+                  : (xi + odx[k] >= n1 || yi + ody[k] >= n2 || zi + odz[k] >= n3)) return false;
       }
+      if (++xi == n1) { xi = 0; if (++yi == n2) { yi = 0; ++zi; } }
     }
     return true;
   };
@@ -654,7 +670,7 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
       const int32_t qa = upper ? H.diag[(size_t)i] + 1 : H.row_lo[(size_t)i], qb = upper ? H.row_hi[(size_t)i] : H.diag[(size_t)i];
       for (int32_t q = qa; q < qb; ++q) {
         const int32_t j = H.col[(size_t)q];
-        if (block_of(j) == b) lv = std::max(lv, llev[(size_t)lpos[(size_t)j]] + 1);
+        if (lpos[(size_t)j] >= 0) lv = std::max(lv, llev[(size_t)lpos[(size_t)j]] + 1);      // lpos >= 0: a row of this block
       }
       llev[(size_t)k] = lv;
       nl = std::max(nl, lv + 1);
@@ -688,14 +704,13 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
       const int32_t qa = upper ? H.diag[(size_t)i] + 1 : H.row_lo[(size_t)i], qb = upper ? H.row_hi[(size_t)i] : H.diag[(size_t)i];
       for (int32_t q = qa; q < qb; ++q) {                   // stored order
         const int32_t j = H.col[(size_t)q];
-        const int64_t bj = block_of(j);
         int slot;
-        if (bj == b) slot = lpos[(size_t)j];
+        if (lpos[(size_t)j] >= 0) slot = lpos[(size_t)j];
         else {
           if (ext_mark[(size_t)j] < 0) {
             ext_mark[(size_t)j] = (int32_t)(ext_gid.size() - (size_t)h.ext0);
             ext_gid.push_back(j);
-            const int32_t tj = ticket_of[(size_t)bj];
+            const int32_t tj = ticket_of[(size_t)block_of(j)];
             if (std::find(deps_here.begin(), deps_here.end(), tj) == deps_here.end()) deps_here.push_back(tj);
           }
           slot = kBlkRows + ext_mark[(size_t)j];
@@ -730,16 +745,22 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
   B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + 1 + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
           sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + max_lvl + 2);
   if (B.lds > (size_t)150 * 1024) return KHIP_ERR_INVALID;
+  bool all_fast = rec_ok;                         // every block on the row-record path: the packed entry arrays are not needed
+  for (const IluBlockHdr &hh : hdr) all_fast = all_fast && hh.pad != 0;
   int rc = upload(ctx, hdr, &B.hdr);
   if (!rc) rc = upload(ctx, row_gid, &B.row_gid);
-  if (!rc) rc = upload(ctx, row_eptr, &B.row_eptr);
   if (!rc) rc = upload(ctx, lvl, &B.lvl);
   if (!rc) rc = upload(ctx, ext_gid, &B.ext_gid);
   if (!rc) rc = upload(ctx, dep, &B.dep);
-  if (!rc) rc = upload(ctx, ent_slot, &B.ent_slot);
+  if (!rc && !all_fast) rc = upload(ctx, row_eptr, &B.row_eptr);
+  if (!rc && !all_fast) rc = upload(ctx, ent_slot, &B.ent_slot);
   if (rc) return rc;
-  KHIP_CHECK_HIP(hipMalloc(&B.ent_val, sizeof(double) * std::max<size_t>(src.size(), 1)));
-  if (upper) KHIP_CHECK_HIP(hipMalloc(&B.diag_val, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  if (!all_fast) {
+    KHIP_CHECK_HIP(hipMalloc(&B.ent_val, sizeof(double) * std::max<size_t>(src.size(), 1)));
+    if (upper) KHIP_CHECK_HIP(hipMalloc(&B.diag_val, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  } else {
+    src.clear(); diag_src.clear();
+  }
   if (rec_ok && n > 0) {          // row records from the factor values (the factorisation is complete)
     int32_t *d_src4 = nullptr;
     unsigned long long *d_meta = nullptr;
@@ -767,14 +788,14 @@ int pack_block_values(khip_ilu0 *P, khip_ilu0::Blocks &B, const std::vector<int3
   khip_ctx *ctx = P->ctx;
   int32_t *d_src = nullptr;
   struct Scratch { int32_t *&p; ~Scratch() { (void)hipFree(p); } } scratch{d_src};
-  if (!src.empty()) {
+  if (!src.empty() && B.ent_val) {
     KHIP_TRY(upload(ctx, src, &d_src));
     hipLaunchKernelGGL(ilu_pack_values_kernel, dim3((unsigned)((src.size() + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src,
                        (int64_t)src.size(), B.ent_val);
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_src); d_src = nullptr;
   }
-  if (upper && !diag_src.empty()) {
+  if (upper && !diag_src.empty() && B.diag_val) {
     KHIP_TRY(upload(ctx, diag_src, &d_src));
     hipLaunchKernelGGL(ilu_pack_values_kernel, dim3((unsigned)((diag_src.size() + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src,
                        (int64_t)diag_src.size(), B.diag_val);
