@@ -24,6 +24,7 @@
 // usual domain-decomposition preconditioner; it needs no communication.
 #include <algorithm>
 #include <map>
+#include <thread>
 
 #include "khip_internal.hpp"
 
@@ -615,9 +616,22 @@ bool detect_grid(const HostPattern &H, int64_t dims[3]) {
 
 // Builds the block schedule of one triangle (lower: the entries before the diagonal, blocks in wavefront order of
 // bx + by + bz; upper: the entries after it, the mirrored order) and uploads it.  src = position in lu of every packed entry.
-int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool upper, khip_ilu0::Blocks &B,
-                 std::vector<int32_t> &src, std::vector<int32_t> &diag_src) {
-  khip_ctx *ctx = P->ctx;
+struct HostBlocks {            // what the analysis of one triangle produces (host memory; the two triangles are analysed side by side)
+  std::vector<IluBlockHdr> hdr;
+  std::vector<int32_t> row_gid, ext_gid, dep, src, diag_src, rec_src;
+  std::vector<uint16_t> row_eptr, lvl, ent_slot;
+  std::vector<unsigned long long> rec_meta;
+  bool rec_ok = true;
+  int64_t nb = 0;
+  int max_ent = 0, max_ext = 0, max_lvl = 0, rc = KHIP_OK;
+};
+
+int analyse_blocks(const HostPattern &H, const int64_t dims[3], bool upper, HostBlocks &hb) {
+  std::vector<IluBlockHdr> &hdr = hb.hdr;
+  std::vector<int32_t> &row_gid = hb.row_gid, &ext_gid = hb.ext_gid, &dep = hb.dep, &src = hb.src, &diag_src = hb.diag_src, &rec_src = hb.rec_src;
+  std::vector<uint16_t> &row_eptr = hb.row_eptr, &lvl = hb.lvl, &ent_slot = hb.ent_slot;
+  std::vector<unsigned long long> &rec_meta = hb.rec_meta;
+  bool &rec_ok = hb.rec_ok;
   const int64_t n = H.n, n1 = dims[0], n2 = dims[1], n3 = dims[2], s2 = n1 * n2;
   const int T1 = n3 > 1 ? 8 : 16, T2 = T1, T3 = n3 > 1 ? 8 : 1;
   const int64_t B1 = (n1 + T1 - 1) / T1, B2 = (n2 + T2 - 1) / T2, B3 = (n3 + T3 - 1) / T3, nb = B1 * B2 * B3;
@@ -638,18 +652,15 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
     const int64_t z = i / s2, r = i - z * s2, y = r / n1, x = r - y * n1;
     return ((z / T3) * B2 + y / T2) * B1 + x / T1;
   };
-  std::vector<IluBlockHdr> hdr((size_t)nb);
-  std::vector<int32_t> row_gid; row_gid.reserve((size_t)n);
-  std::vector<uint16_t> row_eptr; row_eptr.reserve((size_t)(n + nb));
-  std::vector<uint16_t> lvl, ent_slot;
-  std::vector<int32_t> ext_gid, dep;
+  hdr.assign((size_t)nb, IluBlockHdr());
+  row_gid.reserve((size_t)n);
+  row_eptr.reserve((size_t)(n + nb));
   src.clear(); diag_src.clear();
   std::vector<int32_t> lpos((size_t)n, -1), ext_mark((size_t)n, -1);
   std::vector<int32_t> rows, llev, sorted, deps_here;
   std::vector<int32_t> lcount;
-  std::vector<int32_t> rec_src; rec_src.reserve((size_t)n * 4);      // fast path: lu positions of a row's <= 3 entries + pivot
-  std::vector<unsigned long long> rec_meta; rec_meta.reserve((size_t)n);
-  bool rec_ok = true;
+  rec_src.reserve((size_t)n * 4);      // fast path: lu positions of a row's <= 3 entries + pivot
+  rec_meta.reserve((size_t)n);
   int max_ent = 0, max_ext = 0, max_lvl = 0;
   for (int64_t t = 0; t < nb; ++t) {
     const int64_t b = order[(size_t)t];
@@ -736,6 +747,20 @@ int build_blocks(khip_ilu0 *P, const HostPattern &H, const int64_t dims[3], bool
     if (nr > kBlkRows || ne > 60000 || kBlkRows + h.next > 65535) return KHIP_ERR_INVALID;
     max_ent = std::max(max_ent, ne); max_ext = std::max(max_ext, h.next); max_lvl = std::max(max_lvl, nl);
   }
+  hb.nb = nb; hb.max_ent = max_ent; hb.max_ext = max_ext; hb.max_lvl = max_lvl;
+  return KHIP_OK;
+}
+
+// uploads the analysis of one triangle and builds what needs the factor values (the numeric factorisation is complete)
+int upload_blocks(khip_ilu0 *P, bool upper, HostBlocks &hb, khip_ilu0::Blocks &B) {
+  khip_ctx *ctx = P->ctx;
+  const int64_t n = P->n, nb = hb.nb;
+  std::vector<IluBlockHdr> &hdr = hb.hdr;
+  std::vector<int32_t> &row_gid = hb.row_gid, &ext_gid = hb.ext_gid, &dep = hb.dep, &src = hb.src, &diag_src = hb.diag_src, &rec_src = hb.rec_src;
+  std::vector<uint16_t> &row_eptr = hb.row_eptr, &lvl = hb.lvl, &ent_slot = hb.ent_slot;
+  std::vector<unsigned long long> &rec_meta = hb.rec_meta;
+  bool rec_ok = hb.rec_ok;
+  int max_ent = hb.max_ent, max_ext = hb.max_ext, max_lvl = hb.max_lvl;
   if (max_ext > kRecExtCap - 2) rec_ok = false;
   if (rec_ok) {
     max_ent = std::max(max_ent, kBlkRows * kRecDoubles);            // the records share the LDS region of the packed entries
@@ -888,11 +913,15 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
     if (detect_grid(H, P->grid_dims)) {
       KHIP_CHECK_HIP(hipMalloc(&P->blk_fail, sizeof(int)));
       KHIP_CHECK_HIP(hipMemsetAsync(P->blk_fail, 0, sizeof(int), ctx->stream));
-      std::vector<int32_t> src, dsrc;
-      int rb = build_blocks(P, H, P->grid_dims, false, P->blk_lo, src, dsrc);
-      if (rb == KHIP_OK) rb = pack_block_values(P, P->blk_lo, src, dsrc, false);
-      if (rb == KHIP_OK) rb = build_blocks(P, H, P->grid_dims, true, P->blk_up, src, dsrc);
-      if (rb == KHIP_OK) rb = pack_block_values(P, P->blk_up, src, dsrc, true);
+      HostBlocks hlo, hup;                     // the two triangles are analysed side by side (pure host work)
+      std::thread tup([&] { hup.rc = analyse_blocks(H, P->grid_dims, true, hup); });
+      hlo.rc = analyse_blocks(H, P->grid_dims, false, hlo);
+      tup.join();
+      int rb = hlo.rc != KHIP_OK ? hlo.rc : hup.rc;
+      if (rb == KHIP_OK) rb = upload_blocks(P, false, hlo, P->blk_lo);
+      if (rb == KHIP_OK) rb = pack_block_values(P, P->blk_lo, hlo.src, hlo.diag_src, false);
+      if (rb == KHIP_OK) rb = upload_blocks(P, true, hup, P->blk_up);
+      if (rb == KHIP_OK) rb = pack_block_values(P, P->blk_up, hup.src, hup.diag_src, true);
       if (rb == KHIP_OK) P->use_blocks = true;
       else {                                   // not representable (or out of memory): keep the level schedule
         (void)hipGetLastError();
