@@ -234,3 +234,34 @@ def test_ilu0_block_schedule_not_taken_for_other_patterns(K, ctx, oracle):
     dy = ctx.empty(A.n)
     P(ctx.array(x), dy)
     assert np.array_equal(dy.to_host(), oracle.Ilu0(Ap).solve(x))
+
+
+@pytest.mark.parametrize("dims", [(18, 17, 16), (70, 64, 1)])
+def test_ilu0_block_schedule_general_rows(K, ctx, oracle, dims):
+    """More than three entries per row and triangle (second neighbours along every axis: offsets 1, 2, n1, 2 n1, ...): still a
+    grid with dependencies towards smaller coordinates, so the block schedule applies, but on its general path (packed
+    entry lists instead of the 48-byte row records).  Unsymmetric values."""
+    import scipy.sparse as sp
+    n1, n2, n3 = dims
+    def band(n, lo2, lo1, di, up1, up2):
+        return sp.diags([np.full(n - 2, lo2), np.full(n - 1, lo1), np.full(n, di), np.full(n - 1, up1), np.full(n - 2, up2)],
+                        [-2, -1, 0, 1, 2], format="csr")
+    I = lambda n: sp.identity(n, format="csr")
+    S = sp.kron(sp.kron(I(n3), I(n2)), band(n1, -0.25, -1.0, 2.5, -1.5, -0.3)) + \
+        sp.kron(sp.kron(I(n3), band(n2, -0.2, -1.1, 2.5, -0.9, -0.35)), I(n1))
+    if n3 > 1:
+        S = S + sp.kron(sp.kron(band(n3, -0.15, -1.2, 2.5, -0.8, -0.1), I(n2)), I(n1))
+    S = S.tocsr(); S.sort_indices()
+    A = oracle.CsrMatrix.from_arrays(S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data)
+    ref = oracle.Ilu0(A)
+    P = K.Ilu0(_upload(K, ctx, A))
+    got_dims, nb, failed = P.block_info()
+    assert got_dims == dims and nb > 0 and failed == 0, (got_dims, nb, failed)
+    assert np.array_equal(P.values(), ref.lu)
+    rng = np.random.default_rng(n1)
+    for _ in range(2):
+        x = rng.standard_normal(A.n)
+        dy = ctx.empty(A.n)
+        P(ctx.array(x), dy)
+        assert np.array_equal(dy.to_host(), ref.solve(x))
+    assert P.block_info()[2] == 0
