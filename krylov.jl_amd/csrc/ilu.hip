@@ -417,6 +417,7 @@ struct khip_ilu0 {
   } blk_lo, blk_up;
   int *blk_fail = nullptr;
   int64_t grid_dims[3] = {0, 0, 0};          // detected grid (0: none, level scheduling)
+  int grid_skew[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // lattice basis of the block coordinates
   bool use_blocks = false;
   // cached hipGraph of one application, keyed by the (x, y) pointers it was captured with
   hipGraphExec_t graph = nullptr;
@@ -547,12 +548,18 @@ struct HostPattern {
   const std::vector<int32_t> &col, &row_lo, &diag, &row_hi;
 };
 
-// Is the pattern a grid n1 x n2 x n3 in natural ordering (index = x + n1 (y + n2 z)) whose lower entries point to grid
-// points with coordinates <= and whose upper entries to coordinates >= ?  (The 7-point stencils are; the 27-point stencil is
-// not -- row (x, y, z) reaches (x + 1, y - 1, z) in its lower triangle, cubes of grid points would wait for each other.)
+// Is the pattern a stencil on a grid n1 x n2 x n3 in natural ordering (index = x + n1 (y + n2 z)), and is there a lattice
+// basis in which every lower entry of every row points to a grid point with coordinates <= and every upper entry to one
+// with coordinates >= ?  Blocks that are cubes in those coordinates then depend on blocks with smaller block coordinates
+// only.  For the 5- / 7-point stencils (and their second-neighbour relatives) the grid's own axes do; the 9- / 27-point
+// stencils reach (x + 1, y - 1, z) and (x + 1, y + 1, z - 1) in their lower triangle and need the skewed basis
+// c = (x + y + 2 z, y + z, z), in which the cubes are parallelepipeds of the grid.
 // The candidates for n1 and n1 n2 are the centres of the runs of consecutive row - column offsets of a few sample rows; the
-// answer is checked on every entry.
-bool detect_grid(const HostPattern &H, int64_t dims[3]) {
+// answer is checked on EVERY entry: its offset must be one of a few (signed digits |dx|, |dy| <= 2, 0 <= dz <= 2, from a
+// small table -- no division per entry) and must stay inside the grid (no coupling around the faces).
+constexpr int kSkews[2][9] = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {1, 1, 2, 0, 1, 1, 0, 0, 1}};
+
+bool detect_grid(const HostPattern &H, int64_t dims[3], int skew[9]) {
   const int64_t n = H.n;
   if (n < 4096) return false;
   std::vector<int64_t> offs;
@@ -570,15 +577,14 @@ bool detect_grid(const HostPattern &H, int64_t dims[3]) {
     centre.push_back((offs[a] + offs[b]) / 2);
     a = b + 1;
   }
+  auto floordiv = [](int64_t a, int64_t b) { int64_t q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --q; return q; };
   auto valid = [&](int64_t n1, int64_t n2, int64_t n3) {
-    if (n1 < 2 || n2 < 2 || n3 < 1 || n1 * n2 * n3 != n) return false;
+    if (n1 < 6 || n2 < 6 || n3 < 1 || (n3 > 1 && n3 < 3) || n1 * n2 * n3 != n) return false;
     const int64_t s2 = n1 * n2;
-    // j = i - d has coordinates <= those of i exactly when the mixed-radix digits (dx, dy, dz) of d fit under (x, y, z) of i
-    // (no borrow); j = i + d has coordinates >= exactly when they fit under the distance to the far faces (no carry).  The
-    // distinct offsets d are few: their digits come from a small table, the row's coordinates from a running counter --
-    // no division per entry (this check and the packing below used to take 3 s of the setup at 256^3).
-    constexpr int kMaxOffsets = 64;
-    int64_t od[kMaxOffsets], odx[kMaxOffsets], ody[kMaxOffsets], odz[kMaxOffsets];
+    constexpr int kMaxOffsets = 96;
+    int64_t od[kMaxOffsets];
+    int odx[kMaxOffsets], ody[kMaxOffsets], odz[kMaxOffsets];
+    bool lower_seen[kMaxOffsets], upper_seen[kMaxOffsets];
     int nod = 0;
     int64_t xi = 0, yi = 0, zi = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -590,15 +596,32 @@ bool detect_grid(const HostPattern &H, int64_t dims[3]) {
         while (k < nod && od[k] != d) ++k;
         if (k == nod) {
           if (nod == kMaxOffsets) return false;            // not a stencil
-          od[nod] = d; odz[nod] = d / s2; ody[nod] = (d - odz[nod] * s2) / n1; odx[nod] = d - odz[nod] * s2 - ody[nod] * n1;
+          const int64_t dz = floordiv(d + s2 / 2, s2), rem = d - dz * s2;
+          const int64_t dy = floordiv(rem + n1 / 2, n1), dx = rem - dy * n1;
+          if (dz < 0 || dz > 2 || dy < -2 || dy > 2 || dx < -2 || dx > 2) return false;
+          od[nod] = d; odx[nod] = (int)dx; ody[nod] = (int)dy; odz[nod] = (int)dz;
+          lower_seen[nod] = upper_seen[nod] = false;
           ++nod;
         }
-        if (j < i ? (odx[k] > xi || ody[k] > yi || odz[k] > zi)
-                  : (xi + odx[k] >= n1 || yi + ody[k] >= n2 || zi + odz[k] >= n3)) return false;
+        const int sg = j < i ? -1 : 1;
+        const int64_t xj = xi + sg * odx[k], yj = yi + sg * ody[k], zj = zi + sg * odz[k];
+        if (xj < 0 || xj >= n1 || yj < 0 || yj >= n2 || zj < 0 || zj >= n3) return false;      // coupling around a face
+        (j < i ? lower_seen : upper_seen)[k] = true;
       }
       if (++xi == n1) { xi = 0; if (++yi == n2) { yi = 0; ++zi; } }
     }
-    return true;
+    for (const auto &M : kSkews) {
+      bool ok = true;
+      for (int k = 0; k < nod && ok; ++k) {
+        const int v[3] = {odx[k], ody[k], odz[k]};                       // coordinates of j minus those of i, upper entry
+        for (int r = 0; r < 3 && ok; ++r) {
+          const int c = M[3 * r] * v[0] + M[3 * r + 1] * v[1] + M[3 * r + 2] * v[2];
+          if ((upper_seen[k] && c < 0) || (lower_seen[k] && -c > 0)) ok = false;
+        }
+      }
+      if (ok) { for (int e = 0; e < 9; ++e) skew[e] = M[e]; return true; }
+    }
+    return false;
   };
   int tried = 0;
   for (int64_t n1 : centre) {
@@ -614,8 +637,6 @@ bool detect_grid(const HostPattern &H, int64_t dims[3]) {
   return false;
 }
 
-// Builds the block schedule of one triangle (lower: the entries before the diagonal, blocks in wavefront order of
-// bx + by + bz; upper: the entries after it, the mirrored order) and uploads it.  src = position in lu of every packed entry.
 struct HostBlocks {            // what the analysis of one triangle produces (host memory; the two triangles are analysed side by side)
   std::vector<IluBlockHdr> hdr;
   std::vector<int32_t> row_gid, ext_gid, dep, src, diag_src, rec_src;
@@ -626,32 +647,64 @@ struct HostBlocks {            // what the analysis of one triangle produces (ho
   int max_ent = 0, max_ext = 0, max_lvl = 0, rc = KHIP_OK;
 };
 
-int analyse_blocks(const HostPattern &H, const int64_t dims[3], bool upper, HostBlocks &hb) {
+int analyse_blocks(const HostPattern &H, const int64_t dims[3], const int skew[9], bool upper, HostBlocks &hb) {
   std::vector<IluBlockHdr> &hdr = hb.hdr;
   std::vector<int32_t> &row_gid = hb.row_gid, &ext_gid = hb.ext_gid, &dep = hb.dep, &src = hb.src, &diag_src = hb.diag_src, &rec_src = hb.rec_src;
   std::vector<uint16_t> &row_eptr = hb.row_eptr, &lvl = hb.lvl, &ent_slot = hb.ent_slot;
   std::vector<unsigned long long> &rec_meta = hb.rec_meta;
   bool &rec_ok = hb.rec_ok;
   const int64_t n = H.n, n1 = dims[0], n2 = dims[1], n3 = dims[2], s2 = n1 * n2;
+  // block coordinates: c = skew (x, y, z) (entries >= 0, unimodular: a cube of T^3 lattice points holds T^3 grid points), cut
+  // into cubes of T1 x T2 x T3
   const int T1 = n3 > 1 ? 8 : 16, T2 = T1, T3 = n3 > 1 ? 8 : 1;
-  const int64_t B1 = (n1 + T1 - 1) / T1, B2 = (n2 + T2 - 1) / T2, B3 = (n3 + T3 - 1) / T3, nb = B1 * B2 * B3;
-  if (nb > (int64_t)1 << 30) return KHIP_ERR_INVALID;
-  // ticket order: wavefronts of the block grid (mirrored for the upper solve), block id inside a wavefront
-  std::vector<int32_t> order((size_t)nb), ticket_of((size_t)nb);
+  auto cmax = [&](int r) { return skew[3 * r] * (n1 - 1) + skew[3 * r + 1] * (n2 - 1) + skew[3 * r + 2] * (n3 - 1); };
+  const int64_t B1 = cmax(0) / T1 + 1, B2 = cmax(1) / T2 + 1, B3 = cmax(2) / T3 + 1, nslots = B1 * B2 * B3;
+  if (nslots > (int64_t)1 << 30) return KHIP_ERR_INVALID;
+  auto slot_of_xyz = [&](int64_t x, int64_t y, int64_t z) {
+    const int64_t c1 = skew[0] * x + skew[1] * y + skew[2] * z, c2 = skew[3] * x + skew[4] * y + skew[5] * z,
+                  c3 = skew[6] * x + skew[7] * y + skew[8] * z;
+    return ((c3 / T3) * B2 + c2 / T2) * B1 + c1 / T1;
+  };
+  auto block_of = [&](int64_t i) {
+    const int64_t z = i / s2, r = i - z * s2, y = r / n1, x = r - y * n1;
+    return slot_of_xyz(x, y, z);
+  };
+  // the rows of every block slot, ascending (counting sort by slot; the rows' coordinates from a running counter)
+  std::vector<int64_t> slot_ptr((size_t)nslots + 1, 0);
+  std::vector<int32_t> slot_rows((size_t)n);
+  {
+    std::vector<int32_t> slot_of_row((size_t)n);
+    int64_t x = 0, y = 0, z = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int64_t sl = slot_of_xyz(x, y, z);
+      slot_of_row[(size_t)i] = (int32_t)sl;
+      slot_ptr[(size_t)sl + 1]++;
+      if (++x == n1) { x = 0; if (++y == n2) { y = 0; ++z; } }
+    }
+    for (int64_t b = 0; b < nslots; ++b) slot_ptr[(size_t)b + 1] += slot_ptr[(size_t)b];
+    std::vector<int64_t> cur(slot_ptr.begin(), slot_ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) slot_rows[(size_t)cur[(size_t)slot_of_row[(size_t)i]]++] = (int32_t)i;
+  }
+  // ticket order: wavefronts of the block grid (mirrored for the upper solve), slot number inside a wavefront; empty slots
+  // (the corners of the skewed box) get no ticket
+  std::vector<int32_t> order, ticket_of((size_t)nslots, -1);
   {
     std::vector<int64_t> cnt((size_t)(B1 + B2 + B3), 0);
     auto wave = [&](int64_t b) {
       const int64_t bz = b / (B1 * B2), r = b - bz * B1 * B2, by = r / B1, bx = r - by * B1;
       return upper ? (B1 - 1 - bx) + (B2 - 1 - by) + (B3 - 1 - bz) : bx + by + bz;
     };
-    for (int64_t b = 0; b < nb; ++b) cnt[(size_t)wave(b) + 1]++;
+    for (int64_t b = 0; b < nslots; ++b) if (slot_ptr[(size_t)b + 1] > slot_ptr[(size_t)b]) cnt[(size_t)wave(b) + 1]++;
     for (size_t w = 1; w < cnt.size(); ++w) cnt[w] += cnt[w - 1];
-    for (int64_t b = 0; b < nb; ++b) { const int64_t t = cnt[(size_t)wave(b)]++; order[(size_t)t] = (int32_t)b; ticket_of[(size_t)b] = (int32_t)t; }
+    order.assign((size_t)cnt.back(), 0);
+    for (int64_t b = 0; b < nslots; ++b) {
+      if (slot_ptr[(size_t)b + 1] == slot_ptr[(size_t)b]) continue;
+      const int64_t t = cnt[(size_t)wave(b)]++;
+      order[(size_t)t] = (int32_t)b;
+      ticket_of[(size_t)b] = (int32_t)t;
+    }
   }
-  auto block_of = [&](int64_t i) {
-    const int64_t z = i / s2, r = i - z * s2, y = r / n1, x = r - y * n1;
-    return ((z / T3) * B2 + y / T2) * B1 + x / T1;
-  };
+  const int64_t nb = (int64_t)order.size();
   hdr.assign((size_t)nb, IluBlockHdr());
   row_gid.reserve((size_t)n);
   row_eptr.reserve((size_t)(n + nb));
@@ -664,11 +717,7 @@ int analyse_blocks(const HostPattern &H, const int64_t dims[3], bool upper, Host
   int max_ent = 0, max_ext = 0, max_lvl = 0;
   for (int64_t t = 0; t < nb; ++t) {
     const int64_t b = order[(size_t)t];
-    const int64_t bz = b / (B1 * B2), rr = b - bz * B1 * B2, by = rr / B1, bx = rr - by * B1;
-    rows.clear();
-    for (int64_t z = bz * T3; z < std::min<int64_t>((bz + 1) * T3, n3); ++z)
-      for (int64_t y = by * T2; y < std::min<int64_t>((by + 1) * T2, n2); ++y)
-        for (int64_t x = bx * T1; x < std::min<int64_t>((bx + 1) * T1, n1); ++x) rows.push_back((int32_t)(x + n1 * (y + n2 * z)));
+    rows.assign(slot_rows.begin() + slot_ptr[(size_t)b], slot_rows.begin() + slot_ptr[(size_t)b + 1]);
     const int nr = (int)rows.size();                       // ascending row numbers
     // local levels from the dependencies inside the block
     llev.assign((size_t)nr, 0);
@@ -910,12 +959,12 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
   // ---- block schedule of the solves where the pattern is a structured grid (else: level scheduling) ----
   if (ctx->tune.ilu_blocks != 0) {
     const HostPattern H{n, col, row_lo, diag, row_hi};
-    if (detect_grid(H, P->grid_dims)) {
+    if (detect_grid(H, P->grid_dims, P->grid_skew)) {
       KHIP_CHECK_HIP(hipMalloc(&P->blk_fail, sizeof(int)));
       KHIP_CHECK_HIP(hipMemsetAsync(P->blk_fail, 0, sizeof(int), ctx->stream));
       HostBlocks hlo, hup;                     // the two triangles are analysed side by side (pure host work)
-      std::thread tup([&] { hup.rc = analyse_blocks(H, P->grid_dims, true, hup); });
-      hlo.rc = analyse_blocks(H, P->grid_dims, false, hlo);
+      std::thread tup([&] { hup.rc = analyse_blocks(H, P->grid_dims, P->grid_skew, true, hup); });
+      hlo.rc = analyse_blocks(H, P->grid_dims, P->grid_skew, false, hlo);
       tup.join();
       int rb = hlo.rc != KHIP_OK ? hlo.rc : hup.rc;
       if (rb == KHIP_OK) rb = upload_blocks(P, false, hlo, P->blk_lo);
