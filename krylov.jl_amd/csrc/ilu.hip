@@ -271,7 +271,24 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
         if (r < h.nrows) xv[r] = xs[u];
       }
     } else {
-      for (int e = lane; e < h.nent; e += kBlkThreads) { ev[e] = a.ent_val[h.ent0 + e]; es[e] = a.ent_slot[h.ent0 + e]; }
+      // batches of 16 elements per lane: all loads of a batch are in flight before its first LDS store (one element per trip
+      // made the staging of a 27-point block, 6656 entries, the longest phase of the block)
+      for (int b0 = 0; b0 < h.nent; b0 += 16 * kBlkThreads) {
+        double tv[16];
+        uint16_t ts[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int e = b0 + u * kBlkThreads + lane;
+          const int64_t g = h.ent0 + (e < h.nent ? e : 0);
+          tv[u] = a.ent_val[g];
+          ts[u] = a.ent_slot[g];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int e = b0 + u * kBlkThreads + lane;
+          if (e < h.nent) { ev[e] = tv[u]; es[e] = ts[u]; }
+        }
+      }
       for (int r = lane; r <= h.nrows; r += kBlkThreads) ep[r] = a.row_eptr[(int64_t)h.row0 + t + r];
       for (int l = lane; l <= h.nlvl; l += kBlkThreads) lv[l] = a.lvl[h.lvl0 + l];
       for (int r = lane; r < h.nrows; r += kBlkThreads) {
@@ -347,7 +364,14 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
         for (int r = lv[l] + lane; r < r1; r += kBlkThreads) {
           double acc = xv[r];
           const int e1 = ep[r + 1];
-          for (int e = ep[r]; e < e1; ++e) {
+          int e = ep[r];
+          for (; e + 4 <= e1; e += 4) {              // four entries' reads in flight, the subtractions in stored order
+            const double v0 = ev[e], v1 = ev[e + 1], v2 = ev[e + 2], v3 = ev[e + 3];
+            const double y0 = yl[es[e]], y1 = yl[es[e + 1]], y2 = yl[es[e + 2]], y3 = yl[es[e + 3]];
+            const double t0 = v0 * y0, t1 = v1 * y1, t2 = v2 * y2, t3 = v3 * y3;
+            acc = acc - t0; acc = acc - t1; acc = acc - t2; acc = acc - t3;
+          }
+          for (; e < e1; ++e) {
             const double tt = ev[e] * yl[es[e]];
             acc = acc - tt;
           }
