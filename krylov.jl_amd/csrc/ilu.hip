@@ -24,6 +24,7 @@
 // usual domain-decomposition preconditioner; it needs no communication.
 #include <algorithm>
 #include <map>
+#include <functional>
 #include <thread>
 
 #include "khip_internal.hpp"
@@ -987,8 +988,11 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
       KHIP_CHECK_HIP(hipMalloc(&P->blk_fail, sizeof(int)));
       KHIP_CHECK_HIP(hipMemsetAsync(P->blk_fail, 0, sizeof(int), ctx->stream));
       HostBlocks hlo, hup;                     // the two triangles are analysed side by side (pure host work)
-      std::thread tup([&] { hup.rc = analyse_blocks(H, P->grid_dims, P->grid_skew, true, hup); });
-      hlo.rc = analyse_blocks(H, P->grid_dims, P->grid_skew, false, hlo);
+      auto analyse = [&](bool upper, HostBlocks &hb) {           // host memory may run out on a very large slab: then level scheduling
+        try { hb.rc = analyse_blocks(H, P->grid_dims, P->grid_skew, upper, hb); } catch (const std::exception &) { hb.rc = KHIP_ERR_INVALID; }
+      };
+      std::thread tup(analyse, true, std::ref(hup));
+      analyse(false, hlo);
       tup.join();
       int rb = hlo.rc != KHIP_OK ? hlo.rc : hup.rc;
       if (rb == KHIP_OK) rb = upload_blocks(P, false, hlo, P->blk_lo);
