@@ -10,7 +10,7 @@ import krylov_jl_amd as K
 ctx = K.Context(0)
 n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 n = n1 ** 3
-A = K.CsrMatrix.stencil(ctx, "poisson", n1)
+A = K.CsrMatrix.stencil(ctx, sys.argv[2] if len(sys.argv) > 2 else "poisson", n1)
 P = K.Ilu0(A)
 x, y = ctx.empty(n), ctx.empty(n); K.kfill_(x, 1.0)
 for _ in range(3): P(x, y)
