@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
   uint16_t *es = reinterpret_cast<uint16_t *>(ev + a.max_ent);   // [max_ent rounded up to 4]
   uint16_t *ep = es + ((a.max_ent + 3) & ~3);               // [kBlkRows + 2]
   uint16_t *lv = ep + kBlkRows + 2;                         // [max_lvl + 2]
+  int32_t *gl = reinterpret_cast<int32_t *>(lv + ((a.max_lvl + 2 + 1) & ~1));      // [kBlkRows]: row numbers (general path)
   const int lane = threadIdx.x;
   for (;;) {
     // lane 0 draws the ticket; every lane reads it back from LDS
@@ -294,9 +295,18 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       for (int l = lane; l <= h.nlvl; l += kBlkThreads) lv[l] = a.lvl[h.lvl0 + l];
       for (int r = lane; r < h.nrows; r += kBlkThreads) {
         const int32_t gid = a.row_gid[h.row0 + r];
+        gl[r] = gid;
         xv[r] = KIND == 1 ? x[gid] : y[gid];
         if (KIND == 2) dv[r] = a.diag_val[h.row0 + r];
       }
+    }
+    // the row numbers of the faces it will read: fetched now, so that one round trip (the y values) is left after the wait
+    constexpr int kExtRegs = 16;
+    int32_t eg[kExtRegs];
+#pragma unroll
+    for (int u = 0; u < kExtRegs; ++u) {
+      const int k = u * kBlkThreads + lane;
+      eg[u] = a.ext_gid[h.ext0 + (k < h.next ? k : 0)];
     }
     ILU_STAMP(1);
     // the blocks this one reads from
@@ -316,8 +326,18 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
     asm volatile("" ::: "memory");                           // the loads below stay below the spins
     // y of other blocks: written through and read past the L2s (agent scope), so that neither side needs a cache-wide
     // write-back or invalidate per block
-    for (int k = lane; k < h.next; k += kBlkThreads)
-      yl[kBlkRows + k] = __hip_atomic_load(y + a.ext_gid[h.ext0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+      double ye[kExtRegs];
+#pragma unroll
+      for (int u = 0; u < kExtRegs; ++u) ye[u] = __hip_atomic_load(y + eg[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < kExtRegs; ++u) {
+        const int k = u * kBlkThreads + lane;
+        if (k < h.next) yl[kBlkRows + k] = ye[u];
+      }
+      for (int k = kExtRegs * kBlkThreads + lane; k < h.next; k += kBlkThreads)       // more than 1024 face rows
+        yl[kBlkRows + k] = __hip_atomic_load(y + a.ext_gid[h.ext0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     ILU_STAMP(3);
     if (fast) {
@@ -363,28 +383,39 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       for (int l = 0; l < h.nlvl; ++l) {
         const int r1 = lv[l + 1];
         for (int r = lv[l] + lane; r < r1; r += kBlkThreads) {
+          // the row's first 16 (value, slot) pairs are read together, then the y values they point to, then the products are
+          // subtracted one after the other in stored order (the selects keep absent entries out); longer rows go on one by one
           double acc = xv[r];
-          const int e1 = ep[r + 1];
-          int e = ep[r];
-          for (; e + 4 <= e1; e += 4) {              // four entries' reads in flight, the subtractions in stored order
-            const double v0 = ev[e], v1 = ev[e + 1], v2 = ev[e + 2], v3 = ev[e + 3];
-            const double y0 = yl[es[e]], y1 = yl[es[e + 1]], y2 = yl[es[e + 2]], y3 = yl[es[e + 3]];
-            const double t0 = v0 * y0, t1 = v1 * y1, t2 = v2 * y2, t3 = v3 * y3;
-            acc = acc - t0; acc = acc - t1; acc = acc - t2; acc = acc - t3;
+          const int e0 = ep[r], cnt = ep[r + 1] - e0;
+          constexpr int kRowBatch = 16;
+          double v[kRowBatch], yy[kRowBatch];
+          int sl[kRowBatch];
+#pragma unroll
+          for (int u = 0; u < kRowBatch; ++u) {
+            const int e = u < cnt ? e0 + u : 0;
+            v[u] = ev[e];
+            sl[u] = es[e];
           }
-          for (; e < e1; ++e) {
+#pragma unroll
+          for (int u = 0; u < kRowBatch; ++u) yy[u] = yl[sl[u]];
+#pragma unroll
+          for (int u = 0; u < kRowBatch; ++u) {
+            const double tt = v[u] * yy[u];
+            const double an = acc - tt;
+            acc = u < cnt ? an : acc;
+          }
+          for (int e = e0 + kRowBatch; e < e0 + cnt; ++e) {
             const double tt = ev[e] * yl[es[e]];
             acc = acc - tt;
           }
-          yl[r] = KIND == 2 ? acc / dv[r] : acc;
+          const double yv = KIND == 2 ? acc / dv[r] : acc;
+          yl[r] = yv;
+          __hip_atomic_store(y + gl[r], yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // through the L2, in flight during the next levels
         }
         __syncthreads();
       }
     }
     ILU_STAMP(4);
-    if (!fast)
-      for (int r = lane; r < h.nrows; r += kBlkThreads)
-        __hip_atomic_store(y + a.row_gid[h.row0 + r], yl[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the block's y has arrived before its flag is raised
     ILU_STAMP(5);
     __syncthreads();
@@ -842,7 +873,7 @@ int upload_blocks(khip_ilu0 *P, bool upper, HostBlocks &hb, khip_ilu0::Blocks &B
   }
   B.nb = (int)nb; B.max_ent = max_ent; B.max_ext = max_ext; B.max_lvl = max_lvl;
   B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + 1 + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
-          sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + max_lvl + 2);
+          sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + ((max_lvl + 2 + 1) & ~1)) + sizeof(int32_t) * kBlkRows;
   if (B.lds > (size_t)150 * 1024) return KHIP_ERR_INVALID;
   bool all_fast = rec_ok;                         // every block on the row-record path: the packed entry arrays are not needed
   for (const IluBlockHdr &hh : hdr) all_fast = all_fast && hh.pad != 0;
