@@ -184,6 +184,7 @@ constexpr int kBlkThreads = 64;        // one wave: its levels need no s_barrier
 // 48 bytes = v0, v1, v2, pivot, {slot0, slot1, slot2, count} as 4 x u16, the row's number in y -- one LDS round trip of three
 // 16-byte reads brings everything of a row that does not depend on y.
 constexpr int kRecDoubles = 6;
+constexpr int kWideDoubles = 22;      // wide row record (rows with 4..16 entries): 16 values, 16 x u16 slots, pivot, row number = 176 bytes
 constexpr int kRecExtCap = 256;        // fast path: ext slots of the LDS y array; the last two are a constant 0.0 and a dump
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
@@ -207,6 +208,7 @@ struct IluBlkArgs {
   const double *ent_val;
   const double *diag_val;              // upper solve: lu[diag] per row, in block order
   const double *rec;                   // row records (kRecDoubles per row, block order) where every row has <= 3 entries, else null
+  const double *recw;                  // wide row records (kWideDoubles per row) where every row has <= 16 entries, else null
   int *done;                           // [nb]: epoch of the last solve that finished the block
   unsigned *ticket;
   int *fail;
@@ -237,13 +239,15 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
     const IluBlockHdr h = a.hdr[t];
     ILU_STAMP(0);
     const bool fast = a.rec != nullptr && h.pad != 0;        // row records, and no level wider than the wave
-    int my_lv = 0;                                           // fast path: lane l holds level pointer l
+    const bool wide = !fast && a.recw != nullptr && h.pad != 0;
+    int my_lv = 0;                                           // record paths: lane l holds level pointer l
     // stage what does not depend on other blocks
-    if (fast) {
-      // kBlkRows x 48 bytes at most, as 16-byte pieces: all loads of a batch are in flight before the first LDS store
-      const dbl2 *src = reinterpret_cast<const dbl2 *>(a.rec + (int64_t)h.row0 * kRecDoubles);
+    if (fast || wide) {
+      // kBlkRows x 48 (176) bytes at most, as 16-byte pieces: all loads of a batch are in flight before the first LDS store
+      const int rd = fast ? kRecDoubles : kWideDoubles;
+      const dbl2 *src = reinterpret_cast<const dbl2 *>((fast ? a.rec : a.recw) + (int64_t)h.row0 * rd);
       dbl2 *dst = reinterpret_cast<dbl2 *>(ev);
-      const int pieces = h.nrows * (kRecDoubles / 2);
+      const int pieces = h.nrows * (rd / 2);
       for (int b0 = 0; b0 < pieces; b0 += 8 * kBlkThreads) {
         dbl2 tmp[8];
 #pragma unroll
@@ -379,6 +383,47 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
         asm volatile("" ::: "memory");
         r = rn; c0 = n0; c1 = n1; c2 = n2; rhs = nrhs;
       }
+    } else if (wide) {
+      // rows with 4..16 entries: the same walk as above on 176-byte records -- 16 values (absent: 0.0), 16 slots (absent: the
+      // slot of a constant 0.0), pivot, row number -- read with eleven 16-byte LDS loads one level ahead
+      const dbl2 *recs = reinterpret_cast<const dbl2 *>(ev);
+      const int zero_slot = kBlkRows + a.max_ext - 2, dump_slot = kBlkRows + a.max_ext - 1;
+      if (lane == 0) yl[zero_slot] = 0.0;
+      auto row_of = [&](int l) {
+        const int r = __builtin_amdgcn_readlane(my_lv, l) + lane;
+        return r < __builtin_amdgcn_readlane(my_lv, l + 1) ? r : -1;
+      };
+      struct WRow { dbl2 c[kWideDoubles / 2]; double rhs; };
+      auto fetchw = [&](int rr, WRow &w) {
+#pragma unroll
+        for (int q = 0; q < kWideDoubles / 2; ++q) w.c[q] = recs[rr * (kWideDoubles / 2) + q];
+        w.rhs = xv[rr];
+      };
+      int r = row_of(0);
+      WRow cur;
+      fetchw(r >= 0 ? r : 0, cur);
+      for (int l = 0; l < h.nlvl; ++l) {
+        const int rn = l + 1 < h.nlvl ? row_of(l + 1) : -1;
+        WRow nxt;
+        fetchw(rn >= 0 ? rn : 0, nxt);
+        const unsigned long long sw[4] = {(unsigned long long)__double_as_longlong(cur.c[8].x), (unsigned long long)__double_as_longlong(cur.c[8].y),
+                                          (unsigned long long)__double_as_longlong(cur.c[9].x), (unsigned long long)__double_as_longlong(cur.c[9].y)};
+        double yy[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) yy[u] = yl[(sw[u >> 2] >> (16 * (u & 3))) & 0xffff];
+        double acc = cur.rhs;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const double tt = ((u & 1) ? cur.c[u >> 1].y : cur.c[u >> 1].x) * yy[u];
+          acc = acc - tt;
+        }
+        const double yv = KIND == 2 ? acc / cur.c[10].x : acc;
+        yl[r >= 0 ? r : dump_slot] = yv;
+        if (r >= 0) __hip_atomic_store(y + (long long)__double_as_longlong(cur.c[10].y), yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+        r = rn;
+        cur = nxt;
+      }
     } else {
       for (int l = 0; l < h.nlvl; ++l) {
         const int r1 = lv[l + 1];
@@ -438,6 +483,29 @@ __global__ __launch_bounds__(256) void ilu_pack_records_kernel(const double *lu,
   o[5] = __longlong_as_double((long long)row_gid[i]);          // the row's number in y: the level loop writes y as it goes
 }
 
+// wide row records from the packed entry lists: one wave per block
+__global__ __launch_bounds__(kBlkThreads) void ilu_pack_wide_kernel(const IluBlockHdr *hdr, const uint16_t *row_eptr, const double *ent_val,
+                                                                    const uint16_t *ent_slot, const double *lu, const int32_t *diag,
+                                                                    const int32_t *row_gid, int zero_slot, double *recw) {
+  const int t = blockIdx.x;
+  const IluBlockHdr h = hdr[t];
+  for (int r = threadIdx.x; r < h.nrows; r += kBlkThreads) {
+    const int e0 = row_eptr[(int64_t)h.row0 + t + r], e1 = row_eptr[(int64_t)h.row0 + t + r + 1];
+    double *o = recw + ((int64_t)h.row0 + r) * kWideDoubles;
+    unsigned long long sw[4] = {0, 0, 0, 0};
+    for (int u = 0; u < 16; ++u) {
+      const bool on = e0 + u < e1;
+      o[u] = on ? ent_val[h.ent0 + e0 + u] : 0.0;
+      const unsigned long long sl = on ? ent_slot[h.ent0 + e0 + u] : (unsigned)zero_slot;
+      sw[u >> 2] |= sl << (16 * (u & 3));
+    }
+    for (int q = 0; q < 4; ++q) o[16 + q] = __longlong_as_double((long long)sw[q]);
+    const int32_t gid = row_gid[h.row0 + r];
+    o[20] = lu[diag[gid]];
+    o[21] = __longlong_as_double((long long)gid);
+  }
+}
+
 // ent_val[e] = lu[src[e]] (and the pivots of the upper solve) after the numeric factorisation
 __global__ __launch_bounds__(256) void ilu_pack_values_kernel(const double *lu, const int32_t *src, int64_t n, double *out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -464,7 +532,8 @@ struct khip_ilu0 {
     IluBlockHdr *hdr = nullptr;
     int32_t *row_gid = nullptr, *ext_gid = nullptr, *dep = nullptr;
     uint16_t *row_eptr = nullptr, *lvl = nullptr, *ent_slot = nullptr;
-    double *ent_val = nullptr, *diag_val = nullptr, *rec = nullptr;
+    double *ent_val = nullptr, *diag_val = nullptr, *rec = nullptr, *recw = nullptr;
+    bool want_wide = false;
     int *done = nullptr;
     unsigned *ticket = nullptr;
     int epoch = 0;
@@ -522,7 +591,7 @@ int enqueue_solve(khip_ilu0 *P, const double *x, double *y) {
 
 template <int KIND>
 int launch_blocks(khip_ilu0 *P, khip_ilu0::Blocks &B, const double *x, double *y) {
-  IluBlkArgs a{B.hdr, B.row_gid, B.row_eptr, B.lvl, B.ext_gid, B.dep, B.ent_slot, B.ent_val, B.diag_val, B.rec, B.done, B.ticket,
+  IluBlkArgs a{B.hdr, B.row_gid, B.row_eptr, B.lvl, B.ext_gid, B.dep, B.ent_slot, B.ent_val, B.diag_val, B.rec, B.recw, B.done, B.ticket,
                P->blk_fail, B.nb, B.max_ent, B.max_ext, B.max_lvl};
   ++B.epoch;
   hipLaunchKernelGGL((ilu_block_solve_kernel<KIND>), dim3((unsigned)B.grid), dim3(kBlkThreads), B.lds, P->ctx->stream, a, x, y, B.epoch,
@@ -562,7 +631,7 @@ int ilu0_apply(void *self, const double *x, double *y) {
 
 void blocks_free(khip_ilu0::Blocks &B) {
   for (void *p : {(void *)B.hdr, (void *)B.row_gid, (void *)B.ext_gid, (void *)B.dep, (void *)B.row_eptr, (void *)B.lvl,
-                  (void *)B.ent_slot, (void *)B.ent_val, (void *)B.diag_val, (void *)B.rec, (void *)B.done, (void *)B.ticket})
+                  (void *)B.ent_slot, (void *)B.ent_val, (void *)B.diag_val, (void *)B.rec, (void *)B.recw, (void *)B.done, (void *)B.ticket})
     if (p) (void)hipFree(p);
   B = khip_ilu0::Blocks();
 }
@@ -700,7 +769,7 @@ struct HostBlocks {            // what the analysis of one triangle produces (ho
   std::vector<unsigned long long> rec_meta;
   bool rec_ok = true;
   int64_t nb = 0;
-  int max_ent = 0, max_ext = 0, max_lvl = 0, rc = KHIP_OK;
+  int max_ent = 0, max_ext = 0, max_lvl = 0, max_row_ent = 0, rc = KHIP_OK;
 };
 
 int analyse_blocks(const HostPattern &H, const int64_t dims[3], const int skew[9], bool upper, HostBlocks &hb) {
@@ -838,6 +907,7 @@ int analyse_blocks(const HostPattern &H, const int64_t dims[3], const int skew[9
         ++in_row;
       }
       if (in_row > 3) rec_ok = false;
+      hb.max_row_ent = std::max(hb.max_row_ent, in_row);
       for (int kq = in_row; kq < 3; ++kq) meta |= (unsigned long long)(kBlkRows + kRecExtCap - 2) << (16 * kq);   // absent: the 0.0 slot
       rec_meta.push_back(meta | (unsigned long long)std::min(in_row, 3) << 48);
     }
@@ -867,6 +937,12 @@ int upload_blocks(khip_ilu0 *P, bool upper, HostBlocks &hb, khip_ilu0::Blocks &B
   bool rec_ok = hb.rec_ok;
   int max_ent = hb.max_ent, max_ext = hb.max_ext, max_lvl = hb.max_lvl;
   if (max_ext > kRecExtCap - 2) rec_ok = false;
+  const bool wide = !rec_ok && hb.max_row_ent <= 16 && (size_t)kBlkRows + max_ext + 2 < 65535;
+  if (wide) {
+    max_ent = std::max(max_ent, kBlkRows * kWideDoubles);           // the wide records share the LDS region of the packed entries
+    max_ext += 2;                                                   // ... and the y array gets a 0.0 and a dump slot behind the faces
+    B.want_wide = true;
+  }
   if (rec_ok) {
     max_ent = std::max(max_ent, kBlkRows * kRecDoubles);            // the records share the LDS region of the packed entries
     max_ext = kRecExtCap;                                           // ... and the y array has its fixed 0.0 and dump slots
@@ -929,6 +1005,12 @@ int pack_block_values(khip_ilu0 *P, khip_ilu0::Blocks &B, const std::vector<int3
     KHIP_TRY(upload(ctx, diag_src, &d_src));
     hipLaunchKernelGGL(ilu_pack_values_kernel, dim3((unsigned)((diag_src.size() + 255) / 256)), dim3(256), 0, ctx->stream, P->lu, d_src,
                        (int64_t)diag_src.size(), B.diag_val);
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  if (B.want_wide && B.ent_val && B.nb > 0) {
+    KHIP_CHECK_HIP(hipMalloc(&B.recw, sizeof(double) * (size_t)std::max<int64_t>(P->n, 1) * kWideDoubles));
+    hipLaunchKernelGGL(ilu_pack_wide_kernel, dim3((unsigned)B.nb), dim3(kBlkThreads), 0, ctx->stream, B.hdr, B.row_eptr, B.ent_val, B.ent_slot,
+                       P->lu, P->diag, B.row_gid, kBlkRows + B.max_ext - 2, B.recw);
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   KHIP_CHECK_HIP(hipGetLastError());
