@@ -936,8 +936,8 @@ int upload_blocks(khip_ilu0 *P, bool upper, HostBlocks &hb, khip_ilu0::Blocks &B
   std::vector<unsigned long long> &rec_meta = hb.rec_meta;
   bool rec_ok = hb.rec_ok;
   int max_ent = hb.max_ent, max_ext = hb.max_ext, max_lvl = hb.max_lvl;
-  if (max_ext > kRecExtCap - 2) rec_ok = false;
-  const bool wide = !rec_ok && hb.max_row_ent <= 16 && (size_t)kBlkRows + max_ext + 2 < 65535;
+  if (max_ext > kRecExtCap - 2 || ctx->tune.ilu_blocks == 2) rec_ok = false;      // ilu_blocks = 2: packed lists only (tests)
+  const bool wide = !rec_ok && ctx->tune.ilu_blocks != 2 && hb.max_row_ent <= 16 && (size_t)kBlkRows + max_ext + 2 < 65535;
   if (wide) {
     max_ent = std::max(max_ent, kBlkRows * kWideDoubles);           // the wide records share the LDS region of the packed entries
     max_ext += 2;                                                   // ... and the y array gets a 0.0 and a dump slot behind the faces

@@ -209,6 +209,16 @@ def test_ilu0_block_schedule_bit_identical(K, ctx, oracle, gen, args):
         P(dx, dy)                            # again: the epochs and the ticket base move on
         assert np.array_equal(dy.to_host(), want_y)
     assert P.block_info()[2] == 0
+    if gen in ("stencil27_unsym", "kron_unsymmetric"):          # the same on the packed entry lists (no row records)
+        ctx.set_option("ilu_blocks", 2)
+        try:
+            Pp = K.Ilu0(dA)
+        finally:
+            ctx.set_option("ilu_blocks", 1)
+        dx, dy = ctx.array(x), ctx.empty(A.n)
+        Pp(dx, dy)
+        assert np.array_equal(dy.to_host(), ref.solve(x))
+        assert Pp.block_info()[1] > 0 and Pp.block_info()[2] == 0
 
 
 def test_ilu0_block_schedule_not_taken_for_other_patterns(K, ctx, oracle):
@@ -228,11 +238,13 @@ def test_ilu0_block_schedule_not_taken_for_other_patterns(K, ctx, oracle):
     assert np.array_equal(dy.to_host(), oracle.Ilu0(Ap).solve(x))
 
 
+@pytest.mark.parametrize("records", [1, 2])
 @pytest.mark.parametrize("dims", [(18, 17, 16), (70, 64, 1)])
-def test_ilu0_block_schedule_general_rows(K, ctx, oracle, dims):
+def test_ilu0_block_schedule_general_rows(K, ctx, oracle, dims, records):
     """More than three entries per row and triangle (second neighbours along every axis: offsets 1, 2, n1, 2 n1, ...): still a
-    grid with dependencies towards smaller coordinates, so the block schedule applies, but on its general path (packed
-    entry lists instead of the 48-byte row records).  Unsymmetric values."""
+    grid with dependencies towards smaller coordinates, so the block schedule applies -- on the wide row records (rows
+    with 4..16 entries; option ilu_blocks = 1) or on the packed entry lists every pattern can fall back to (= 2).
+    Unsymmetric values."""
     import scipy.sparse as sp
     n1, n2, n3 = dims
     def band(n, lo2, lo1, di, up1, up2):
@@ -246,7 +258,11 @@ def test_ilu0_block_schedule_general_rows(K, ctx, oracle, dims):
     S = S.tocsr(); S.sort_indices()
     A = oracle.CsrMatrix.from_arrays(S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data)
     ref = oracle.Ilu0(A)
-    P = K.Ilu0(_upload(K, ctx, A))
+    ctx.set_option("ilu_blocks", records)
+    try:
+        P = K.Ilu0(_upload(K, ctx, A))
+    finally:
+        ctx.set_option("ilu_blocks", 1)
     got_dims, nb, failed = P.block_info()
     assert got_dims == dims and nb > 0 and failed == 0, (got_dims, nb, failed)
     assert np.array_equal(P.values(), ref.lu)
