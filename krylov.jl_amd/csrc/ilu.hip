@@ -156,13 +156,15 @@ __global__ __launch_bounds__(kIluBlock) void ilu_small_levels_kernel(IluView v, 
 // Block schedule of the triangular solves (operators whose pattern is a structured grid in natural ordering).
 //
 // Level scheduling pays one kernel boundary per level -- 2 (n1 + n2 + n3 - 2) of them for a 7-point grid, ~7 us each: the
-// solves are launch-latency bound.  Here the rows are cut into BLOCKS of a few hundred rows (8 x 8 x 8 grid
-// points; 16 x 16 on a 2-D grid) whose dependencies point to blocks with smaller grid coordinates only.  One persistent
-// launch per triangle: a workgroup of ONE wave takes the next block off a ticket counter (tickets run along the block
-// wavefronts bx + by + bz, a topological order of the block graph), copies the block's packed factor entries to LDS while it
-// waits for the (at most three) blocks it depends on, fetches the y values of their faces, and then walks the block's OWN
-// levels out of LDS -- a dependent step costs an LDS round trip instead of a kernel boundary, and device-wide traffic (a
-// flag per block, y written through and read past the L2s) happens once per block, not once per level.  Every row is
+// solves are launch-latency bound.  Here the rows are cut into BLOCKS of a few hundred rows (8 x 8 x 8
+// lattice points of a basis in which all dependencies point towards smaller coordinates -- the grid's axes for the 5- / 7-point
+// stencils, a skewed basis for the 9- / 27-point ones, see detect_grid; 16 x 16 on a 2-D grid), so that a block depends on
+// blocks with smaller block coordinates only.  One persistent launch per triangle: a workgroup of ONE wave takes the next
+// block off a ticket counter (tickets run along the block wavefronts bx + by + bz, a topological order of the block graph),
+// copies the block's rows to LDS -- 48-byte records for rows with up to 3 entries, 176-byte records up to 16, packed (value,
+// slot) lists beyond -- while it waits for the blocks it depends on, fetches the y values of their faces, and then walks
+// the block's OWN levels out of LDS: a dependent step costs an LDS round trip instead of a kernel boundary, and device-wide
+// traffic (a flag per block, y written through and read past the L2s) happens once per block, not once per level.  Every row is
 // still computed by one lane that walks its entries in stored order with a rounded multiply and a rounded subtract per
 // entry: y is bit-identical to the level-scheduled kernels and to the oracle's serial loops (ko_ilu0_solve).
 // No deadlock: a block waits only for blocks with SMALLER tickets; tickets are handed out in order to running workgroups,
