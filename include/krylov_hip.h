@@ -306,7 +306,8 @@ int khip_ilu0_set_graph(khip_operator *op, int enable);
  * dependencies towards smaller coordinates; the solves then run block by block, one persistent launch per triangle) or
  * 0, 0, 0 (level scheduling, one launch per level); blocks per triangle; failed = 1 if a bounded wait of the block schedule
  * ever gave up (never expected).  Synchronises the context's stream.  Option "ilu_blocks" = 0 at create keeps level scheduling,
- * = 2 runs the block schedule on packed entry lists only (no row records; for tests). */
+ * = 2 runs the block schedule on packed entry lists only (no row records; for tests), = 3 takes the blocks from the level-sorted
+ * row sequence even where a grid is recognised (what patterns without a grid get: dims3 = 0, 0, 0 but blocks > 0). */
 int khip_ilu0_block_info(const khip_operator *op, int64_t *dims3, int64_t *blocks, int *failed);
 
 typedef int (*khip_callback_fn)(void *workspace, void *userdata);       /* callback(workspace)::Bool */

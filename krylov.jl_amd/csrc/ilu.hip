@@ -774,13 +774,17 @@ struct HostBlocks {            // what the analysis of one triangle produces (ho
   int max_ent = 0, max_ext = 0, max_lvl = 0, max_row_ent = 0, rc = KHIP_OK;
 };
 
-int analyse_blocks(const HostPattern &H, const int64_t dims[3], const int skew[9], bool upper, HostBlocks &hb) {
-  std::vector<IluBlockHdr> &hdr = hb.hdr;
-  std::vector<int32_t> &row_gid = hb.row_gid, &ext_gid = hb.ext_gid, &dep = hb.dep, &src = hb.src, &diag_src = hb.diag_src, &rec_src = hb.rec_src;
-  std::vector<uint16_t> &row_eptr = hb.row_eptr, &lvl = hb.lvl, &ent_slot = hb.ent_slot;
-  std::vector<unsigned long long> &rec_meta = hb.rec_meta;
-  bool &rec_ok = hb.rec_ok;
-  const int64_t n = H.n, n1 = dims[0], n2 = dims[1], n3 = dims[2], s2 = n1 * n2;
+// A partition of the rows into blocks and an order of the blocks in which every block depends on earlier ones only.
+struct Partition {
+  int64_t nslots = 0;
+  std::vector<int64_t> slot_ptr;                 // rows of slot b: slot_rows[slot_ptr[b] .. slot_ptr[b + 1]), ascending
+  std::vector<int32_t> slot_rows, slot_of_row;
+  std::vector<int32_t> order, ticket_of;         // ticket -> slot, slot -> ticket (-1: empty slot)
+};
+
+// cubes of 8 x 8 x 8 lattice points of the basis detect_grid found (16 x 16 on a 2-D grid), in wavefront order
+int make_grid_partition(const HostPattern &H, const int64_t dims[3], const int skew[9], bool upper, Partition &P) {
+  const int64_t n = H.n, n1 = dims[0], n2 = dims[1], n3 = dims[2];
   // block coordinates: c = skew (x, y, z) (entries >= 0, unimodular: a cube of T^3 lattice points holds T^3 grid points), cut
   // into cubes of T1 x T2 x T3
   const int T1 = n3 > 1 ? 8 : 16, T2 = T1, T3 = n3 > 1 ? 8 : 1;
@@ -792,45 +796,90 @@ int analyse_blocks(const HostPattern &H, const int64_t dims[3], const int skew[9
                   c3 = skew[6] * x + skew[7] * y + skew[8] * z;
     return ((c3 / T3) * B2 + c2 / T2) * B1 + c1 / T1;
   };
-  auto block_of = [&](int64_t i) {
-    const int64_t z = i / s2, r = i - z * s2, y = r / n1, x = r - y * n1;
-    return slot_of_xyz(x, y, z);
-  };
+  P.nslots = nslots;
   // the rows of every block slot, ascending (counting sort by slot; the rows' coordinates from a running counter)
-  std::vector<int64_t> slot_ptr((size_t)nslots + 1, 0);
-  std::vector<int32_t> slot_rows((size_t)n);
+  P.slot_ptr.assign((size_t)nslots + 1, 0);
+  P.slot_rows.assign((size_t)n, 0);
+  P.slot_of_row.assign((size_t)n, 0);
   {
-    std::vector<int32_t> slot_of_row((size_t)n);
     int64_t x = 0, y = 0, z = 0;
     for (int64_t i = 0; i < n; ++i) {
       const int64_t sl = slot_of_xyz(x, y, z);
-      slot_of_row[(size_t)i] = (int32_t)sl;
-      slot_ptr[(size_t)sl + 1]++;
+      P.slot_of_row[(size_t)i] = (int32_t)sl;
+      P.slot_ptr[(size_t)sl + 1]++;
       if (++x == n1) { x = 0; if (++y == n2) { y = 0; ++z; } }
     }
-    for (int64_t b = 0; b < nslots; ++b) slot_ptr[(size_t)b + 1] += slot_ptr[(size_t)b];
-    std::vector<int64_t> cur(slot_ptr.begin(), slot_ptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i) slot_rows[(size_t)cur[(size_t)slot_of_row[(size_t)i]]++] = (int32_t)i;
+    for (int64_t b = 0; b < nslots; ++b) P.slot_ptr[(size_t)b + 1] += P.slot_ptr[(size_t)b];
+    std::vector<int64_t> cur(P.slot_ptr.begin(), P.slot_ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) P.slot_rows[(size_t)cur[(size_t)P.slot_of_row[(size_t)i]]++] = (int32_t)i;
   }
   // ticket order: wavefronts of the block grid (mirrored for the upper solve), slot number inside a wavefront; empty slots
   // (the corners of the skewed box) get no ticket
-  std::vector<int32_t> order, ticket_of((size_t)nslots, -1);
-  {
-    std::vector<int64_t> cnt((size_t)(B1 + B2 + B3), 0);
-    auto wave = [&](int64_t b) {
-      const int64_t bz = b / (B1 * B2), r = b - bz * B1 * B2, by = r / B1, bx = r - by * B1;
-      return upper ? (B1 - 1 - bx) + (B2 - 1 - by) + (B3 - 1 - bz) : bx + by + bz;
-    };
-    for (int64_t b = 0; b < nslots; ++b) if (slot_ptr[(size_t)b + 1] > slot_ptr[(size_t)b]) cnt[(size_t)wave(b) + 1]++;
-    for (size_t w = 1; w < cnt.size(); ++w) cnt[w] += cnt[w - 1];
-    order.assign((size_t)cnt.back(), 0);
-    for (int64_t b = 0; b < nslots; ++b) {
-      if (slot_ptr[(size_t)b + 1] == slot_ptr[(size_t)b]) continue;
-      const int64_t t = cnt[(size_t)wave(b)]++;
-      order[(size_t)t] = (int32_t)b;
-      ticket_of[(size_t)b] = (int32_t)t;
+  P.ticket_of.assign((size_t)nslots, -1);
+  std::vector<int64_t> cnt((size_t)(B1 + B2 + B3), 0);
+  auto wave = [&](int64_t b) {
+    const int64_t bz = b / (B1 * B2), r = b - bz * B1 * B2, by = r / B1, bx = r - by * B1;
+    return upper ? (B1 - 1 - bx) + (B2 - 1 - by) + (B3 - 1 - bz) : bx + by + bz;
+  };
+  for (int64_t b = 0; b < nslots; ++b) if (P.slot_ptr[(size_t)b + 1] > P.slot_ptr[(size_t)b]) cnt[(size_t)wave(b) + 1]++;
+  for (size_t w = 1; w < cnt.size(); ++w) cnt[w] += cnt[w - 1];
+  P.order.assign((size_t)cnt.back(), 0);
+  for (int64_t b = 0; b < nslots; ++b) {
+    if (P.slot_ptr[(size_t)b + 1] == P.slot_ptr[(size_t)b]) continue;
+    const int64_t t = cnt[(size_t)wave(b)]++;
+    P.order[(size_t)t] = (int32_t)b;
+    P.ticket_of[(size_t)b] = (int32_t)t;
+  }
+  return KHIP_OK;
+}
+
+// No grid: blocks are pieces of the level-sorted row sequence (perm, level pointers lvl) -- a level of 64 rows or more is cut
+// into blocks of 64 rows (one local level, one row per lane), consecutive narrower levels are merged into a block while it
+// stays within kBlkRows rows and 48 levels.  A row's dependencies lie in earlier levels, i.e. in earlier blocks or in its
+// own: the sequence order is topological.  Instead of one kernel boundary per level, a level costs the flag round trip
+// between two blocks, and only between blocks that really depend on each other.
+int make_level_partition(int64_t n, const std::vector<int32_t> &perm, const std::vector<int64_t> &lvl, Partition &P) {
+  const int nl = (int)lvl.size() - 1;
+  P.slot_ptr.assign(1, 0);
+  P.slot_rows.assign(perm.begin(), perm.end());
+  P.slot_of_row.assign((size_t)n, 0);
+  int64_t cur_rows = 0;
+  int cur_levels = 0;
+  auto close = [&](int64_t end) { if (end > P.slot_ptr.back()) P.slot_ptr.push_back(end); cur_rows = 0; cur_levels = 0; };
+  for (int l = 0; l < nl; ++l) {
+    const int64_t a = lvl[(size_t)l], b = lvl[(size_t)l + 1], w = b - a;
+    if (w >= kBlkThreads) {
+      close(a);
+      for (int64_t q = a; q < b; q += kBlkThreads) close(std::min<int64_t>(q + kBlkThreads, b));
+    } else {
+      if (cur_rows + w > kBlkRows || cur_levels >= 48) close(a);
+      cur_rows += w;
+      ++cur_levels;
     }
   }
+  close(n);
+  P.nslots = (int64_t)P.slot_ptr.size() - 1;
+  if (P.nslots > (int64_t)1 << 30) return KHIP_ERR_INVALID;
+  P.order.resize((size_t)P.nslots);
+  P.ticket_of.resize((size_t)P.nslots);
+  for (int64_t b = 0; b < P.nslots; ++b) {
+    P.order[(size_t)b] = P.ticket_of[(size_t)b] = (int32_t)b;
+    std::sort(P.slot_rows.begin() + P.slot_ptr[(size_t)b], P.slot_rows.begin() + P.slot_ptr[(size_t)b + 1]);      // ascending inside a block
+    for (int64_t q = P.slot_ptr[(size_t)b]; q < P.slot_ptr[(size_t)b + 1]; ++q) P.slot_of_row[(size_t)P.slot_rows[(size_t)q]] = (int32_t)b;
+  }
+  return KHIP_OK;
+}
+
+int analyse_blocks(const HostPattern &H, const Partition &part, bool upper, HostBlocks &hb) {
+  std::vector<IluBlockHdr> &hdr = hb.hdr;
+  std::vector<int32_t> &row_gid = hb.row_gid, &ext_gid = hb.ext_gid, &dep = hb.dep, &src = hb.src, &diag_src = hb.diag_src, &rec_src = hb.rec_src;
+  std::vector<uint16_t> &row_eptr = hb.row_eptr, &lvl = hb.lvl, &ent_slot = hb.ent_slot;
+  std::vector<unsigned long long> &rec_meta = hb.rec_meta;
+  bool &rec_ok = hb.rec_ok;
+  const int64_t n = H.n;
+  const std::vector<int64_t> &slot_ptr = part.slot_ptr;
+  const std::vector<int32_t> &slot_rows = part.slot_rows, &order = part.order, &ticket_of = part.ticket_of;
+  auto block_of = [&](int64_t i) { return (int64_t)part.slot_of_row[(size_t)i]; };
   const int64_t nb = (int64_t)order.size();
   hdr.assign((size_t)nb, IluBlockHdr());
   row_gid.reserve((size_t)n);
@@ -1099,12 +1148,20 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
   // ---- block schedule of the solves where the pattern is a structured grid (else: level scheduling) ----
   if (ctx->tune.ilu_blocks != 0) {
     const HostPattern H{n, col, row_lo, diag, row_hi};
-    if (detect_grid(H, P->grid_dims, P->grid_skew)) {
+    const bool grid = ctx->tune.ilu_blocks != 3 && detect_grid(H, P->grid_dims, P->grid_skew);      // 3: level-sequence blocks even on a grid (for comparison)
+    // without a grid: blocks from the level-sorted row sequence, where the levels are wide enough to be worth a flag each
+    const int64_t nlev = (int64_t)P->lvl_lo.size() - 1 + (int64_t)P->lvl_up.size() - 1;
+    if (grid || (n >= 4096 && nlev > 0 && 2 * n / nlev >= 32)) {
       KHIP_CHECK_HIP(hipMalloc(&P->blk_fail, sizeof(int)));
       KHIP_CHECK_HIP(hipMemsetAsync(P->blk_fail, 0, sizeof(int), ctx->stream));
       HostBlocks hlo, hup;                     // the two triangles are analysed side by side (pure host work)
       auto analyse = [&](bool upper, HostBlocks &hb) {           // host memory may run out on a very large slab: then level scheduling
-        try { hb.rc = analyse_blocks(H, P->grid_dims, P->grid_skew, upper, hb); } catch (const std::exception &) { hb.rc = KHIP_ERR_INVALID; }
+        try {
+          Partition part;
+          hb.rc = grid ? make_grid_partition(H, P->grid_dims, P->grid_skew, upper, part)
+                       : make_level_partition(n, upper ? perm_up : perm_lo, upper ? P->lvl_up : P->lvl_lo, part);
+          if (hb.rc == KHIP_OK) hb.rc = analyse_blocks(H, part, upper, hb);
+        } catch (const std::exception &) { hb.rc = KHIP_ERR_INVALID; }
       };
       std::thread tup(analyse, true, std::ref(hup));
       analyse(false, hlo);

@@ -75,7 +75,7 @@ struct Tuning {
   int mgs_keep = -1;        // MGS cascade: keep q and the freshly dotted basis vector cacheable for the next step (-1 auto: when they fit the Infinity Cache; 0 off; 1 on; 2 nothing streamed)
   int hist_window = 1 << 14;   // device-resident loops: residual-history entries kept on the device between drains
   int red_u = 0;            // reductions: 16-byte accesses per lane (0 auto: 4 for long vectors, else 1)
-  int ilu_blocks = 1;        // ILU(0) solves: block schedule where the pattern is a structured grid (0: level scheduling always; 2: block schedule on packed entry lists only, no row records)
+  int ilu_blocks = 1;        // ILU(0) solves: block schedule where the pattern is a structured grid (0: level scheduling always; 2: block schedule on packed entry lists only, no row records; 3: blocks from the level-sorted row sequence even where a grid is recognised)
   int panel_multi_tiles = 2; // X += sum V_i Y_i: factor blocks in LDS, this many 16-row tiles per wave (0 = the one-tile kernel that re-reads the factors per tile)
   int panel_signs = 1;      // panel QR: LAPACK's Householder signs / tau from the top p x p block (block.cpp); 0 = positive diagonal of R
   int panel_fuse = 1;       // block Gram-Schmidt: apply Psi_i and form Psi_{i+1} in one pass (panel.hip, single rank)

@@ -221,8 +221,11 @@ def test_ilu0_block_schedule_bit_identical(K, ctx, oracle, gen, args):
         assert Pp.block_info()[1] > 0 and Pp.block_info()[2] == 0
 
 
-def test_ilu0_block_schedule_not_taken_for_other_patterns(K, ctx, oracle):
-    """A pattern that is no grid in natural ordering (a random symmetric permutation of one) keeps level scheduling."""
+@pytest.mark.parametrize("blocks", [1, 2])
+def test_ilu0_block_schedule_without_a_grid(K, ctx, oracle, blocks):
+    """A pattern that is no grid in natural ordering (a random symmetric permutation of one): the blocks are pieces of the
+    level-sorted row sequence (dims 0, 0, 0 but blocks > 0) -- on row records and on the packed lists -- and y is still the
+    oracle's, bit for bit.  A chain (levels of one row) keeps level scheduling: see the next test."""
     import scipy.sparse as sp
     A = oracle.poisson3d(16)
     S = A.to_scipy().tocsr()
@@ -230,12 +233,24 @@ def test_ilu0_block_schedule_not_taken_for_other_patterns(K, ctx, oracle):
     Sp = S[perm][:, perm].tocsr(); Sp.sort_indices()
     Ap = oracle.CsrMatrix.from_arrays(Sp.indptr.astype(np.int64), Sp.indices.astype(np.int32), Sp.data)
     dA = _upload(K, ctx, Ap)
-    P = K.Ilu0(dA)
-    assert P.block_info()[:2] == ((0, 0, 0), 0)
-    x = np.linspace(-1, 1, A.n)
-    dy = ctx.empty(A.n)
-    P(ctx.array(x), dy)
-    assert np.array_equal(dy.to_host(), oracle.Ilu0(Ap).solve(x))
+    ctx.set_option("ilu_blocks", blocks)
+    try:
+        P = K.Ilu0(dA)
+    finally:
+        ctx.set_option("ilu_blocks", 1)
+    dims, nb, failed = P.block_info()
+    assert dims == (0, 0, 0) and nb > 0 and failed == 0, (dims, nb, failed)
+    ref = oracle.Ilu0(Ap)
+    assert np.array_equal(P.values(), ref.lu)
+    for seed in range(3):
+        x = np.random.default_rng(seed).standard_normal(A.n)
+        dy = ctx.empty(A.n)
+        P(ctx.array(x), dy)
+        assert np.array_equal(dy.to_host(), ref.solve(x))
+    assert P.block_info()[2] == 0
+    T = oracle.tridiag(5000, -1.0, 2.5, -1.5)                  # a chain: levels of one row, no blocks
+    Pt = K.Ilu0(_upload(K, ctx, T))
+    assert Pt.block_info()[:2] == ((0, 0, 0), 0)
 
 
 @pytest.mark.parametrize("records", [1, 2])
