@@ -780,8 +780,9 @@ class Ilu0:
         return lo.value, up.value
 
     def block_info(self):
-        """(grid dims the pattern was recognised as, or (0, 0, 0): level scheduling; blocks per triangle; 1 if a bounded spin
-        of the block schedule ever gave up).  Synchronises."""
+        """(grid dims the pattern was recognised as, or (0, 0, 0); blocks per triangle -- 0: level scheduling, > 0 with dims
+        (0, 0, 0): blocks from the level-sorted row sequence; 1 if a bounded spin of the block schedule ever gave up).
+        Synchronises."""
         dims, nb, failed = (_i64 * 3)(), _i64(), _int()
         _ck(lib().khip_ilu0_block_info(C.byref(self.op), dims, C.byref(nb), C.byref(failed)))
         return tuple(dims), nb.value, failed.value
