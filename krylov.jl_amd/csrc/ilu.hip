@@ -206,7 +206,7 @@ struct IluBlkArgs {
   const uint16_t *row_eptr;            // [n + nb]: per block nrows + 1 local entry offsets, at row0 + ticket
   const uint16_t *lvl;
   const int32_t *ext_gid, *dep;
-  const uint16_t *ent_slot;            // per packed entry: local row (< kBlkRows) or kBlkRows + index into the block's ext list
+  const uint16_t *ent_slot;            // per packed entry: local row (< rows_cap) or rows_cap + index into the block's ext list
   const double *ent_val;
   const double *diag_val;              // upper solve: lu[diag] per row, in block order
   const double *rec;                   // row records (kRecDoubles per row, block order) where every row has <= 3 entries, else null
@@ -215,6 +215,7 @@ struct IluBlkArgs {
   unsigned *ticket;
   int *fail;
   int nb, max_ent, max_ext, max_lvl;
+  int rows_cap;                        // rows of the largest block, rounded up to the wave: the LDS arrays and the slot numbers are laid out for it
 };
 
 template <int KIND>     // 1: lower solve y = L^{-1} x, 2: upper solve y = U^{-1} y
@@ -222,14 +223,15 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
                                                                        unsigned ticket_base) {
   extern __shared__ double ilu_sm[];
   __shared__ int s_ticket;
-  double *yl = ilu_sm;                                      // [kBlkRows + max_ext + 1]: y of the block's rows, of the ext list, a spare
-  double *xv = yl + kBlkRows + a.max_ext + 1;               // [kBlkRows]: right-hand side
-  double *dv = xv + kBlkRows;                               // [kBlkRows]: pivots (upper solve)
-  double *ev = dv + (KIND == 2 ? kBlkRows : 0);             // [max_ent]
+  const int RC = a.rows_cap;                                // <= kBlkRows
+  double *yl = ilu_sm;                                      // [RC + max_ext + 1]: y of the block's rows, of the ext list, a spare
+  double *xv = yl + RC + a.max_ext + 1;                     // [RC]: right-hand side
+  double *dv = xv + RC;                                     // [RC]: pivots (upper solve)
+  double *ev = dv + (KIND == 2 ? RC : 0);                   // [max_ent]
   uint16_t *es = reinterpret_cast<uint16_t *>(ev + a.max_ent);   // [max_ent rounded up to 4]
-  uint16_t *ep = es + ((a.max_ent + 3) & ~3);               // [kBlkRows + 2]
-  uint16_t *lv = ep + kBlkRows + 2;                         // [max_lvl + 2]
-  int32_t *gl = reinterpret_cast<int32_t *>(lv + ((a.max_lvl + 2 + 1) & ~1));      // [kBlkRows]: row numbers (general path)
+  uint16_t *ep = es + ((a.max_ent + 3) & ~3);               // [RC + 2]
+  uint16_t *lv = ep + RC + 2;                               // [max_lvl + 2]
+  int32_t *gl = reinterpret_cast<int32_t *>(lv + ((a.max_lvl + 2 + 1) & ~1));      // [RC]: row numbers (general path)
   const int lane = threadIdx.x;
   for (;;) {
     // lane 0 draws the ticket; every lane reads it back from LDS
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
 #pragma unroll
       for (int u = 0; u < kBlkRows / kBlkThreads; ++u) {
         const int r = u * kBlkThreads + lane;
-        gid[u] = a.row_gid[h.row0 + (r < h.nrows ? r : 0)];
+        gid[u] = a.row_gid[h.row0 + (r < h.nrows ? r : 0)];       // no branch around a load: all of them are in flight together
       }
       double xs[kBlkRows / kBlkThreads];
 #pragma unroll
@@ -339,10 +341,10 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
 #pragma unroll
       for (int u = 0; u < kExtRegs; ++u) {
         const int k = u * kBlkThreads + lane;
-        if (k < h.next) yl[kBlkRows + k] = ye[u];
+        if (k < h.next) yl[RC + k] = ye[u];
       }
       for (int k = kExtRegs * kBlkThreads + lane; k < h.next; k += kBlkThreads)       // more than 1024 face rows
-        yl[kBlkRows + k] = __hip_atomic_load(y + a.ext_gid[h.ext0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        yl[RC + k] = __hip_atomic_load(y + a.ext_gid[h.ext0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     ILU_STAMP(3);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       // one row per lane and level; the row's record and right-hand side are read one level AHEAD (they do not depend on y),
       // so a level costs one dependent LDS round trip: the (at most three) y values
       const dbl2 *recs = reinterpret_cast<const dbl2 *>(ev);
-      if (lane == 0) yl[kBlkRows + kRecExtCap - 2] = 0.0;
+      if (lane == 0) yl[RC + kRecExtCap - 2] = 0.0;
       auto row_of = [&](int l) {                                    // this lane's row of level l, or -1
         const int r = __builtin_amdgcn_readlane(my_lv, l) + lane;
         return r < __builtin_amdgcn_readlane(my_lv, l + 1) ? r : -1;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
         const double t2 = c1.x * y2;
         acc = acc - t2;
         const double yv = KIND == 2 ? acc / c1.y : acc;
-        yl[r >= 0 ? r : kBlkRows + kRecExtCap - 1] = yv;        // idle lanes write the dump slot: no branch
+        yl[r >= 0 ? r : RC + kRecExtCap - 1] = yv;              // idle lanes write the dump slot: no branch
         // ... and through the L2 to y at once: the stores are in flight while the remaining levels run, instead of a separate
         // pass over the block at the end whose latency sits on the critical path of the block wavefronts
         if (r >= 0) __hip_atomic_store(y + (long long)__double_as_longlong(c2.y), yv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       // rows with 4..16 entries: the same walk as above on 176-byte records -- 16 values (absent: 0.0), 16 slots (absent: the
       // slot of a constant 0.0), pivot, row number -- read with eleven 16-byte LDS loads one level ahead
       const dbl2 *recs = reinterpret_cast<const dbl2 *>(ev);
-      const int zero_slot = kBlkRows + a.max_ext - 2, dump_slot = kBlkRows + a.max_ext - 1;
+      const int zero_slot = RC + a.max_ext - 2, dump_slot = RC + a.max_ext - 1;
       if (lane == 0) yl[zero_slot] = 0.0;
       auto row_of = [&](int l) {
         const int r = __builtin_amdgcn_readlane(my_lv, l) + lane;
@@ -530,7 +532,7 @@ struct khip_ilu0 {
   int *bad_row = nullptr;
   // block schedule (structured grids; see ilu_block_solve_kernel): one per triangle
   struct Blocks {
-    int nb = 0, max_ent = 0, max_ext = 0, max_lvl = 0, grid = 0;
+    int nb = 0, max_ent = 0, max_ext = 0, max_lvl = 0, grid = 0, rows_cap = kBlkRows;
     IluBlockHdr *hdr = nullptr;
     int32_t *row_gid = nullptr, *ext_gid = nullptr, *dep = nullptr;
     uint16_t *row_eptr = nullptr, *lvl = nullptr, *ent_slot = nullptr;
@@ -594,7 +596,7 @@ int enqueue_solve(khip_ilu0 *P, const double *x, double *y) {
 template <int KIND>
 int launch_blocks(khip_ilu0 *P, khip_ilu0::Blocks &B, const double *x, double *y) {
   IluBlkArgs a{B.hdr, B.row_gid, B.row_eptr, B.lvl, B.ext_gid, B.dep, B.ent_slot, B.ent_val, B.diag_val, B.rec, B.recw, B.done, B.ticket,
-               P->blk_fail, B.nb, B.max_ent, B.max_ext, B.max_lvl};
+               P->blk_fail, B.nb, B.max_ent, B.max_ext, B.max_lvl, B.rows_cap};
   ++B.epoch;
   hipLaunchKernelGGL((ilu_block_solve_kernel<KIND>), dim3((unsigned)B.grid), dim3(kBlkThreads), B.lds, P->ctx->stream, a, x, y, B.epoch,
                      B.ticket_base);
@@ -771,7 +773,7 @@ struct HostBlocks {            // what the analysis of one triangle produces (ho
   std::vector<unsigned long long> rec_meta;
   bool rec_ok = true;
   int64_t nb = 0;
-  int max_ent = 0, max_ext = 0, max_lvl = 0, max_row_ent = 0, rc = KHIP_OK;
+  int max_ent = 0, max_ext = 0, max_lvl = 0, max_row_ent = 0, rows_cap = kBlkRows, rc = KHIP_OK;
 };
 
 // A partition of the rows into blocks and an order of the blocks in which every block depends on earlier ones only.
@@ -780,6 +782,7 @@ struct Partition {
   std::vector<int64_t> slot_ptr;                 // rows of slot b: slot_rows[slot_ptr[b] .. slot_ptr[b + 1]), ascending
   std::vector<int32_t> slot_rows, slot_of_row;
   std::vector<int32_t> order, ticket_of;         // ticket -> slot, slot -> ticket (-1: empty slot)
+  int rows_cap = kBlkRows;                       // rows of the largest block, rounded up to a multiple of the wave
 };
 
 // cubes of 8 x 8 x 8 lattice points of the basis detect_grid found (16 x 16 on a 2-D grid), in wavefront order
@@ -797,6 +800,7 @@ int make_grid_partition(const HostPattern &H, const int64_t dims[3], const int s
     return ((c3 / T3) * B2 + c2 / T2) * B1 + c1 / T1;
   };
   P.nslots = nslots;
+  P.rows_cap = std::min(kBlkRows, (T1 * T2 * T3 + kBlkThreads - 1) / kBlkThreads * kBlkThreads);
   // the rows of every block slot, ascending (counting sort by slot; the rows' coordinates from a running counter)
   P.slot_ptr.assign((size_t)nslots + 1, 0);
   P.slot_rows.assign((size_t)n, 0);
@@ -835,9 +839,11 @@ int make_grid_partition(const HostPattern &H, const int64_t dims[3], const int s
 
 // No grid: blocks are pieces of the level-sorted row sequence (perm, level pointers lvl) -- a level of 64 rows or more is cut
 // into blocks of 64 rows (one local level, one row per lane), consecutive narrower levels are merged into a block while it
-// stays within kBlkRows rows and 48 levels.  A row's dependencies lie in earlier levels, i.e. in earlier blocks or in its
+// stays within kLevelMergeRows rows and 48 levels.  A row's dependencies lie in earlier levels, i.e. in earlier blocks or in its
 // own: the sequence order is topological.  Instead of one kernel boundary per level, a level costs the flag round trip
 // between two blocks, and only between blocks that really depend on each other.
+constexpr int kLevelMergeRows = 512;    // (128 -- smaller LDS footprint, more workgroups per CU -- was no faster: the path is bound by the chain of flags)
+
 int make_level_partition(int64_t n, const std::vector<int32_t> &perm, const std::vector<int64_t> &lvl, Partition &P) {
   const int nl = (int)lvl.size() - 1;
   P.slot_ptr.assign(1, 0);
@@ -852,7 +858,7 @@ int make_level_partition(int64_t n, const std::vector<int32_t> &perm, const std:
       close(a);
       for (int64_t q = a; q < b; q += kBlkThreads) close(std::min<int64_t>(q + kBlkThreads, b));
     } else {
-      if (cur_rows + w > kBlkRows || cur_levels >= 48) close(a);
+      if (cur_rows + w > kLevelMergeRows || cur_levels >= 48) close(a);
       cur_rows += w;
       ++cur_levels;
     }
@@ -862,6 +868,9 @@ int make_level_partition(int64_t n, const std::vector<int32_t> &perm, const std:
   if (P.nslots > (int64_t)1 << 30) return KHIP_ERR_INVALID;
   P.order.resize((size_t)P.nslots);
   P.ticket_of.resize((size_t)P.nslots);
+  int64_t biggest = 0;
+  for (int64_t b = 0; b < P.nslots; ++b) biggest = std::max(biggest, P.slot_ptr[(size_t)b + 1] - P.slot_ptr[(size_t)b]);
+  P.rows_cap = (int)std::min<int64_t>(kBlkRows, (biggest + kBlkThreads - 1) / kBlkThreads * kBlkThreads);
   for (int64_t b = 0; b < P.nslots; ++b) {
     P.order[(size_t)b] = P.ticket_of[(size_t)b] = (int32_t)b;
     std::sort(P.slot_rows.begin() + P.slot_ptr[(size_t)b], P.slot_rows.begin() + P.slot_ptr[(size_t)b + 1]);      // ascending inside a block
@@ -880,6 +889,8 @@ int analyse_blocks(const HostPattern &H, const Partition &part, bool upper, Host
   const std::vector<int64_t> &slot_ptr = part.slot_ptr;
   const std::vector<int32_t> &slot_rows = part.slot_rows, &order = part.order, &ticket_of = part.ticket_of;
   auto block_of = [&](int64_t i) { return (int64_t)part.slot_of_row[(size_t)i]; };
+  const int RC = part.rows_cap;
+  hb.rows_cap = RC;
   const int64_t nb = (int64_t)order.size();
   hdr.assign((size_t)nb, IluBlockHdr());
   row_gid.reserve((size_t)n);
@@ -949,7 +960,7 @@ int analyse_blocks(const HostPattern &H, const Partition &part, bool upper, Host
             const int32_t tj = ticket_of[(size_t)block_of(j)];
             if (std::find(deps_here.begin(), deps_here.end(), tj) == deps_here.end()) deps_here.push_back(tj);
           }
-          slot = kBlkRows + ext_mark[(size_t)j];
+          slot = RC + ext_mark[(size_t)j];
         }
         ent_slot.push_back((uint16_t)slot);
         src.push_back(q);
@@ -959,7 +970,7 @@ int analyse_blocks(const HostPattern &H, const Partition &part, bool upper, Host
       }
       if (in_row > 3) rec_ok = false;
       hb.max_row_ent = std::max(hb.max_row_ent, in_row);
-      for (int kq = in_row; kq < 3; ++kq) meta |= (unsigned long long)(kBlkRows + kRecExtCap - 2) << (16 * kq);   // absent: the 0.0 slot
+      for (int kq = in_row; kq < 3; ++kq) meta |= (unsigned long long)(RC + kRecExtCap - 2) << (16 * kq);   // absent: the 0.0 slot
       rec_meta.push_back(meta | (unsigned long long)std::min(in_row, 3) << 48);
     }
     row_eptr.push_back((uint16_t)ne);
@@ -970,7 +981,7 @@ int analyse_blocks(const HostPattern &H, const Partition &part, bool upper, Host
     }
     for (int32_t k = h.ext0; k < h.ext0 + h.next; ++k) ext_mark[(size_t)ext_gid[(size_t)k]] = -1;
     for (int k = 0; k < nr; ++k) lpos[(size_t)sorted[(size_t)k]] = -1;
-    if (nr > kBlkRows || ne > 60000 || kBlkRows + h.next > 65535) return KHIP_ERR_INVALID;
+    if (nr > RC || ne > 60000 || RC + h.next > 65535) return KHIP_ERR_INVALID;
     max_ent = std::max(max_ent, ne); max_ext = std::max(max_ext, h.next); max_lvl = std::max(max_lvl, nl);
   }
   hb.nb = nb; hb.max_ent = max_ent; hb.max_ext = max_ext; hb.max_lvl = max_lvl;
@@ -988,19 +999,21 @@ int upload_blocks(khip_ilu0 *P, bool upper, HostBlocks &hb, khip_ilu0::Blocks &B
   bool rec_ok = hb.rec_ok;
   int max_ent = hb.max_ent, max_ext = hb.max_ext, max_lvl = hb.max_lvl;
   if (max_ext > kRecExtCap - 2 || ctx->tune.ilu_blocks == 2) rec_ok = false;      // ilu_blocks = 2: packed lists only (tests)
-  const bool wide = !rec_ok && ctx->tune.ilu_blocks != 2 && hb.max_row_ent <= 16 && (size_t)kBlkRows + max_ext + 2 < 65535;
+  const int RC = hb.rows_cap;
+  const bool wide = !rec_ok && ctx->tune.ilu_blocks != 2 && hb.max_row_ent <= 16 && (size_t)RC + max_ext + 2 < 65535;
   if (wide) {
-    max_ent = std::max(max_ent, kBlkRows * kWideDoubles);           // the wide records share the LDS region of the packed entries
+    max_ent = std::max(max_ent, RC * kWideDoubles);                 // the wide records share the LDS region of the packed entries
     max_ext += 2;                                                   // ... and the y array gets a 0.0 and a dump slot behind the faces
     B.want_wide = true;
   }
   if (rec_ok) {
-    max_ent = std::max(max_ent, kBlkRows * kRecDoubles);            // the records share the LDS region of the packed entries
+    max_ent = std::max(max_ent, RC * kRecDoubles);                  // the records share the LDS region of the packed entries
     max_ext = kRecExtCap;                                           // ... and the y array has its fixed 0.0 and dump slots
   }
   B.nb = (int)nb; B.max_ent = max_ent; B.max_ext = max_ext; B.max_lvl = max_lvl;
-  B.lds = sizeof(double) * ((size_t)kBlkRows + max_ext + 1 + kBlkRows + (upper ? kBlkRows : 0) + max_ent) +
-          sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + kBlkRows + 2 + ((max_lvl + 2 + 1) & ~1)) + sizeof(int32_t) * kBlkRows;
+  B.rows_cap = RC;
+  B.lds = sizeof(double) * ((size_t)RC + max_ext + 1 + RC + (upper ? RC : 0) + max_ent) +
+          sizeof(uint16_t) * ((size_t)((max_ent + 3) & ~3) + RC + 2 + ((max_lvl + 2 + 1) & ~1)) + sizeof(int32_t) * RC;
   if (B.lds > (size_t)150 * 1024) return KHIP_ERR_INVALID;
   bool all_fast = rec_ok;                         // every block on the row-record path: the packed entry arrays are not needed
   for (const IluBlockHdr &hh : hdr) all_fast = all_fast && hh.pad != 0;
@@ -1035,7 +1048,7 @@ int upload_blocks(khip_ilu0 *P, bool upper, HostBlocks &hb, khip_ilu0::Blocks &B
   const void *fn = upper ? (const void *)ilu_block_solve_kernel<2> : (const void *)ilu_block_solve_kernel<1>;
   if (B.lds > 64 * 1024) KHIP_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B.lds));
   int per_cu = (int)((size_t)(160 * 1024) / std::max<size_t>(B.lds, 1));
-  per_cu = std::max(1, std::min(per_cu, 8));
+  per_cu = std::max(1, std::min(per_cu, 16));
   B.grid = (int)std::min<int64_t>(nb, (int64_t)ctx->num_cu * per_cu);
   return KHIP_OK;
 }
@@ -1061,7 +1074,7 @@ int pack_block_values(khip_ilu0 *P, khip_ilu0::Blocks &B, const std::vector<int3
   if (B.want_wide && B.ent_val && B.nb > 0) {
     KHIP_CHECK_HIP(hipMalloc(&B.recw, sizeof(double) * (size_t)std::max<int64_t>(P->n, 1) * kWideDoubles));
     hipLaunchKernelGGL(ilu_pack_wide_kernel, dim3((unsigned)B.nb), dim3(kBlkThreads), 0, ctx->stream, B.hdr, B.row_eptr, B.ent_val, B.ent_slot,
-                       P->lu, P->diag, B.row_gid, kBlkRows + B.max_ext - 2, B.recw);
+                       P->lu, P->diag, B.row_gid, B.rows_cap + B.max_ext - 2, B.recw);
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   }
   KHIP_CHECK_HIP(hipGetLastError());
