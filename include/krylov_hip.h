@@ -309,6 +309,11 @@ int khip_ilu0_set_graph(khip_operator *op, int enable);
  * = 2 runs the block schedule on packed entry lists only (no row records; for tests), = 3 takes the blocks from the level-sorted
  * row sequence even where a grid is recognised (what patterns without a grid get: dims3 = 0, 0, 0 but blocks > 0). */
 int khip_ilu0_block_info(const khip_operator *op, int64_t *dims3, int64_t *blocks, int *failed);
+/* test-only, host-only: the analysis behind the block schedule on a CSR pattern in host memory (no device; checks that
+ * every row lands in exactly one block and no block depends on a later one).  mode 1 = as khip_ilu0_create, 3 = level
+ * sequence.  out10 = grid dims[3], skewed basis, blocks lower / upper, largest face list, 48-byte records possible,
+ * largest row, rows of the largest block rounded up to the wave. */
+int khip_test_ilu_blocks_host(int64_t n, const int64_t *rowptr, const int32_t *col, int mode, int64_t *out10);
 
 typedef int (*khip_callback_fn)(void *workspace, void *userdata);       /* callback(workspace)::Bool */
 

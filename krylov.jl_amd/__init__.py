@@ -111,6 +111,7 @@ SIGNATURES = {
     "khip_ilu0_info": (_int, [C.POINTER(COperator), C.POINTER(_i64), C.POINTER(_i64), c_void_pp]),
     "khip_ilu0_set_graph": (_int, [C.POINTER(COperator), _int]),
     "khip_ilu0_block_info": (_int, [C.POINTER(COperator), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
+    "khip_test_ilu_blocks_host": (_int, [_i64, C.POINTER(_i64), C.POINTER(C.c_int32), _int, C.POINTER(_i64)]),
     "khip_spmv_dot": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
     "khip_axpy2_dot": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),

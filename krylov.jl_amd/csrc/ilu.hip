@@ -1237,6 +1237,60 @@ int khip_debug_ilu_trace(unsigned long long *out512) {
 }
 #endif
 
+// Host-only check of the block schedule's analysis (no device needed: tests/test_ilu_blocks_host.py): the pattern as CSR
+// with sorted columns and a diagonal in every row; mode 1 = as khip_ilu0_create would (grid if recognised, else the level
+// sequence), 3 = level sequence.  out: [0..2] grid dims (0 if none), [3] 1 = skewed basis, [4] blocks lower, [5] blocks upper,
+// [6] largest face list, [7] 1 = 48-byte records possible (lower), [8] largest row (entries in a triangle), [9] rows_cap.
+// Returns KHIP_ERR_INVALID if a block would depend on a later one (the analysis checks every dependency).
+int khip_test_ilu_blocks_host(int64_t n, const int64_t *rowptr, const int32_t *colidx, int mode, int64_t *out10) {
+  KHIP_REQUIRE(n > 0 && rowptr && colidx && out10, "test_ilu_blocks_host: bad arguments");
+  const int64_t nnz = rowptr[n];
+  std::vector<int32_t> col(colidx, colidx + nnz), row_lo((size_t)n), diag((size_t)n), row_hi((size_t)n), lev_lo((size_t)n), lev_up((size_t)n);
+  int32_t nlev_lo = 0, nlev_up = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t d = -1, lv = 0;
+    for (int64_t q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+      const int32_t j = col[(size_t)q];
+      if (j < 0 || j >= n || (q > rowptr[i] && col[(size_t)q - 1] >= j)) { set_error("test_ilu_blocks_host: row %lld not sorted", (long long)i); return KHIP_ERR_INVALID; }
+      if (j == i) d = (int32_t)q;
+      if (j < i) lv = std::max(lv, lev_lo[(size_t)j] + 1);
+    }
+    if (d < 0) { set_error("test_ilu_blocks_host: row %lld has no diagonal", (long long)i); return KHIP_ERR_INVALID; }
+    row_lo[(size_t)i] = (int32_t)rowptr[i]; diag[(size_t)i] = d; row_hi[(size_t)i] = (int32_t)rowptr[i + 1]; lev_lo[(size_t)i] = lv;
+    nlev_lo = std::max(nlev_lo, lv + 1);
+  }
+  for (int64_t i = n - 1; i >= 0; --i) {
+    int32_t lv = 0;
+    for (int32_t q = diag[(size_t)i] + 1; q < row_hi[(size_t)i]; ++q) lv = std::max(lv, lev_up[(size_t)col[(size_t)q]] + 1);
+    lev_up[(size_t)i] = lv;
+    nlev_up = std::max(nlev_up, lv + 1);
+  }
+  std::vector<int32_t> perm_lo, perm_up;
+  std::vector<int64_t> lvl_lo, lvl_up;
+  sort_by_level(lev_lo, nlev_lo, perm_lo, lvl_lo);
+  sort_by_level(lev_up, nlev_up, perm_up, lvl_up);
+  const HostPattern H{n, col, row_lo, diag, row_hi};
+  int64_t dims[3] = {0, 0, 0};
+  int skew[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const bool grid = mode != 3 && detect_grid(H, dims, skew);
+  for (int k = 0; k < 3; ++k) out10[k] = grid ? dims[k] : 0;
+  out10[3] = grid && skew[1] != 0;
+  HostBlocks hb[2];
+  for (int up = 0; up < 2; ++up) {
+    Partition part;
+    int rc = grid ? make_grid_partition(H, dims, skew, up != 0, part) : make_level_partition(n, up ? perm_up : perm_lo, up ? lvl_up : lvl_lo, part);
+    if (rc == KHIP_OK) rc = analyse_blocks(H, part, up != 0, hb[up]);
+    if (rc != KHIP_OK) return rc;
+    // every row in exactly one block
+    std::vector<char> seen((size_t)n, 0);
+    for (int32_t g : hb[up].row_gid) { if (g < 0 || g >= n || seen[(size_t)g]) { set_error("test_ilu_blocks_host: row %d twice or out of range", g); return KHIP_ERR_INVALID; } seen[(size_t)g] = 1; }
+    if ((int64_t)hb[up].row_gid.size() != n) { set_error("test_ilu_blocks_host: %lld of %lld rows in blocks", (long long)hb[up].row_gid.size(), (long long)n); return KHIP_ERR_INVALID; }
+  }
+  out10[4] = hb[0].nb; out10[5] = hb[1].nb; out10[6] = std::max(hb[0].max_ext, hb[1].max_ext); out10[7] = hb[0].rec_ok;
+  out10[8] = std::max(hb[0].max_row_ent, hb[1].max_row_ent); out10[9] = hb[0].rows_cap;
+  return KHIP_OK;
+}
+
 int khip_ilu0_set_graph(khip_operator *op, int enable) {
   KHIP_REQUIRE(op && op->apply == ilu0_apply && op->self, "ilu0_set_graph: not an ILU(0) operator");
   static_cast<khip_ilu0 *>(op->self)->use_graph = enable != 0;
