@@ -26,6 +26,7 @@
 #include <map>
 #include <functional>
 #include <thread>
+#include <unistd.h>
 
 #include "khip_internal.hpp"
 
@@ -1164,7 +1165,10 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
     const bool grid = ctx->tune.ilu_blocks != 3 && detect_grid(H, P->grid_dims, P->grid_skew);      // 3: level-sequence blocks even on a grid (for comparison)
     // without a grid: blocks from the level-sorted row sequence, where the levels are wide enough to be worth a flag each
     const int64_t nlev = (int64_t)P->lvl_lo.size() - 1 + (int64_t)P->lvl_up.size() - 1;
-    if (grid || (n >= 4096 && nlev > 0 && 2 * n / nlev >= 32)) {
+    // the analysis holds ~80 bytes per row and triangle in host memory (two triangles side by side): not on a host that is short
+    const long avail_pages = sysconf(_SC_AVPHYS_PAGES), page = sysconf(_SC_PAGESIZE);
+    const bool host_ok = avail_pages <= 0 || page <= 0 || (double)avail_pages * (double)page > 200.0 * (double)n;
+    if (host_ok && (grid || (n >= 4096 && nlev > 0 && 2 * n / nlev >= 32))) {
       KHIP_CHECK_HIP(hipMalloc(&P->blk_fail, sizeof(int)));
       KHIP_CHECK_HIP(hipMemsetAsync(P->blk_fail, 0, sizeof(int), ctx->stream));
       HostBlocks hlo, hup;                     // the two triangles are analysed side by side (pure host work)
