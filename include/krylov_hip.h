@@ -104,6 +104,15 @@ int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
  * codes operators of at least 4 M entries (smaller ones are latency bound and keep the int32 stream), 2 codes whatever the
  * size, 16 forces two-byte codes, 0 keeps the int32 stream (environment variable KHIP_SPMV_CODES sets the initial value).  ref: the product is kmul!(y, A, x), src/krylov_utils.jl:305. */
 int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
+/* Which SpMM kernel a product with 16 right-hand sides runs on this handle (csrc/spmm_tile.hip): *state = 1 when the handle
+ * keeps group records for the wave-private-window kernel (built by the first khip_spmm with p = 16; 0 before that, -1 when
+ * the operator lacks the locality and the other SpMM kernels are used); *window = distinct panel rows a group's LDS window
+ * holds; *grid_tiles = 1 when the 32-row groups are 4 x 4 x 2 tiles of a structured grid recognised from the pattern, 0 when
+ * they are 32 consecutive rows; *direct_groups of *groups go down the direct-gather path (a row longer than 32 entries, or
+ * more distinct columns than the window takes); *reuse = entries per distinct column of a group.  Y is bit-identical in
+ * every case; ctx option "spmm_tile" = 0 switches the kernel off.  ref: mul!(W, A, P), src/block_gmres.jl:242. */
+int khip_csr_tile_info(const khip_csr *A, int *state, int *window, int *grid_tiles, int64_t *groups, int64_t *direct_groups,
+                       double *reuse);
 /* How a distributed handle fetches the remote part of x before a product (csrc/comm.cpp; the reference's MPI recipe,
  * docs/src/custom_workspaces.md:517-521 and :583-586): *gather_mode = 0: only the entries this rank's columns reference
  * travel (grouped Send/Recv with the owning ranks; *n_ghost entries received, *n_send sent per product); 1: every rank's

@@ -88,6 +88,8 @@ SIGNATURES = {
     "khip_spmm": (_int, [_vp, _vp, _vp, _vp, _int]),
     "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
     "khip_csr_code_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "khip_csr_tile_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "khip_csr_halo_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "khip_profile_spmv": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),
     "khip_dot": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
@@ -627,6 +629,15 @@ class CsrMatrix:
         b, t = C.c_int(), C.c_int()
         _ck(lib().khip_csr_code_info(self._h, C.byref(b), C.byref(t)))
         return b.value, t.value
+
+    @property
+    def tile_info(self):
+        """dict(state, window, grid_tiles, groups, direct_groups, reuse): the p = 16 SpMM kernel of this handle
+        (csrc/spmm_tile.hip); state 1 = wave-private LDS windows, -1 = not usable, 0 = no 16-column product yet."""
+        st, w, gt = C.c_int(), C.c_int(), C.c_int()
+        g, d, r = C.c_int64(), C.c_int64(), C.c_double()
+        _ck(lib().khip_csr_tile_info(self._h, C.byref(st), C.byref(w), C.byref(gt), C.byref(g), C.byref(d), C.byref(r)))
+        return dict(state=st.value, window=w.value, grid_tiles=gt.value, groups=g.value, direct_groups=d.value, reuse=r.value)
 
     @property
     def halo_info(self):

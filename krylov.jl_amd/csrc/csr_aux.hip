@@ -583,6 +583,7 @@ namespace khip {
 #endif
 
 int spmm_window_build(khip_ctx *ctx, khip_csr *A, int L);   // below
+int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a);   // spmm_tile.hip
 
 template <int L>
 static void launch_window(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p) {
@@ -675,6 +676,11 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
         const int64_t K2 = (want2 + S2 - 1) / S2;
         if (K2 * Spad <= gcap) { a.sweep_s = (int)S2; a.sweep_w = W2; grid2 = (int)(K2 * Spad); }
       }
+    }
+    if (ctx->tune.spmm_tile && p == 16 && A->m > 0 && A->nnz > 0) {  // wave-private windows, LDS-DMA, grid-tile row groups (spmm_tile.hip)
+      khip_csr *At = const_cast<khip_csr *>(A);
+      if (At->tile_state == 0) KHIP_TRY(spmm_tile_build(ctx, At));
+      if (At->tile_state == 1) return launch_spmm_tile16(ctx, A, a);
     }
     if (ctx->tune.spmm_window && want2 <= gcap && A->m > 0) {      // panel-row window in LDS: one row group per workgroup
       khip_csr *Aw = const_cast<khip_csr *>(A);
@@ -795,6 +801,25 @@ __global__ __launch_bounds__(kBlock) void csr_validate_kernel(const int32_t *row
   }
 }
 
+// histogram of the row lengths 0..256 (longer rows: bin 256)
+__global__ __launch_bounds__(kBlock) void row_len_hist_kernel(const int32_t *rowptr, int64_t m, unsigned long long *hist) {
+  __shared__ unsigned int h[257];
+  for (int i = threadIdx.x; i < 257; i += kBlock) h[i] = 0;
+  __syncthreads();
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (int64_t)gridDim.x * kBlock) {
+    const int len = rowptr[r + 1] - rowptr[r];
+    atomicAdd(&h[len < 256 ? len : 256], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 257; i += kBlock) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+// first row >= lo with exactly `len` entries
+__global__ __launch_bounds__(kBlock) void row_find_kernel(const int32_t *rowptr, int64_t m, int64_t lo, int len, unsigned long long *out) {
+  for (int64_t r = lo + (int64_t)blockIdx.x * kBlock + threadIdx.x; r < m; r += (int64_t)gridDim.x * kBlock) {
+    if (rowptr[r + 1] - rowptr[r] == len) { atomicMin(out, (unsigned long long)r); break; }
+  }
+}
+
 int csr_finalize(khip_ctx *ctx, khip_csr *A) {
   A->mean_row_nnz = A->m > 0 ? (double)A->nnz / (double)A->m : 0.0;
   A->max_row_nnz = 0;
@@ -852,24 +877,55 @@ int csr_finalize(khip_ctx *ctx, khip_csr *A) {
   // its positive offsets fall into clusters (a new one starts where an offset more than doubles): 1 | n1 | n1^2 for the
   // 7-point operator, 1 | n1-1..n1+1 | n1^2-n1-1..n1^2+n1+1 for the 27-point one.  plane_rows = centre of the last cluster.
   A->plane_rows = 0;
-  if (A->m >= 128 && A->max_row_nnz >= 2 && A->max_row_nnz <= 256) {
-    const int64_t r0 = A->m / 2;
-    const int span = 64;
-    std::vector<int32_t> rp((size_t)span + 1);
-    KHIP_CHECK_HIP(hipMemcpy(rp.data(), A->rowptr + r0, sizeof(int32_t) * (size_t)(span + 1), hipMemcpyDeviceToHost));
-    int best = 0;
-    for (int i = 1; i < span; ++i) if (rp[(size_t)i + 1] - rp[(size_t)i] > rp[(size_t)best + 1] - rp[(size_t)best]) best = i;
-    const int len = rp[(size_t)best + 1] - rp[(size_t)best];
-    if (len >= 2) {
-      std::vector<int32_t> cols((size_t)len);
-      KHIP_CHECK_HIP(hipMemcpy(cols.data(), A->col + rp[(size_t)best], sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost));
-      std::vector<int64_t> pos;
-      for (int32_t cidx : cols) if ((int64_t)cidx > r0 + best) pos.push_back((int64_t)cidx - (r0 + best));
-      std::sort(pos.begin(), pos.end());
-      if (!pos.empty()) {
-        size_t start = 0;
-        for (size_t i = 1; i < pos.size(); ++i) if (pos[i] > 2 * pos[i - 1] + 2) start = i;
-        A->plane_rows = (pos[start] + pos.back()) / 2;
+  A->line_rows = 0;
+  if (A->m >= 128 && A->max_row_nnz >= 2) {
+    // an INTERIOR row: the first row of the second half whose length is the most frequent one (<= 256) -- the rows around
+    // m / 2 alone may all lie on a face of the grid (216^3: row m / 2 is (0, 0, 108)) and lack whole clusters
+    unsigned long long *d_hist = nullptr;
+    KHIP_CHECK_HIP(hipMalloc(&d_hist, 258 * sizeof(unsigned long long)));
+    struct Free { unsigned long long *&p; ~Free() { (void)hipFree(p); } } fr{d_hist};
+    KHIP_CHECK_HIP(hipMemsetAsync(d_hist, 0, 258 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(row_len_hist_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->rowptr, A->m, d_hist);
+    KHIP_CHECK_HIP(hipGetLastError());
+    unsigned long long hh[258];
+    KHIP_CHECK_HIP(hipMemcpyAsync(hh, d_hist, sizeof(hh), hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    int mode = 2;
+    for (int l = 2; l <= 256; ++l) if (hh[l] > hh[mode]) mode = l;
+    if (hh[mode] > 0) {
+      unsigned long long init = (unsigned long long)A->m;
+      KHIP_CHECK_HIP(hipMemcpyAsync(d_hist + 257, &init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(row_find_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, A->rowptr, A->m, A->m / 2, mode, d_hist + 257);
+      KHIP_CHECK_HIP(hipGetLastError());
+      unsigned long long found = init;
+      KHIP_CHECK_HIP(hipMemcpyAsync(&found, d_hist + 257, sizeof(found), hipMemcpyDeviceToHost, ctx->stream));
+      KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if (found < (unsigned long long)A->m) {
+        const int64_t row = (int64_t)found;
+        int32_t rp[2];
+        KHIP_CHECK_HIP(hipMemcpy(rp, A->rowptr + row, sizeof(rp), hipMemcpyDeviceToHost));
+        const int len = rp[1] - rp[0];
+        std::vector<int32_t> cols((size_t)len);
+        KHIP_CHECK_HIP(hipMemcpy(cols.data(), A->col + rp[0], sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToHost));
+        std::vector<int64_t> pos;
+        for (int32_t cidx : cols) if ((int64_t)cidx > row) pos.push_back((int64_t)cidx - row);
+        std::sort(pos.begin(), pos.end());
+        if (!pos.empty()) {
+          size_t start = 0, second = 0, second_end = 0;      // second cluster = the neighbouring grid line (n1-1..n1+1)
+          int clusters = 1;
+          for (size_t i = 1; i < pos.size(); ++i)
+            if (pos[i] > 2 * pos[i - 1] + 2) {
+              ++clusters;
+              if (clusters == 2) second = i;
+              if (clusters == 3) second_end = i;
+              start = i;
+            }
+          A->plane_rows = (pos[start] + pos.back()) / 2;
+          if (clusters >= 2) {
+            if (clusters == 2) second_end = pos.size();
+            A->line_rows = (pos[second] + pos[second_end - 1]) / 2;
+          }
+        }
       }
     }
   }

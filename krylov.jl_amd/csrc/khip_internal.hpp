@@ -81,6 +81,7 @@ struct Tuning {
   int panel_fuse = 1;       // block Gram-Schmidt: apply Psi_i and form Psi_{i+1} in one pass (panel.hip, single rank)
   int spmm_wide = 1;        // SpMM: two panel columns per lane (16-byte gathers) when p is even
   int spmm_window_grid = 0; // workgroups of the persistent window kernel (0 = CUs x LDS-limited residency)
+  int spmm_tile = 1;        // SpMM with 16 columns: wave-private LDS windows filled by LDS-DMA, grid-tile row groups (spmm_tile.hip)
   int spmm_window = 1;      // SpMM: stage the distinct panel rows of a row group in LDS (csr_aux.hip, spmm_window_kernel)
   int spmm_sweep = 0;       // SpMM direct kernel: plane-sweep tile order when the band is wider than the L2 can hold (csr_aux.hip; measured no faster)
   int spmm_win_sweep = 0;   // SpMM window kernel: plane-sweep order of the row groups (each XCD walks columns of spmm_sweep_w groups through all planes); measured 15 % slower although it removes the re-fetches (profiles/r02_spmm_experiments.log)
@@ -144,6 +145,7 @@ struct khip_csr {
   int64_t max_row_nnz = 0;
   int64_t band = 0;                    // max |column - row| (local indices)
   int64_t plane_rows = 0;              // estimated distance (rows) between the outermost coupling planes of a 3-D operator (0 = unknown; csr_finalize)
+  int64_t line_rows = 0;               // estimated distance (rows) between neighbouring grid lines (0 = unknown; csr_finalize)
   double mean_row_nnz = 0;
   // distributed state (null / zero when single GPU)
   bool dist = false;
@@ -172,6 +174,12 @@ struct khip_csr {
   int32_t *win_list = nullptr;         // [groups][STRIDE(L)] distinct columns of a row group, padded with 0
   int32_t *win_flag = nullptr;         // per row group: 1 = direct-gather group (too many panel rows or nonzeros for the window)
   uint16_t *win_slot = nullptr;        // per nonzero: position of its column in the group's list
+  // optional group records of the p = 16 tile SpMM (spmm_tile.hip, built on the first SpMM with 16 columns)
+  int tile_state = 0;                  // 0 = not tried, 1 = built, -1 = tried, not usable
+  char *tile_meta = nullptr;           // [tile_groups] records of tile_stride bytes
+  int tile_cap = 0, tile_stride = 0, tile_grid = 0;   // window size (panel rows); tile_grid: 1 = groups are grid tiles, 0 = consecutive rows
+  int64_t tile_groups = 0, tile_direct = 0;           // tile_direct: groups on the direct-gather path
+  double tile_reuse = 0;               // references per distinct column of a group
   // optional dictionary-coded column stream of the staged SpMV (colcode.hip, built on the first product that can use it)
   int code_state = 0;                  // 0 = not tried, 1 = built, -1 = tried, not usable (too many distinct diagonals)
   int code_bits = 0;                   // 8 or 16
@@ -257,6 +265,8 @@ int launch_diagonal(khip_ctx *ctx, const khip_csr *A, double *diag);
 // template.hip
 void csr_free_templates(khip_csr *A);
 void csr_free_window(khip_csr *A);
+void csr_free_tiles(khip_csr *A);                  // spmm_tile.hip
+int spmm_tile_build(khip_ctx *ctx, khip_csr *A);   // spmm_tile.hip: sets A->tile_state to 1 or -1
 void csr_free_codes(khip_csr *A);                  // colcode.hip
 int csr_build_codes(khip_ctx *ctx, khip_csr *A);   // colcode.hip: sets A->code_state to 1 or -1
 int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,

@@ -1,0 +1,472 @@
+// spmm_tile.hip -- SpMM for p = 16 right-hand sides: wave-private panel-row windows filled by LDS-DMA.
+//
+//   Y(m x 16, row-major) = A * X(n x 16, row-major)            (mul!(W, A, P), src/block_gmres.jl:242)
+//
+// Why another kernel.  spmm_window_kernel (csr_aux.hip) shares one 44 KB window between the four waves of a
+// persistent workgroup: two workgroups per CU, every row group one memory round trip behind a workgroup barrier, and a
+// window of 32 CONSECUTIVE rows of the 27-point operator holds 9 x 34 panel rows -- each panel row crosses L2 -> LDS 9.6
+// times (16.4 GB of L2 misses for 5.9 GB algorithmic, 2.2 ms).  Here
+//   * a row group (32 rows) belongs to ONE wave: no workgroup barrier anywhere, 8+ independent waves per CU, each either
+//     waiting for its loads or computing -- the hardware interleaves them;
+//   * the group's distinct panel rows land in the wave's LDS window by global_load_lds_dwordx4 (1 KiB per instruction, no
+//     staging registers, no ds_write);
+//   * the 32 rows of a group need not be consecutive: on operators whose pattern is a structured grid the groups are
+//     4 x 4 x 2 grid tiles (6 x 6 x 4 = 144 panel rows instead of 306: 18 KB windows, 4.5 instead of 9.6 L2 -> LDS passes
+//     per panel row), found from the row order alone (spmm_tile_build tries the identity order and the tile order and keeps
+//     the one with fewer distinct columns per group); the groups are dealt to the XCDs in eight contiguous runs so that
+//     neighbouring tiles share an L2;
+//   * a lane owns FOUR panel columns of a row (4 lanes per row, 16 rows per wave pass): per entry one broadcast of
+//     (val, slot) inside a quad (v_mov_dpp quad_perm) and two ds_read_b128 -- half the per-entry VALU work of two columns per lane;
+//   * everything a group needs besides val sits in one contiguous record: {row, first entry, length} per row, the list of
+//     distinct columns, one byte per nonzero (position of its column in the list).
+// Arithmetic: per row and column a rounded multiply and a rounded add in stored order, as in spmm_kernel / spmm2_kernel /
+// spmm_window_kernel and p SpMVs => Y is bit-identical to all of them (tests/test_gpu_block.py::test_spmm_tile_*).
+// Groups with a row longer than 32 entries or more distinct columns than the window takes are flagged at build time and
+// go down a direct-gather path inside the same kernel.
+#include <algorithm>
+#include <vector>
+
+#include "spmv_common.hpp"
+
+namespace khip {
+
+constexpr int kTileR = 32;          // rows per group (two passes of 16 rows x 4 lanes)
+constexpr int kTileLen = 32;        // entries per row the register path takes
+constexpr int kTileCapMax = 256;    // distinct panel rows per group (one-byte slots); the window is cap x 128 B of LDS
+constexpr int kTileDescBytes = kTileR * 16;
+constexpr int kTileSlotBytes = kTileR * kTileLen;
+
+struct TileArgs {
+  const char *meta;       // [groups] records: int4 {row, start, len, aux}[32] | int32 list[cap] | uint8 slot[32][32]
+  int64_t groups, per_xcd;
+  int cap;                // list entries per group (multiple of 8)
+  int stride;             // bytes per record
+};
+
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ int quad_bcast(int v, int k) {      // value of lane k of every quad (k wave-uniform)
+  switch (k) {
+    case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, true);
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xF, 0xF, true);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xF, 0xF, true);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, true);
+  }
+}
+template <int K>
+__device__ __forceinline__ int quad_bcast_c(int v) {
+  constexpr int QP = K | (K << 2) | (K << 4) | (K << 6);
+  return __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true);
+}
+template <int K>
+__device__ __forceinline__ double quad_bcast_c(double v) {
+  return __hiloint2double(quad_bcast_c<K>(__double2hiint(v)), quad_bcast_c<K>(__double2loint(v)));
+}
+
+// One entry step of 16 rows: (val, slot) of entry 8 F + K spread over the quad, the two 16-byte pieces of the panel row
+// out of the window, four rounded products and four rounded adds.
+template <int F, int K, bool MASK>
+__device__ __forceinline__ void tile_entry(const dbl2 (&v)[4], const int2v &s, const char *xb, int len, double (&acc)[4]) {
+  const double vv = quad_bcast_c<K / 2>((K & 1) ? v[F].y : v[F].x);
+  const int sw = quad_bcast_c<F>((K & 4) ? s.y : s.x);
+  const int off = (int)(((unsigned)sw >> (8 * (K & 3))) & 0xffu) << 7;
+  const dbl2 x0 = *reinterpret_cast<const dbl2 *>(xb + off);
+  const dbl2 x1 = *reinterpret_cast<const dbl2 *>(xb + off + 64);
+  const double p0 = vv * x0.x, p1 = vv * x0.y, p2 = vv * x1.x, p3 = vv * x1.y;
+  if (!MASK || 8 * F + K < len) {
+    acc[0] = acc[0] + p0;
+    acc[1] = acc[1] + p1;
+    acc[2] = acc[2] + p2;
+    acc[3] = acc[3] + p3;
+  }
+}
+template <int F, bool MASK>
+__device__ __forceinline__ void tile_batch(const dbl2 (&v)[4], const int2v &s, const char *xb, int len, int n, double (&acc)[4]) {
+  // n: wave-uniform number of entries of this batch that any row still has (1..8)
+  tile_entry<F, 0, MASK>(v, s, xb, len, acc);
+  if (n > 1) tile_entry<F, 1, MASK>(v, s, xb, len, acc);
+  if (n > 2) tile_entry<F, 2, MASK>(v, s, xb, len, acc);
+  if (n > 3) tile_entry<F, 3, MASK>(v, s, xb, len, acc);
+  if (n > 4) tile_entry<F, 4, MASK>(v, s, xb, len, acc);
+  if (n > 5) tile_entry<F, 5, MASK>(v, s, xb, len, acc);
+  if (n > 6) tile_entry<F, 6, MASK>(v, s, xb, len, acc);
+  if (n > 7) tile_entry<F, 7, MASK>(v, s, xb, len, acc);
+}
+template <bool MASK>
+__device__ __forceinline__ void tile_rows(const dbl2 (&v)[4], const int2v &s, const char *xb, int len, int nmax, double (&acc)[4]) {
+  if (nmax > 0) tile_batch<0, MASK>(v, s, xb, len, nmax < 8 ? nmax : 8, acc);
+  if (nmax > 8) tile_batch<1, MASK>(v, s, xb, len, nmax < 16 ? nmax - 8 : 8, acc);
+  if (nmax > 16) tile_batch<2, MASK>(v, s, xb, len, nmax < 24 ? nmax - 16 : 8, acc);
+  if (nmax > 24) tile_batch<3, MASK>(v, s, xb, len, nmax - 24, acc);
+}
+
+template <bool DIST, int NL>      // NL = ceil(cap / 64): list words per lane
+__global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w) {
+  extern __shared__ dbl2 tile_win[];                 // [cap][8]: the group's distinct panel rows
+  const int lane = threadIdx.x, sub = lane >> 2, c = lane & 3;
+  const int64_t b = blockIdx.x;
+  const int64_t g = (b & 7) * w.per_xcd + (b >> 3);   // workgroup b runs on XCD b % 8: eight contiguous runs of groups
+  if (g >= w.groups) return;
+  const char *rec = w.meta + g * (int64_t)w.stride;
+  const int4v *desc = reinterpret_cast<const int4v *>(rec);
+  const int32_t *lst = reinterpret_cast<const int32_t *>(rec + kTileDescBytes);
+  const char *slots = rec + kTileDescBytes + 4 * w.cap;
+  const int4v d0 = desc[sub], d1 = desc[16 + sub];
+  int lw[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int q = lane + 64 * j;
+    lw[j] = lst[q < w.cap ? q : w.cap - 1];
+  }
+  const bool direct = __builtin_amdgcn_readfirstlane(__shfl(d0.w, 4)) != 0;      // aux of row slot 1 = the group's flag
+  if (!direct) {
+    // the (val, slot) stream of the lane's two rows: entries 2 c, 2 c + 1 (+ 8 f) and the slot bytes 8 c .. 8 c + 7
+    const int64_t vlast = a.nnz_bound - 2;
+    dbl2 v0[4], v1[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      int64_t i0 = (int64_t)d0.y + 2 * c + 8 * f, i1 = (int64_t)d1.y + 2 * c + 8 * f;
+      i0 = i0 < vlast ? i0 : vlast;
+      i1 = i1 < vlast ? i1 : vlast;
+      v0[f] = *reinterpret_cast<const dbl2u *>(a.val + i0);
+      v1[f] = *reinterpret_cast<const dbl2u *>(a.val + i1);
+    }
+    const int2v s0 = *reinterpret_cast<const int2v *>(slots + sub * kTileLen + 8 * c);
+    const int2v s1 = *reinterpret_cast<const int2v *>(slots + (16 + sub) * kTileLen + 8 * c);
+    // panel rows -> LDS: instruction wq copies list entries 8 wq .. 8 wq + 7, lane i the 16-byte piece i % 8 of entry i / 8
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(1))) const void glb_cvoid;
+    lds_char *win = (lds_char *)tile_win;
+    // (all cross-lane moves first: hipcc drains vmcnt before any LDS-class instruction that follows an LDS-DMA)
+    int cols[8 * NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) cols[8 * j + w8] = __builtin_amdgcn_ds_bpermute(4 * (8 * w8 + (lane >> 3)), lw[j]);
+    }
+#pragma unroll
+    for (int wq = 0; wq < 8 * NL; ++wq) {
+      if (8 * wq < w.cap) {
+        const int col = cols[wq];
+        const char *src = reinterpret_cast<const char *>(a.x);
+        uint64_t r = (unsigned)col;
+        if (DIST) {
+          const bool own = (int64_t)col < a.n_owned;
+          src = own ? src : reinterpret_cast<const char *>(a.ghost);
+          r = own ? r : r - (uint64_t)a.n_owned;
+        }
+        __builtin_amdgcn_global_load_lds((glb_cvoid *)(src + (r << 7) + 16 * (lane & 7)), (lds_void *)(win + 1024 * wq), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing but the issuing wave's vmcnt orders a ds_read behind an LDS-DMA
+    const char *xb = reinterpret_cast<const char *>(tile_win) + 16 * c;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int4v &d = q ? d1 : d0;
+      const int len = d.z;
+      const int len0 = __builtin_amdgcn_readfirstlane(len);
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (__ballot(len != len0) == 0) {
+        tile_rows<false>(q ? v1 : v0, q ? s1 : s0, xb, len, len0, acc);
+      } else {
+        int nmax = len;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(nmax, sft); nmax = o > nmax ? o : nmax; }
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        tile_rows<true>(q ? v1 : v0, q ? s1 : s0, xb, len, nmax, acc);
+      }
+      if (d.x >= 0) {
+        double *yr = a.y + (int64_t)d.x * 16 + 2 * c;
+        *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
+        *reinterpret_cast<dbl2 *>(yr + 8) = dbl2{acc[2], acc[3]};
+      }
+    }
+  } else {
+    // direct gathers (a row longer than 32 entries, or more distinct columns than the window holds): same order of operations
+#pragma unroll 1
+    for (int q = 0; q < 2; ++q) {
+      const int4v &d = q ? d1 : d0;
+      if (d.x < 0) continue;
+      const int64_t s = d.y, e = s + d.z;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int64_t base = s; base < e; base += 4) {
+        const int cnt = (int)((e - base) < 4 ? (e - base) : 4);
+        const bool mine = c < cnt;
+        const double myv = mine ? a.val[base + c] : 0.0;
+        const int32_t myc = mine ? a.col[base + c] : 0;
+        for (int t = 0; t < cnt; ++t) {
+          const int32_t cc = __shfl(myc, t, 4);
+          const double vv = __shfl(myv, t, 4);
+          const bool own = !DIST || cc < a.n_owned;
+          const double *src = own ? a.x : a.ghost;
+          const int64_t r = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
+          const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + r * 16 + 2 * c);
+          const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + r * 16 + 8 + 2 * c);
+          const double p0 = vv * x0.x, p1 = vv * x0.y, p2 = vv * x1.x, p3 = vv * x1.y;
+          acc[0] = acc[0] + p0;
+          acc[1] = acc[1] + p1;
+          acc[2] = acc[2] + p2;
+          acc[3] = acc[3] + p3;
+        }
+      }
+      double *yr = a.y + (int64_t)d.x * 16 + 2 * c;
+      *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
+      *reinterpret_cast<dbl2 *>(yr + 8) = dbl2{acc[2], acc[3]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------- metadata ----------
+// Row of slot t (0..31) of group g.  Tile order (s1 > 0): the group is the 4 x 4 x 2 (or, for one plane, 8 x 4 x 1) tile
+// (ti, tj, tk) of the n1 x n2 x n3 grid whose row index is i + s1 j + s2 k; identity order: rows 32 g .. 32 g + 31.
+struct TileOrder {
+  int64_t m;
+  int64_t s1, s2;       // s1 == 0: identity order
+  int n1, n2, n3;
+  int bi, bj, bk;       // tile extents (bi * bj * bk == 32)
+  int gi, gj;           // tiles along i and j
+};
+__device__ __forceinline__ int64_t tile_row_of(const TileOrder &o, int64_t g, int t) {
+  if (o.s1 == 0) { const int64_t r = g * kTileR + t; return r < o.m ? r : -1; }
+  const int64_t ti = g % o.gi, tj = (g / o.gi) % o.gj, tk = g / ((int64_t)o.gi * o.gj);
+  const int di = t % o.bi, dj = (t / o.bi) % o.bj, dk = t / (o.bi * o.bj);
+  const int64_t i = ti * o.bi + di, j = tj * o.bj + dj, k = tk * o.bk + dk;
+  if (i >= o.n1 || j >= o.n2 || k >= o.n3) return -1;
+  const int64_t r = i + o.s1 * j + o.s2 * k;
+  return r < o.m ? r : -1;
+}
+
+constexpr int kTileKeys = kTileR * kTileLen;   // 1024 column indices of a group at most
+constexpr int kTileEmpty = 0x7fffffff;
+
+// One workgroup per group: the group's column indices sorted (bitonic, LDS), made unique, counted.  FILL = false:
+// cnt[g] = number of distinct columns, or -1 when a row has more than 32 entries; statistics for the choice of the order
+// and of the window size.  FILL = true: the group's record.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void spmm_tile_build_kernel(const int32_t *rowptr, const int32_t *col, TileOrder o, int cap,
+                                                                  int stride, char *meta, int32_t *cnt,
+                                                                  unsigned long long *stat /* [0] long-row groups, [1] sum cnt, [2..34] histogram of ceil(cnt / 8) */) {
+  __shared__ int keys[kTileKeys];
+  __shared__ int uniq[kTileKeys];
+  __shared__ int scan[kBlock];
+  __shared__ int rrow[kTileR], rstart[kTileR], rlen[kTileR];
+  __shared__ int too_long;
+  const int tid = threadIdx.x;
+  const int64_t g = blockIdx.x;
+  if (tid == 0) too_long = 0;
+  __syncthreads();
+  if (tid < kTileR) {
+    const int64_t r = tile_row_of(o, g, tid);
+    int s = 0, len = 0;
+    if (r >= 0) { s = rowptr[r]; len = rowptr[r + 1] - s; }
+    rrow[tid] = (int)r; rstart[tid] = s; rlen[tid] = len;
+    if (len > kTileLen) too_long = 1;
+  }
+  __syncthreads();
+  const bool longrow = too_long != 0;
+  for (int q = tid; q < kTileKeys; q += kBlock) {
+    const int t = q / kTileLen, k = q % kTileLen;
+    keys[q] = (!longrow && k < rlen[t]) ? col[(int64_t)rstart[t] + k] : kTileEmpty;
+  }
+  __syncthreads();
+  int n_uniq = 0;
+  if (!longrow) {
+    for (int size = 2; size <= kTileKeys; size <<= 1) {
+      for (int strd = size >> 1; strd > 0; strd >>= 1) {
+        for (int q = tid; q < kTileKeys / 2; q += kBlock) {
+          const int lo = 2 * q - (q & (strd - 1));      // index with bit `strd` clear
+          const int hi = lo + strd;
+          const bool up = (lo & size) == 0;
+          const int x = keys[lo], y = keys[hi];
+          if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+        }
+        __syncthreads();
+      }
+    }
+    // unique: thread t owns keys 4 t .. 4 t + 3
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = 4 * tid + j;
+      const int k = keys[q];
+      mine += (k != kTileEmpty && (q == 0 || keys[q - 1] != k)) ? 1 : 0;
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < kBlock; d <<= 1) {
+      const int add = tid >= d ? scan[tid - d] : 0;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    n_uniq = scan[kBlock - 1];
+    int pos = scan[tid] - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = 4 * tid + j;
+      const int k = keys[q];
+      if (k != kTileEmpty && (q == 0 || keys[q - 1] != k)) uniq[pos++] = k;
+    }
+    __syncthreads();
+  }
+  if (!FILL) {
+    if (tid == 0) {
+      cnt[g] = longrow ? -1 : n_uniq;
+      if (longrow) atomicAdd(&stat[0], 1ull);
+      else {
+        atomicAdd(&stat[1], (unsigned long long)n_uniq);
+        atomicAdd(&stat[2 + (n_uniq + 7) / 8], 1ull);
+      }
+    }
+    return;
+  }
+  char *rec = meta + g * (int64_t)stride;
+  const bool direct = longrow || n_uniq > cap;
+  if (tid < kTileR) {
+    int4v d;
+    d.x = rrow[tid]; d.y = rstart[tid]; d.z = rlen[tid];
+    d.w = tid == 0 ? n_uniq : (tid == 1 ? (direct ? 1 : 0) : 0);
+    reinterpret_cast<int4v *>(rec)[tid] = d;
+  }
+  int32_t *lst = reinterpret_cast<int32_t *>(rec + kTileDescBytes);
+  uint8_t *slots = reinterpret_cast<uint8_t *>(rec + kTileDescBytes + 4 * cap);
+  if (direct) {
+    for (int q = tid; q < cap; q += kBlock) lst[q] = 0;
+    for (int q = tid; q < kTileSlotBytes; q += kBlock) slots[q] = 0;
+    return;
+  }
+  for (int q = tid; q < cap; q += kBlock) lst[q] = n_uniq > 0 ? uniq[q < n_uniq ? q : n_uniq - 1] : 0;   // padding: the last column again
+  for (int q = tid; q < kTileKeys; q += kBlock) {
+    const int t = q / kTileLen, k = q % kTileLen;
+    int sl = 0;
+    if (k < rlen[t]) {
+      const int key = col[(int64_t)rstart[t] + k];
+      int lo = 0, hi = n_uniq - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (uniq[mid] < key) lo = mid + 1; else hi = mid;
+      }
+      sl = lo;
+    }
+    slots[q] = (uint8_t)sl;
+  }
+}
+
+void csr_free_tiles(khip_csr *A) {
+  (void)hipFree(A->tile_meta);
+  A->tile_meta = nullptr;
+  A->tile_state = 0;
+}
+
+static TileOrder tile_order_for(const khip_csr *A, bool tiles) {
+  TileOrder o{};
+  o.m = A->m;
+  if (!tiles) return o;
+  const int64_t s1 = A->line_rows, s2 = A->plane_rows > A->line_rows ? A->plane_rows : A->m;
+  o.s1 = s1; o.s2 = s2;
+  o.n1 = (int)s1; o.n2 = (int)((s2 + s1 - 1) / s1); o.n3 = (int)((A->m + s2 - 1) / s2);
+  if (o.n3 > 1) { o.bi = 4; o.bj = 4; o.bk = 2; } else { o.bi = 8; o.bj = 4; o.bk = 1; }
+  o.gi = (o.n1 + o.bi - 1) / o.bi;
+  o.gj = (o.n2 + o.bj - 1) / o.bj;
+  return o;
+}
+static int64_t tile_groups_for(const TileOrder &o) {
+  if (o.s1 == 0) return (o.m + kTileR - 1) / kTileR;
+  return (int64_t)o.gi * o.gj * ((o.n3 + o.bk - 1) / o.bk);
+}
+
+// Builds the group records of A for the p = 16 tile kernel.  On return A->tile_state is 1 (usable) or -1 (the operator
+// lacks the locality, or memory is short: the caller keeps the other kernels and does not ask again).
+int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
+  csr_free_tiles(A);
+  A->tile_state = -1;
+  if (A->m <= 0 || A->nnz <= 0) return KHIP_OK;
+  constexpr int NSTAT = 2 + kTileCapMax / 8 + 1 + 128;        // histogram bins for up to 1024 distinct columns
+  int32_t *cnt = nullptr;
+  unsigned long long *stat = nullptr;
+  struct Scratch { int32_t *&c; unsigned long long *&s; ~Scratch() { (void)hipFree(c); (void)hipFree(s); } } scratch{cnt, stat};
+  KHIP_CHECK_HIP(hipMalloc(&stat, NSTAT * sizeof(unsigned long long)));
+  // candidate orders: identity, and the grid tiles when csr_finalize saw a line / plane structure
+  const bool grid_ok = A->line_rows >= 4 && A->line_rows < A->m &&
+                       (A->plane_rows <= A->line_rows || (A->plane_rows % A->line_rows == 0 && A->plane_rows / A->line_rows >= 4));
+  TileOrder best{};
+  std::vector<unsigned long long> best_st;
+  double best_score = -1.0;
+  for (int cand = 0; cand < (grid_ok ? 2 : 1); ++cand) {
+    const TileOrder o = tile_order_for(A, cand == 1);
+    const int64_t groups = tile_groups_for(o);
+    if (groups <= 0 || groups > ((int64_t)1 << 30)) continue;
+    (void)hipFree(cnt); cnt = nullptr;
+    KHIP_CHECK_HIP(hipMalloc(&cnt, sizeof(int32_t) * (size_t)groups));
+    KHIP_CHECK_HIP(hipMemsetAsync(stat, 0, NSTAT * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL((spmm_tile_build_kernel<false>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, o, 0, 0,
+                       (char *)nullptr, cnt, stat);
+    KHIP_CHECK_HIP(hipGetLastError());
+    std::vector<unsigned long long> st(NSTAT);
+    KHIP_CHECK_HIP(hipMemcpyAsync(st.data(), stat, NSTAT * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    // score: references per distinct column (higher is better); long-row groups count as no reuse
+    const double score = st[1] > 0 ? (double)A->nnz / ((double)st[1] + 32.0 * (double)st[0]) : 0.0;
+    if (score > best_score) { best_score = score; best = o; best_st = st; }
+  }
+  if (best_score < 1.5) return KHIP_OK;                       // fewer than 1.5 references per distinct column: no reuse to stage
+  const int64_t groups = tile_groups_for(best);
+  // window size: the smallest multiple of 8 that takes 99 % of the groups (the others go down the direct path)
+  unsigned long long fit = 0;
+  int cap = -1;
+  for (int bin = 0; bin <= kTileCapMax / 8; ++bin) {
+    fit += best_st[2 + (size_t)bin];
+    if (100 * fit >= 99 * (unsigned long long)groups) { cap = 8 * bin; break; }
+  }
+  if (cap < 0) {
+    if (2 * fit < (unsigned long long)groups) return KHIP_OK;          // most groups exceed the largest window
+    cap = kTileCapMax;
+  }
+  if (cap < 8) cap = 8;
+  const int stride = kTileDescBytes + 4 * cap + kTileSlotBytes;
+  size_t free_b = 0, total_b = 0;
+  KHIP_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+  if ((size_t)groups * (size_t)stride + ((size_t)1 << 30) > free_b) return KHIP_OK;
+  KHIP_CHECK_HIP(hipMalloc(&A->tile_meta, (size_t)groups * (size_t)stride));
+  hipLaunchKernelGGL((spmm_tile_build_kernel<true>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, best, cap, stride,
+                     A->tile_meta, (int32_t *)nullptr, (unsigned long long *)nullptr);
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  A->tile_state = 1;
+  A->tile_cap = cap;
+  A->tile_stride = stride;
+  A->tile_groups = groups;
+  A->tile_grid = best.s1 != 0 ? 1 : 0;
+  unsigned long long over = 0;
+  for (size_t bin = (size_t)cap / 8 + 1; bin + 2 < best_st.size(); ++bin) over += best_st[2 + bin];
+  A->tile_direct = (int64_t)(best_st[0] + over);
+  A->tile_reuse = best_score;
+  return KHIP_OK;
+}
+
+int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
+  TileArgs w;
+  w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride;
+  const int64_t grid = 8 * w.per_xcd;
+  const size_t lds = (size_t)w.cap * 128;
+  const bool dist = a.ghost != a.x;
+  const int NL = (w.cap + 63) / 64;
+  const dim3 gd((unsigned)grid), bd(64);
+#define KHIP_TILE_LAUNCH(D, N)                                                                                          \
+  do {                                                                                                                  \
+    if (lds > 64 * 1024)                                                                                                \
+      (void)hipFuncSetAttribute((const void *)spmm_tile16_kernel<D, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((spmm_tile16_kernel<D, N>), gd, bd, lds, ctx->stream, a, w);                                     \
+  } while (0)
+  if (dist) {
+    switch (NL) { case 1: KHIP_TILE_LAUNCH(true, 1); break; case 2: KHIP_TILE_LAUNCH(true, 2); break; case 3: KHIP_TILE_LAUNCH(true, 3); break; default: KHIP_TILE_LAUNCH(true, 4); break; }
+  } else {
+    switch (NL) { case 1: KHIP_TILE_LAUNCH(false, 1); break; case 2: KHIP_TILE_LAUNCH(false, 2); break; case 3: KHIP_TILE_LAUNCH(false, 3); break; default: KHIP_TILE_LAUNCH(false, 4); break; }
+  }
+#undef KHIP_TILE_LAUNCH
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
+}  // namespace khip

@@ -126,3 +126,58 @@ if 5 in which:
         n=A.n, nnz=A.nnz, p=p, memory=mem, niter=res.niter, status=res.status,
         residuals=[float(v) for v in res.residuals], x_index=idx,
         x_sample=[[float(v) for v in res.x[i]] for i in idx], seconds=time.time() - t0))
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full solves TO CONVERGENCE at the BASELINE sizes: the benchmark definition of the reference,
+# cg(A, b, atol = 0.0, rtol = 1.0e-8, itmax = n) (benchmark/benchmarks.jl:14-21), applied to all three configs.
+# Legs 12 / 13 / 15 = cfg 2 / 3 / 5.  One-off: ~40 / ~30 / ~15 minutes on 8 cores.  The whole history is kept so the GPU
+# test can compare every iterate, the iteration count and the status string.
+# ---------------------------------------------------------------------------------------------------------------------
+FULL_RTOL = 1.0e-8
+
+if 12 in which:
+    t0 = time.time()
+    A = ok.poisson3d(512)
+    b = np.ones(A.n)
+    res = ok.cg(A, b, atol=0.0, rtol=FULL_RTOL, itmax=A.n, history=True)
+    idx = sample_idx(A.n)
+    dump("oracle_cfg2_cg512_full.json", dict(
+        generator="tests/golden/make_scale_golden.py 12", oracle="oracle/krylov_oracle.c ko_cg (src/cg.jl:120-291)",
+        config="BASELINE cfg 2 to convergence: cg!(get_div_grad(512,512,512), ones; atol = 0, rtol = 1e-8, itmax = n) "
+               "(benchmark/benchmarks.jl:14-21)",
+        n=A.n, nnz=A.nnz, atol=0.0, rtol=FULL_RTOL, niter=res.niter, solved=bool(res.solved), status=res.status,
+        residuals=[float(v) for v in res.residuals], x_index=idx, x_sample=[float(res.x[i]) for i in idx],
+        seconds=time.time() - t0))
+    del A, b, res
+
+if 13 in which:
+    t0 = time.time()
+    A = ok.kron_unsymmetric(256)
+    b = A.matvec(np.ones(A.n))
+    res = ok.gmres(A, b, memory=30, restart=True, atol=0.0, rtol=FULL_RTOL, itmax=A.n, history=True)
+    idx = sample_idx(A.n)
+    dump("oracle_cfg3_gmres256_full.json", dict(
+        generator="tests/golden/make_scale_golden.py 13", oracle="oracle/krylov_oracle.c ko_gmres (src/gmres.jl:121-384)",
+        config="BASELINE cfg 3 to convergence: gmres!(memory = 30, restart = true) on kron_unsymmetric(256), b = A*ones, "
+               "atol = 0, rtol = 1e-8, itmax = n",
+        n=A.n, nnz=A.nnz, memory=30, atol=0.0, rtol=FULL_RTOL, niter=res.niter, solved=bool(res.solved), status=res.status,
+        residuals=[float(v) for v in res.residuals], x_index=idx, x_sample=[float(res.x[i]) for i in idx],
+        seconds=time.time() - t0))
+    del A, b, res
+
+if 15 in which:
+    t0 = time.time()
+    n1, p, mem = 216, 16, 5
+    A = ok.stencil27_unsym(n1)
+    Xt = cfg5_xtrue(A.n, p)
+    B = np.stack([A.matvec(np.ascontiguousarray(Xt[:, j])) for j in range(p)], axis=1)
+    res = ok.block_gmres(A, B, memory=mem, restart=True, atol=0.0, rtol=FULL_RTOL, itmax=A.n, history=True)
+    idx = sample_idx(A.n)
+    dump("oracle_cfg5_block216_full.json", dict(
+        generator="tests/golden/make_scale_golden.py 15",
+        oracle="oracle/krylov_oracle.c ko_block_gmres (src/block_gmres.jl:110-358)",
+        config="BASELINE cfg 5 to convergence: block_gmres!(memory = 5, restart = true), p = 16, 27-point 216^3 operator "
+               "(ko_csr_stencil27_unsym), B = A*X_true, X_true[i, j] = cos(j pi (i+1)/n) + 0.1 j, atol = 0, rtol = 1e-8",
+        n=A.n, nnz=A.nnz, p=p, memory=mem, atol=0.0, rtol=FULL_RTOL, niter=res.niter, solved=bool(res.solved),
+        status=res.status, residuals=[float(v) for v in res.residuals], x_index=idx,
+        x_sample=[[float(v) for v in res.x[i]] for i in idx], seconds=time.time() - t0))

@@ -236,6 +236,127 @@ def test_spmm_window_mixed_groups_and_fallbacks(K, ctx, oracle):
     check(ragged, "ragged rows")
 
 
+# ---- SpMM with 16 columns: wave-private windows filled by LDS-DMA, grid-tile row groups (spmm_tile.hip) ----------
+
+def _spmm_three(K, ctx, dA, X):
+    """Y (16 columns) with the tile kernel, the window kernel and the direct-gather kernel, as host arrays."""
+    dX = K.Panel.from_host(ctx, X)
+    out = []
+    for tile, window in ((1, 1), (0, 1), (0, 0)):
+        ctx.set_option("spmm_tile", tile)
+        ctx.set_option("spmm_window", window)
+        dY = K.Panel(ctx, dA.m, 16)
+        K.spmm_(dA, dX, dY)
+        out.append(dY.to_host())
+    ctx.set_option("spmm_tile", 1)
+    ctx.set_option("spmm_window", 1)
+    return out
+
+
+def _serial_spmm(S, X):
+    ref = np.zeros((S.shape[0], X.shape[1]))
+    for i in range(S.shape[0]):                          # serial row loops, column by column = the order of the kernels
+        for q in range(S.indptr[i], S.indptr[i + 1]):
+            ref[i] = ref[i] + S.data[q] * X[S.indices[q]]
+    return ref
+
+
+@pytest.mark.parametrize("kind,dims", [("stencil27", (14, 14, 14)), ("stencil27", (21, 13, 10)), ("poisson", (33, 33, 33)),
+                                       ("kron_unsymmetric", (18, 18, 18)), ("poisson", (40, 40, 1))])
+def test_spmm_tile_grid_operators_bit_identical(K, ctx, oracle, kind, dims):
+    """Structured-grid operators: the 32-row groups are grid tiles (tile_info.grid_tiles), extents that are no multiple of
+    the tile (partial tiles), a single plane (8 x 4 x 1 tiles).  Y == window kernel == direct kernel == serial loop."""
+    n1, n2, n3 = dims
+    dA = K.CsrMatrix.stencil(ctx, kind, n1, n2, n3)
+    X = np.random.default_rng(n1).standard_normal((dA.n, 16))
+    Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
+    info = dA.tile_info
+    assert info["state"] == 1 and info["grid_tiles"] == 1 and info["direct_groups"] == 0, info
+    assert np.array_equal(Yt, Yd) and np.array_equal(Yw, Yd)
+    A = None
+    if kind == "stencil27" and n1 == n2 == n3:
+        A = oracle.stencil27_unsym(n1)
+    elif kind == "poisson":
+        A = oracle.poisson3d(n1, n2, n3)
+    elif kind == "kron_unsymmetric":
+        A = oracle.kron_unsymmetric(n1)
+    if A is not None:
+        ref = np.stack([A.matvec(np.ascontiguousarray(X[:, j])) for j in range(16)], axis=1)
+        assert np.array_equal(Yt, ref)
+    if kind == "poisson" and n3 > 1:
+        assert info["window"] <= 6 * 4 * 4 + 8, info          # 7-point tile: far fewer than the 6 x 6 x 4 box
+
+
+def test_spmm_tile_general_operators_and_fallbacks(K, ctx, oracle):
+    """No grid: (a) band + seeded long-range columns (identity order, window from the histogram of distinct columns);
+    (b) band with dense rows (their groups are flagged: direct path inside the tile kernel); (c) scattered (no reuse: the
+    handle keeps the other kernels, state -1); (d) rectangular; (e) ragged rows incl. empty ones, with Inf / NaN in X --
+    the masked path must not pick up entries past the end of a row."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    n = 6000
+
+    def check(S, tag, want_state=None, special=False):
+        S = S.tocsr()
+        S.sort_indices()
+        dA = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data.copy(), S.shape)
+        X = rng.standard_normal((S.shape[1], 16))
+        if special:
+            X[::97, 3] = np.inf
+            X[5::131, 9] = np.nan
+        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
+        info = dA.tile_info
+        if want_state is not None:
+            assert info["state"] == want_state, (tag, info)
+        with np.errstate(invalid="ignore", over="ignore"):
+            ref = _serial_spmm(S, X)
+        assert np.array_equal(Yt, Yd, equal_nan=True) and np.array_equal(Yw, Yd, equal_nan=True), tag
+        assert np.array_equal(Yt, ref, equal_nan=True), tag
+        return info
+
+    band = sp.diags([rng.standard_normal(n - abs(k)) for k in range(-10, 11)], list(range(-10, 11)), format="lil")
+    far = sp.random(n, n, density=3.0 / n, random_state=5, format="lil")
+    info = check((band + far).tocsr(), "band + random", want_state=1)
+    assert info["grid_tiles"] == 0 and info["window"] >= 64, info
+    band2 = sp.diags([rng.standard_normal(n - abs(k)) for k in range(-6, 7)], list(range(-6, 7)), format="lil")
+    for r in (100, 101, 3333):
+        band2[r, :] = rng.standard_normal(n) * (rng.random(n) < 0.3)
+    info = check(band2, "band + dense rows", want_state=1)
+    assert info["direct_groups"] >= 2, info
+    check(sp.random(n, n, density=0.004, random_state=7) + sp.eye(n), "scattered", want_state=-1)
+    check(sp.diags([np.ones(900), 2 * np.ones(900), 3 * np.ones(900)], [0, 40, 1], shape=(900, 1400)), "rectangular")
+    ragged = sp.lil_matrix((n, n))
+    for i in range(n):
+        k = (i * 7) % 23
+        cols = np.unique(np.clip(i + np.arange(k) - k // 2, 0, n - 1))
+        if cols.size:
+            ragged[i, cols] = rng.standard_normal(cols.size)
+    check(ragged, "ragged rows", want_state=1, special=True)
+    # exactly 32 and 33 entries in a row: the longest row of the register path, and the first one past it
+    edge = sp.lil_matrix((400, 400))
+    for i in range(400):
+        k = 32 if i % 2 == 0 else (33 if i == 201 else 5)
+        cols = (i + np.arange(k)) % 400
+        edge[i, cols] = rng.standard_normal(k)
+    info = check(edge, "rows of 32 / 33 entries", want_state=1)
+    assert info["direct_groups"] >= 1, info
+
+
+def test_block_gmres_same_history_with_and_without_tile_kernel(K, ctx, oracle):
+    A = oracle.stencil27_unsym(12)
+    S = A.to_scipy()
+    B, _ = _rhs(S, A.n, 16)
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (A.n, A.n))
+    res = []
+    for tile in (1, 0):
+        ctx.set_option("spmm_tile", tile)
+        X, st, _ = K.block_gmres(dA, B, memory=5, ctx=ctx, history=True, restart=True, itmax=20)
+        res.append((X, st.niter, np.array(st.residuals)))
+    ctx.set_option("spmm_tile", 1)
+    assert dA.tile_info["state"] == 1
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][0], res[1][0])
+
+
 def test_block_gmres_same_history_with_and_without_window(K, ctx, oracle):
     A = oracle.stencil27_unsym(12)
     S = A.to_scipy()

@@ -244,16 +244,19 @@ def test_distributed_spmm_window_local_ranks(K, oracle):
         A = K.CsrMatrix.stencil(c, "stencil27", n1, rows=(r0, r1), distributed=True)
         X = K.Panel.from_host(c, Xh[r0:r1])
         out = []
-        for window in (1, 0):
+        for tile, window in ((1, 1), (0, 1), (0, 0)):     # p = 16: spmm_tile.hip's DIST instantiation, then the window and direct kernels
+            c.set_option("spmm_tile", tile)
             c.set_option("spmm_window", window)
             Y = K.Panel(c, r1 - r0, p)
             K.spmm_(A, X, Y)
             out.append(Y.to_host())
+        out.append(A.tile_info)
         return out
 
-    for rank, (Yw, Yd) in enumerate(_run_ranks(K, world, 515151, body)):
+    for rank, (Yt, Yw, Yd, info) in enumerate(_run_ranks(K, world, 515151, body)):
         r0, r1 = starts[rank], starts[rank + 1]
-        assert np.array_equal(Yw, Yd) and np.array_equal(Yw, ref[r0:r1])
+        assert info["state"] == 1, info
+        assert np.array_equal(Yt, Yd) and np.array_equal(Yw, Yd) and np.array_equal(Yw, ref[r0:r1])
 
 
 @pytest.mark.parametrize("world,n1", [(2, 12), (3, 10), (4, 13)])
