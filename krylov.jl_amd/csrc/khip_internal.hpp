@@ -82,6 +82,12 @@ struct Tuning {
   int spmm_wide = 1;        // SpMM: two panel columns per lane (16-byte gathers) when p is even
   int spmm_window_grid = 0; // workgroups of the persistent window kernel (0 = CUs x LDS-limited residency)
   int spmm_tile = 1;        // SpMM with 16 columns: wave-private LDS windows filled by LDS-DMA, grid-tile row groups (spmm_tile.hip)
+  int spmm_tile_exp = 0;    // experiments on the tile kernel (WRONG results): 1 no panel-row copies, 2 no products, 4 no (val, slot) loads, 8 round-robin XCD order
+  int spmm_tile_waves = 0;  // persistent waves of the tile kernel = this multiple of the LDS-limited residency (0 = 1)
+  int spmm_tile_grid = 0;   // ... or this many waves outright
+  int spmm_tile_pencil = 0; // tile rows per pencil in the group order of grid operators (0 = 4)
+  int spmm_tile_nt = 0;     // non-temporal hints on the record / entry / Y streams of the tile kernel
+  int spmm_tile_shape = 0;  // grid tile of a 32-row group at build time: 0 = 4x4x2, 1 = 8x2x2, 2 = 2x4x4, 3 = 4x2x4, 4 = 8x4x1, 5 = 32x1x1
   int spmm_window = 1;      // SpMM: stage the distinct panel rows of a row group in LDS (csr_aux.hip, spmm_window_kernel)
   int spmm_sweep = 0;       // SpMM direct kernel: plane-sweep tile order when the band is wider than the L2 can hold (csr_aux.hip; measured no faster)
   int spmm_win_sweep = 0;   // SpMM window kernel: plane-sweep order of the row groups (each XCD walks columns of spmm_sweep_w groups through all planes); measured 15 % slower although it removes the re-fetches (profiles/r02_spmm_experiments.log)
@@ -177,6 +183,7 @@ struct khip_csr {
   // optional group records of the p = 16 tile SpMM (spmm_tile.hip, built on the first SpMM with 16 columns)
   int tile_state = 0;                  // 0 = not tried, 1 = built, -1 = tried, not usable
   char *tile_meta = nullptr;           // [tile_groups] records of tile_stride bytes
+  int32_t *tile_direct_list = nullptr; // [tile_direct] groups on the direct-gather path
   int tile_cap = 0, tile_stride = 0, tile_grid = 0;   // window size (panel rows); tile_grid: 1 = groups are grid tiles, 0 = consecutive rows
   int64_t tile_groups = 0, tile_direct = 0;           // tile_direct: groups on the direct-gather path
   double tile_reuse = 0;               // references per distinct column of a group

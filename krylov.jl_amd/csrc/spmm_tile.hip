@@ -41,6 +41,7 @@ struct TileArgs {
   int64_t groups, per_xcd;
   int cap;                // list entries per group (multiple of 8)
   int stride;             // bytes per record
+  int exp;                // tuning experiments, WRONG results: 1 no panel-row copies, 2 no products, 4 no (val, slot) loads, 8 groups dealt round-robin to the XCDs
 };
 
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
@@ -65,14 +66,19 @@ __device__ __forceinline__ double quad_bcast_c(double v) {
 }
 
 // One entry step of 16 rows: (val, slot) of entry 8 F + K spread over the quad, the two 16-byte pieces of the panel row
-// out of the window, four rounded products and four rounded adds.
+// out of the window, four rounded products and four rounded adds.  xa / xb_: the lane's window base for its first and
+// second piece.  Which half of the 128-byte panel row a quad reads FIRST alternates with bit 1 of the quad number: a
+// ds_read_b128 is served in four groups of four quads, a quad touches 16 of the 64 banks, and which 16 is decided by (parity
+// of the slot, half of the row) -- with every quad reading the same half first, the four quads of a group share two bank
+// ranges (45 % of the LDS cycles were conflicts, profiles/r03_spmm_tile_pmc.log); alternating halves gives the four quads of
+// a group the four ranges whenever their slot parities alternate too (consecutive rows of a grid tile).
 template <int F, int K, bool MASK>
-__device__ __forceinline__ void tile_entry(const dbl2 (&v)[4], const int2v &s, const char *xb, int len, double (&acc)[4]) {
+__device__ __forceinline__ void tile_entry(const dbl2 (&v)[4], const int2v &s, const char *xa, const char *xb_, int len, double (&acc)[4]) {
   const double vv = quad_bcast_c<K / 2>((K & 1) ? v[F].y : v[F].x);
   const int sw = quad_bcast_c<F>((K & 4) ? s.y : s.x);
   const int off = (int)(((unsigned)sw >> (8 * (K & 3))) & 0xffu) << 7;
-  const dbl2 x0 = *reinterpret_cast<const dbl2 *>(xb + off);
-  const dbl2 x1 = *reinterpret_cast<const dbl2 *>(xb + off + 64);
+  const dbl2 x0 = *reinterpret_cast<const dbl2 *>(xa + off);
+  const dbl2 x1 = *reinterpret_cast<const dbl2 *>(xb_ + off);
   const double p0 = vv * x0.x, p1 = vv * x0.y, p2 = vv * x1.x, p3 = vv * x1.y;
   if (!MASK || 8 * F + K < len) {
     acc[0] = acc[0] + p0;
@@ -82,139 +88,236 @@ __device__ __forceinline__ void tile_entry(const dbl2 (&v)[4], const int2v &s, c
   }
 }
 template <int F, bool MASK>
-__device__ __forceinline__ void tile_batch(const dbl2 (&v)[4], const int2v &s, const char *xb, int len, int n, double (&acc)[4]) {
+__device__ __forceinline__ void tile_batch(const dbl2 (&v)[4], const int2v &s, const char *xa, const char *xb_, int len, int n, double (&acc)[4]) {
   // n: wave-uniform number of entries of this batch that any row still has (1..8)
-  tile_entry<F, 0, MASK>(v, s, xb, len, acc);
-  if (n > 1) tile_entry<F, 1, MASK>(v, s, xb, len, acc);
-  if (n > 2) tile_entry<F, 2, MASK>(v, s, xb, len, acc);
-  if (n > 3) tile_entry<F, 3, MASK>(v, s, xb, len, acc);
-  if (n > 4) tile_entry<F, 4, MASK>(v, s, xb, len, acc);
-  if (n > 5) tile_entry<F, 5, MASK>(v, s, xb, len, acc);
-  if (n > 6) tile_entry<F, 6, MASK>(v, s, xb, len, acc);
-  if (n > 7) tile_entry<F, 7, MASK>(v, s, xb, len, acc);
+  tile_entry<F, 0, MASK>(v, s, xa, xb_, len, acc);
+  if (n > 1) tile_entry<F, 1, MASK>(v, s, xa, xb_, len, acc);
+  if (n > 2) tile_entry<F, 2, MASK>(v, s, xa, xb_, len, acc);
+  if (n > 3) tile_entry<F, 3, MASK>(v, s, xa, xb_, len, acc);
+  if (n > 4) tile_entry<F, 4, MASK>(v, s, xa, xb_, len, acc);
+  if (n > 5) tile_entry<F, 5, MASK>(v, s, xa, xb_, len, acc);
+  if (n > 6) tile_entry<F, 6, MASK>(v, s, xa, xb_, len, acc);
+  if (n > 7) tile_entry<F, 7, MASK>(v, s, xa, xb_, len, acc);
 }
 template <bool MASK>
-__device__ __forceinline__ void tile_rows(const dbl2 (&v)[4], const int2v &s, const char *xb, int len, int nmax, double (&acc)[4]) {
-  if (nmax > 0) tile_batch<0, MASK>(v, s, xb, len, nmax < 8 ? nmax : 8, acc);
-  if (nmax > 8) tile_batch<1, MASK>(v, s, xb, len, nmax < 16 ? nmax - 8 : 8, acc);
-  if (nmax > 16) tile_batch<2, MASK>(v, s, xb, len, nmax < 24 ? nmax - 16 : 8, acc);
-  if (nmax > 24) tile_batch<3, MASK>(v, s, xb, len, nmax - 24, acc);
+__device__ __forceinline__ void tile_rows(const dbl2 (&v)[4], const int2v &s, const char *xa, const char *xb_, int len, int nmax, double (&acc)[4]) {
+  if (nmax > 0) tile_batch<0, MASK>(v, s, xa, xb_, len, nmax < 8 ? nmax : 8, acc);
+  if (nmax > 8) tile_batch<1, MASK>(v, s, xa, xb_, len, nmax < 16 ? nmax - 8 : 8, acc);
+  if (nmax > 16) tile_batch<2, MASK>(v, s, xa, xb_, len, nmax < 24 ? nmax - 16 : 8, acc);
+  if (nmax > 24) tile_batch<3, MASK>(v, s, xa, xb_, len, nmax - 24, acc);
 }
 
-template <bool DIST, int NL>      // NL = ceil(cap / 64): list words per lane
+template <int NL>
+struct TileRec {            // what a lane holds of a group's record: its two row descriptors and its share of the list
+  int4v d0, d1;
+  int lw[NL];
+};
+struct TileEnt {            // ... and of the (val, slot) stream of its two rows
+  dbl2 v0[4], v1[4];
+  int2v s0, s1;
+};
+
+// Persistent waves, one per workgroup, wave i takes the groups i, i + G, i + 2 G, ...  Three stages in flight per wave:
+// the record of group g + 2 G, the (val, slot) entries of g + G (they need its record), the panel rows of g (LDS-DMA; they need
+// its list).  After issuing all three the wave waits for the DMA alone (vmcnt = the loads issued after it), so that per
+// group ONE latency -- that of panel rows, mostly L2 / Infinity-Cache hits -- is exposed, and the HBM streams (val, records)
+// run a whole group ahead.  (The one-shot form, one group per wave launch, spent 8.8 us per wave, 63 % of it waiting on
+// two dependent round trips: 1.35-1.5 ms; profiles/r03_spmm_tile_sweep.log.)
+template <bool DIST, int NL, bool NT>      // NL = ceil(cap / 64): list words per lane; NT: non-temporal hints on the streams
 __global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w) {
   extern __shared__ dbl2 tile_win[];                 // [cap][8]: the group's distinct panel rows
+  typedef __attribute__((address_space(3))) char lds_char;
   const int lane = threadIdx.x, sub = lane >> 2, c = lane & 3;
-  const int64_t b = blockIdx.x;
-  const int64_t g = (b & 7) * w.per_xcd + (b >> 3);   // workgroup b runs on XCD b % 8: eight contiguous runs of groups
-  if (g >= w.groups) return;
-  const char *rec = w.meta + g * (int64_t)w.stride;
-  const int4v *desc = reinterpret_cast<const int4v *>(rec);
-  const int32_t *lst = reinterpret_cast<const int32_t *>(rec + kTileDescBytes);
-  const char *slots = rec + kTileDescBytes + 4 * w.cap;
-  const int4v d0 = desc[sub], d1 = desc[16 + sub];
-  int lw[NL];
-#pragma unroll
-  for (int j = 0; j < NL; ++j) {
-    const int q = lane + 64 * j;
-    lw[j] = lst[q < w.cap ? q : w.cap - 1];
+  // Wave b runs on XCD b % 8 (round-robin dispatch of the workgroups).  XCD x takes the x-th of eight contiguous runs of
+  // groups and its waves walk that run side by side, so that the groups in flight on an XCD are neighbours and share
+  // panel rows through its L2 (exp & 8: plain round-robin over all waves instead).
+  const int64_t last = w.groups - 1;
+  int64_t G = gridDim.x, g = blockIdx.x, gend = w.groups;
+  if (!(w.exp & 8) && (gridDim.x & 7) == 0) {
+    const int64_t x = blockIdx.x & 7;
+    G = gridDim.x >> 3;
+    g = x * w.per_xcd + (blockIdx.x >> 3);
+    gend = (x + 1) * w.per_xcd < w.groups ? (x + 1) * w.per_xcd : w.groups;
   }
-  const bool direct = __builtin_amdgcn_readfirstlane(__shfl(d0.w, 4)) != 0;      // aux of row slot 1 = the group's flag
-  if (!direct) {
-    // the (val, slot) stream of the lane's two rows: entries 2 c, 2 c + 1 (+ 8 f) and the slot bytes 8 c .. 8 c + 7
-    const int64_t vlast = a.nnz_bound - 2;
-    dbl2 v0[4], v1[4];
+  if (g >= gend) return;
+  const int hq = (lane & 8) ? 64 : 0;                // quads with bit 1 set read the second half of a panel row first
+  const char *xa = reinterpret_cast<const char *>(tile_win) + 16 * c + hq;
+  const char *xb_ = reinterpret_cast<const char *>(tile_win) + 16 * c + (64 - hq);
+  const int64_t vlast = a.nnz_bound - 2;
+
+  auto load_rec = [&](int64_t gg, TileRec<NL> &r) {
+    const char *rec = w.meta + (gg < last ? gg : last) * (int64_t)w.stride;
+    const int4v *desc = reinterpret_cast<const int4v *>(rec);
+    const int32_t *lst = reinterpret_cast<const int32_t *>(rec + kTileDescBytes);
+    r.d0 = ld<NT>(desc + sub);              // records, entries and Y are streams: they should not push
+    r.d1 = ld<NT>(desc + 16 + sub);         // the panel rows the neighbouring groups share out of the L2
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int q = lane + 64 * j;
+      r.lw[j] = ld<NT>(lst + (q < w.cap ? q : w.cap - 1));
+    }
+  };
+  // the (val, slot) stream of the lane's two rows: entries 2 c, 2 c + 1 (+ 8 f) and the slot bytes 8 c .. 8 c + 7
+  auto load_ent = [&](int64_t gg, const TileRec<NL> &r, TileEnt &e) {
+    const char *slots = w.meta + (gg < last ? gg : last) * (int64_t)w.stride + kTileDescBytes + 4 * w.cap;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      int64_t i0 = (int64_t)d0.y + 2 * c + 8 * f, i1 = (int64_t)d1.y + 2 * c + 8 * f;
+      int64_t i0 = (int64_t)r.d0.y + 2 * c + 8 * f, i1 = (int64_t)r.d1.y + 2 * c + 8 * f;
       i0 = i0 < vlast ? i0 : vlast;
       i1 = i1 < vlast ? i1 : vlast;
-      v0[f] = *reinterpret_cast<const dbl2u *>(a.val + i0);
-      v1[f] = *reinterpret_cast<const dbl2u *>(a.val + i1);
+      if (w.exp & 4) { i0 = 2 * c + 8 * f; i1 = i0; }
+      e.v0[f] = NT ? __builtin_nontemporal_load(reinterpret_cast<const dbl2u *>(a.val + i0)) : *reinterpret_cast<const dbl2u *>(a.val + i0);
+      e.v1[f] = NT ? __builtin_nontemporal_load(reinterpret_cast<const dbl2u *>(a.val + i1)) : *reinterpret_cast<const dbl2u *>(a.val + i1);
     }
-    const int2v s0 = *reinterpret_cast<const int2v *>(slots + sub * kTileLen + 8 * c);
-    const int2v s1 = *reinterpret_cast<const int2v *>(slots + (16 + sub) * kTileLen + 8 * c);
-    // panel rows -> LDS: instruction wq copies list entries 8 wq .. 8 wq + 7, lane i the 16-byte piece i % 8 of entry i / 8
-    typedef __attribute__((address_space(3))) char lds_char;
-    typedef __attribute__((address_space(1))) const void glb_cvoid;
-    lds_char *win = (lds_char *)tile_win;
-    // (all cross-lane moves first: hipcc drains vmcnt before any LDS-class instruction that follows an LDS-DMA)
+    e.s0 = ld<NT>(reinterpret_cast<const int2v *>(slots + sub * kTileLen + 8 * c));
+    e.s1 = ld<NT>(reinterpret_cast<const int2v *>(slots + (16 + sub) * kTileLen + 8 * c));
+  };
+  // panel rows -> LDS: instruction wq copies list entries 8 wq .. 8 wq + 7, lane i the 16-byte piece i % 8 of entry i / 8
+  // The copy is inline asm on purpose: with the builtin, hipcc tracks the LDS-DMA as a pending LDS write and puts a vmcnt
+  // wait that also drains the prefetches of the next groups behind every ds_read of the product loop (seen in the ISA);
+  // an asm VMEM instruction is outside its bookkeeping, which is safe here: the copies are OLDER than every load the
+  // compiler counts in this iteration, so its counted waits stay sufficient, and the wait for the copies themselves is
+  // the explicit vmcnt below.  M0 (the LDS destination base) is compiler-reserved: saved and restored per statement.
+  const unsigned win_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_char *)tile_win);
+  auto issue_dma = [&](const TileRec<NL> &r) {
     int cols[8 * NL];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) cols[8 * j + w8] = __builtin_amdgcn_ds_bpermute(4 * (8 * w8 + (lane >> 3)), lw[j]);
+      for (int w8 = 0; w8 < 8; ++w8) cols[8 * j + w8] = __builtin_amdgcn_ds_bpermute(4 * (8 * w8 + (lane >> 3)), r.lw[j]);
     }
 #pragma unroll
     for (int wq = 0; wq < 8 * NL; ++wq) {
-      if (8 * wq < w.cap) {
-        const int col = cols[wq];
+      if (8 * wq < w.cap && !(w.exp & 1)) {
+        const int col = (w.exp & 16) ? 8 * wq + (lane >> 3) : cols[wq];
         const char *src = reinterpret_cast<const char *>(a.x);
-        uint64_t r = (unsigned)col;
+        uint64_t rr = (unsigned)col;
         if (DIST) {
           const bool own = (int64_t)col < a.n_owned;
           src = own ? src : reinterpret_cast<const char *>(a.ghost);
-          r = own ? r : r - (uint64_t)a.n_owned;
+          rr = own ? rr : rr - (uint64_t)a.n_owned;
         }
-        __builtin_amdgcn_global_load_lds((glb_cvoid *)(src + (r << 7) + 16 * (lane & 7)), (lds_void *)(win + 1024 * wq), 16, 0, 0);
+        const char *gsrc = src + (rr << 7) + 16 * (lane & 7);
+        const unsigned dst = win_lds + 1024u * (unsigned)wq;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing but the issuing wave's vmcnt orders a ds_read behind an LDS-DMA
-    const char *xb = reinterpret_cast<const char *>(tile_win) + 16 * c;
+  };
+  auto products = [&](const TileRec<NL> &r, const TileEnt &e) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int4v &d = q ? d1 : d0;
+      const int4v &d = q ? r.d1 : r.d0;
       const int len = d.z;
       const int len0 = __builtin_amdgcn_readfirstlane(len);
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      if (__ballot(len != len0) == 0) {
-        tile_rows<false>(q ? v1 : v0, q ? s1 : s0, xb, len, len0, acc);
+      if (w.exp & 2) {
+        acc[0] = (q ? e.v1 : e.v0)[0].x + (q ? e.v1 : e.v0)[1].x + (q ? e.v1 : e.v0)[2].x + (q ? e.v1 : e.v0)[3].y + (double)(q ? e.s1 : e.s0).x;
+      } else if (__ballot(len != len0) == 0) {
+        tile_rows<false>(q ? e.v1 : e.v0, q ? e.s1 : e.s0, xa, xb_, len, len0, acc);
       } else {
         int nmax = len;
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(nmax, sft); nmax = o > nmax ? o : nmax; }
         nmax = __builtin_amdgcn_readfirstlane(nmax);
-        tile_rows<true>(q ? v1 : v0, q ? s1 : s0, xb, len, nmax, acc);
+        tile_rows<true>(q ? e.v1 : e.v0, q ? e.s1 : e.s0, xa, xb_, len, nmax, acc);
       }
       if (d.x >= 0) {
         double *yr = a.y + (int64_t)d.x * 16 + 2 * c;
-        *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
-        *reinterpret_cast<dbl2 *>(yr + 8) = dbl2{acc[2], acc[3]};
-      }
-    }
-  } else {
-    // direct gathers (a row longer than 32 entries, or more distinct columns than the window holds): same order of operations
-#pragma unroll 1
-    for (int q = 0; q < 2; ++q) {
-      const int4v &d = q ? d1 : d0;
-      if (d.x < 0) continue;
-      const int64_t s = d.y, e = s + d.z;
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int64_t base = s; base < e; base += 4) {
-        const int cnt = (int)((e - base) < 4 ? (e - base) : 4);
-        const bool mine = c < cnt;
-        const double myv = mine ? a.val[base + c] : 0.0;
-        const int32_t myc = mine ? a.col[base + c] : 0;
-        for (int t = 0; t < cnt; ++t) {
-          const int32_t cc = __shfl(myc, t, 4);
-          const double vv = __shfl(myv, t, 4);
-          const bool own = !DIST || cc < a.n_owned;
-          const double *src = own ? a.x : a.ghost;
-          const int64_t r = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
-          const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + r * 16 + 2 * c);
-          const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + r * 16 + 8 + 2 * c);
-          const double p0 = vv * x0.x, p1 = vv * x0.y, p2 = vv * x1.x, p3 = vv * x1.y;
-          acc[0] = acc[0] + p0;
-          acc[1] = acc[1] + p1;
-          acc[2] = acc[2] + p2;
-          acc[3] = acc[3] + p3;
+        if (NT) {
+          __builtin_nontemporal_store(dbl2{acc[0], acc[1]}, reinterpret_cast<dbl2 *>(yr + (hq >> 3)));          // the half this quad read first
+          __builtin_nontemporal_store(dbl2{acc[2], acc[3]}, reinterpret_cast<dbl2 *>(yr + 8 - (hq >> 3)));
+        } else {
+          *reinterpret_cast<dbl2 *>(yr + (hq >> 3)) = dbl2{acc[0], acc[1]};
+          *reinterpret_cast<dbl2 *>(yr + 8 - (hq >> 3)) = dbl2{acc[2], acc[3]};
         }
       }
-      double *yr = a.y + (int64_t)d.x * 16 + 2 * c;
-      *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
-      *reinterpret_cast<dbl2 *>(yr + 8) = dbl2{acc[2], acc[3]};
     }
+  };
+  TileRec<NL> r0, r1, r2;
+  TileEnt e0, e1;
+  load_rec(g, r0);
+  load_rec(g + G, r1);
+  load_ent(g, r0, e0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): the loop starts with nothing in flight
+  for (;;) {
+    const bool direct = __builtin_amdgcn_readfirstlane(__shfl(r0.d0.w, 4)) != 0;      // aux of row slot 1 = the group's flag
+    if (!direct) issue_dma(r0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    load_ent(g + G, r1, e1);
+    load_rec(g + 2 * G, r2);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!direct) {
+      // the DMA is older than the 10 + 2 + NL loads just issued: wait for it alone (nothing but the issuing wave's vmcnt
+      // orders a ds_read behind an LDS-DMA)
+      // (the builtin, not inline asm: hipcc's own wait-count bookkeeping sees it and does not add vmcnt(0) at the first use
+      // of the entries loaded one iteration ago; gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
+      if (NL == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 13);
+      else if (NL == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 14);
+      else if (NL == 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 15);
+      else __builtin_amdgcn_s_waitcnt(0x4F70 | 0);             // vmcnt(16)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      products(r0, e0);
+    }                                                        // (flagged groups: spmm_tile16_direct_kernel, launched next)
+    g += G;
+    if (g >= gend) break;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every window read of this group has returned before the next DMA
+    r0 = r1; e0 = e1; r1 = r2;
   }
+}
+
+// The flagged groups (a row longer than 32 entries, or more distinct columns than the window holds): direct gathers, same
+// order of operations.  One wave per flagged group, launched after the main kernel over the handle's list of such groups (kept
+// out of the main kernel: a second arm with loads of its own made hipcc's wait-count merging drain the prefetches there).
+template <bool DIST>
+__global__ __launch_bounds__(64) void spmm_tile16_direct_kernel(SpmvArgs a, TileArgs w, const int32_t *glist, int64_t count) {
+  const int lane = threadIdx.x, sub = lane >> 2, c = lane & 3;
+  if ((int64_t)blockIdx.x >= count) return;
+  const int64_t g = glist[blockIdx.x];
+  const int4v *desc = reinterpret_cast<const int4v *>(w.meta + g * (int64_t)w.stride);
+#pragma unroll 1
+  for (int q = 0; q < 2; ++q) {
+    const int4v d = desc[16 * q + sub];
+    if (d.x < 0) continue;
+    const int64_t s = d.y, e = s + d.z;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t base = s; base < e; base += 4) {
+      const int cnt = (int)((e - base) < 4 ? (e - base) : 4);
+      const bool mine = c < cnt;
+      const double myv = mine ? a.val[base + c] : 0.0;
+      const int32_t myc = mine ? a.col[base + c] : 0;
+      for (int t = 0; t < cnt; ++t) {
+        const int32_t cc = __shfl(myc, t, 4);
+        const double vv = __shfl(myv, t, 4);
+        const bool own = !DIST || cc < a.n_owned;
+        const double *src = own ? a.x : a.ghost;
+        const int64_t rr = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
+        const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 2 * c);
+        const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 8 + 2 * c);
+        const double p0 = vv * x0.x, p1 = vv * x0.y, p2 = vv * x1.x, p3 = vv * x1.y;
+        acc[0] = acc[0] + p0;
+        acc[1] = acc[1] + p1;
+        acc[2] = acc[2] + p2;
+        acc[3] = acc[3] + p3;
+      }
+    }
+    double *yr = a.y + (int64_t)d.x * 16 + 2 * c;
+    *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
+    *reinterpret_cast<dbl2 *>(yr + 8) = dbl2{acc[2], acc[3]};
+  }
+}
+
+// list of the flagged groups (order irrelevant)
+__global__ __launch_bounds__(kBlock) void spmm_tile_flagged_kernel(const char *meta, int stride, int64_t groups, int32_t *glist,
+                                                                    unsigned long long *count) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= groups) return;
+  const int4v d1 = reinterpret_cast<const int4v *>(meta + g * (int64_t)stride)[1];
+  if (d1.w != 0) glist[atomicAdd(count, 1ull)] = (int32_t)g;
 }
 
 // ---------------------------------------------------------------- metadata ----------
@@ -225,11 +328,20 @@ struct TileOrder {
   int64_t s1, s2;       // s1 == 0: identity order
   int n1, n2, n3;
   int bi, bj, bk;       // tile extents (bi * bj * bk == 32)
-  int gi, gj;           // tiles along i and j
+  int gi, gj, gk;       // tiles along i, j, k
+  int pj;               // pencil width in tiles along j (group order: i fastest, then j inside a pencil, then k, then the pencils)
 };
 __device__ __forceinline__ int64_t tile_row_of(const TileOrder &o, int64_t g, int t) {
   if (o.s1 == 0) { const int64_t r = g * kTileR + t; return r < o.m ? r : -1; }
-  const int64_t ti = g % o.gi, tj = (g / o.gi) % o.gj, tk = g / ((int64_t)o.gi * o.gj);
+  // pencil order: the groups of pj tile rows are walked through ALL planes before the next pj tile rows, so that the
+  // k-neighbours of a tile are pj * gi groups away (inside the set of groups an XCD has in flight) instead of gi * gj
+  const int64_t per_pencil = (int64_t)o.gi * o.pj * o.gk;          // groups of a full-width pencil
+  const int64_t pen = g / per_pencil;
+  const int wj = (pen + 1) * o.pj <= o.gj ? o.pj : o.gj - (int)(pen * o.pj);      // the last pencil may be narrower
+  const int64_t rem = g - pen * per_pencil;
+  const int64_t ti = rem % o.gi, tjj = (rem / o.gi) % wj, tk = rem / ((int64_t)o.gi * wj);
+  const int64_t tj = pen * o.pj + tjj;
+  if (tk >= o.gk) return -1;
   const int di = t % o.bi, dj = (t / o.bi) % o.bj, dk = t / (o.bi * o.bj);
   const int64_t i = ti * o.bi + di, j = tj * o.bj + dj, k = tk * o.bk + dk;
   if (i >= o.n1 || j >= o.n2 || k >= o.n3) return -1;
@@ -355,7 +467,9 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_kernel(const int32_t *
 
 void csr_free_tiles(khip_csr *A) {
   (void)hipFree(A->tile_meta);
+  (void)hipFree(A->tile_direct_list);
   A->tile_meta = nullptr;
+  A->tile_direct_list = nullptr;
   A->tile_state = 0;
 }
 
@@ -363,17 +477,30 @@ static TileOrder tile_order_for(const khip_csr *A, bool tiles) {
   TileOrder o{};
   o.m = A->m;
   if (!tiles) return o;
+  const int shape = A->ctx ? A->ctx->tune.spmm_tile_shape : 0;
   const int64_t s1 = A->line_rows, s2 = A->plane_rows > A->line_rows ? A->plane_rows : A->m;
   o.s1 = s1; o.s2 = s2;
   o.n1 = (int)s1; o.n2 = (int)((s2 + s1 - 1) / s1); o.n3 = (int)((A->m + s2 - 1) / s2);
-  if (o.n3 > 1) { o.bi = 4; o.bj = 4; o.bk = 2; } else { o.bi = 8; o.bj = 4; o.bk = 1; }
+  if (o.n3 > 1) {
+    switch (shape) {                       // 4 x 4 x 2 (default): 6 x 6 x 4 = 144 panel rows of the 27-point box, runs of 4 consecutive rows
+      case 1: o.bi = 8; o.bj = 2; o.bk = 2; break;
+      case 2: o.bi = 2; o.bj = 4; o.bk = 4; break;
+      case 3: o.bi = 4; o.bj = 2; o.bk = 4; break;
+      case 4: o.bi = 8; o.bj = 4; o.bk = 1; break;
+      case 5: o.bi = 32; o.bj = 1; o.bk = 1; break;
+      default: o.bi = 4; o.bj = 4; o.bk = 2; break;
+    }
+  } else { o.bi = 8; o.bj = 4; o.bk = 1; }
   o.gi = (o.n1 + o.bi - 1) / o.bi;
   o.gj = (o.n2 + o.bj - 1) / o.bj;
+  o.gk = (o.n3 + o.bk - 1) / o.bk;
+  o.pj = A->ctx && A->ctx->tune.spmm_tile_pencil > 0 ? A->ctx->tune.spmm_tile_pencil : 4;      // 3..16 measure alike (1.20-1.31 ms at 216^3 x 16), 1 / 2 / whole planes 1.35 (profiles/r03g_spmm_tile_sweep.log)
+  if (o.pj > o.gj) o.pj = o.gj;
   return o;
 }
 static int64_t tile_groups_for(const TileOrder &o) {
   if (o.s1 == 0) return (o.m + kTileR - 1) / kTileR;
-  return (int64_t)o.gi * o.gj * ((o.n3 + o.bk - 1) / o.bk);
+  return (int64_t)o.gi * o.gj * o.gk;
 }
 
 // Builds the group records of A for the p = 16 tile kernel.  On return A->tile_state is 1 (usable) or -1 (the operator
@@ -432,39 +559,69 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
   hipLaunchKernelGGL((spmm_tile_build_kernel<true>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, best, cap, stride,
                      A->tile_meta, (int32_t *)nullptr, (unsigned long long *)nullptr);
   KHIP_CHECK_HIP(hipGetLastError());
+  unsigned long long over = 0;
+  for (size_t bin = (size_t)cap / 8 + 1; bin + 2 < best_st.size(); ++bin) over += best_st[2 + bin];
+  const int64_t n_direct = (int64_t)(best_st[0] + over);
+  if (n_direct > 0) {
+    KHIP_CHECK_HIP(hipMalloc(&A->tile_direct_list, sizeof(int32_t) * (size_t)n_direct));
+    KHIP_CHECK_HIP(hipMemsetAsync(stat, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(spmm_tile_flagged_kernel, dim3((unsigned)((groups + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream,
+                       A->tile_meta, stride, groups, A->tile_direct_list, stat);
+    KHIP_CHECK_HIP(hipGetLastError());
+    unsigned long long got = 0;
+    KHIP_CHECK_HIP(hipMemcpyAsync(&got, stat, sizeof(got), hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if ((int64_t)got != n_direct) { set_error("spmm_tile_build: %lld flagged groups listed, %lld counted", (long long)got, (long long)n_direct); csr_free_tiles(A); A->tile_state = -1; return KHIP_ERR_HIP; }
+  }
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   A->tile_state = 1;
   A->tile_cap = cap;
   A->tile_stride = stride;
   A->tile_groups = groups;
   A->tile_grid = best.s1 != 0 ? 1 : 0;
-  unsigned long long over = 0;
-  for (size_t bin = (size_t)cap / 8 + 1; bin + 2 < best_st.size(); ++bin) over += best_st[2 + bin];
-  A->tile_direct = (int64_t)(best_st[0] + over);
+  A->tile_direct = n_direct;
   A->tile_reuse = best_score;
   return KHIP_OK;
 }
 
 int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
   TileArgs w;
-  w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride;
-  const int64_t grid = 8 * w.per_xcd;
+  w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride; w.exp = ctx->tune.spmm_tile_exp;
   const size_t lds = (size_t)w.cap * 128;
+  int per_cu = (int)((size_t)(160 * 1024) / lds);                    // LDS-limited residency of the one-wave workgroups
+  if (per_cu >= 5) --per_cu;                                         // one wave short of the LDS limit measures 3 % faster (7 instead of 8 at 144 panel rows)
+  if (per_cu > 16) per_cu = 16;
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = (int64_t)ctx->num_cu * per_cu * (ctx->tune.spmm_tile_waves > 0 ? ctx->tune.spmm_tile_waves : 1);
+  if (ctx->tune.spmm_tile_grid > 0) grid = ctx->tune.spmm_tile_grid;
+  if (grid > w.groups) grid = w.groups;
+  if (grid >= 64) grid &= ~(int64_t)7;                               // whole waves per XCD
   const bool dist = a.ghost != a.x;
   const int NL = (w.cap + 63) / 64;
   const dim3 gd((unsigned)grid), bd(64);
-#define KHIP_TILE_LAUNCH(D, N)                                                                                          \
+#define KHIP_TILE_LAUNCH1(D, N, T)                                                                                      \
   do {                                                                                                                  \
     if (lds > 64 * 1024)                                                                                                \
-      (void)hipFuncSetAttribute((const void *)spmm_tile16_kernel<D, N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((spmm_tile16_kernel<D, N>), gd, bd, lds, ctx->stream, a, w);                                     \
+      (void)hipFuncSetAttribute((const void *)spmm_tile16_kernel<D, N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((spmm_tile16_kernel<D, N, T>), gd, bd, lds, ctx->stream, a, w);                                  \
   } while (0)
+#define KHIP_TILE_LAUNCH(D, N)                                                                                          \
+  do {                                                                                                                  \
+    if (nt) KHIP_TILE_LAUNCH1(D, N, true); else KHIP_TILE_LAUNCH1(D, N, false);                                         \
+  } while (0)
+  const bool nt = ctx->tune.spmm_tile_nt != 0;
   if (dist) {
     switch (NL) { case 1: KHIP_TILE_LAUNCH(true, 1); break; case 2: KHIP_TILE_LAUNCH(true, 2); break; case 3: KHIP_TILE_LAUNCH(true, 3); break; default: KHIP_TILE_LAUNCH(true, 4); break; }
   } else {
     switch (NL) { case 1: KHIP_TILE_LAUNCH(false, 1); break; case 2: KHIP_TILE_LAUNCH(false, 2); break; case 3: KHIP_TILE_LAUNCH(false, 3); break; default: KHIP_TILE_LAUNCH(false, 4); break; }
   }
 #undef KHIP_TILE_LAUNCH
+#undef KHIP_TILE_LAUNCH1
+  if (A->tile_direct > 0) {
+    const dim3 gdd((unsigned)A->tile_direct);
+    if (dist) hipLaunchKernelGGL((spmm_tile16_direct_kernel<true>), gdd, bd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+    else hipLaunchKernelGGL((spmm_tile16_direct_kernel<false>), gdd, bd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+  }
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }

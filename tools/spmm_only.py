@@ -10,6 +10,9 @@ n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 216
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 p = 16
 n = n1 ** 3
+for kv in filter(None, os.environ.get("KHIP_OPTS", "").split(",")):      # e.g. KHIP_OPTS=spmm_tile_pencil=54,spmm_tile_exp=8
+    k, v = kv.split("=")
+    ctx.set_option(k, int(v))
 A = K.CsrMatrix.stencil(ctx, "stencil27", n1)
 X, Y = K.Panel(ctx, n, p), K.Panel(ctx, n, p)
 K.spmm_(A, X, Y); ctx.sync()
