@@ -127,6 +127,16 @@ int khip_csr_halo_info(const khip_csr *A, int *gather_mode, int64_t *n_ghost, in
  * col int32[nnz] (global, 0-based), val double[nnz]. */
 int khip_gen_stencil(khip_ctx *ctx, int kind, int n1, int n2, int n3, int64_t row0, int64_t m,
                      int32_t **rowptr_dev, int32_t **col_dev, double **val_dev, int64_t *nnz);
+/* Generator of the "banded + random, fixed seed" benchmark operator (csrc/gen_irregular.cpp; the stand-in for the
+ * SuiteSparse matrices of the reference's benchmarks, benchmark/cg_bmark.jl:29-54, benchmark/gpu.jl:15-47, which cannot be
+ * fetched offline): a symmetric band of half width half_band with 1 entry in 8 left out, `links` long-range partners per row
+ * from seeded involutions of blocks of 2^20 rows (far more than 2048 distinct diagonals), off-diagonal entries in (-2, -1],
+ * diagonal = 1/16 + the row's absolute sum (strictly diagonally dominant; SPD when symmetric).  flags bit 0: nonsymmetric values
+ * (entries above the diagonal halved); dense_rows > 0 (nonsymmetric only): that many rows with 3000 further entries each.
+ * Built on the host, rows [row0, row0 + m) of the global operator; outputs as khip_gen_stencil.  The definition is restated in
+ * the file's header and, independently, by the oracle (ko_csr_banded_random). */
+int khip_gen_banded_random(khip_ctx *ctx, int64_t n, int half_band, int links, uint64_t seed, int flags, int dense_rows,
+                           int64_t row0, int64_t m, int32_t **rowptr_dev, int32_t **col_dev, double **val_dev, int64_t *nnz);
 
 /* y <- A x.  ref: kmul!(y, A, x) src/krylov_utils.jl:305; sites src/cg.jl:155,196,
  * src/gmres.jl:159,222,257, src/bicgstab.jl:160,221,228.  For a distributed handle x and y are

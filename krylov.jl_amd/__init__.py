@@ -84,6 +84,8 @@ SIGNATURES = {
     "khip_csr_shape": (_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "khip_gen_stencil": (_int, [_vp, _int, _int, _int, _int, _i64, _i64, c_void_pp, c_void_pp, c_void_pp,
                                 C.POINTER(_i64)]),
+    "khip_gen_banded_random": (_int, [_vp, _i64, _int, _int, C.c_uint64, _int, _int, _i64, _i64, c_void_pp, c_void_pp, c_void_pp,
+                                      C.POINTER(_i64)]),
     "khip_spmv": (_int, [_vp, _vp, _vp, _vp]),
     "khip_spmm": (_int, [_vp, _vp, _vp, _vp, _int]),
     "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
@@ -684,6 +686,28 @@ class CsrMatrix:
         return cls.from_host(ctx, S.indptr, S.indices, S.data, S.shape)
 
     @classmethod
+    def banded_random(cls, ctx, n, half_band=13, links=3, seed=1, unsym=False, dense_rows=0, rows=None, distributed=False):
+        """The "banded + random, fixed seed" benchmark operator (csrc/gen_irregular.cpp): the non-stencil stand-in for the
+        SuiteSparse matrices of benchmark/cg_bmark.jl:29-54 -- a thinned symmetric band plus seeded long-range links,
+        diagonally dominant; unsym halves the entries above the diagonal, dense_rows adds rows of 3000 more entries."""
+        r0, r1 = rows if rows is not None else (0, n)
+        rp, cl, vl, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        _ck(lib().khip_gen_banded_random(ctx._h, n, half_band, links, seed, 1 if unsym else 0, dense_rows, r0, r1 - r0,
+                                         C.byref(rp), C.byref(cl), C.byref(vl), C.byref(nnz)))
+        h = C.c_void_p()
+        try:
+            if distributed:
+                _ck(lib().khip_csr_create_dist(ctx._h, n, r0, r1 - r0, nnz.value, rp, 32, cl, vl, 0, 1, C.byref(h)))
+            else:
+                if (r0, r1) != (0, n):
+                    raise ValueError("a row slice needs distributed=True")
+                _ck(lib().khip_csr_create(ctx._h, n, n, nnz.value, rp, 32, cl, vl, 0, 1, C.byref(h)))
+        finally:
+            for p in (rp, cl, vl):
+                lib().khip_free(ctx._h, p)
+        return cls(ctx, h)
+
+    @classmethod
     def stencil(cls, ctx, kind: str, n1, n2=None, n3=None, rows=None, distributed=False):
         """Device-side generator of the benchmark operators: 'poisson' = get_div_grad(n1,n2,n3)
         (test/get_div_grad.jl:8-25), 'kron_unsymmetric' (test/test_utils.jl:160-169), 'stencil27' (cfg 5)."""
@@ -735,6 +759,25 @@ def gen_stencil_arrays(ctx, kind, n1, n2=None, n3=None, rows=None):
     rp, cl, vl, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
     _ck(lib().khip_gen_stencil(ctx._h, kinds[kind], n1, n2, n3, r0, r1 - r0, C.byref(rp), C.byref(cl), C.byref(vl),
                                C.byref(nnz)))
+    m = r1 - r0
+    rowptr = np.empty(m + 1, dtype=np.int32)
+    col = np.empty(nnz.value, dtype=np.int32)
+    val = np.empty(nnz.value, dtype=np.float64)
+    _ck(lib().khip_memcpy_d2h(ctx._h, rowptr.ctypes.data, rp, 4 * (m + 1)))
+    if nnz.value:
+        _ck(lib().khip_memcpy_d2h(ctx._h, col.ctypes.data, cl, 4 * nnz.value))
+        _ck(lib().khip_memcpy_d2h(ctx._h, val.ctypes.data, vl, 8 * nnz.value))
+    for p in (rp, cl, vl):
+        lib().khip_free(ctx._h, p)
+    return rowptr, col, val
+
+
+def gen_banded_random_arrays(ctx, n, half_band=13, links=3, seed=1, unsym=False, dense_rows=0, rows=None):
+    """Raw (rowptr, col, val) of khip_gen_banded_random copied to host -- used by the parity tests."""
+    r0, r1 = rows if rows is not None else (0, n)
+    rp, cl, vl, nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+    _ck(lib().khip_gen_banded_random(ctx._h, n, half_band, links, seed, 1 if unsym else 0, dense_rows, r0, r1 - r0,
+                                     C.byref(rp), C.byref(cl), C.byref(vl), C.byref(nnz)))
     m = r1 - r0
     rowptr = np.empty(m + 1, dtype=np.int32)
     col = np.empty(nnz.value, dtype=np.int32)

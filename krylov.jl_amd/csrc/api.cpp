@@ -339,9 +339,17 @@ int khip_spmv_bytes(const khip_csr *A, int64_t *bytes) {
 }  // extern "C"
 int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, const double *dotw,
                    int dot_sq) {
-  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5) {   // only the staged / template kernels carry the second reduction
-    KHIP_TRY(spmv_any(ctx, A, x, y, dot_slot, dotw, 0));
-    return launch_nrm2sq(ctx, A->m, dot_sq == 1 ? y : (dotw ? dotw : x), dot_slot + 1);
+  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5 && spmv_kernel_choice(ctx, A) != 1) {   // the ordered / vector kernels do not carry the second reduction
+    // two reductions instead of one: inside a device-resident loop the scalar epilogue must see BOTH results, so it is
+    // taken off the two finish kernels and run on its own afterwards (it used to run after the first one, on a stale second
+    // scalar: bicgstab!(fused = 2) diverged on operators that do not take the staged kernel)
+    const int epi = ctx->ctl.epi;
+    ctx->ctl.epi = 0;
+    int rc = spmv_any(ctx, A, x, y, dot_slot, dotw, 0);
+    if (rc == KHIP_OK) rc = launch_nrm2sq(ctx, A->m, dot_sq == 1 ? y : (dotw ? dotw : x), dot_slot + 1);
+    ctx->ctl.epi = epi;
+    if (rc == KHIP_OK && epi != 0) rc = launch_epilogue_only(ctx, dot_slot);
+    return rc;
   }
   if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m, nullptr, true, dotw, dot_sq);
   KHIP_TRY(comm_halo_exchange_begin(ctx, A, x));

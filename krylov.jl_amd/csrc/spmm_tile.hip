@@ -271,43 +271,55 @@ __global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w)
 }
 
 // The flagged groups (a row longer than 32 entries, or more distinct columns than the window holds): direct gathers, same
-// order of operations.  One wave per flagged group, launched after the main kernel over the handle's list of such groups (kept
-// out of the main kernel: a second arm with loads of its own made hipcc's wait-count merging drain the prefetches there).
+// order of operations.  One workgroup per flagged group, launched after the main kernel over the handle's list of such groups
+// (kept out of the main kernel: a second arm with loads of its own made hipcc's wait-count merging drain the prefetches there).
+// A row of thousands of entries must not be one serial chain of dependent gathers (four such rows cost 1.5 ms at 10 M rows,
+// profiles/r03_bench_irregular.jsonl): the 256 threads form the 4 x 16 products of 64 entries at a time in parallel (thread
+// t: entry t / 4, columns 4 (t % 4) .. + 3), park them in LDS, and ONE quad adds them up in stored order -- the same rounded
+// multiply and rounded add per entry and column as everywhere else.
 template <bool DIST>
-__global__ __launch_bounds__(64) void spmm_tile16_direct_kernel(SpmvArgs a, TileArgs w, const int32_t *glist, int64_t count) {
-  const int lane = threadIdx.x, sub = lane >> 2, c = lane & 3;
+__global__ __launch_bounds__(kBlock) void spmm_tile16_direct_kernel(SpmvArgs a, TileArgs w, const int32_t *glist, int64_t count) {
+  __shared__ double prod[64][16];
+  const int tid = threadIdx.x, e = tid >> 2, c = tid & 3;
   if ((int64_t)blockIdx.x >= count) return;
   const int64_t g = glist[blockIdx.x];
   const int4v *desc = reinterpret_cast<const int4v *>(w.meta + g * (int64_t)w.stride);
-#pragma unroll 1
-  for (int q = 0; q < 2; ++q) {
-    const int4v d = desc[16 * q + sub];
-    if (d.x < 0) continue;
-    const int64_t s = d.y, e = s + d.z;
+  for (int t = 0; t < kTileR; ++t) {
+    const int4v d = desc[t];
+    if (d.x < 0) continue;                                  // (uniform)
+    const int64_t s = d.y, len = d.z;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t base = s; base < e; base += 4) {
-      const int cnt = (int)((e - base) < 4 ? (e - base) : 4);
-      const bool mine = c < cnt;
-      const double myv = mine ? a.val[base + c] : 0.0;
-      const int32_t myc = mine ? a.col[base + c] : 0;
-      for (int t = 0; t < cnt; ++t) {
-        const int32_t cc = __shfl(myc, t, 4);
-        const double vv = __shfl(myv, t, 4);
+    for (int64_t base = 0; base < len; base += 64) {
+      const int cnt = (int)((len - base) < 64 ? (len - base) : 64);
+      if (e < cnt) {
+        const double vv = a.val[s + base + e];
+        const int32_t cc = a.col[s + base + e];
         const bool own = !DIST || cc < a.n_owned;
         const double *src = own ? a.x : a.ghost;
         const int64_t rr = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
-        const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 2 * c);
-        const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 8 + 2 * c);
-        const double p0 = vv * x0.x, p1 = vv * x0.y, p2 = vv * x1.x, p3 = vv * x1.y;
-        acc[0] = acc[0] + p0;
-        acc[1] = acc[1] + p1;
-        acc[2] = acc[2] + p2;
-        acc[3] = acc[3] + p3;
+        const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 4 * c);
+        const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 4 * c + 2);
+        prod[e][4 * c + 0] = vv * x0.x;
+        prod[e][4 * c + 1] = vv * x0.y;
+        prod[e][4 * c + 2] = vv * x1.x;
+        prod[e][4 * c + 3] = vv * x1.y;
       }
+      __syncthreads();
+      if (tid < 4) {
+        for (int k = 0; k < cnt; ++k) {
+          acc[0] = acc[0] + prod[k][4 * c + 0];
+          acc[1] = acc[1] + prod[k][4 * c + 1];
+          acc[2] = acc[2] + prod[k][4 * c + 2];
+          acc[3] = acc[3] + prod[k][4 * c + 3];
+        }
+      }
+      __syncthreads();
     }
-    double *yr = a.y + (int64_t)d.x * 16 + 2 * c;
-    *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
-    *reinterpret_cast<dbl2 *>(yr + 8) = dbl2{acc[2], acc[3]};
+    if (tid < 4) {
+      double *yr = a.y + (int64_t)d.x * 16 + 4 * c;
+      *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
+      *reinterpret_cast<dbl2 *>(yr + 2) = dbl2{acc[2], acc[3]};
+    }
   }
 }
 
@@ -618,9 +630,9 @@ int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
 #undef KHIP_TILE_LAUNCH
 #undef KHIP_TILE_LAUNCH1
   if (A->tile_direct > 0) {
-    const dim3 gdd((unsigned)A->tile_direct);
-    if (dist) hipLaunchKernelGGL((spmm_tile16_direct_kernel<true>), gdd, bd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
-    else hipLaunchKernelGGL((spmm_tile16_direct_kernel<false>), gdd, bd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+    const dim3 gdd((unsigned)A->tile_direct), bdd(kBlock);
+    if (dist) hipLaunchKernelGGL((spmm_tile16_direct_kernel<true>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+    else hipLaunchKernelGGL((spmm_tile16_direct_kernel<false>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
   }
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;

@@ -83,8 +83,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
   const int cid = chunk_id(blockIdx.x, G, a.xcd_remap);
   const int64_t rb_begin = nrb * cid / G;
   const int64_t rb_end = nrb * (cid + 1) / G;
-  dd dacc[1];
+  dd dacc[2];                                // [0] = w . y ; [1] = y . y or w . w (only when a.dot_sq)
   dacc[0] = dd{0.0, 0.0};
+  dacc[1] = dd{0.0, 0.0};
 
   for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
     const int64_t r0 = a.row_lo + rb * ROWS;
@@ -155,10 +156,18 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
     }
     if (tid < nr) {
       if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
-      if (DOT) acc_prod<COMP>(dacc[0], a.dotw[r0 + tid], acc);
+      if (DOT) {
+        const double wv = a.dotw[r0 + tid];
+        acc_prod<COMP>(dacc[0], wv, acc);
+        if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);        // y . y
+        else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);     // w . w
+      }
     }
   }
-  if (DOT) wave_publish<1>(dacc, ra);
+  if (DOT) {
+    if (a.dot_sq) wave_publish<2>(dacc, ra);
+    else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
+  }
 }
 
 // ---------------------------------------------------------------- staged rows ------------
@@ -839,9 +848,17 @@ static inline unsigned pick_grid(khip_ctx *ctx, int64_t tiles, bool persist) {
 int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A) {
   if (A->tmpl_id && ctx->tune.spmv_template) return 5;      // compressed handle (khip_csr_compress)
   int kernel = ctx->tune.spmv_kernel;
-  // short rows (stencils, <= 8 entries on average): staged-rows kernel; mid-size rows: ordered
-  // sub-wave kernel; very long rows: strided vector kernel
-  if (kernel == 0) kernel = (A->mean_row_nnz <= 8.0 && A->max_row_nnz <= 64) ? 4 : (A->mean_row_nnz <= 96.0 ? 3 : 2);
+  // Measured on seven operators (profiles/r03_sweep_spmv_choice.log, int32 columns): the staged-rows kernel wins for short
+  // rows (7 per row: 0.69-0.71 of the HBM peak on the algorithmic bytes, stream kernel 0.61, ordered 0.46-0.51), the stream
+  // kernel for everything longer (27 per row: 0.51-0.59, staged 0.41-0.59, ordered 0.13; 75 per row: 0.49 / 0.28 / 0.05);
+  // the ordered sub-wave kernel (one row per lane group, serial fold by shuffles) never -- it stays selectable (3).  An
+  // operator whose columns are dictionary coded (colcode.hip: stencils of up to 64 entries per row) keeps the staged kernel,
+  // which is the one that streams the codes.  Very long rows: strided vector kernel (not bit-identical).
+  if (kernel == 0) {
+    const bool short_rows = A->mean_row_nnz <= 12.0 && A->max_row_nnz <= 64;
+    const bool coded = A->code_state == 1 && ctx->tune.spmv_codes != 0 && A->max_row_nnz <= 64;
+    kernel = (short_rows || coded) ? 4 : (A->mean_row_nnz <= 96.0 ? 1 : 2);
+  }
   return kernel;
 }
 
@@ -850,7 +867,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   int64_t local_cursor = 0;
   if (!wave_cursor) wave_cursor = &local_cursor;
   const int nout = dot_sq ? 2 : 1;
-  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5) { set_error("spmv: the y.y output needs the staged kernel"); return KHIP_ERR_UNSUPPORTED; }
+  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5 && spmv_kernel_choice(ctx, A) != 1) { set_error("spmv: the second reduction output needs the staged, stream or template kernel"); return KHIP_ERR_UNSUPPORTED; }
   if (row_hi <= row_lo) {
     if (dot_slot >= 0 && finish) {
       if (*wave_cursor == 0) {                                              // nothing at all: writes 0
@@ -901,6 +918,11 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     ctx->prof_used += 2;
   }
 
+  // mid-length rows on few diagonals (the 27-point stencil): try the coded column stream once, it decides between the staged
+  // and the stream kernel (spmv_kernel_choice)
+  if (ctx->tune.spmv_kernel == 0 && A->code_state == 0 && A->mean_row_nnz > 12.0 && A->mean_row_nnz <= 64.0 && A->max_row_nnz <= 64 &&
+      ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && !nt && !a.fake_gather && !(A->tmpl_id && ctx->tune.spmv_template))
+    KHIP_TRY(csr_build_codes(ctx, const_cast<khip_csr *>(A)));
   const int kernel = spmv_kernel_choice(ctx, A);
   unsigned grid = 1;
   RedArgs ra;

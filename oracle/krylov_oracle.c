@@ -167,6 +167,156 @@ int ko_csr_stencil27_unsym(int n1, ko_csr *A) {
   return csr_stencil3d(n1, n1, n1, 1, coef_stencil27, A);
 }
 
+/* "banded + random, fixed seed": the non-stencil benchmark operator (stands in for the SuiteSparse
+ * matrices of benchmark/cg_bmark.jl:29-54).  Restated from its definition in the header of
+ * krylov.jl_amd/csrc/gen_irregular.cpp, independently of that code: candidate lists per row, then an insertion sort.
+ * tests/test_gpu_primitives.py compares the two generators array by array. */
+static uint64_t br_mix(uint64_t z) {
+  z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull;
+  z ^= z >> 27; z *= 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return z;
+}
+typedef struct {
+  int64_t n; int hb, K, B, h, unsym, ndense;
+  uint64_t seed, mask, a1[16], a2[16], a1i[16], a2i[16];
+  int64_t stride;
+} br_spec;
+static uint64_t br_key(const br_spec *S, int64_t lo, int64_t hi) {
+  return br_mix(S->seed ^ ((uint64_t)lo * 0x9E3779B97F4A7C15ull + (uint64_t)hi));
+}
+static uint64_t br_inverse(uint64_t a, uint64_t mask) {
+  /* a odd: bit-by-bit solve of a * x = 1 (mod 2^B) */
+  uint64_t x = 0, prod = 0;
+  for (uint64_t bit = 1; bit != 0 && bit <= mask; bit <<= 1) {
+    if (((prod ^ 1) & bit) != 0) { x |= bit; prod += a * bit; }
+  }
+  return x & mask;
+}
+static int64_t br_partner(const br_spec *S, int k, int64_t r) {
+  int64_t blk = r >> S->B;
+  if (blk >= (S->n >> S->B)) return -1;
+  uint64_t s = br_mix(S->seed + 0x51 + 131ull * (uint64_t)k + 977ull * (uint64_t)blk) & S->mask;
+  uint64_t x = ((uint64_t)r & S->mask) ^ s;
+  x = (x * S->a1[k]) & S->mask; x ^= x >> S->h;
+  x = (x * S->a2[k]) & S->mask; x ^= x >> S->h;
+  x ^= 1;
+  x ^= x >> S->h; x = (x * S->a2i[k]) & S->mask;
+  x ^= x >> S->h; x = (x * S->a1i[k]) & S->mask;
+  return (blk << S->B) | (int64_t)(x ^ s);
+}
+/* off-diagonal entries of row r into (c, v), unsorted; returns their number (cap >= 2 hb + K + 3000) */
+static int br_row(const br_spec *S, int64_t r, int64_t *c, double *v) {
+  int cnt = 0;
+  for (int d = 1; d <= S->hb; d++) {
+    if (r - d >= 0 && (br_key(S, r - d, r) & 7) != 0) {
+      c[cnt] = r - d; v[cnt] = -(1.0 + (double)((br_key(S, r - d, r) >> 8) & 255) / 256.0); cnt++;
+    }
+    if (r + d < S->n && (br_key(S, r, r + d) & 7) != 0) {
+      double m = 1.0 + (double)((br_key(S, r, r + d) >> 8) & 255) / 256.0;
+      c[cnt] = r + d; v[cnt] = S->unsym ? -0.5 * m : -m; cnt++;
+    }
+  }
+  int first_link = cnt;
+  for (int k = 0; k < S->K; k++) {
+    int64_t p = br_partner(S, k, r);
+    if (p < 0 || p >= S->n) continue;
+    if (llabs((long long)(p - r)) <= S->hb) continue;
+    int dup = 0;
+    for (int q = first_link; q < cnt; q++) if (c[q] == p) dup = 1;
+    if (dup) continue;
+    int64_t lo = p < r ? p : r, hi = p < r ? r : p;
+    double m = 1.0 + (double)((br_key(S, lo, hi) >> 8) & 255) / 256.0;
+    c[cnt] = p; v[cnt] = (S->unsym && p > r) ? -0.5 * m : -m; cnt++;
+  }
+  if (S->unsym) {
+    for (int q = 0; q < S->ndense; q++) {
+      if (r != (int64_t)(q + 1) * S->n / (S->ndense + 1)) continue;
+      int base = cnt;
+      for (int t = 0; t < 3000; t++) {
+        int64_t cc = (r + 1 + (int64_t)t * S->stride) % S->n;
+        if (cc == r) continue;
+        int have = 0;
+        for (int u = 0; u < cnt && !have; u++) have = c[u] == cc;      /* band, links and earlier extras */
+        if (have) continue;
+        int64_t lo = cc < r ? cc : r, hi = cc < r ? r : cc;
+        c[cnt] = cc; v[cnt] = -(1.0 + (double)((br_key(S, lo, hi) >> 8) & 255) / 256.0) / 64.0; cnt++;
+      }
+      (void)base;
+    }
+  }
+  return cnt;
+}
+int ko_csr_banded_random(int64_t n, int half_band, int links, uint64_t seed, int unsym, int dense_rows, ko_csr *A) {
+  if (n < 2 || half_band < 0 || half_band > 64 || links < 0 || links > 16 || dense_rows < 0 || dense_rows > 64) return -2;
+  br_spec S;
+  S.n = n; S.hb = half_band; S.K = links; S.seed = seed; S.unsym = unsym != 0; S.ndense = dense_rows;
+  int B = 0;
+  while (((int64_t)2 << B) <= n) B++;
+  S.B = B < 20 ? B : 20;
+  S.mask = ((uint64_t)1 << S.B) - 1;
+  S.h = (S.B + 1) / 2; if (S.h < 1) S.h = 1;
+  for (int k = 0; k < links; k++) {
+    S.a1[k] = (br_mix(seed * 4 + 4ull * (uint64_t)k + 1) | 1) & S.mask;
+    S.a2[k] = (br_mix(seed * 4 + 4ull * (uint64_t)k + 2) | 1) & S.mask;
+    S.a1i[k] = br_inverse(S.a1[k], S.mask);
+    S.a2i[k] = br_inverse(S.a2[k], S.mask);
+  }
+  S.stride = (n / 3001) | 1;
+  const int cap = 2 * half_band + links + 3000 + 8;
+  A->n = n; A->nnz = 0; A->col = NULL; A->val = NULL;
+  A->rowptr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+  if (!A->rowptr) return -1;
+  int fail = 0;
+#pragma omp parallel
+  {
+    int64_t *c = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+    double *v = (double *)malloc(sizeof(double) * (size_t)cap);
+    if (!c || !v) {
+#pragma omp atomic write
+      fail = 1;
+    } else {
+#pragma omp for schedule(static)
+      for (int64_t r = 0; r < n; r++) A->rowptr[r + 1] = br_row(&S, r, c, v) + 1;
+    }
+    free(c); free(v);
+  }
+  if (fail) { ko_csr_free(A); return -1; }
+  A->rowptr[0] = 0;
+  for (int64_t r = 0; r < n; r++) A->rowptr[r + 1] += A->rowptr[r];
+  A->nnz = A->rowptr[n];
+  A->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)A->nnz);
+  A->val = (double *)malloc(sizeof(double) * (size_t)A->nnz);
+  if (!A->col || !A->val) { ko_csr_free(A); return -1; }
+#pragma omp parallel
+  {
+    int64_t *c = (int64_t *)malloc(sizeof(int64_t) * (size_t)cap);
+    double *v = (double *)malloc(sizeof(double) * (size_t)cap);
+    if (c && v) {
+#pragma omp for schedule(static)
+      for (int64_t r = 0; r < n; r++) {
+        int cnt = br_row(&S, r, c, v);
+        double diag = 0.0625;
+        for (int q = 0; q < cnt; q++) diag += fabs(v[q]);
+        c[cnt] = r; v[cnt] = diag; cnt++;
+        for (int q = 1; q < cnt; q++) {                 /* insertion sort by column */
+          int64_t cq = c[q]; double vq = v[q]; int u = q - 1;
+          while (u >= 0 && c[u] > cq) { c[u + 1] = c[u]; v[u + 1] = v[u]; u--; }
+          c[u + 1] = cq; v[u + 1] = vq;
+        }
+        int64_t k = A->rowptr[r];
+        for (int q = 0; q < cnt; q++) { A->col[k + q] = (int32_t)c[q]; A->val[k + q] = v[q]; }
+      }
+    } else {
+#pragma omp atomic write
+      fail = 1;
+    }
+    free(c); free(v);
+  }
+  if (fail) { ko_csr_free(A); return -1; }
+  return 0;
+}
+
 int ko_csr_tridiag(int n, double lo, double di, double up, ko_csr *A) {
   int64_t nnz = n <= 0 ? 0 : 3 * (int64_t)n - 2;
   if (csr_alloc(A, n, nnz)) return -1;

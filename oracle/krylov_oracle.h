@@ -50,6 +50,8 @@ typedef struct {
 int  ko_csr_poisson3d(int n1, int n2, int n3, ko_csr *A);
 int  ko_csr_kron_unsymmetric(int n1, ko_csr *A);
 int  ko_csr_stencil27_unsym(int n1, ko_csr *A);   /* cfg-5 synthetic, documented in DESIGN.md */
+/* banded + random, fixed seed (non-stencil benchmark operator; definition: krylov.jl_amd/csrc/gen_irregular.cpp header) */
+int  ko_csr_banded_random(int64_t n, int half_band, int links, uint64_t seed, int unsym, int dense_rows, ko_csr *A);
 int  ko_csr_tridiag(int n, double lo, double di, double up, ko_csr *A);
 void ko_csr_free(ko_csr *A);
 /* slice rows [r0,r1) keeping global column indices */

@@ -93,6 +93,7 @@ def lib():
         "ko_csr_poisson3d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Csr)]),
         "ko_csr_kron_unsymmetric": (C.c_int, [C.c_int, C.POINTER(Csr)]),
         "ko_csr_stencil27_unsym": (C.c_int, [C.c_int, C.POINTER(Csr)]),
+        "ko_csr_banded_random": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.POINTER(Csr)]),
         "ko_csr_tridiag": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(Csr)]),
         "ko_csr_free": (None, [C.POINTER(Csr)]),
         "ko_csr_row_slice": (C.c_int, [C.POINTER(Csr), i64, i64, C.POINTER(Csr)]),
@@ -262,6 +263,11 @@ def kron_unsymmetric(n1):
 
 def stencil27_unsym(n1):
     return _gen(lib().ko_csr_stencil27_unsym, n1)
+
+
+def banded_random(n, half_band=13, links=3, seed=1, unsym=False, dense_rows=0):
+    """The "banded + random, fixed seed" non-stencil benchmark operator (krylov.jl_amd/csrc/gen_irregular.cpp)."""
+    return _gen(lib().ko_csr_banded_random, n, half_band, links, seed, 1 if unsym else 0, dense_rows)
 
 
 def tridiag(n, lo, di, up):

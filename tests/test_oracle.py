@@ -654,3 +654,34 @@ def test_scale_goldens_are_well_formed():
         assert all(np.isfinite(g["residuals"])) and len(g["x_sample"]) == len(g["x_index"]) == 16
     g2 = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg2_cg512.json")))
     assert g2["residuals"][0] == math.sqrt(512 ** 3) and g2["nnz"] == 7 * 512 ** 3 - 6 * 512 ** 2      # ||ones||, SURVEY 8
+
+
+def test_banded_random_operator_is_what_its_definition_says(oracle):
+    """The non-stencil benchmark operator (SURVEY.md 8d "banded + random, fixed seed"; definition in the header of
+    krylov.jl_amd/csrc/gen_irregular.cpp): symmetric, ascending columns, diagonal = 1/16 + absolute row sum, every long-range
+    link an involution inside its block of rows, seeds differ, the nonsymmetric variant halves the upper triangle."""
+    n = 20000
+    A = oracle.banded_random(n, seed=3)
+    S = A.to_scipy()
+    assert abs(S - S.T).max() == 0.0
+    lens = np.diff(A.rowptr)
+    assert 20 <= A.nnz / n <= 31 and lens.max() <= 2 * 13 + 3 + 1
+    off = abs(S).sum(axis=1).A1 - abs(S.diagonal())
+    assert np.all(S.diagonal() == off + 0.0625)
+    rows = np.repeat(np.arange(n), lens)
+    far = np.abs(A.col - rows) > 13
+    # links: block size 2^14 here; a far entry (i, j) has its mirror (j, i) and stays inside the block
+    assert np.all((A.col[far] >> 14) == (rows[far] >> 14))
+    assert far.sum() > 2.5 * (n >> 14 << 14)                       # ~3 per row inside the full blocks
+    B = oracle.banded_random(n, seed=4)
+    assert B.nnz != A.nnz or not np.array_equal(B.col, A.col)
+    U = oracle.banded_random(n, seed=3, unsym=True)
+    SU = U.to_scipy()
+    assert np.array_equal(U.col, A.col)
+    import scipy.sparse as sp
+    assert abs(sp.triu(SU, 1) * 2 - sp.triu(S, 1)).max() == 0.0 and abs(sp.tril(SU, -1) - sp.tril(S, -1)).max() == 0.0
+    # CG on it converges to the benchmark tolerance in a few hundred iterations
+    xt = np.cos(np.arange(n) * 1e-3) + 0.5
+    res = oracle.cg(A, A.matvec(xt), atol=0.0, rtol=1e-8)
+    assert res.solved and 50 < res.niter < 600
+    assert np.max(np.abs(res.x - xt)) < 1e-6
