@@ -187,3 +187,112 @@ def test_product_roots_quadratic_known_answers():
     for nit in (0, 1):
         r = rq(-1.0e-7, 1.0, 1.0, nitref=nit)
         assert math.isclose(r[0], 1.0e7, rel_tol=1e-6) and math.isclose(r[1], -1.0, rel_tol=1e-6)
+
+
+# ---- the Julia glue of INTEGRATION.md against the C header --------------------------------------------
+
+def _c_declarations():
+    """name -> (return type, [parameter types]) of every function declared in include/*.h, normalised: comments and
+    parameter names dropped, `const` dropped, whitespace collapsed ("double *", "void * *", "int64_t")."""
+    import re
+    decls = {}
+    for hdr in ("krylov_hip.h", "krylov_hip_ext.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+        txt = re.sub(r"//[^\n]*", " ", txt)
+        for m in re.finditer(r"(?:^|[;}\n])\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\**)\s*(khip_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", txt, flags=re.S):
+            ret, name, params = m.group(1), m.group(2), m.group(3)
+
+            def norm(t, is_param):
+                t = re.sub(r"\bconst\b", " ", t)
+                t = t.replace("*", " * ")
+                toks = t.split()
+                if is_param and toks and toks[-1] != "*" and len(toks) > 1 and re.fullmatch(r"[A-Za-z_][A-Za-z0-9_]*", toks[-1]):
+                    toks = toks[:-1]                                   # the parameter's name
+                return " ".join(toks)
+            plist = [] if params.strip() in ("", "void") else [norm(p, True) for p in params.split(",")]
+            decls[name] = (norm(ret, False), plist)
+    return decls
+
+
+def _julia_ccalls():
+    """(symbol, return type, [argument types], number of actual arguments) of every ccall((:sym, lib), ...) in INTEGRATION.md."""
+    import re
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    out = []
+    for m in re.finditer(r"ccall\(\(:(khip_[a-z0-9_]+),\s*lib\),\s*([A-Za-z0-9_{}]+),\s*\(", txt):
+        sym, ret = m.group(1), m.group(2)
+        i = m.end()                                                   # just inside the argument-type tuple
+        depth, j = 1, i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(txt[j], 0)
+            j += 1
+        tup = txt[i:j - 1]
+        types, cur, d = [], "", 0
+        for ch in tup:
+            if ch in "{(":
+                d += 1
+            elif ch in "})":
+                d -= 1
+            if ch == "," and d == 0:
+                types.append(cur.strip()); cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            types.append(cur.strip())
+        # the actual arguments up to the ccall's closing parenthesis
+        depth, k = 1, j
+        while depth:
+            depth += {"(": 1, ")": -1, "[": 1, "]": -1}.get(txt[k], 0)
+            k += 1
+        args, cur, d = [], "", 0
+        for ch in txt[j:k - 1]:
+            if ch in "([{":
+                d += 1
+            elif ch in ")]}":
+                d -= 1
+            if ch == "," and d == 0:
+                args.append(cur.strip()); cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            args.append(cur.strip())
+        out.append((sym, ret, types, len([a for a in args if a])))
+    return out
+
+
+_JULIA_TO_C = {
+    "Cint": {"int"}, "Int64": {"int64_t"}, "Csize_t": {"size_t"}, "Cdouble": {"double"}, "Cstring": {"char *"},
+    "Ptr{Cdouble}": {"double *"}, "Ptr{Float64}": {"double *"}, "Ref{Cdouble}": {"double *"},
+    "Ptr{Int32}": {"int32_t *"}, "Ref{Int64}": {"int64_t *"},
+    "Ref{Ptr{Cvoid}}": {"POINTER_TO_POINTER"}, "Ptr{Cvoid}": {"ANY_POINTER"}, "Ref{Operator}": {"khip_operator *"},
+}
+
+
+def test_integration_md_ccalls_match_header():
+    """Every ccall of the Julia glue names an exported function and passes what its declaration takes: same arity, the same
+    return type, and argument types that map onto the C parameter types (Ptr{Cvoid} = any object pointer, Ref{Ptr{Cvoid}} = any
+    pointer to a pointer).  Catches exactly what an executed binding would: a misspelt symbol, a missing or swapped argument,
+    an Int64 where the ABI takes an int."""
+    decls = _c_declarations()
+    calls = _julia_ccalls()
+    assert len(calls) >= 35 and len(decls) >= 100, (len(calls), len(decls))
+    import krylov_jl_amd as K
+    L = K.lib()
+    for sym, ret, types, nargs in calls:
+        assert sym in decls, f"{sym}: not declared in include/*.h"
+        assert hasattr(L, sym), f"{sym}: not exported by libkrylov_hip.so"
+        cret, cparams = decls[sym]
+        assert cret in _JULIA_TO_C[ret] or (ret == "Cstring" and cret == "char *"), (sym, ret, cret)
+        assert len(types) == len(cparams), f"{sym}: {len(types)} argument types in the ccall, {len(cparams)} parameters in the header"
+        assert nargs == len(types), f"{sym}: {nargs} arguments for {len(types)} argument types"
+        for pos, (jt, ct) in enumerate(zip(types, cparams)):
+            assert jt in _JULIA_TO_C, (sym, pos, jt)
+            want = _JULIA_TO_C[jt]
+            if "ANY_POINTER" in want:
+                ok = ct.endswith("*") and not ct.endswith("* *")
+            elif "POINTER_TO_POINTER" in want:
+                ok = ct.endswith("* *")
+            else:
+                ok = ct in want
+            assert ok, f"{sym}: argument {pos + 1} is {jt} in the ccall but `{ct}` in the header"

@@ -144,3 +144,82 @@ def test_bicgstab_256_matches_oracle_within_the_derived_tolerance(K, ctx, parity
     parity_log(test="bicgstab_256_vs_oracle", fused=fused, iterations=st.niter, gpu_vs_quad=d_gpu, cpu_oracle_vs_quad=d,
                gpu_vs_oracle=_rel(st.residuals, href))
     assert d_gpu <= 8 * d and _rel(st.residuals, href) <= 9 * d
+
+
+# ---- full solves TO CONVERGENCE at the BASELINE sizes ----------------------------------------------
+# The benchmark definition of the reference, cg(A, b, atol = 0, rtol = 1e-8, itmax = n) (benchmark/benchmarks.jl:14-21), on
+# cfg 2 / 3 / 5; goldens: tests/golden/oracle_cfg*_full.json (make_scale_golden.py legs 12 / 13 / 15, the oracle's own full
+# solves: 1225 / 940 / 35 iterations).  Asserted: the SAME iteration count, status and solved flag, and every residual norm of
+# the whole history within FULL_TOL of the oracle's.  FULL_TOL: see DESIGN.md 3.2c -- the oracle's double-precision history
+# is itself up to ~1e-9 (restarted GMRES) away from the exact recurrence at small sizes (tests/golden/quad_histories.json),
+# so 1e-12 cannot hold over ~1000 iterations; the bound below is 100 x the measured deviation's order and 1e4 x smaller than
+# the 2 % margin by which the oracle's last iterates clear the stopping threshold (so equal counts are not luck).
+FULL_TOL = {"cg": 1e-8, "gmres": 1e-6, "block_gmres": 1e-6}
+
+
+def _full_check(g, st, parity_log, name, extra):
+    href = np.array(g["residuals"])
+    h = np.asarray(st.residuals)
+    m = min(len(h), len(href))
+    devs = np.abs(h[:m] - href[:m]) / href[:m]
+    eps = g["rtol"] * href[0]
+    margin = float(np.min(np.abs(href[-3:] / eps - 1.0)))          # how clearly the oracle's last iterates decide the stop
+    parity_log(test=name, iterations=st.niter, ref_iterations=g["niter"], status=st.status, hist_max_rel=float(devs.max()),
+               hist_max_rel_first100=float(devs[:101].max()), oracle_stop_margin=margin, **extra)
+    assert st.niter == g["niter"] and st.status == g["status"] and bool(st.solved) == bool(g["solved"]), (st.niter, g["niter"], st.status)
+    return float(devs.max())
+
+
+@pytest.mark.parametrize("fused", [2, 0])
+def test_cg_512_full_solve_equal_iteration_count(K, ctx, parity_log, fused):
+    g = _golden("oracle_cfg2_cg512_full.json")
+    n = 512 ** 3
+    A = K.CsrMatrix.stencil(ctx, "poisson", 512)
+    b = ctx.empty(n)
+    K.kfill_(b, 1.0)
+    ws = K.CgWorkspace(ctx, n, n)
+    K.cg_(ws, A, b, atol=g["atol"], rtol=g["rtol"], itmax=n, history=True, fused=fused)
+    dev = _full_check(g, ws.stats, parity_log, "cg_512_full_vs_oracle", dict(fused=fused))
+    xs = ws.x.to_host()
+    xg = np.array(g["x_sample"])
+    xdev = float(np.max(np.abs(xs[g["x_index"]] - xg)) / np.max(np.abs(xg)))
+    assert dev <= FULL_TOL["cg"] and xdev <= 1e-9, (dev, xdev)
+
+
+def test_gmres_cfg3_full_solve_equal_iteration_count(K, ctx, parity_log):
+    g = _golden("oracle_cfg3_gmres256_full.json")
+    n = 256 ** 3
+    A = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", 256)
+    ones = ctx.empty(n)
+    K.kfill_(ones, 1.0)
+    b = ctx.empty(n)
+    A.matvec(ones, b)
+    ws = K.GmresWorkspace(ctx, n, n, memory=g["memory"])
+    K.gmres_(ws, A, b, restart=True, atol=g["atol"], rtol=g["rtol"], itmax=n, history=True)
+    dev = _full_check(g, ws.stats, parity_log, "gmres_cfg3_full_vs_oracle", {})
+    xs = ws.x.to_host()
+    xg = np.array(g["x_sample"])
+    xdev = float(np.max(np.abs(xs[g["x_index"]] - xg)) / np.max(np.abs(xg)))
+    assert dev <= FULL_TOL["gmres"] and xdev <= 1e-8, (dev, xdev)
+
+
+def test_block_gmres_cfg5_full_solve_equal_iteration_count(K, ctx, parity_log):
+    g = _golden("oracle_cfg5_block216_full.json")
+    n1, p = 216, g["p"]
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "stencil27", n1)
+    t = (np.arange(n) + 1.0) / n
+    Xt = np.stack([np.cos(j * np.pi * t) + 0.1 * j for j in range(p)], axis=1)
+    dXt = K.Panel.from_host(ctx, Xt)
+    dB = K.Panel(ctx, n, p)
+    K.spmm_(A, dXt, dB)
+    Bh = dB.to_host()
+    del dXt, dB
+    ws = K.BlockGmresWorkspace(ctx, n, n, p, memory=g["memory"])
+    Bd = ctx.array(np.asfortranarray(Bh).ravel(order="F"))
+    K.block_gmres_(ws, A, Bd, restart=True, atol=g["atol"], rtol=g["rtol"], itmax=n, history=True)
+    dev = _full_check(g, ws.stats, parity_log, "block_gmres_cfg5_full_vs_oracle", {})
+    X = ws.X
+    xg = np.array(g["x_sample"])
+    xdev = float(np.max(np.abs(X[g["x_index"], :] - xg)) / np.max(np.abs(xg)))
+    assert dev <= FULL_TOL["block_gmres"] and xdev <= 1e-8, (dev, xdev)
