@@ -256,11 +256,17 @@ int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t 
   KHIP_REQUIRE(ctx && ctx->comm, "csr_create_dist: call khip_comm_init first");
   KHIP_REQUIRE(row0 >= 0 && row0 + m <= n_global, "csr_create_dist: row range outside the operator");
   khip_csr *A = nullptr;
-  KHIP_TRY(csr_create_common(ctx, m, n_global, nnz, rowptr, rowptr_bits, col, val, index_base, on_device, &A));
-  A->dist = true;
-  A->n_global = n_global;
-  A->row0 = row0;
-  int rc = comm_build_plan(ctx, A);
+  // a failure of this rank alone (validation, index narrowing, a HIP error) still enters the plan's first collective, with
+  // the failure in its status word: all ranks return an error together instead of the others blocking in the all-gather
+  const int rc_local = csr_create_common(ctx, m, n_global, nnz, rowptr, rowptr_bits, col, val, index_base, on_device, &A);
+  if (rc_local == KHIP_OK) {
+    A->dist = true;
+    A->n_global = n_global;
+    A->row0 = row0;
+  } else {
+    A = nullptr;
+  }
+  int rc = comm_build_plan(ctx, A, rc_local);
   if (rc != KHIP_OK) { khip_csr_destroy(A); return rc; }
   *out = A;
   return KHIP_OK;

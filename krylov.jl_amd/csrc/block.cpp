@@ -133,6 +133,16 @@ void householder_signs(int p, int64_t n, double *Q1, double *S, double *tau) {
       tau[j] = 0.0;
       continue;
     }
+    // DLARFG with an exactly zero sub-column (an identity-like or already triangular panel: the reduced column is +-e_j):
+    // H = I, tau = 0, beta = alpha -- the entry keeps its sign.  Seen here as |pivot| == 1 with zeros below it in the top
+    // block (rows past p cannot hold more than rounding dust then, the column has unit norm).
+    bool unit_column = std::fabs(a) == 1.0;
+    for (int i = j + 1; i < p && unit_column; ++i) unit_column = Q1[(size_t)i * p + j] == 0.0;
+    if (unit_column) {
+      S[j] = std::signbit(a) ? -1.0 : 1.0;
+      tau[j] = 0.0;
+      continue;                                        // nothing below the pivot to eliminate
+    }
     S[j] = std::signbit(a) ? 1.0 : -1.0;
     tau[j] = 1.0 + std::fabs(a);
     const double piv = a - S[j];                       // |piv| >= 1

@@ -223,16 +223,20 @@ struct DevScratch {                        // frees setup-time device buffers on
 
 enum PlanStatus : int64_t { PLAN_OK = 0, PLAN_WANT_GATHER = 1, PLAN_FAILED = 2 };
 
-int comm_build_plan(khip_ctx *ctx, khip_csr *A) {
+int comm_build_plan(khip_ctx *ctx, khip_csr *A, int local_rc) {
   Comm *c = ctx->comm;
   if (!c) { set_error("distributed operator needs khip_comm_init first"); return KHIP_ERR_INVALID; }
   const int G = c->nranks;
   DevScratch scratch;
   // 1. off-rank columns of my rows (device filter -> host sort/unique).  The staging buffer counts REFERENCES; a shard
   //    whose references do not fit is not an error: it asks for gather mode, which needs no list at all.
+  //    Nothing returns before the first collective: a rank whose handle could not be created (local_rc != 0, A == null) or
+  //    whose filter fails reports PLAN_FAILED in its status word, so that ALL ranks leave with an error instead of the
+  //    healthy ones blocking in the all-gather for good.
   std::vector<int32_t> ghost;
-  int64_t status = PLAN_OK;
-  {
+  int64_t status = (local_rc == KHIP_OK && A) ? PLAN_OK : PLAN_FAILED;
+  std::string local_error = status == PLAN_FAILED ? std::string(khip_last_error()) : std::string();
+  auto collect = [&]() -> int {
     int64_t cap = A->nnz < (64ll << 20) ? A->nnz : (64ll << 20);
     if (cap < 1) cap = 1;
     int32_t *d_list = nullptr;
@@ -252,11 +256,23 @@ int comm_build_plan(khip_ctx *ctx, khip_csr *A) {
       std::sort(ghost.begin(), ghost.end());
       ghost.erase(std::unique(ghost.begin(), ghost.end()), ghost.end());
     }
+    return KHIP_OK;
+  };
+  if (status != PLAN_FAILED && collect() != KHIP_OK) {
+    status = PLAN_FAILED;
+    local_error = khip_last_error();
+    ghost.clear();
   }
   // 2. partition, list sizes and status of every rank
-  int64_t mine[4] = {A->row0, A->m, (int64_t)ghost.size(), status};
+  int64_t mine[4] = {A ? A->row0 : 0, A ? A->m : 0, (int64_t)ghost.size(), status};
   std::vector<int64_t> all(4 * (size_t)G);
   KHIP_TRY(allgather_host(ctx, mine, all.data(), sizeof(mine)));
+  for (int r = 0; r < G; ++r)
+    if (all[4 * r + 3] == PLAN_FAILED) {
+      if (status == PLAN_FAILED) set_error("csr_create_dist: %s", local_error.c_str());
+      else set_error("csr_create_dist: rank %d could not create its shard of the operator", r);
+      return local_rc != KHIP_OK ? local_rc : KHIP_ERR_INVALID;
+    }
   std::vector<int64_t> row_starts(G + 1), ghost_off(G + 1, 0);
   int64_t maxcnt = 1, maxm = 1;
   bool bad_partition = false, want_gather = ctx->tune.halo_mode == 2;

@@ -214,7 +214,8 @@ struct IluBlkArgs {
   const double *recw;                  // wide row records (kWideDoubles per row) where every row has <= 16 entries, else null
   int *done;                           // [nb]: epoch of the last solve that finished the block
   unsigned *ticket;
-  int *fail;
+  int *fail;                           // device word: a wait of THIS solve gave up (checked by the other waits of the same solve)
+  int *fail_host;                      // pinned host mirror (device pointer to mapped host memory): read by the host without a sync
   int nb, max_ent, max_ext, max_lvl;
   int rows_cap;                        // rows of the largest block, rounded up to the wave: the LDS arrays and the slot numbers are laid out for it
 };
@@ -315,7 +316,9 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
 #pragma unroll
     for (int u = 0; u < kExtRegs; ++u) {
       const int k = u * kBlkThreads + lane;
-      eg[u] = a.ext_gid[h.ext0 + (k < h.next ? k : 0)];
+      // lanes past the face list (all of them when the block has no external dependency: ext_gid may then be empty) read
+      // the block's own first row instead of an entry that does not exist
+      eg[u] = k < h.next ? a.ext_gid[h.ext0 + k] : a.row_gid[h.row0];
     }
     ILU_STAMP(1);
     // the blocks this one reads from
@@ -324,8 +327,11 @@ __global__ __launch_bounds__(kBlkThreads) void ilu_block_solve_kernel(IluBlkArgs
       int spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > KHIP_ILU_SPIN || __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(a.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > KHIP_ILU_SPIN || __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+          // give up: mark THIS solve (the word holds the epoch, so a past failure does not cut later solves' waits short)
+          // and tell the host, which checks at the next application / block_info and falls back to level scheduling
+          __hip_atomic_store(a.fail, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (a.fail_host) __hip_atomic_store(a.fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
       }
@@ -546,6 +552,7 @@ struct khip_ilu0 {
     size_t lds = 0;
   } blk_lo, blk_up;
   int *blk_fail = nullptr;
+  int *blk_fail_host = nullptr, *blk_fail_host_dev = nullptr;   // pinned mirror of "a wait gave up" and its device address
   int64_t grid_dims[3] = {0, 0, 0};          // detected grid (0: none, level scheduling)
   int grid_skew[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // lattice basis of the block coordinates
   bool use_blocks = false;
@@ -597,7 +604,7 @@ int enqueue_solve(khip_ilu0 *P, const double *x, double *y) {
 template <int KIND>
 int launch_blocks(khip_ilu0 *P, khip_ilu0::Blocks &B, const double *x, double *y) {
   IluBlkArgs a{B.hdr, B.row_gid, B.row_eptr, B.lvl, B.ext_gid, B.dep, B.ent_slot, B.ent_val, B.diag_val, B.rec, B.recw, B.done, B.ticket,
-               P->blk_fail, B.nb, B.max_ent, B.max_ext, B.max_lvl, B.rows_cap};
+               P->blk_fail, P->blk_fail_host_dev, B.nb, B.max_ent, B.max_ext, B.max_lvl, B.rows_cap};
   ++B.epoch;
   hipLaunchKernelGGL((ilu_block_solve_kernel<KIND>), dim3((unsigned)B.grid), dim3(kBlkThreads), B.lds, P->ctx->stream, a, x, y, B.epoch,
                      B.ticket_base);
@@ -610,6 +617,15 @@ int ilu0_apply(void *self, const double *x, double *y) {
   khip_ilu0 *P = static_cast<khip_ilu0 *>(self);
   if (P->n == 0) return KHIP_OK;
   khip_ctx *ctx = P->ctx;
+  if (P->use_blocks && P->blk_fail_host && __atomic_load_n(P->blk_fail_host, __ATOMIC_RELAXED) != 0) {
+    // a wait of an earlier application timed out: its result was wrong.  Say so (the solver loop stops on the error), and
+    // schedule by levels from now on.
+    __atomic_store_n(P->blk_fail_host, 0, __ATOMIC_RELAXED);
+    P->use_blocks = false;
+    set_error("ilu0: a block of the triangular solves waited too long for the blocks it depends on (result invalid); "
+              "this operator falls back to level scheduling");
+    return KHIP_ERR_NUMERIC;
+  }
   if (P->use_blocks && ctx->tune.ilu_blocks != 0) {
     KHIP_TRY((launch_blocks<1>(P, P->blk_lo, x, y)));
     return launch_blocks<2>(P, P->blk_up, x, y);
@@ -647,6 +663,7 @@ void ilu0_free(khip_ilu0 *P) {
   blocks_free(P->blk_lo);
   blocks_free(P->blk_up);
   if (P->blk_fail) (void)hipFree(P->blk_fail);
+  if (P->blk_fail_host) (void)hipHostFree(P->blk_fail_host);
   for (void *p : {(void *)P->lu, (void *)P->row_lo, (void *)P->diag, (void *)P->row_hi, (void *)P->perm_lo,
                   (void *)P->perm_up, (void *)P->bad_row, (void *)P->d_lvl_lo, (void *)P->d_lvl_up})
     if (p) (void)hipFree(p);
@@ -668,6 +685,7 @@ template <typename T>
 int upload(khip_ctx *ctx, const std::vector<T> &h, T **dev) {
   KHIP_CHECK_HIP(hipMalloc(dev, sizeof(T) * std::max<size_t>(h.size(), 1)));
   if (!h.empty()) KHIP_CHECK_HIP(hipMemcpy(*dev, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+  else KHIP_CHECK_HIP(hipMemset(*dev, 0, sizeof(T)));          // an empty list still has one addressable, defined element
   return KHIP_OK;
 }
 
@@ -1171,6 +1189,13 @@ int khip_ilu0_create(khip_ctx *ctx, const khip_csr *A, khip_operator *op_out) {
     if (host_ok && (grid || (n >= 4096 && nlev > 0 && 2 * n / nlev >= 32))) {
       KHIP_CHECK_HIP(hipMalloc(&P->blk_fail, sizeof(int)));
       KHIP_CHECK_HIP(hipMemsetAsync(P->blk_fail, 0, sizeof(int), ctx->stream));
+      if (hipHostMalloc(reinterpret_cast<void **>(&P->blk_fail_host), sizeof(int), hipHostMallocMapped) == hipSuccess) {
+        *P->blk_fail_host = 0;
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&P->blk_fail_host_dev), P->blk_fail_host, 0) != hipSuccess) P->blk_fail_host_dev = nullptr;
+      } else {
+        (void)hipGetLastError();
+        P->blk_fail_host = nullptr;
+      }
       HostBlocks hlo, hup;                     // the two triangles are analysed side by side (pure host work)
       auto analyse = [&](bool upper, HostBlocks &hb) {           // host memory may run out on a very large slab: then level scheduling
         try {
@@ -1229,7 +1254,9 @@ int khip_ilu0_block_info(const khip_operator *op, int64_t *dims3, int64_t *block
     *failed = 0;
     if (P->blk_fail) {
       KHIP_CHECK_HIP(hipStreamSynchronize(P->ctx->stream));
-      KHIP_CHECK_HIP(hipMemcpy(failed, P->blk_fail, sizeof(int), hipMemcpyDeviceToHost));
+      int epoch_failed = 0;
+      KHIP_CHECK_HIP(hipMemcpy(&epoch_failed, P->blk_fail, sizeof(int), hipMemcpyDeviceToHost));
+      *failed = (epoch_failed != 0 || (P->blk_fail_host && *P->blk_fail_host != 0)) ? 1 : 0;
     }
   }
   return KHIP_OK;

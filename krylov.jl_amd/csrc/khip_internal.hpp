@@ -300,7 +300,7 @@ int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count);
 int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x, int width = 1);   // width p: row-major panel
 int comm_allreduce_sum_host(khip_ctx *ctx, double *vals, int count);
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A);
-int comm_build_plan(khip_ctx *ctx, khip_csr *A);
+int comm_build_plan(khip_ctx *ctx, khip_csr *A, int local_rc = 0);   // local_rc != 0 / A == null: this rank failed before the plan; every rank then returns an error
 
 // "time limit exceeded" decided COLLECTIVELY: every stopping test of the solver loops comes from all-reduced scalars and
 // is therefore identical on all ranks -- except the wall clock.  A rank that alone ran out of time would leave its peers

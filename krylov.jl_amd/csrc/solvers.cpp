@@ -863,6 +863,10 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
         const int k = inner_iter;
         const int kpad = (k + 3) & ~3;
         if (2 * kpad + 1 > kResultSlots) return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 1: too many basis vectors for the device scalar ring");
+        // with several ranks the k coefficients of a step travel in ONE all-reduce of at most kMaxRedOut scalars: refuse a
+        // longer basis before the solve starts rather than abort in the middle of a cycle
+        if (comm_nranks(ctx) > 1 && mem > kMaxRedOut)
+          return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 1 on several ranks: memory must not exceed 64 (one all-reduce carries the coefficients of a step)");
         const int slot = take_slots(ctx, 2 * kpad + 1);
         const bool multi = comm_nranks(ctx) > 1;
         for (int pass = 0; pass < 2; ++pass) {

@@ -64,6 +64,23 @@ def test_panel_qr(K, ctx, n, p):
         ctx.set_option("panel_signs", 1)
 
 
+def test_panel_qr_unit_columns_take_dlarfg_tau_zero(K, ctx):
+    """a reduced column that is exactly +-e_j (identity columns, an already triangular panel) has a zero
+    sub-column: DLARFG returns tau = 0 and keeps the sign of the pivot, and so does the panel QR -- same R and tau as geqrf."""
+    import scipy.linalg as sl
+    n, p = 500, 8
+    for A in (np.eye(n, p), np.vstack([np.triu(np.random.default_rng(1).standard_normal((p, p))) + 3 * np.diag([1, -1, 1, 1, -1, 1, -1, 1]),
+                                        np.zeros((n - p, p))])):
+        dQ = K.Panel.from_host(ctx, A)
+        R, tau = K.panel_qr_tau_(dQ)
+        Qh = dQ.to_host()
+        (_, tau_l), _ = sl.qr(A, mode="raw")
+        Ql, Rl = sl.qr(A, mode="economic")
+        assert np.all(tau_l == 0.0) and np.all(tau == 0.0), (tau, tau_l)
+        assert np.allclose(R, Rl, atol=1e-13 * np.abs(Rl).max()) and np.allclose(Qh, Ql, atol=1e-13)
+        assert np.allclose(Qh @ R, A, atol=1e-13 * np.abs(A).max() * p)
+
+
 @pytest.mark.parametrize("eps_col", [1e-6, 1e-9, 1e-12])
 def test_panel_qr_ill_conditioned_takes_the_shifted_pass(K, ctx, eps_col):
     """cond(A) up to ~1e12: CholeskyQR2 alone is unsafe (cond^2 > 1/eps); the shifted first pass (shifted

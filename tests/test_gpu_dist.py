@@ -339,3 +339,29 @@ def test_time_limit_is_agreed_on_by_all_ranks(K, oracle):
     res = _run_ranks(K, world, 60606, body)
     assert res[0] == res[1]
     assert all(status == "time limit exceeded" and niter < 1000 for niter, status in res[0])
+
+
+def test_create_dist_failure_on_one_rank_fails_on_all_local_ranks(K, oracle):
+    """a shard that is rejected on ONE rank before the halo plan's first collective (here: a column index outside
+    [0, n), caught by the device-side validation) used to leave the other ranks blocked in the all-gather.  Now the failure
+    travels in the plan's status word and every rank raises."""
+    world, n1 = 3, 8
+    A_cpu = oracle.poisson3d(n1)
+    n = A_cpu.n
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        sl = A_cpu.row_slice(r0, r1)
+        col = sl.col.copy()
+        if rank == 1:
+            col[3] = n + 5                                  # invalid on this rank only
+        try:
+            K.CsrMatrix.from_host(c, sl.rowptr, col, sl.val, (n, n), dist_rows=(r0, r1), n_global=n)
+            return "created"
+        except K.KhipError as e:
+            return "error: " + str(e)
+
+    res = _run_ranks(K, world, 626262, body)
+    assert all(r.startswith("error") for r in res), res
+    assert "column index" in res[1] or "csr" in res[1], res[1]

@@ -112,5 +112,5 @@ for fused in (1, 0):
     ctx.sync()
     dt = (time.perf_counter() - t0) / 40
     emit(kernel="cg_iteration", fused=fused, ms=dt * 1e3, its=1 / dt,
-         gbps_fused_bytes=(sb + 72 * n) / dt / GB, gbps_reference_bytes=(sb + 104 * n) / dt / GB)
+         gbps_algorithmic=(sb + (64 if fused else 104) * n) / dt / GB)      # the bytes the path that ran moves, never the other one's
 ctx.close()
