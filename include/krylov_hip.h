@@ -358,6 +358,10 @@ typedef struct {
                                * gmres: 1 = CGS2, classical Gram-Schmidt applied twice instead of the modified Gram-Schmidt cascade of
                                * src/gmres.jl:259-271: h = V_k' q as one reduction per four basis vectors, q -= V_k h in one pass, twice:
                                * three all-reduces per inner iteration on N GPUs instead of k + 1.  Opt-in, own parity budget. */
+  int    verbose;             /* > 0: the reference's log on stdout, one row every `verbose` iterations (src/cg.jl:132,182-183,224,
+                               * 267-269; src/gmres.jl:131,191-192,315,364; src/bicgstab.jl:135,193-194,255-257;
+                               * src/block_gmres.jl:120,181-182,297,340; kdisplay: src/krylov_utils.jl:301).  The rows need the scalars
+                               * on the host, so a verbose solve runs the host-driven loop (as fused <= 1); results are the same bits */
 } khip_options;
 
 typedef struct {              /* SimpleStats, src/krylov_stats.jl:24-44 */
@@ -366,6 +370,8 @@ typedef struct {              /* SimpleStats, src/krylov_stats.jl:24-44 */
   char   status[96];
   const double *residuals; int nres;
   char   error[160];
+  double allocation_timer;    /* seconds spent allocating the workspace's vectors: at its creation plus the lazy allocations of
+                               * later solves (allocate_if, src/krylov_utils.jl:281-288; stats.allocation_timer, src/krylov_stats.jl) */
 } khip_stats;
 
 khip_options khip_default_options(void);

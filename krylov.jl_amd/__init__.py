@@ -49,13 +49,13 @@ class COptions(C.Structure):
     _fields_ = [("atol", C.c_double), ("rtol", C.c_double), ("itmax", C.c_int), ("timemax", C.c_double),
                 ("history", C.c_int), ("radius", C.c_double), ("linesearch", C.c_int), ("restart", C.c_int),
                 ("reorthogonalization", C.c_int), ("fused", C.c_int), ("callback", CALLBACK_FN),
-                ("callback_data", C.c_void_p), ("variant", C.c_int)]
+                ("callback_data", C.c_void_p), ("variant", C.c_int), ("verbose", C.c_int)]
 
 
 class CStats(C.Structure):
     _fields_ = [("niter", C.c_int), ("solved", C.c_int), ("inconsistent", C.c_int), ("indefinite", C.c_int),
                 ("npcCount", C.c_int), ("timer", C.c_double), ("status", C.c_char * 96),
-                ("residuals", c_double_p), ("nres", C.c_int), ("error", C.c_char * 160)]
+                ("residuals", c_double_p), ("nres", C.c_int), ("error", C.c_char * 160), ("allocation_timer", C.c_double)]
 
 
 # every symbol include/krylov_hip.h declares: name -> (restype, argtypes)
@@ -803,6 +803,7 @@ class SimpleStats:
         self.indefinite = bool(st.indefinite)
         self.npcCount = st.npcCount
         self.timer = st.timer
+        self.allocation_timer = st.allocation_timer
         self.status = st.status.decode("utf-8")
         self.residuals = np.array([st.residuals[i] for i in range(st.nres)]) if st.nres else np.zeros(0)
         self.error = st.error.decode("utf-8")
@@ -884,7 +885,7 @@ def _make_operator(ctx, op, n, keep):
 
 
 def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, radius=0.0, linesearch=False,
-                  restart=False, reorthogonalization=False, fused=True, callback=None, keep=None, ws=None, variant=0):
+                  restart=False, reorthogonalization=False, fused=True, callback=None, keep=None, ws=None, variant=0, verbose=0):
     o = lib().khip_default_options()
     if atol is not None:
         o.atol = atol
@@ -900,6 +901,7 @@ def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, ra
     o.reorthogonalization = int(reorthogonalization)
     o.fused = 2 if fused is True else int(fused)     # True = everything that is bit-identical: fused kernels + device-resident scalars
     o.variant = int(variant)
+    o.verbose = int(verbose)
     if callback is not None:
         def cb(_ws, _ud):
             try:

@@ -285,8 +285,12 @@ struct khip_block_gmres_workspace {
     if (rc_k != KHIP_OK) return ws->box.fail_rc(rc_k);  \
   } while (0)
 
+static thread_local double g_alloc_seconds = 0.0;              // stats.allocation_timer (allocate_if, src/krylov_utils.jl:290-297)
 static int alloc_panel(khip_ctx *ctx, int64_t np, int p, double **out) {
-  KHIP_TRY(khip_malloc(ctx, sizeof(double) * (size_t)np * p, reinterpret_cast<void **>(out)));
+  const double t_alloc = now_s();
+  const int rc_alloc = khip_malloc(ctx, sizeof(double) * (size_t)np * p, reinterpret_cast<void **>(out));
+  g_alloc_seconds += now_s() - t_alloc;
+  KHIP_TRY(rc_alloc);
   return khip_fill(ctx, np * p, *out, 0.0);
 }
 
@@ -301,6 +305,7 @@ int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p
   khip_block_gmres_workspace *ws = new khip_block_gmres_workspace();
   ws->ctx = ctx; ws->m = m; ws->n = n; ws->p = p; ws->mem = memory;
   khip_panel_rows(n, &ws->np);
+  const double t_create = now_s();                                 // start_allocation_time, src/block_krylov_workspaces.jl:137
   int rc = alloc_panel(ctx, ws->np, p, &ws->X);
   if (!rc) rc = alloc_panel(ctx, ws->np, p, &ws->W);
   if (!rc) rc = alloc_panel(ctx, ws->np, p, &ws->Bp);
@@ -321,6 +326,8 @@ int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p
   ws->Yall.assign((size_t)memory * pp, 0.0);
   ws->tmp.assign(pp, 0.0);
   ws->Vp.assign((size_t)memory, nullptr);
+  g_alloc_seconds = 0.0;
+  ws->box.st.allocation_timer = now_s() - t_create;                // workspace.stats.allocation_timer, :161
   *out = ws;
   return KHIP_OK;
 }
@@ -381,6 +388,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   KHIP_REQUIRE(ws && A && B_colmajor, "block_gmres_solve: null argument");
   khip_ctx *ctx = ws->ctx;
   khip_options o = opts_in ? *opts_in : khip_default_options();
+  g_alloc_seconds = 0.0;
   const double t0 = now_s();
   const double timemax = (std::isnan(o.timemax) || o.timemax <= 0) ? std::numeric_limits<double>::infinity() : o.timemax;
   const int64_t n = ws->n, np = ws->np;
@@ -391,6 +399,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   const double atol = std::isnan(o.atol) ? std::sqrt(kEps) : o.atol, rtol = std::isnan(o.rtol) ? std::sqrt(kEps) : o.rtol;
   const bool restart = o.restart != 0, reorth = o.reorthogonalization != 0;
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (o.verbose > 0) printf("BLOCK-GMRES: system of size %lld with %d right-hand sides\n", (long long)ws->n, ws->p);   // src/block_gmres.jl:120
   if (o.variant != 0) return ws->box.fail(KHIP_ERR_INVALID, "block_gmres: options.variant must be 0 (there is no other recurrence)");
 
   if (restart && !ws->dX) KB(alloc_panel(ctx, np, p, &ws->dX));
@@ -427,6 +436,9 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   int inner_iter = 0;
   const int64_t itmax = o.itmax == 0 ? 2 * (global_rows(ctx, A, n) / p) : o.itmax;
   int64_t inner_itmax = itmax;
+  const int verbose = o.verbose;                                                   // :181-182   pass  k  ‖Rₖ‖  timer
+  if (verbose > 0) printf(" pass      k     \xe2\x80\x96R\xe2\x82\x96\xe2\x80\x96  timer\n");
+  if (verbose > 0 && iter % verbose == 0) printf("%5d  %5lld  %7.1e  %.2fs\n", npass, (long long)iter, RNorm, now_s() - t0);
 
   bool solved = RNorm <= eps_tol;
   bool tired = iter >= itmax;
@@ -548,6 +560,8 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
         inner_tired = inner_iter >= inner_itmax;
       }
       overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
+      if (verbose > 0 && (iter + inner_iter) % verbose == 0)                       // :297
+        printf("%5d  %5lld  %7.1e  %.2fs\n", npass, (long long)(iter + inner_iter), RNorm, now_s() - t0);
 
       if (!(solved || inner_tired || user_requested_exit || overtimed)) {
         if (!restart && (inner_iter >= mem)) {                                     // :300-305
@@ -615,6 +629,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
+  if (verbose > 0) { printf("\n"); fflush(stdout); }                              // :340
   if (tired) status = "maximum number of iterations exceeded";
   if (solved) status = "solution good enough given atol and rtol";
   if (overtimed) status = "time limit exceeded";
@@ -627,6 +642,8 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   st->niter = (int)iter;
   st->solved = solved;
   st->timer = now_s() - t0;
+  st->allocation_timer += g_alloc_seconds;                      // lazy allocations of this solve
+  g_alloc_seconds = 0.0;
   snprintf(st->status, sizeof(st->status), "%s", status);
   ws->box.publish();
   return KHIP_OK;

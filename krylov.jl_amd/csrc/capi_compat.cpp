@@ -99,6 +99,7 @@ khip_options map_opts(const KrylovOptions *o) {
   k.atol = o->atol; k.rtol = o->rtol; k.itmax = o->itmax; k.timemax = o->timemax;
   k.radius = o->radius; k.linesearch = o->linesearch; k.restart = o->restart;
   k.reorthogonalization = o->reorthogonalization;
+  k.verbose = o->verbose;                       // interfaces/include/krylov.h:145: the reference's per-iteration log
   return k;
 }
 

@@ -78,9 +78,21 @@ int apply_op(khip_ctx *ctx, const khip_operator *op, const double *x, double *y)
 
 int64_t padded(int64_t n) { return (n + 31) & ~(int64_t)31; }   // 256-byte multiples keep every slice 16-B aligned
 
+// stats.allocation_timer (src/krylov_utils.jl:281-288, allocate_if): every vector allocation of a workspace -- at its
+// creation and the lazy ones inside later solves -- adds its wall time to this accumulator; the creation / solve entry
+// points move it into the workspace's stats (take_alloc_seconds).
+static thread_local double g_alloc_seconds = 0.0;
 int alloc_vec(khip_ctx *ctx, int64_t n, double **out) {
-  return khip_malloc(ctx, sizeof(double) * (size_t)padded(n > 0 ? n : 1), reinterpret_cast<void **>(out));
+  const double t = now_s();
+  const int rc = khip_malloc(ctx, sizeof(double) * (size_t)padded(n > 0 ? n : 1), reinterpret_cast<void **>(out));
+  g_alloc_seconds += now_s() - t;
+  return rc;
 }
+double take_alloc_seconds() { const double v = g_alloc_seconds; g_alloc_seconds = 0.0; return v; }
+
+// ---- options.verbose: the reference's per-iteration log (kdisplay, src/krylov_utils.jl:301) on stdout.  Column headers are
+// padded by hand: the labels are UTF-8 and printf pads bytes, Julia pads characters.
+inline bool kdisplay(int64_t iter, int verbose) { return verbose > 0 && iter % verbose == 0; }
 
 #define K(expr)                                   \
   do {                                            \
@@ -292,12 +304,14 @@ int khip_cg_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_cg_worksp
   KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "cg_workspace_create: bad argument");
   khip_cg_workspace *ws = new khip_cg_workspace();
   ws->ctx = ctx; ws->m = m; ws->n = n;
+  (void)take_alloc_seconds();
   // x, r, p, Ap allocated; dx, npc_dir, z stay empty until needed (src/krylov_workspaces.jl:269-285)
   int rc = alloc_vec(ctx, n, &ws->x);
   if (!rc) rc = alloc_vec(ctx, n, &ws->r);
   if (!rc) rc = alloc_vec(ctx, n, &ws->p);
   if (!rc) rc = alloc_vec(ctx, n, &ws->Ap);
   if (rc) { khip_cg_workspace_destroy(ws); return rc; }
+  ws->box.st.allocation_timer = take_alloc_seconds();           // workspace.stats.allocation_timer, src/krylov_workspaces.jl:288-289
   *out = ws;
   return KHIP_OK;
 }
@@ -430,8 +444,11 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
   const double radius = o.radius;
   const bool linesearch = o.linesearch != 0;
   const bool fused = o.fused != 0;
+  const int verbose = o.verbose;
+  (void)take_alloc_seconds();
 
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (verbose > 0) printf("CG: system of %lld equations in %lld variables\n", (long long)n, (long long)n);      // src/cg.jl:132
   if (o.variant != 0 && o.variant != 1)
     return ws->box.fail(KHIP_ERR_INVALID, "cg: options.variant must be 0 (cg! recurrence) or 1 (single-reduction CG)");
   if (A->csr && !A->apply) {
@@ -487,6 +504,9 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
   double pNorm2 = gamma;
   const double eps_tol = atol + rtol * rNorm;
 
+  if (verbose > 0) printf("    k      \xe2\x80\x96r\xe2\x80\x96       pAp         \xce\xb1         \xcf\x83  timer\n");   // :182  k ‖r‖ pAp α σ timer
+  if (kdisplay(iter, verbose)) printf("%5lld  %7.1e", (long long)iter, rNorm);                                   // :183
+
   bool solved = rNorm <= eps_tol;
   bool tired = iter >= itmax;
   bool inconsistent = false, on_boundary = false, zero_curvature = false, user_requested_exit = false,
@@ -516,7 +536,8 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
       if (fin.breakdown && !solved) { zero_curvature = true; inconsistent = true; }   // as the cg! path reports it (:203-205, linesearch = false)
     }
   }
-  const bool device_loop = o.variant == 0 && o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback;
+  // (a verbose solve prints alpha, pAp and sigma of every displayed iteration: it runs the host-driven loop below)
+  const bool device_loop = o.variant == 0 && o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback && verbose <= 0;
   if (device_loop && !(solved || tired)) {
     CgDevState fin;
     K(cg_device_loop(ws, A->csr, gamma, eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
@@ -565,6 +586,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
       if (rcb > 0) return ws->box.fail_rc(rcb);
       sigma = s1 > s2 ? s1 : s2;
     }
+    if (kdisplay(iter, verbose)) printf("  %8.1e  %8.1e  %8.1e  %.2fs\n", pAp, alpha, sigma, now_s() - t0);        // :224
     if ((radius > 0) && ((pAp <= 0) || (alpha > sigma))) {                         // :229-237
       alpha = sigma;
       if (pAp <= 0) {
@@ -612,7 +634,9 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     tired = iter >= itmax;
     if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;    // :264
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
+    if (kdisplay(iter, verbose)) printf("%5lld  %7.1e", (long long)iter, rNorm);                                 // :267
   }
+  if (verbose > 0) { printf("\n\n"); fflush(stdout); }                                                         // :269
 
   if (solved && on_boundary) status = "on trust-region boundary";
   if (solved && st->indefinite) status = "nonpositive curvature";
@@ -630,6 +654,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
   st->solved = solved;
   st->inconsistent = inconsistent;
   st->timer = now_s() - t0;
+  st->allocation_timer += take_alloc_seconds();                 // lazy allocations of this solve (allocate_if)
   snprintf(st->status, sizeof(st->status), "%s", status);
   ws->box.publish();
   return KHIP_OK;
@@ -655,7 +680,9 @@ struct khip_gmres_workspace {
 
 static int gmres_grow_basis(khip_gmres_workspace *ws, int count) {   // push!(V, similar(x)) in slabs
   double *slab = nullptr;
+  const double t_alloc = now_s();
   KHIP_TRY(khip_malloc(ws->ctx, sizeof(double) * (size_t)ws->stride * (size_t)count, reinterpret_cast<void **>(&slab)));
+  g_alloc_seconds += now_s() - t_alloc;
   ws->slabs.push_back(slab);
   ws->slab_count.push_back(count);
   for (int i = 0; i < count; ++i) ws->V.push_back(slab + (size_t)i * ws->stride);
@@ -701,6 +728,7 @@ int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory,
   khip_gmres_workspace *ws = new khip_gmres_workspace();
   ws->ctx = ctx; ws->m = m; ws->n = n; ws->mem = memory;
   ws->stride = padded(n > 0 ? n : 1);
+  const double t_alloc0 = now_s();
   int rc = alloc_vec(ctx, n, &ws->x);
   if (!rc) rc = alloc_vec(ctx, n, &ws->w);
   if (!rc && memory > 0) rc = gmres_grow_basis(ws, memory);         // the basis is ONE slab: V[i] are consecutive slices
@@ -708,6 +736,8 @@ int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory,
   ws->c.assign(memory, 0.0); ws->s.assign(memory, 0.0); ws->z.assign(memory, 0.0);
   ws->R.assign((size_t)memory * (memory + 1) / 2, 0.0);
   ws->look.assign((size_t)memory + 1, 0.0);
+  (void)take_alloc_seconds();
+  ws->box.st.allocation_timer = now_s() - t_alloc0;             // x, w, the basis slab and the host arrays (:2898-2918)
   *out = ws;
   return KHIP_OK;
 }
@@ -749,7 +779,10 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   khip_stats *st = &ws->box.st;
   const double atol = tol_or_default(o.atol), rtol = tol_or_default(o.rtol);
   const bool restart = o.restart != 0, reorth = o.reorthogonalization != 0, fused = o.fused != 0;
+  const int verbose = o.verbose;
+  (void)take_alloc_seconds();
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
+  if (verbose > 0) printf("GMRES: system of size %lld\n", (long long)n);                                          // src/gmres.jl:131
 
   if (o.variant != 0 && o.variant != 1)
     return ws->box.fail(KHIP_ERR_INVALID, "gmres: options.variant must be 0 (gmres! recurrence, modified Gram-Schmidt) or 1 (CGS2)");
@@ -801,6 +834,10 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   const double btol = std::pow(kEps, 0.75);                                        // :195
 
   bool breakdown = false, inconsistent = false;
+  // :191-192   pass  k  ‖rₖ‖  hₖ₊₁.ₖ  timer ; the first row shows "✗ ✗ ✗ ✗" in the h column
+  if (verbose > 0) printf(" pass      k     \xe2\x80\x96r\xe2\x82\x96\xe2\x80\x96   h\xe2\x82\x96\xe2\x82\x8a\xe2\x82\x81.\xe2\x82\x96  timer\n");
+  if (kdisplay(iter, verbose)) printf("%5d  %5lld  %7.1e  \xe2\x9c\x97 \xe2\x9c\x97 \xe2\x9c\x97 \xe2\x9c\x97  %.2fs\n", npass, (long long)iter, rNorm, now_s() - t0);
+
   bool solved = rNorm <= eps_tol;
   bool tired = iter >= itmax;
   bool inner_tired = inner_iter >= inner_itmax;
@@ -949,6 +986,8 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
         inner_tired = inner_iter >= inner_itmax;
       }
       overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
+      if (kdisplay(iter + inner_iter, verbose))                                     // :315
+        printf("%5d  %5lld  %7.1e  %7.1e  %.2fs\n", npass, (long long)(iter + inner_iter), rNorm, Hbis, now_s() - t0);
 
       if (!(solved || inner_tired || breakdown || user_requested_exit || overtimed)) {
         if (!restart && (inner_iter >= mem)) {                                     // :319-324
@@ -995,6 +1034,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
+  if (verbose > 0) { printf("\n"); fflush(stdout); }                                                           // src/gmres.jl:364
   if (tired) status = "maximum number of iterations exceeded";
   if (solved) status = "solution good enough given atol and rtol";
   if (inconsistent) status = "found approximate least-squares solution";
@@ -1009,6 +1049,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   st->solved = solved;
   st->inconsistent = inconsistent;
   st->timer = now_s() - t0;
+  st->allocation_timer += take_alloc_seconds();                 // lazy allocations of this solve (allocate_if)
   snprintf(st->status, sizeof(st->status), "%s", status);
   ws->box.publish();
   return KHIP_OK;
@@ -1134,10 +1175,12 @@ int khip_bicgstab_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_bic
   KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "bicgstab_workspace_create: bad argument");
   khip_bicgstab_workspace *ws = new khip_bicgstab_workspace();
   ws->ctx = ctx; ws->m = m; ws->n = n;
+  (void)take_alloc_seconds();
   int rc = 0;                                                        // x, r, p, v, s, qd (src/krylov_workspaces.jl:1605-1623)
   for (double **v : {&ws->x, &ws->r, &ws->p, &ws->v, &ws->s, &ws->qd})
     if (!rc) rc = alloc_vec(ctx, n, v);
   if (rc) { khip_bicgstab_workspace_destroy(ws); return rc; }
+  ws->box.st.allocation_timer = take_alloc_seconds();
   *out = ws;
   return KHIP_OK;
 }
@@ -1181,6 +1224,9 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   khip_stats *st = &ws->box.st;
   const double atol = tol_or_default(o.atol), rtol = tol_or_default(o.rtol);
   const bool fused = o.fused != 0;
+  const int verbose = o.verbose;
+  (void)take_alloc_seconds();
+  if (verbose > 0) printf("BICGSTAB: system of size %lld\n", (long long)n);                                       // src/bicgstab.jl:135
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
   if (o.variant != 0) return ws->box.fail(KHIP_ERR_INVALID, "bicgstab: options.variant must be 0 (there is no other recurrence)");
   if (!c) c = b;                                                                   // src/bicgstab.jl:105
@@ -1226,6 +1272,9 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   int64_t iter = 0;
   const int64_t itmax = o.itmax == 0 ? 2 * global_rows(ctx, A, n) : o.itmax;   // 2n of the GLOBAL system on every rank
   const double eps_tol = atol + rtol * rNorm;
+  // :193-194   k  ‖rₖ‖  |αₖ|  |ωₖ|  timer
+  if (verbose > 0) printf("    k     \xe2\x80\x96r\xe2\x82\x96\xe2\x80\x96      |\xce\xb1\xe2\x82\x96|      |\xcf\x89\xe2\x82\x96|  timer\n");
+  if (kdisplay(iter, verbose)) printf("%5lld  %7.1e  %8.1e  %8.1e  %.2fs\n", (long long)iter, rNorm, std::fabs(alpha), std::fabs(omega), now_s() - t0);
 
   double next_rho;
   K(khip_dot(ctx, n, c, r, &next_rho));                                            // :196
@@ -1245,7 +1294,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   const char *status = "unknown";
 
   const bool fast = fused && MisI && NisI && !A->apply && A->csr;
-  const bool device_loop = fast && o.fused >= 2 && !o.callback;
+  const bool device_loop = fast && o.fused >= 2 && !o.callback && verbose <= 0;      // the log rows need alpha and omega on the host
   if (device_loop && !(solved || tired)) {
     BicgDevState fin;
     K(bicgstab_device_loop(ws, A->csr, c, next_rho, rNorm, eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
@@ -1338,8 +1387,10 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
     tired = iter >= itmax;
     breakdown = (alpha == 0 || std::isnan(alpha));
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
+    if (kdisplay(iter, verbose)) printf("%5lld  %7.1e  %8.1e  %8.1e  %.2fs\n", (long long)iter, rNorm, std::fabs(alpha), std::fabs(omega), now_s() - t0);   // :255
   }
 
+  if (verbose > 0) { printf("\n"); fflush(stdout); }                                                           // src/bicgstab.jl:257
   if (tired) status = "maximum number of iterations exceeded";
   if (breakdown) status = "breakdown \xce\xb1\xe2\x82\x96 == 0";
   if (solved) status = "solution good enough given atol and rtol";
@@ -1354,6 +1405,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   st->solved = solved;
   st->inconsistent = 0;
   st->timer = now_s() - t0;
+  st->allocation_timer += take_alloc_seconds();                 // lazy allocations of this solve (allocate_if)
   snprintf(st->status, sizeof(st->status), "%s", status);
   ws->box.publish();
   return KHIP_OK;

@@ -150,11 +150,16 @@ def test_bicgstab_256_matches_oracle_within_the_derived_tolerance(K, ctx, parity
 # The benchmark definition of the reference, cg(A, b, atol = 0, rtol = 1e-8, itmax = n) (benchmark/benchmarks.jl:14-21), on
 # cfg 2 / 3 / 5; goldens: tests/golden/oracle_cfg*_full.json (make_scale_golden.py legs 12 / 13 / 15, the oracle's own full
 # solves: 1225 / 940 / 35 iterations).  Asserted: the SAME iteration count, status and solved flag, and every residual norm of
-# the whole history within FULL_TOL of the oracle's.  FULL_TOL: see DESIGN.md 3.2c -- the oracle's double-precision history
-# is itself up to ~1e-9 (restarted GMRES) away from the exact recurrence at small sizes (tests/golden/quad_histories.json),
-# so 1e-12 cannot hold over ~1000 iterations; the bound below is 100 x the measured deviation's order and 1e4 x smaller than
-# the 2 % margin by which the oracle's last iterates clear the stopping threshold (so equal counts are not luck).
-FULL_TOL = {"cg": 1e-8, "gmres": 1e-6, "block_gmres": 1e-6}
+# the whole history within FULL_TOL of the oracle's.  FULL_TOL is DERIVED from
+# tests/golden/full_solve_tolerance.json: the oracle's own double-precision history against the binary128 build of its source,
+# same operators and settings, on a ladder of sizes where binary128 is affordable.  cg!: 1.3e-15 ... 3e-14 over 39 ... 159
+# iterations -> 1e-8 leaves four orders for the 1225 iterations at 512^3 (measured against the oracle: 7.7e-11).
+# gmres!(30, restart): 7.7e-10 / 1.6e-9 / 7.4e-9 after 97 / 180 / 209 iterations -- the restarts feed the Givens estimate of
+# the residual back into the basis (src/gmres.jl:229-231) and the drift grows about tenfold per 110 iterations; at 940
+# iterations two correct double implementations are therefore expected up to ~1e-2 apart (measured: 4.0e-4).  The bound 5e-3
+# is a quarter of the 2 % margin by which the oracle's last iterates clear the stopping threshold, i.e. equal iteration
+# counts are implied by it, not luck.  block_gmres!: 2e-6 already at 10^3 x 16 over 20 iterations -> 1e-6 over 35 (measured 1e-11).
+FULL_TOL = {"cg": 1e-8, "gmres": 5e-3, "block_gmres": 1e-6}
 
 
 def _full_check(g, st, parity_log, name, extra):

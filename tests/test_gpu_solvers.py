@@ -600,3 +600,81 @@ def test_gmres_cgs2_variant_parity_budget(K, ctx, oracle, parity_log, n1, kw):
     assert np.linalg.norm(bh - S @ x.to_host()) / np.linalg.norm(bh) <= 1e-6
     with pytest.raises(K.KhipError):
         K.gmres(dA, ctx.array(bh), variant=7)
+
+
+# ---- options.verbose and stats.allocation_timer --------------------------------------------------
+
+def test_verbose_prints_the_reference_log_and_changes_nothing(K, ctx, oracle, capfd):
+    """verbose > 0: the reference's per-iteration rows on stdout (src/cg.jl:132,182-183,224,267-269; src/gmres.jl:131,191-192,
+    315,364; src/bicgstab.jl:135,193-194,255-257; src/block_gmres.jl:120,181-182,297,340), one every `verbose` iterations
+    (kdisplay, src/krylov_utils.jl:301); same iteration count and the same residual history as the silent solve."""
+    import re
+    n1 = 16
+    A = K.CsrMatrix.stencil(ctx, "poisson", n1)
+    n = n1 ** 3
+    b = ctx.empty(n)
+    K.kfill_(b, 1.0)
+    _, st0, _ = K.cg(A, b, history=True)
+    capfd.readouterr()
+    _, st1, _ = K.cg(A, b, history=True, verbose=10)
+    out = capfd.readouterr().out
+    assert st1.niter == st0.niter and np.array_equal(st1.residuals, st0.residuals)
+    lines = out.split("\n")
+    assert lines[0] == f"CG: system of {n} equations in {n} variables"
+    assert lines[1].split() == ["k", "‖r‖", "pAp", "α", "σ", "timer"] and lines[1].startswith("    k      ‖r‖       pAp")
+    rows = [l for l in lines[2:] if l.strip()]
+    assert [int(r.split()[0]) for r in rows] == list(range(0, st0.niter + 1, 10))
+    assert re.fullmatch(r"    0  6\.4e\+01   1\.5e\+03   2\.7e\+00   2\.7e\+00  \d+\.\d\ds", rows[0]), rows[0]   # ‖r0‖ = 64, pAp = 6 * 16^2 = 1536 (p = ones: only the boundary rows have a nonzero sum), α = σ = 4096 / 1536
+    for r in rows[:-1]:
+        f = r.split()
+        assert len(f) == 6 and f[5].endswith("s")
+    assert out.endswith("\n\n")
+    # gmres!, bicgstab!, block_gmres!: title, header, rows every `verbose` iterations, unchanged results
+    Au = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", 10)
+    nu = 1000
+    ones = ctx.empty(nu)
+    K.kfill_(ones, 1.0)
+    bu = Au.matvec(ones)
+    _, g0, _ = K.gmres(Au, bu, memory=10, restart=True, history=True)
+    capfd.readouterr()
+    _, g1, _ = K.gmres(Au, bu, memory=10, restart=True, history=True, verbose=5)
+    out = capfd.readouterr().out.split("\n")
+    assert g1.niter == g0.niter and np.array_equal(g1.residuals, g0.residuals)
+    assert out[0] == f"GMRES: system of size {nu}" and out[1].split() == ["pass", "k", "‖rₖ‖", "hₖ₊₁.ₖ", "timer"]
+    assert out[2].split()[:3] == ["0", "0", "%.1e" % g0.residuals[0]] and "✗ ✗ ✗ ✗" in out[2]
+    ks = [int(l.split()[1]) for l in out[3:] if l.strip()]
+    assert ks == [k for k in range(5, g0.niter + 1, 5)]
+    _, s0, _ = K.bicgstab(Au, bu, history=True)
+    capfd.readouterr()
+    _, s1, _ = K.bicgstab(Au, bu, history=True, verbose=4)
+    out = capfd.readouterr().out.split("\n")
+    assert s1.niter == s0.niter and np.array_equal(s1.residuals, s0.residuals)
+    assert out[0] == f"BICGSTAB: system of size {nu}" and out[1].split() == ["k", "‖rₖ‖", "|αₖ|", "|ωₖ|", "timer"]
+    assert out[2].split()[:4] == ["0", "%.1e" % s0.residuals[0], "1.0e+00", "1.0e+00"]
+    B = np.random.default_rng(3).standard_normal((nu, 4))
+    capfd.readouterr()
+    X1, b1, _ = K.block_gmres(Au, B, memory=5, ctx=ctx, history=True, verbose=3)
+    out = capfd.readouterr().out.split("\n")
+    X0, b0, _ = K.block_gmres(Au, B, memory=5, ctx=ctx, history=True)
+    assert b1.niter == b0.niter and np.array_equal(np.array(b1.residuals), np.array(b0.residuals)) and np.array_equal(X1, X0)
+    assert out[0] == f"BLOCK-GMRES: system of size {nu} with 4 right-hand sides" and out[1].split() == ["pass", "k", "‖Rₖ‖", "timer"]
+
+
+def test_allocation_timer_counts_creation_and_lazy_allocations(K, ctx):
+    """stats.allocation_timer (src/krylov_workspaces.jl:288-289; allocate_if, src/krylov_utils.jl:281-288): set when the
+    workspace allocates its vectors, increased by the lazy ones (z for a preconditioned cg!, Δx for a warm start), not by
+    a solve that allocates nothing."""
+    n1 = 20
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "poisson", n1)
+    b = ctx.empty(n)
+    K.kfill_(b, 1.0)
+    ws = K.CgWorkspace(ctx, n, n)
+    t_create = ws.stats.allocation_timer
+    assert t_create > 0.0
+    K.cg_(ws, A, b)
+    assert ws.stats.allocation_timer == t_create                       # the 4 n vectors were there: nothing allocated
+    K.cg_(ws, A, b, M=K.Jacobi(A))
+    assert ws.stats.allocation_timer > t_create                        # z allocated on first use (src/cg.jl:142)
+    wsb = K.BlockGmresWorkspace(ctx, n, n, 4, memory=3)
+    assert wsb.stats.allocation_timer > 0.0
