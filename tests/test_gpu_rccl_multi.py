@@ -3,7 +3,7 @@
 device-resident loops running several iterations ahead of the host -- against the CPU oracle's solve of the global
 system.  Needs >= 2 GPUs in one box: skipped (cleanly, at collection of the parametrisation) on the 1-GPU boxes the
 round's own runs get; the in-process backend (tests/test_gpu_dist.py) covers everything above the three transport calls
-there.  World sizes 2 and, when 8 GPUs are visible, 8.  ref: docs/src/custom_workspaces.md:477-586 (the MPI recipe)."""
+there.  World sizes 2, 4 and 8, each where that many GPUs are visible.  ref: docs/src/custom_workspaces.md:477-586 (the MPI recipe)."""
 import os
 import subprocess
 import sys
@@ -23,7 +23,7 @@ def _ngpu():
     return K.device_count() if K.gpu_available() else 0
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_rccl_ranks_match_oracle(oracle, world):
     ngpu = _ngpu()
     if ngpu < world:
@@ -91,3 +91,29 @@ def test_rccl_ranks_match_oracle(oracle, world):
                 assert np.array_equal(h, res[0][key])
             assert np.allclose(out[f"blockX{mode}"], k_ref.x[q0:q1], atol=1e-8 * np.abs(k_ref.x).max())
         assert np.array_equal(out["cg12_hist"], out["cg22_hist"])                                           # the two halo modes agree bit for bit
+
+
+
+def test_bench_with_one_rank_communicator_equals_the_plain_path():
+    """bench.py's distributed code path with ONE rank over real RCCL (KHIP_FORCE_COMM=1: ncclCommInitRank, the row-partitioned
+    handle, the all-gathered (hi, lo) dots inside the device-resident loop) gives the same residuals as the plain single-GPU
+    path and reports the rank RCCL saw.  What an 8-GPU run adds on top is only peer traffic (rows above, when there are GPUs)."""
+    import json
+    outs = {}
+    for force in ("0", "1"):
+        env = dict(os.environ, KHIP_FORCE_COMM=force, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n1", "96", "--steps", "30", "--warmup", "2", "--no-cpu-baseline",
+                            "--also-variant1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+        lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+        assert len(lines) == 1, lines                                   # exactly one JSON line on stdout
+        outs[force] = json.loads(lines[0])
+    plain, comm = outs["0"], outs["1"]
+    assert plain["rccl_ranks_seen"] == 0 and comm["rccl_ranks_seen"] == 1
+    assert comm["final_residual_norm"] == plain["final_residual_norm"]                  # same bits through the communicator
+    assert comm["steps"] == plain["steps"] == 30 and comm["n_gpus"] == 1
+    for o in (plain, comm):
+        sr = o["single_reduction_cg"]
+        assert sr is not None and "NOT_THE_HEADLINE" in sr and sr["steps"] == 30 and sr["value"] > 0
+        assert o["roofline"]["frac"] > 0 and o["metric"] == "cg_iters_per_sec_poisson3d_csr_512cubed"
