@@ -85,7 +85,10 @@ int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t 
                          const double *val, int index_base, int on_device, khip_csr **out);
 /* The adjoint operator A' as its own handle (built on the device; entries of a row of A' in increasing column
  * order = the order of a column of A).  khip_spmv(At, x, y) is then `mul!(y, A', x)` (docs/src/matrix_free.md:36-42),
- * what MINRES-QLP / LSQR / LSMR / BiLQ / QMR ... ask of an operator besides `mul!(y, A, x)`. */
+ * what MINRES-QLP / LSQR / LSMR / BiLQ / QMR ... ask of an operator besides `mul!(y, A, x)`.
+ * A row-partitioned handle (khip_csr_create_dist) gives a row-partitioned A' with the SAME partition: every rank's entries
+ * travel to the owners of their columns (one all-to-all at set-up, collective: call it on every rank), and y = A' x is
+ * bit-identical to the single-GPU product.  ref: the two-sided processes and solvers, src/krylov_processes.jl:133-222. */
 int khip_csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr **At_out);
 int khip_csr_destroy(khip_csr *A);
 /* Optional internal re-encoding of a handle whose rows repeat few (column - row, value) sequences (stencils):

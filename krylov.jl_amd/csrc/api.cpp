@@ -274,7 +274,7 @@ int khip_csr_create_dist(khip_ctx *ctx, int64_t n_global, int64_t row0, int64_t 
 
 int khip_csr_transpose(khip_ctx *ctx, const khip_csr *A, khip_csr **out) {
   KHIP_REQUIRE(ctx && A && out, "csr_transpose: null argument");
-  KHIP_REQUIRE(!A->dist, "csr_transpose: distributed handles are not supported (transpose the global operator, then partition)");
+  if (A->dist) return comm_transpose_dist(ctx, A, out);       // row-partitioned: all-to-all of the entries, same partition
   khip_csr *T = new khip_csr();
   int rc = csr_transpose(ctx, A, T);
   if (rc != KHIP_OK) { khip_csr_destroy(T); return rc; }

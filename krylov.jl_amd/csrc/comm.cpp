@@ -287,6 +287,7 @@ int comm_build_plan(khip_ctx *ctx, khip_csr *A, int local_rc) {
       want_gather = true;                      // this rank would fetch more than halo_gather_pct % of its own size
   }
   row_starts[G] = all[4 * (G - 1)] + all[4 * (G - 1) + 1];
+  A->part_starts = row_starts;
   if (bad_partition || row_starts[0] != 0 || row_starts[G] != A->n_global) {     // same data on every rank: all fail together
     set_error("row partition [%lld, %lld) is not contiguous or does not cover n_global = %lld", (long long)row_starts[0],
               (long long)row_starts[G], (long long)A->n_global);
@@ -343,6 +344,7 @@ int comm_build_plan(khip_ctx *ctx, khip_csr *A, int local_rc) {
   if (failed > 0) { set_error("halo plan construction failed on %d rank(s)", (int)failed); return rc != KHIP_OK ? rc : KHIP_ERR_INVALID; }
   A->n_ghost = (int64_t)ghost.size();
   A->n_send = (int64_t)send_idx.size();
+  A->ghost_gid = ghost;
   // 5. device state
   int32_t *d_ghost_sorted = nullptr;
   KHIP_TRY(scratch.alloc(&d_ghost_sorted, (size_t)std::max<int64_t>(A->n_ghost, 1)));
@@ -362,6 +364,125 @@ int comm_build_plan(khip_ctx *ctx, khip_csr *A, int local_rc) {
   A->interior_lo = lo_hi[0];
   A->interior_hi = lo_hi[1];
   return KHIP_OK;
+}
+
+// --------------------------------------------------------------------------- setup-time all-to-all, distributed transpose
+// Variable-size exchange of device buffers between all ranks (setup only): send_off / recv_off are BYTE offsets per peer
+// (size nranks + 1).  RCCL: grouped Send / Recv on the main communicator; local backend: copies out of the peers' buffers.
+static int alltoallv_dev(khip_ctx *ctx, const char *send_dev, const std::vector<int64_t> &send_off, char *recv_dev,
+                         const std::vector<int64_t> &recv_off) {
+  Comm *c = ctx->comm;
+  const int G = c->nranks, me = c->rank;
+  const int64_t self = send_off[me + 1] - send_off[me];
+  if (self > 0) KHIP_CHECK_HIP(hipMemcpyAsync(recv_dev + recv_off[me], send_dev + send_off[me], (size_t)self, hipMemcpyDeviceToDevice, ctx->stream));
+  if (c->hub) {
+    LocalHub *h = c->hub;
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    h->sendbuf[me] = reinterpret_cast<const double *>(send_dev);
+    h->send_off[me] = send_off;
+    h->barrier();
+    for (int r = 0; r < G; ++r) {
+      if (r == me) continue;
+      const int64_t nb = recv_off[r + 1] - recv_off[r];
+      if (nb > 0)
+        KHIP_CHECK_HIP(hipMemcpyAsync(recv_dev + recv_off[r], reinterpret_cast<const char *>(h->sendbuf[r]) + h->send_off[r][me], (size_t)nb,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    h->barrier();
+    return KHIP_OK;
+  }
+  KHIP_CHECK_NCCL(g_rccl.GroupStart());
+  for (int r = 0; r < G; ++r) {
+    if (r == me) continue;
+    const int64_t ns = send_off[r + 1] - send_off[r], nr = recv_off[r + 1] - recv_off[r];
+    if (ns > 0) KHIP_CHECK_NCCL(g_rccl.Send(send_dev + send_off[r], (size_t)ns, ncclUint8, r, c->comm, ctx->stream));
+    if (nr > 0) KHIP_CHECK_NCCL(g_rccl.Recv(recv_dev + recv_off[r], (size_t)nr, ncclUint8, r, c->comm, ctx->stream));
+  }
+  KHIP_CHECK_NCCL(g_rccl.GroupEnd());
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return KHIP_OK;
+}
+
+// A' of a row-partitioned operator, partitioned the same way (the two-sided processes and solvers of the reference need
+// mul!(y, A', x): src/krylov_processes.jl:133-222, docs/src/matrix_free.md:36-42).  Every entry (i, j, v) of my rows goes to the
+// owner of row j of A'; the receiver lines its entries up by local row, peers in rank order and each peer's entries in its
+// own (row-major) order, so that a row of A' holds a column of A in ascending row order -- the entry order of the
+// single-GPU khip_csr_transpose and of the CSC matrix the reference's users hold; y = A' x is bit-identical to that.
+// Set-up code: the bucketing runs on the host (one D2H of the shard), the exchange on the device buffers RCCL needs.
+int comm_transpose_dist(khip_ctx *ctx, const khip_csr *A, khip_csr **out) {
+  Comm *c = ctx->comm;
+  if (!c || !A->dist || (int)A->part_starts.size() != c->nranks + 1) { set_error("csr_transpose: not a distributed handle of this communicator"); return KHIP_ERR_INVALID; }
+  const int G = c->nranks, me = c->rank;
+  const int64_t m = A->m, nnz = A->nnz, row0 = A->row0;
+  const std::vector<int64_t> &starts = A->part_starts;
+  std::vector<int32_t> rp((size_t)m + 1), col((size_t)nnz);
+  std::vector<double> val((size_t)nnz);
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  KHIP_CHECK_HIP(hipMemcpy(rp.data(), A->rowptr, sizeof(int32_t) * (size_t)(m + 1), hipMemcpyDeviceToHost));
+  if (nnz) {
+    KHIP_CHECK_HIP(hipMemcpy(col.data(), A->col, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost));
+    KHIP_CHECK_HIP(hipMemcpy(val.data(), A->val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+  }
+  // local column -> global column: [owned | ghost]; ghost slots are the sorted ghost list (neighbour mode) or the peers'
+  // slices at stride gather_maxm (gather mode)
+  auto global_col = [&](int32_t lc) -> int64_t {
+    if (lc < m) return row0 + lc;
+    const int64_t g = (int64_t)lc - m;
+    if (A->gather) { const int64_t r = g / A->gather_maxm; return starts[(size_t)r] + (g - r * A->gather_maxm); }
+    return A->ghost_gid[(size_t)g];
+  };
+  auto owner = [&](int64_t j) -> int { return (int)(std::upper_bound(starts.begin(), starts.end(), j) - starts.begin()) - 1; };
+  struct Trip { int32_t row, col; double v; };             // (global row of A, global column of A, value): 16 bytes
+  std::vector<int64_t> cnt((size_t)G, 0);
+  for (int64_t q = 0; q < nnz; ++q) cnt[(size_t)owner(global_col(col[(size_t)q]))]++;
+  std::vector<int64_t> send_off((size_t)G + 1, 0);
+  for (int r = 0; r < G; ++r) send_off[(size_t)r + 1] = send_off[(size_t)r] + cnt[(size_t)r];
+  std::vector<Trip> sendbuf((size_t)nnz);
+  {
+    std::vector<int64_t> cur(send_off.begin(), send_off.end() - 1);
+    for (int64_t i = 0; i < m; ++i)
+      for (int32_t q = rp[(size_t)i]; q < rp[(size_t)i + 1]; ++q) {
+        const int64_t j = global_col(col[(size_t)q]);
+        sendbuf[(size_t)cur[(size_t)owner(j)]++] = Trip{(int32_t)(row0 + i), (int32_t)j, val[(size_t)q]};
+      }
+  }
+  // everybody's counts: recv_cnt[r] = what rank r sends to me
+  std::vector<int64_t> all((size_t)G * G);
+  KHIP_TRY(allgather_host(ctx, cnt.data(), all.data(), sizeof(int64_t) * (size_t)G));
+  std::vector<int64_t> recv_off((size_t)G + 1, 0);
+  for (int r = 0; r < G; ++r) recv_off[(size_t)r + 1] = recv_off[(size_t)r] + all[(size_t)r * G + me];
+  const int64_t nnzT = recv_off[(size_t)G];
+  if (nnzT >= (1ll << 31) - 64) { set_error("csr_transpose: the transposed shard has %lld entries (int32 row pointers)", (long long)nnzT); return KHIP_ERR_UNSUPPORTED; }
+  DevScratch scratch;
+  char *d_send = nullptr, *d_recv = nullptr;
+  KHIP_TRY(scratch.alloc(&d_send, sizeof(Trip) * (size_t)std::max<int64_t>(nnz, 1)));
+  KHIP_TRY(scratch.alloc(&d_recv, sizeof(Trip) * (size_t)std::max<int64_t>(nnzT, 1)));
+  if (nnz) KHIP_CHECK_HIP(hipMemcpy(d_send, sendbuf.data(), sizeof(Trip) * (size_t)nnz, hipMemcpyHostToDevice));
+  std::vector<int64_t> so((size_t)G + 1), ro((size_t)G + 1);
+  for (int r = 0; r <= G; ++r) { so[(size_t)r] = send_off[(size_t)r] * (int64_t)sizeof(Trip); ro[(size_t)r] = recv_off[(size_t)r] * (int64_t)sizeof(Trip); }
+  KHIP_TRY(alltoallv_dev(ctx, d_send, so, d_recv, ro));
+  std::vector<Trip> got((size_t)nnzT);
+  if (nnzT) KHIP_CHECK_HIP(hipMemcpy(got.data(), d_recv, sizeof(Trip) * (size_t)nnzT, hipMemcpyDeviceToHost));
+  // stable counting sort by local row of A' (= global column of A - row0); `got` is already ordered (peer, row of A)
+  std::vector<int64_t> rpT((size_t)m + 1, 0);
+  for (const Trip &t : got) {
+    const int64_t lr = (int64_t)t.col - row0;
+    if (lr < 0 || lr >= m) { set_error("csr_transpose: received an entry of column %d outside [%lld, %lld)", t.col, (long long)row0, (long long)(row0 + m)); return KHIP_ERR_INVALID; }
+    rpT[(size_t)lr + 1]++;
+  }
+  for (int64_t i = 0; i < m; ++i) rpT[(size_t)i + 1] += rpT[(size_t)i];
+  std::vector<int32_t> colT((size_t)std::max<int64_t>(nnzT, 1));
+  std::vector<double> valT((size_t)std::max<int64_t>(nnzT, 1));
+  {
+    std::vector<int64_t> cur(rpT.begin(), rpT.end() - 1);
+    for (const Trip &t : got) {
+      const int64_t k = cur[(size_t)((int64_t)t.col - row0)]++;
+      colT[(size_t)k] = t.row;
+      valT[(size_t)k] = t.v;
+    }
+  }
+  return khip_csr_create_dist(ctx, A->n_global, row0, m, nnzT, rpT.data(), 64, colT.data(), valT.data(), 0, 0, out);
 }
 
 // --------------------------------------------------------------------------- per-SpMV / per-SpMM exchange

@@ -164,6 +164,8 @@ struct khip_csr {
   int halo_w_cap = 0;
   int64_t n_send = 0;
   std::vector<int64_t> send_off, recv_off;   // per-peer offsets (size nranks+1)
+  std::vector<int64_t> part_starts;          // row partition of the global operator (size nranks+1), kept for khip_csr_transpose
+  std::vector<int32_t> ghost_gid;            // neighbour mode: global column of every ghost slot (ascending), kept for khip_csr_transpose
   // gather mode (comm.cpp): x is all-gathered before the product instead of exchanging the needed entries only
   bool gather = false;
   int64_t gather_maxm = 0;                   // slice stride of the receive buffer (largest local row count)
@@ -300,6 +302,7 @@ int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count);
 int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x, int width = 1);   // width p: row-major panel
 int comm_allreduce_sum_host(khip_ctx *ctx, double *vals, int count);
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A);
+int comm_transpose_dist(khip_ctx *ctx, const khip_csr *A, khip_csr **out);   // A' of a row-partitioned handle, same partition
 int comm_build_plan(khip_ctx *ctx, khip_csr *A, int local_rc = 0);   // local_rc != 0 / A == null: this rank failed before the plan; every rank then returns an error
 
 // "time limit exceeded" decided COLLECTIVELY: every stopping test of the solver loops comes from all-reduced scalars and

@@ -82,7 +82,11 @@ for mode in (1, 2):
     X, stk, _ = K.block_gmres(A, Bloc, memory=8, history=True, ctx=ctx)
     out[f"block{mode}"] = stk.residuals.copy()
     out[f"blockX{mode}"] = X
-    del A
+    # A' of the partitioned operator (one all-to-all of the entries over RCCL), applied to the slab of `ones`-like data
+    At = A.transpose()
+    xt = np.cos(np.arange(n2) * 0.01)
+    out[f"At{mode}"] = At.matvec(ctx.array(xt[q0:q1])).to_host()
+    del A, At
 ctx.barrier()
 np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
 ctx.close()

@@ -365,3 +365,45 @@ def test_create_dist_failure_on_one_rank_fails_on_all_local_ranks(K, oracle):
     res = _run_ranks(K, world, 626262, body)
     assert all(r.startswith("error") for r in res), res
     assert "column index" in res[1] or "csr" in res[1], res[1]
+
+
+@pytest.mark.parametrize("world,mode", [(3, 1), (3, 2), (2, 0), (1, 0)])
+def test_distributed_transpose_local_ranks(K, oracle, world, mode):
+    """khip_csr_transpose of a row-partitioned handle (the two-sided processes need mul!(y, A', x),
+    src/krylov_processes.jl:133-222): A' comes back with the same partition, y = A' x is bit-identical to the serial loop over
+    the columns of A (the single-GPU transpose's order), in neighbour-exchange and in gather mode; (A')' x == A x; and
+    bilq-style use: the nonhermitian Lanczos process runs on (A, A') of the partitioned operator."""
+    n1 = 9
+    A_cpu = oracle.kron_unsymmetric(n1)
+    n = A_cpu.n
+    S = A_cpu.to_scipy().tocsr()
+    St = S.T.tocsr()
+    St.sort_indices()
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(n)
+    yt_ref = np.zeros(n)
+    for j in range(n):
+        acc = 0.0
+        for q in range(St.indptr[j], St.indptr[j + 1]):
+            acc = acc + St.data[q] * x[St.indices[q]]
+        yt_ref[j] = acc
+    y_ref = A_cpu.matvec(x)
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        c.set_option("halo_mode", mode)
+        A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+        At = A.transpose()
+        xs = c.array(x[r0:r1])
+        yt = At.matvec(xs).to_host()
+        Att = At.transpose()
+        ytt = Att.matvec(xs).to_host()
+        return dict(yt=yt, ytt=ytt, y=A.matvec(xs).to_host(), nnz=(A.nnz, At.nnz), shape=At.shape)
+
+    res = _run_ranks(K, world, 717100 + 10 * world + mode, body)
+    assert sum(r["nnz"][1] for r in res) == A_cpu.nnz
+    for rank, out in enumerate(res):
+        r0, r1 = starts[rank], starts[rank + 1]
+        assert np.array_equal(out["yt"], yt_ref[r0:r1]), (rank, "A' x")
+        assert np.array_equal(out["ytt"], y_ref[r0:r1]) and np.array_equal(out["y"], y_ref[r0:r1]), (rank, "(A')' x")

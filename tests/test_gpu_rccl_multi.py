@@ -65,6 +65,10 @@ def test_rccl_ranks_match_oracle(oracle, world):
     B = np.stack([Ab.matvec(np.ascontiguousarray(Xt[:, j])) for j in range(p)], axis=1)
     k_ref = oracle.block_gmres(Ab, B, memory=8, history=True)
     startsb = K.row_partition(nb, world)
+    xt = np.cos(np.arange(nb) * 0.01)
+    Sb = Ab.to_scipy().T.tocsr()
+    Sb.sort_indices()
+    yt_ref = oracle.CsrMatrix.from_arrays(Sb.indptr.astype(np.int64), Sb.indices.astype(np.int32), Sb.data.copy()).matvec(xt)
 
     for rank, out in enumerate(res):
         assert int(out["rccl_ranks"]) == world
@@ -90,6 +94,7 @@ def test_rccl_ranks_match_oracle(oracle, world):
                 assert np.max(np.abs(h - ref.residuals) / (tol * ref.residuals + 100 * EPS * ref.residuals[0])) <= 1.0, key
                 assert np.array_equal(h, res[0][key])
             assert np.allclose(out[f"blockX{mode}"], k_ref.x[q0:q1], atol=1e-8 * np.abs(k_ref.x).max())
+            assert np.array_equal(out[f"At{mode}"], yt_ref[q0:q1]), (rank, mode, "A' x over RCCL")
         assert np.array_equal(out["cg12_hist"], out["cg22_hist"])                                           # the two halo modes agree bit for bit
 
 
