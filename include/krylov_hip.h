@@ -358,6 +358,11 @@ typedef struct {
                                * 2 passes per iteration).  Different rounding: same solution to the requested tolerance, iteration
                                * counts within a few of the reference recurrence -- opt-in, own parity budget.
                                * Needs M = I, a CSR operator, no trust region / linesearch / callback (else KHIP_ERR_UNSUPPORTED).
+                               * cg: 2 = pipelined CG (Ghysels & Vanroose 2014): r, w = A r and their images are recurred, the one
+                               * reduction (r.w, r.r) of an iteration does not feed the product q = A w that runs beside it; on N GPUs
+                               * its all-gather, the cross-rank combine and the scalar update run on the communication stream while the
+                               * product runs (needs a second communicator, else in order).  104n + SpMV bytes per iteration and two more
+                               * work vectors.  Opt-in, own parity budget; same requirements as variant 1.
                                * gmres: 1 = CGS2, classical Gram-Schmidt applied twice instead of the modified Gram-Schmidt cascade of
                                * src/gmres.jl:259-271: h = V_k' q as one reduction per four basis vectors, q -= V_k h in one pass, twice:
                                * three all-reduces per inner iteration on N GPUs instead of k + 1.  Opt-in, own parity budget. */

@@ -81,6 +81,7 @@ int khip_ctx_destroy(khip_ctx *ctx) {
   (void)hipFree(ctx->results_dd);
   (void)hipHostFree(ctx->results_pinned);
   if (ctx->ev_fetch) (void)hipEventDestroy(ctx->ev_fetch);
+  if (ctx->ev_red) (void)hipEventDestroy(ctx->ev_red);
   for (int i = 0; i < khip_ctx::kEvRing; ++i) {
     if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
     if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);

@@ -262,6 +262,70 @@ int launch_cgcg_update(khip_ctx *ctx, int64_t n, const void *st_dev, long long s
   return KHIP_OK;
 }
 
+// ---------------------------------------------------------------- pipelined CG update ----
+// Ghysels & Vanroose (2014): z <- q + beta z (z = A s) ; s <- w + beta s (s = A p) ; p <- r + beta p ; x <- x + alpha p ;
+// r <- r - alpha s ; w <- w - alpha z (w = A r), with q = A w from the product that ran beside the reduction.  One pass,
+// 7 reads + 6 writes = 104n bytes; alpha, beta from the device state the reduction epilogue maintains.
+template <int VEC, bool NT>
+__global__ __launch_bounds__(kBlock) void pcg_update_kernel(int64_t n, const CgcgDevState *st, long long seq, const double *q,
+                                                            double *z, double *s, double *p, double *x, double *r, double *w) {
+  using T = typename VecT<VEC>::type;
+  if (seq >= st->stop_seq) return;
+  const double a = st->alpha, b = st->beta;
+  const int64_t nvec = n / VEC;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < nvec) {
+    const T qv = ldg<NT>(reinterpret_cast<const T *>(q) + i), zv = ldg<NT>(reinterpret_cast<T *>(z) + i);
+    const T sv = ldg<NT>(reinterpret_cast<T *>(s) + i), pv = ldg<NT>(reinterpret_cast<T *>(p) + i);
+    const T xv = ldg<NT>(reinterpret_cast<T *>(x) + i), rv = ldg<NT>(reinterpret_cast<T *>(r) + i);
+    const T wv = ldg<NT>(reinterpret_cast<T *>(w) + i);
+    T zo, so, po, xo, ro, wo;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const double zn = fma(b, vget(zv, e), vget(qv, e));
+      const double sn = fma(b, vget(sv, e), vget(wv, e));
+      const double pn = fma(b, vget(pv, e), vget(rv, e));
+      vset(zo, e, zn);
+      vset(so, e, sn);
+      vset(po, e, pn);
+      vset(xo, e, fma(a, pn, vget(xv, e)));
+      vset(ro, e, fma(-a, sn, vget(rv, e)));
+      vset(wo, e, fma(-a, zn, vget(wv, e)));
+    }
+    stg<NT>(zo, reinterpret_cast<T *>(z) + i);
+    stg<NT>(so, reinterpret_cast<T *>(s) + i);
+    stg<NT>(po, reinterpret_cast<T *>(p) + i);
+    stg<NT>(xo, reinterpret_cast<T *>(x) + i);
+    stg<NT>(ro, reinterpret_cast<T *>(r) + i);
+    stg<NT>(wo, reinterpret_cast<T *>(w) + i);
+  }
+  if (VEC == 2 && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t t = n - 1;
+    const double zn = fma(b, z[t], q[t]), sn = fma(b, s[t], w[t]), pn = fma(b, p[t], r[t]);
+    z[t] = zn; s[t] = sn; p[t] = pn;
+    x[t] = fma(a, pn, x[t]);
+    r[t] = fma(-a, sn, r[t]);
+    w[t] = fma(-a, zn, w[t]);
+  }
+}
+
+int launch_pcg_update(khip_ctx *ctx, int64_t n, const void *st_dev, long long seq, const double *q, double *z, double *s, double *p,
+                      double *x, double *r, double *w) {
+  if (n <= 0) return KHIP_OK;
+  const CgcgDevState *st = static_cast<const CgcgDevState *>(st_dev);
+  const bool v2 = n >= 2 && aligned16(q) && aligned16(z) && aligned16(s) && aligned16(p) && aligned16(x) && aligned16(r) && aligned16(w);
+  const bool nt = use_nt(ctx, n);
+  const int64_t g = tiles_for(v2 ? n / 2 : n, 1);
+  if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
+#define KHIP_L(VEC, NT) \
+  hipLaunchKernelGGL((pcg_update_kernel<VEC, NT>), dim3((unsigned)g), dim3(kBlock), 0, ctx->stream, n, st, seq, q, z, s, p, x, r, w)
+  if (v2) { if (nt) KHIP_L(2, true); else KHIP_L(2, false); }
+  else    { if (nt) KHIP_L(1, true); else KHIP_L(1, false); }
+#undef KHIP_L
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
+
 // ---------------------------------------------------------------- BiCGSTAB fused updates ----
 // The elementwise work of one bicgstab! iteration (src/bicgstab.jl:224-237) in three passes instead of
 // nine; every expression is the one the separate kernels use (OP_WAXPY, OP_AXPY, OP_AXPBY), so all vectors
@@ -507,10 +571,10 @@ __global__ void combine_kernel(const dd *gathered, int nranks, int count, RedArg
   if (threadIdx.x == 0 && ra.epi) solver_epilogue(ra.epi, ra.epi_state, ra.results + ra.slot, ra.seq);
 }
 
-int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot) {
+int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot, hipStream_t stream) {
   if (count > 64) { set_error("combine: too many scalars"); return KHIP_ERR_INVALID; }
   RedArgs ra = make_red_args(ctx, slot);
-  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, ctx->stream, gathered_dev, nranks, count, ra);
+  hipLaunchKernelGGL(combine_kernel, dim3(1), dim3(64), 0, stream ? stream : ctx->stream, gathered_dev, nranks, count, ra);
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }

@@ -658,6 +658,33 @@ int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count) {
   return launch_combine(ctx, c->gather_dev, c->nranks, count, slot);
 }
 
+static thread_local bool g_allreduce_pending = false;
+int comm_allreduce_dd_device_begin(khip_ctx *ctx, int slot, int count) {
+  Comm *c = ctx->comm;
+  g_allreduce_pending = false;
+  if (!c || c->hub || c->halo_comm == c->comm || !ctx->tune.overlap_halo) return comm_allreduce_dd_device(ctx, slot, count);
+  if (count > kMaxRedOut) { set_error("allreduce: too many scalars"); return KHIP_ERR_INVALID; }
+  // The (hi, lo) partials are final on the main stream; everything from here to the epilogue runs on the communication
+  // stream, on the communicator that lives there (halo_comm: its collectives are issued from one stream, in one order on
+  // all ranks -- this all-gather first, then whatever halo exchange the overlapped product needs).
+  hipStream_t cs = ctx->comm_stream;
+  ctx->ev_cur = (ctx->ev_cur + 1) % khip_ctx::kEvRing;
+  KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a[ctx->ev_cur], ctx->stream));
+  KHIP_CHECK_HIP(hipStreamWaitEvent(cs, ctx->ev_a[ctx->ev_cur], 0));
+  KHIP_CHECK_NCCL(g_rccl.AllGather(ctx->results_dd + slot, c->gather_dev, (size_t)count * 2, ncclFloat64, c->halo_comm, cs));
+  KHIP_TRY(launch_combine(ctx, c->gather_dev, c->nranks, count, slot, cs));
+  if (!ctx->ev_red) KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_red, hipEventDisableTiming));
+  KHIP_CHECK_HIP(hipEventRecord(ctx->ev_red, cs));
+  g_allreduce_pending = true;
+  return KHIP_OK;
+}
+int comm_allreduce_dd_device_end(khip_ctx *ctx) {
+  if (!g_allreduce_pending) return KHIP_OK;
+  g_allreduce_pending = false;
+  KHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_red, 0));
+  return KHIP_OK;
+}
+
 }  // namespace khip
 
 using namespace khip;

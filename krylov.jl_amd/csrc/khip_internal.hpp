@@ -121,6 +121,7 @@ struct khip_ctx {
   hipEvent_t ev_a[kEvRing] = {}, ev_b[kEvRing] = {};
   unsigned ev_cur = 0;
   hipEvent_t ev_fetch = nullptr;       // results_copy_begin / _end (look-ahead fetch of device scalars)
+  hipEvent_t ev_red = nullptr;         // comm_allreduce_dd_device_begin / _end (all-reduce on the communication stream)
   int num_cu = 256;
   // reduction scratch (grown on demand by ensure_reduction_scratch)
   khip::dd *partials = nullptr;        // [kMaxNout][red_cap1]  one per wave of the streaming kernel
@@ -226,10 +227,13 @@ int launch_cg_update_dev(khip_ctx *ctx, int64_t n, const void *cg_state_dev, lon
 // run the scalar epilogue in ctx->ctl on results[slot..] (1-thread kernel; used when the reduction result was
 // produced outside a finish kernel) / fold nranks gathered (hi, lo) partials per scalar and run it
 int launch_epilogue_only(khip_ctx *ctx, int slot);
-int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot);
+int launch_combine(khip_ctx *ctx, const dd *gathered_dev, int nranks, int count, int slot, hipStream_t stream = nullptr);
 // single-reduction CG: p, s, x, r updated in one pass with alpha / beta from a CgcgDevState
 int launch_cgcg_update(khip_ctx *ctx, int64_t n, const void *st_dev, long long seq, const double *w, double *r, double *p,
                        double *s, double *x);
+// pipelined CG (Ghysels-Vanroose): z, s, p, x, r, w updated in one pass with alpha / beta from a CgcgDevState
+int launch_pcg_update(khip_ctx *ctx, int64_t n, const void *st_dev, long long seq, const double *q, double *z, double *s, double *p,
+                      double *x, double *r, double *w);
 // fused elementwise passes of one bicgstab! iteration (blas1.hip)
 // st_dev != null: alpha / omega / beta and the stop word are read from a BicgDevState (solver_device.hpp)
 int launch_bicg_sx(khip_ctx *ctx, int64_t n, double alpha, const double *r, const double *v, const double *y, double *s,
@@ -299,6 +303,13 @@ int comm_rank_of(const khip_ctx *ctx);
 int comm_allreduce_dd(khip_ctx *ctx, dd *vals_dev, int count, double *out_host);
 // all-reduce results_dd[slot..slot+count) into results[slot..] ON THE DEVICE (no host sync with RCCL), then run ctx->ctl's epilogue
 int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count);
+// the same in two halves, for recurrences that put work between the reduction and its first use (pipelined CG): `begin`
+// issues the all-gather and the combine (+ epilogue) on the COMMUNICATION stream behind an event of the main stream and
+// returns; `end` makes the main stream wait for them.  What is enqueued on the main stream in between overlaps with the
+// collective.  Falls back to the in-order form (all in `begin`) where there is no second communicator to keep the two streams'
+// collectives apart, with the in-process backend, and without a communicator.
+int comm_allreduce_dd_device_begin(khip_ctx *ctx, int slot, int count);
+int comm_allreduce_dd_device_end(khip_ctx *ctx);
 int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A, const double *x, int width = 1);   // width p: row-major panel
 int comm_allreduce_sum_host(khip_ctx *ctx, double *vals, int count);
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A);

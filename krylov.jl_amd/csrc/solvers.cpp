@@ -112,7 +112,8 @@ struct khip_cg_workspace {
   // device-resident loop state (fused = 2), allocated on first use
   CgDevState *dev_state = nullptr;
   CgDevState *snap = nullptr;          // pinned host snapshots [2]
-  CgcgDevState *cgcg_state = nullptr, *cgcg_snap = nullptr;   // single-reduction variant
+  CgcgDevState *cgcg_state = nullptr, *cgcg_snap = nullptr;   // single-reduction and pipelined variants
+  double *pz = nullptr, *pq = nullptr;                        // pipelined variant: z = A s, q = A w (allocated on first use)
   double *hist_dev = nullptr;
   hipEvent_t snap_ev[2] = {nullptr, nullptr};
 };
@@ -288,6 +289,98 @@ int cg_single_reduction_loop(khip_cg_workspace *ws, const khip_csr *A, double ga
   return drain_history(out->iter);
 }
 
+// Pipelined CG (Ghysels & Vanroose 2014), opt-in as options.variant = 2: per iteration ONE reduction (r.w, r.r) and one
+// product q = A w that does not depend on it, then all recurrences in one pass (launch_pcg_update).  On N GPUs the
+// all-gather of the reduction runs on the communication stream WHILE the product runs on the main stream (RCCL backend with a
+// separate halo communicator; otherwise in program order).  Scalars: the same epilogue as the single-reduction variant
+// (beta = gamma' / gamma, alpha = gamma' / (delta - beta gamma' / alpha)).  Not the reference's recurrence: own parity budget.
+// On entry r = b - A x0, w = A r, p = s = z = 0-initialised by the first update (beta_0 = 0), state = (gamma0, alpha0, 0).
+int cg_pipelined_loop(khip_cg_workspace *ws, const khip_csr *A, double gamma0, double delta0, double eps_tol, int64_t itmax,
+                      bool history, double t0, double timemax, CgcgDevState *out, bool *overtimed) {
+  khip_ctx *ctx = ws->ctx;
+  const int64_t n = ws->n;
+  if (!ws->cgcg_state) {
+    KHIP_CHECK_HIP(hipMalloc(&ws->cgcg_state, sizeof(CgcgDevState)));
+    KHIP_CHECK_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->cgcg_snap), 2 * sizeof(CgcgDevState), hipHostMallocDefault));
+  }
+  if (!ws->hist_dev) KHIP_CHECK_HIP(hipMalloc(&ws->hist_dev, sizeof(double) * (size_t)kHistWindowMax));
+  for (auto &e : ws->snap_ev) if (!e) KHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  long long window = ctx->tune.hist_window;
+  if (window < kDevChunk) window = kDevChunk;
+  if (window > kHistWindowMax) window = kHistWindowMax;
+  CgcgDevState *dev = ws->cgcg_state;
+  CgcgDevState h;
+  memset(&h, 0, sizeof(h));
+  h.gamma = gamma0; h.alpha = gamma0 / delta0; h.beta = 0.0; h.rNorm = std::sqrt(gamma0); h.eps_tol = eps_tol;
+  h.stop_seq = kSeqNever;
+  h.hist = history ? ws->hist_dev : nullptr;
+  h.hist_cap = window;
+  KHIP_CHECK_HIP(hipMemcpyAsync(dev, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  double *x = ws->x, *r = ws->r, *p = ws->p, *s = ws->Ap, *w = ws->z, *z = ws->pz, *q = ws->pq;
+  int64_t enq = 0;
+  long long hist_base = 0;
+  std::vector<double> win;
+  auto drain_history = [&](long long upto_iter) -> int {
+    const long long cnt = upto_iter - hist_base;
+    if (!history || cnt <= 0) return KHIP_OK;
+    win.resize((size_t)cnt);
+    KHIP_CHECK_HIP(hipMemcpy(win.data(), ws->hist_dev, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost));
+    for (double val : win) ws->box.push(val);
+    return KHIP_OK;
+  };
+  int rc = KHIP_OK;
+  bool stopped = false;
+  for (int chunk = 0; !stopped; ++chunk) {
+    const int64_t cnt = std::min<int64_t>(kDevChunk, itmax - enq);
+    if (history && enq + cnt - hist_base > window) {
+      KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      CgcgDevState cur;
+      KHIP_CHECK_HIP(hipMemcpy(&cur, dev, sizeof(cur), hipMemcpyDeviceToHost));
+      if (cur.stop_seq != kSeqNever) break;
+      if ((rc = drain_history(cur.iter)) != KHIP_OK) break;
+      hist_base = cur.iter;
+      KHIP_CHECK_HIP(hipMemcpy(&dev->hist_base, &hist_base, sizeof(hist_base), hipMemcpyHostToDevice));
+    }
+    for (int64_t i = 0; i < cnt && rc == KHIP_OK; ++i) {
+      const long long j = (long long)(enq + i);
+      // (a) q = A w: needs nothing of the reduction still in flight on the communication stream
+      ctx->ctl = SeqCtl{&dev->stop_seq, 3 * j, EPI_NONE, nullptr};
+      rc = spmv_any(ctx, A, w, q, -1);
+      if (rc != KHIP_OK) break;
+      // (b) the recurrences with the alpha, beta the PREVIOUS reduction's epilogue left in the state: wait for it now
+      if (ctx->comm) rc = comm_allreduce_dd_device_end(ctx);
+      if (rc == KHIP_OK) rc = launch_pcg_update(ctx, n, dev, 3 * j + 1, q, z, s, p, x, r, w);
+      if (rc != KHIP_OK) break;
+      // (c) (r.w, r.r) of the new iterate and the scalars of the next iteration; on several ranks its all-gather, the
+      //     cross-rank combine and the scalar epilogue run on the communication stream while the NEXT product (a) runs here
+      ctx->ctl = SeqCtl{&dev->stop_seq, 3 * j + 2, EPI_CGCG, dev};
+      const int slot = take_slots(ctx, 2);
+      rc = launch_dot2(ctx, n, r, w, slot);
+      if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device_begin(ctx, slot, 2);
+      ctx->ctl = SeqCtl{};
+    }
+    if (rc == KHIP_OK && ctx->comm) rc = comm_allreduce_dd_device_end(ctx);      // the snapshot below reads the state the epilogue writes
+    ctx->ctl = SeqCtl{};
+    if (rc != KHIP_OK) break;
+    enq += cnt;
+    const int b = chunk & 1;
+    KHIP_CHECK_HIP(hipMemcpyAsync(&ws->cgcg_snap[b], dev, sizeof(CgcgDevState), hipMemcpyDeviceToHost, ctx->stream));
+    KHIP_CHECK_HIP(hipEventRecord(ws->snap_ev[b], ctx->stream));
+    if (chunk >= 1) {
+      KHIP_CHECK_HIP(hipEventSynchronize(ws->snap_ev[b ^ 1]));
+      if (ws->cgcg_snap[b ^ 1].stop_seq != kSeqNever) stopped = true;
+    }
+    if (enq >= itmax) stopped = true;
+    if (!stopped && time_limit_reached(ctx, now_s() - t0, timemax)) { *overtimed = true; stopped = true; }
+  }
+  ctx->ctl = SeqCtl{};
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (rc != KHIP_OK) return rc;
+  KHIP_CHECK_HIP(hipMemcpy(out, dev, sizeof(CgcgDevState), hipMemcpyDeviceToHost));
+  return drain_history(out->iter);
+}
+
 }  // namespace
 
 extern "C" {
@@ -318,7 +411,7 @@ int khip_cg_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_cg_worksp
 
 int khip_cg_workspace_destroy(khip_cg_workspace *ws) {
   if (!ws) return KHIP_OK;
-  for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z}) khip_free(ws->ctx, v);
+  for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z, ws->pz, ws->pq}) khip_free(ws->ctx, v);
   if (ws->dev_state) (void)hipFree(ws->dev_state);
   if (ws->snap) (void)hipHostFree(ws->snap);
   if (ws->cgcg_state) (void)hipFree(ws->cgcg_state);
@@ -449,8 +542,8 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
 
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
   if (verbose > 0) printf("CG: system of %lld equations in %lld variables\n", (long long)n, (long long)n);      // src/cg.jl:132
-  if (o.variant != 0 && o.variant != 1)
-    return ws->box.fail(KHIP_ERR_INVALID, "cg: options.variant must be 0 (cg! recurrence) or 1 (single-reduction CG)");
+  if (o.variant != 0 && o.variant != 1 && o.variant != 2)
+    return ws->box.fail(KHIP_ERR_INVALID, "cg: options.variant must be 0 (cg! recurrence), 1 (single-reduction CG) or 2 (pipelined CG)");
   if (A->csr && !A->apply) {
     int64_t am, an;
     khip_csr_shape(A->csr, &am, &an, nullptr);
@@ -537,6 +630,33 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     }
   }
   // (a verbose solve prints alpha, pAp and sigma of every displayed iteration: it runs the host-driven loop below)
+  if (o.variant == 2) {                                                           // pipelined CG, opt-in
+    if (A->apply || !A->csr || !MisI || radius != 0 || linesearch || o.callback)
+      return ws->box.fail(KHIP_ERR_UNSUPPORTED, "cg variant 2 needs a CSR operator, M = I, no trust region / linesearch / callback");
+    if (!(solved || tired)) {
+      if (!ws->z) K(alloc_vec(ctx, n, &ws->z));                                     // w = A r lives in the (unused) z slot
+      if (!ws->pz) K(alloc_vec(ctx, n, &ws->pz));
+      if (!ws->pq) K(alloc_vec(ctx, n, &ws->pq));
+      K(khip_fill(ctx, n, Ap, 0.0));                                                // s, z, p start as 0 (beta_0 = 0: the first update overwrites them)
+      K(khip_fill(ctx, n, ws->pz, 0.0));
+      K(khip_fill(ctx, n, p, 0.0));
+      double two[2];
+      const int slot = take_slots(ctx, 2);
+      K(spmv_any(ctx, A->csr, r, ws->z, slot, nullptr, 2));                         // w = A r ; (r.w, r.r)
+      K(fetch_results(ctx, slot, 2, two));
+      if (!(two[0] > 0))
+        return ws->box.fail(KHIP_ERR_NUMERIC,
+                            "The linear operator `A` or the preconditioner `M` is not symmetric positive definite.");
+      CgcgDevState fin;
+      K(cg_pipelined_loop(ws, A->csr, gamma, two[0], eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
+      iter = fin.iter;
+      rNorm = fin.rNorm;
+      solved = fin.solved != 0;
+      inconsistent = false;
+      tired = iter >= itmax;
+      if (fin.breakdown && !solved) { zero_curvature = true; inconsistent = true; }
+    }
+  }
   const bool device_loop = o.variant == 0 && o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback && verbose <= 0;
   if (device_loop && !(solved || tired)) {
     CgDevState fin;

@@ -194,6 +194,41 @@ def test_cg_single_reduction_variant_parity_budget(K, ctx, oracle, parity_log, n
     assert st3.niter == st.niter and np.array_equal(x3.to_host(), xh)
 
 
+@pytest.mark.parametrize("n1", [16, 32, 48])
+def test_cg_pipelined_variant_parity_budget(K, ctx, oracle, parity_log, n1):
+    """options.variant = 2: pipelined CG (Ghysels & Vanroose 2014): one reduction per
+    iteration and a product that does not depend on it.  NOT the reference's recurrence (the residual and its image are
+    recurred, not recomputed) -- its own parity budget against the oracle's cg!: solved to the requested tolerance, iteration
+    count within 3, residual histories within 1e-5 relative while above 1e-5 r_0, the TRUE residual within 5x the oracle's."""
+    A = oracle.poisson3d(n1)
+    b = np.ones(A.n)
+    ref = oracle.cg(A, b, history=True)
+    dA = _upload(K, ctx, A)
+    x, st, ws = K.cg(dA, ctx.array(b), history=True, variant=2)
+    assert st.solved and st.status == ref.status
+    assert abs(st.niter - ref.niter) <= 3
+    k = min(len(st.residuals), len(ref.residuals))
+    big = ref.residuals[:k] >= 1e-5 * ref.residuals[0]
+    dev = float(np.max(np.abs(st.residuals[:k] - ref.residuals[:k])[big] / ref.residuals[:k][big]))
+    xh = x.to_host()
+    res = np.linalg.norm(b - A.matvec(xh)) / np.linalg.norm(b)
+    res_ref = np.linalg.norm(b - A.matvec(ref.x)) / np.linalg.norm(b)
+    parity_log(test="cg_pipelined", n1=n1, niter=st.niter, niter_ref=ref.niter, hist_max_rel=dev, res=res, res_ref=res_ref)
+    assert dev <= 1e-5
+    assert res <= 5 * res_ref + 1e-12
+    assert np.allclose(xh, ref.x, rtol=0, atol=1e-6 * np.abs(ref.x).max())
+    _, st2, _ = K.cg(dA, ctx.array(b), variant=2, itmax=5)
+    assert st2.niter == 5 and not st2.solved and st2.status == "maximum number of iterations exceeded"
+    with pytest.raises(K.KhipError):
+        K.cg(dA, ctx.array(b), variant=2, M=K.Jacobi(dA))
+    with pytest.raises(K.KhipError):
+        K.cg(dA, ctx.array(b), variant=3)
+    # warm start (the tolerance is relative to the warm-start residual, as in cg!): same solution
+    x0 = ctx.array(ref.x * (1 + 1e-3 * np.cos(np.arange(A.n))))
+    x4, st4, _ = K.cg(dA, ctx.array(b), x0=x0, variant=2)
+    assert st4.solved and np.allclose(x4.to_host(), ref.x, rtol=0, atol=1e-6 * np.abs(ref.x).max())
+
+
 def test_cg_edge_cases(K, ctx, oracle):
     A = oracle.tridiag(10, -1.0, 4.0, -1.0)                               # symmetric_definite(10)
     bh = A.matvec(np.arange(1.0, 11.0))
