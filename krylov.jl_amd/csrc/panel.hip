@@ -23,6 +23,7 @@
 namespace khip {
 
 typedef double dbl4 __attribute__((ext_vector_type(4)));
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 constexpr int kRowsPerWaveTN = 256;   // rows folded by one wave of the V^T Q kernel (64 MFMAs per tile pair)
 
@@ -198,12 +199,14 @@ __global__ __launch_bounds__(kBlock) void panel_gemm_nn_kernel(int64_t n_pad, in
 template <int NT, int UNT, bool SELF>
 __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int p, double alpha, const double *Vi,
                                                              const double *Psi_dev, double beta, const double *Vn, double *Q,
-                                                             double *partials) {
+                                                             double *partials, int a_stage) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int64_t row_begin = wid * kRowsPerWaveTN;
   const int i = lane & 15, k = lane >> 4;
   constexpr int KK = NT * 4;
+  __shared__ __attribute__((aligned(16))) char a_lds[NT == 1 ? kWavesPerBlock * UNT * 2048 : 16];
+  const bool a_via_lds = NT == 1 && p == 16 && a_stage != 0;
   dbl4 tn[NT][NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a)
@@ -226,10 +229,32 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
       for (int t = 0; t < UNT; ++t) {
         const int64_t r0 = r + 16 * t;
         const bool tok = r0 < row_end;
+        if (NT == 1 && a_via_lds) {
+          // The A operand wants V_i[r0 + i][4 kk + k]: 16 lanes of one k read 16 DIFFERENT rows, i.e. every one of the four
+          // loads touches all 16 lines of the 2 KB tile.  Instead the tile is fetched as what it is in memory -- 128
+          // consecutive 16-byte pieces, two fully coalesced loads per lane -- parked in the wave's own LDS slice with the pieces
+          // of row i rotated by i (XOR swizzle: the column reads below are then free of bank conflicts) and read back in operand
+          // order.  Same values into the same MFMAs: bit-identical.  Only this wave touches the slice: no barrier.
+          char *slice = a_lds + (size_t)((threadIdx.x >> 6) * UNT + t) * 2048;
+          if (tok) {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          const int vcol = 4 * kk + k;
-          af[t][kk] = (tok && vcol < p) ? Vi[(r0 + i) * p + vcol] : 0.0;
+            for (int h = 0; h < 2; ++h) {
+              const int c16 = lane + 64 * h, row = c16 >> 3, c = c16 & 7;
+              const dbl2 piece = *reinterpret_cast<const dbl2 *>(Vi + (r0 + row) * 16 + 2 * c);
+              *reinterpret_cast<dbl2 *>(slice + row * 128 + ((c ^ (row & 7)) << 4)) = piece;
+            }
+          }
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk) {
+            const int vcol = 4 * kk + k;
+            af[t][kk] = tok ? *reinterpret_cast<const double *>(slice + i * 128 + (((vcol >> 1) ^ (i & 7)) << 4) + ((vcol & 1) << 3)) : 0.0;
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk) {
+            const int vcol = 4 * kk + k;
+            af[t][kk] = (tok && vcol < p) ? Vi[(r0 + i) * p + vcol] : 0.0;
+          }
         }
 #pragma unroll
         for (int b = 0; b < NT; ++b)
@@ -585,8 +610,8 @@ int khip::panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const dou
   double *psi_h = g_ps.psi_pinned + (size_t)slot * 1024, *psi_d = g_ps.psi_dev + (size_t)slot * 1024;
   memcpy(psi_h, Ri_host, sizeof(double) * (size_t)p * p);
   KHIP_CHECK_HIP(hipMemcpyAsync(psi_d, psi_h, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, ctx->stream));
-  if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials);
-  else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials);
+  if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, ctx->tune.panel_a_lds);
+  else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, ctx->tune.panel_a_lds);
   tn_reduce(ctx, t, p, g_ps.psi_dev);
   KHIP_CHECK_HIP(hipGetLastError());
   KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned, g_ps.psi_dev, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -671,8 +696,8 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
     double *psi_i = g_ps.psi_dev + (size_t)(i + 1) * 1024;
     if (i + 1 < k) {
       double *psi_n = g_ps.psi_dev + (size_t)(i + 2) * 1024;
-      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
-      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials);
+      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, ctx->tune.panel_a_lds);
+      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, ctx->tune.panel_a_lds);
       tn_reduce(ctx, t, p, psi_n);
     } else if (tiles > 0) {
       launch_gemm_nn(ctx, np, p, -1.0, V_host[i], psi_i, 1.0, Q);
