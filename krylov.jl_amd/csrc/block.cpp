@@ -122,6 +122,28 @@ void matmul_pp(int p, const double *A, const double *B, double *C) {   // C = A 
     }
 }
 
+// R factor (p x p, row-major, arbitrary diagonal signs) of a small rows x p row-major matrix by unblocked Householder QR on the
+// host: the last level of TSQR when several ranks contribute a triangle each.  Overwrites A.
+void householder_r_host(int rows, int p, double *A, double *R) {
+  for (int j = 0; j < p && j < rows; ++j) {
+    double sigma = 0.0;
+    for (int i = j + 1; i < rows; ++i) sigma += A[(size_t)i * p + j] * A[(size_t)i * p + j];
+    const double alpha = A[(size_t)j * p + j];
+    if (sigma == 0.0) continue;
+    const double nrm = std::sqrt(alpha * alpha + sigma);
+    const double beta = alpha >= 0.0 ? -nrm : nrm, tau = (beta - alpha) / beta, scale = 1.0 / (alpha - beta);
+    for (int c = j + 1; c < p; ++c) {
+      double w = A[(size_t)j * p + c];
+      for (int i = j + 1; i < rows; ++i) w += A[(size_t)i * p + j] * scale * A[(size_t)i * p + c];
+      A[(size_t)j * p + c] -= tau * w;
+      for (int i = j + 1; i < rows; ++i) A[(size_t)i * p + c] -= tau * w * A[(size_t)i * p + j] * scale;
+    }
+    A[(size_t)j * p + j] = beta;
+  }
+  for (int i = 0; i < p; ++i)
+    for (int c = 0; c < p; ++c) R[(size_t)i * p + c] = (c >= i && i < rows) ? A[(size_t)i * p + c] : 0.0;
+}
+
 // Signs and tau of LAPACK's Householder QR from the top p x p block Q1 (row-major, row i at Q1 + i p) of a panel with
 // orthonormal columns: LU without pivoting of Q1 - S, the sign of each pivot chosen as DLARFG chooses beta
 // (beta = -sign(alpha) |x|, sign(+0) = +).  Overwrites Q1.
@@ -184,11 +206,42 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
   // device; only p x p matrices visit the host, as in the reference (src/block_gmres.jl:250-283).
   bool shifted_done = false;
   bool have_G = false;                    // G of this round came out of the kernel that applied the previous R^-1
+  const bool tsqr = ctx->tune.panel_qr_tsqr != 0;
   for (int pass = 0; pass < 2; ++pass) {
-    if (!have_G) KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, Q, Q, G.data()));
-    have_G = false;
-    bool ok = chol_upper(p, G.data(), R.data());
-    if (ok && pass == 0 && !shifted_done) {
+    if (tsqr) {
+      // R by TSQR (panel.hip: block Householder QRs out of LDS, tree of triangles) instead of chol(Q'Q): backward
+      // stable for any conditioning, so no conditioning test and no shifted pass.  Row-partitioned panels: every rank reduces
+      // its rows to one triangle, the triangles are gathered (a sum of zero-padded slots) and the host finishes the tree.
+      // The diagonal is made positive, which makes R the Cholesky factor's equal in exact arithmetic; from there on the
+      // round is the same: Q <- Q R^-1, LAPACK's signs and tau from the top block in the last round.
+      std::vector<double> Rrow(pp);
+      KHIP_TRY(panel_tsqr_r(ctx, n, p, Q, Rrow.data()));
+      const int G_ = comm_nranks(ctx);
+      if (G_ > 1) {
+        std::vector<double> all((size_t)G_ * pp, 0.0);
+        std::copy(Rrow.begin(), Rrow.end(), all.begin() + (size_t)comm_rank_of(ctx) * pp);
+        KHIP_TRY(comm_allreduce_sum_host(ctx, all.data(), (int)all.size()));
+        householder_r_host(G_ * p, p, all.data(), Rrow.data());           // QR of the stacked triangles
+      }
+      double dmax = 0, dmin = std::numeric_limits<double>::infinity();
+      for (int i = 0; i < p; ++i) {
+        const double d = std::fabs(Rrow[(size_t)i * p + i]);
+        dmax = std::fmax(dmax, d); dmin = std::fmin(dmin, d);
+      }
+      if (!(dmin > 16.0 * (double)p * std::numeric_limits<double>::epsilon() * dmax) || !std::isfinite(dmax)) {
+        set_error("panel_qr: the block is numerically rank deficient (block_gmres! needs full column rank)");
+        return KHIP_ERR_NUMERIC;
+      }
+      for (int i = 0; i < p; ++i) {                                        // row-major -> upper, column-major, positive diagonal
+        const double sgn = Rrow[(size_t)i * p + i] < 0 ? -1.0 : 1.0;
+        for (int j = 0; j < p; ++j) R[(size_t)j * p + i] = j >= i ? sgn * Rrow[(size_t)i * p + j] : 0.0;
+      }
+      have_G = false;
+    }
+    if (!tsqr && !have_G) KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, Q, Q, G.data()));
+    if (!tsqr) have_G = false;
+    bool ok = tsqr ? true : chol_upper(p, G.data(), R.data());
+    if (!tsqr && ok && pass == 0 && !shifted_done) {
       double dmax = 0, dmin = std::numeric_limits<double>::infinity();
       for (int i = 0; i < p; ++i) { dmax = std::fmax(dmax, R[(size_t)i * p + i]); dmin = std::fmin(dmin, R[(size_t)i * p + i]); }
       if (!(dmin > 1e-7 * dmax)) ok = false;                             // cond(Q)^2 would exceed 1/eps
@@ -242,7 +295,7 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
         if (S[j] < 0)
           for (int i = 0; i < p; ++i) Ri[(size_t)j * p + i] = -Ri[(size_t)j * p + i];
     }
-    if (pass == 0 && ctx->tune.panel_fuse != 0) {
+    if (pass == 0 && ctx->tune.panel_fuse != 0 && !tsqr) {
       // first ordinary round: Q <- Q R^-1 and the Gram matrix of the second round in one pass (same bits)
       KHIP_TRY(panel_scale_gram(ctx, n, p, Q, Ri.data(), G.data()));
       have_G = true;

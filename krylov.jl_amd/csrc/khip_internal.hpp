@@ -78,6 +78,7 @@ struct Tuning {
   int ilu_blocks = 1;        // ILU(0) solves: block schedule where the pattern is a structured grid (0: level scheduling always; 2: block schedule on packed entry lists only, no row records; 3: blocks from the level-sorted row sequence even where a grid is recognised)
   int panel_multi_tiles = 2; // X += sum V_i Y_i: factor blocks in LDS, this many 16-row tiles per wave (0 = the one-tile kernel that re-reads the factors per tile)
   int panel_a_lds = 1;      // fused Gram-Schmidt step at p = 16: the A operand (V_i tile) by two coalesced loads per lane + an LDS transpose instead of four loads that each touch all 16 lines of the tile
+  int panel_qr_tsqr = 0;    // panel QR: R factor by TSQR (block Householder QRs out of LDS, tree of triangles) instead of the Cholesky of the Gram matrix: any conditioning, no shifted pass (block.cpp)
   int panel_signs = 1;      // panel QR: LAPACK's Householder signs / tau from the top p x p block (block.cpp); 0 = positive diagonal of R
   int panel_fuse = 1;       // block Gram-Schmidt: apply Psi_i and form Psi_{i+1} in one pass (panel.hip, single rank)
   int spmm_wide = 1;        // SpMM: two panel columns per lane (16-byte gathers) when p is even
@@ -285,6 +286,7 @@ void csr_free_codes(khip_csr *A);                  // colcode.hip
 int csr_build_codes(khip_ctx *ctx, khip_csr *A);   // colcode.hip: sets A->code_state to 1 or -1
 int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,
                    double *X);   // panel.hip
+int panel_tsqr_r(khip_ctx *ctx, int64_t n, int p, const double *Q, double *R_host_rowmajor);   // panel.hip: R factor by TSQR
 int panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const double *Ri_host, double *G_host);   // panel.hip
 
 // api.cpp: the MGS cascade of khip_mgs in two halves (enqueue: launches only; the k coefficients and ||q||^2 end up in

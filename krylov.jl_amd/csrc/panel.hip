@@ -497,9 +497,128 @@ int ensure_panel_scratch(khip_ctx *ctx, size_t elems) {
   }
   return KHIP_OK;
 }
+
+// ---------------------------------------------------------------- TSQR: the R factor of a tall panel ----
+// Communication-avoiding QR (Demmel, Grigori, Hoemmen, Langou 2012), the R factor only: every workgroup
+// runs an unblocked Householder QR of one block of rows out of LDS and keeps its p x p upper triangle; the stacked triangles
+// are a new tall matrix with p / kTsqrRows as many rows, reduced the same way until one block is left.  Backward stable
+// whatever the conditioning of the panel (the Cholesky of the Gram matrix squares the condition number).  Fixed reduction
+// order: deterministic.  Thread layout per block: 16 row groups x 16 column lanes; P = columns rounded up to 16 or 32.
+constexpr int kTsqrRows = 256;           // rows of a block for P = 16 (P = 32: half of it)
+
+template <int P>
+__global__ __launch_bounds__(kBlock) void panel_block_qr_kernel(const double *A, int64_t rows, int p, double *Rout) {
+  constexpr int B = P == 16 ? kTsqrRows : kTsqrRows / 2;
+  constexpr int LD = P + 1;                                  // padded leading dimension: column walks without bank conflicts
+  extern __shared__ double tsqr_a[];                         // [B][LD] block, then [16][P] partial sums, then [P] w
+  double *part = tsqr_a + B * LD;
+  double *wv = part + 16 * P;
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * B;
+  for (int q = tid; q < B * P; q += kBlock) {
+    const int i = q / P, c = q % P;
+    const int64_t r = r0 + i;
+    tsqr_a[i * LD + c] = (r < rows && c < p) ? A[r * p + c] : 0.0;
+  }
+  __syncthreads();
+  const int cl = tid & 15, rg = tid >> 4;                    // column lane, row group
+  for (int j = 0; j < p; ++j) {
+    // sigma = sum_{i > j} a[i][j]^2 : every row group sums its rows, lane 0 of the groups publishes, thread 0 folds in order
+    if (cl == 0) {
+      double sg = 0.0;
+      for (int i = rg; i < B; i += 16) if (i > j) sg += tsqr_a[i * LD + j] * tsqr_a[i * LD + j];
+      part[rg] = sg;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sigma = 0.0;
+      for (int g = 0; g < 16; ++g) sigma += part[g];
+      const double alpha = tsqr_a[j * LD + j];
+      const double nrm = sqrt(alpha * alpha + sigma);
+      double beta = 0.0, tau = 0.0, scale = 0.0;
+      if (sigma != 0.0) {                                    // DLARFG: beta = -sign(alpha) norm, tau = (beta - alpha) / beta, v = x / (alpha - beta)
+        beta = alpha >= 0.0 ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      } else {
+        beta = alpha;                                        // H = I
+      }
+      wv[0] = beta; wv[1] = tau; wv[2] = scale;
+    }
+    __syncthreads();
+    const double beta = wv[0], tau = wv[1], scale = wv[2];
+    __syncthreads();
+    if (tau != 0.0) {
+      // w_c = a[j][c] + sum_{i > j} v_i a[i][c] for the columns c > j (v_i = a[i][j] * scale); 16 lanes x P / 16 columns each
+      for (int c = cl; c < p; c += 16) {
+        double acc = 0.0;
+        if (c > j)
+          for (int i = rg; i < B; i += 16) if (i > j) acc += tsqr_a[i * LD + j] * scale * tsqr_a[i * LD + c];
+        part[rg * P + c] = acc;
+      }
+      __syncthreads();
+      if (tid < p && tid > j) {
+        double acc = tsqr_a[j * LD + tid];
+        for (int g = 0; g < 16; ++g) acc += part[g * P + tid];
+        wv[4 + tid] = acc;
+      }
+      __syncthreads();
+      for (int c = cl; c < p; c += 16) {
+        if (c > j) {
+          const double tw = tau * wv[4 + c];
+          for (int i = rg; i < B; i += 16) {
+            if (i > j) tsqr_a[i * LD + c] -= tsqr_a[i * LD + j] * scale * tw;
+            else if (i == j) tsqr_a[i * LD + c] -= tw;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) tsqr_a[j * LD + j] = beta;
+    __syncthreads();
+  }
+  // the block's R: rows blockIdx.x * p .. + p of the next level's matrix (zeros below the diagonal)
+  for (int q = tid; q < p * p; q += kBlock) {
+    const int i = q / p, c = q % p;
+    Rout[((int64_t)blockIdx.x * p + i) * p + c] = c >= i ? tsqr_a[i * LD + c] : 0.0;
+  }
+}
+
+// R (p x p, row-major, as the last block leaves it: arbitrary diagonal signs) of the n x p row-major panel Q -> R_host
+int panel_tsqr_r_impl(khip_ctx *ctx, int64_t n, int p, const double *Q, double *R_host_rowmajor) {
+  if (p < 1 || p > 32) { set_error("panel_tsqr_r: 1 <= p <= 32 required"); return KHIP_ERR_INVALID; }
+  const int P = p <= 16 ? 16 : 32;
+  const int B = P == 16 ? kTsqrRows : kTsqrRows / 2;
+  const size_t lds = sizeof(double) * ((size_t)B * (P + 1) + 16 * P + 4 + P);
+  int64_t rows = n;
+  int64_t nb = (rows + B - 1) / B;
+  if (nb < 1) nb = 1;
+  // two ping-pong regions for the stacked triangles of the levels
+  const size_t lvl1 = (size_t)nb * p * p;
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * lvl1 + 64));
+  double *ping = g_ps.partials, *pong = g_ps.partials + lvl1 + 32;
+  const double *src = Q;
+  for (;;) {
+    nb = (rows + B - 1) / B;
+    if (nb < 1) nb = 1;
+    if (P == 16) hipLaunchKernelGGL((panel_block_qr_kernel<16>), dim3((unsigned)nb), dim3(kBlock), lds, ctx->stream, src, rows, p, ping);
+    else hipLaunchKernelGGL((panel_block_qr_kernel<32>), dim3((unsigned)nb), dim3(kBlock), lds, ctx->stream, src, rows, p, ping);
+    KHIP_CHECK_HIP(hipGetLastError());
+    if (nb == 1) break;
+    rows = nb * p;
+    src = ping;
+    std::swap(ping, pong);
+  }
+  KHIP_CHECK_HIP(hipMemcpyAsync(R_host_rowmajor, ping, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return KHIP_OK;
+}
 }  // namespace
 
 namespace khip {
+int panel_tsqr_r(khip_ctx *ctx, int64_t n, int p, const double *Q, double *R_host_rowmajor) {
+  return panel_tsqr_r_impl(ctx, n, p, Q, R_host_rowmajor);
+}
 void panel_scratch_destroy(khip_ctx *ctx) {
   if (!ctx->panel_scratch) return;
   PanelScratch *ps = static_cast<PanelScratch *>(ctx->panel_scratch);
