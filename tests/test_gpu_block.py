@@ -412,6 +412,40 @@ def test_spmm_tile_general_operators_and_fallbacks(K, ctx, oracle):
     assert info["direct_groups"] >= 1, info
 
 
+def test_spmm_tile_fuzz_small_and_odd_shapes(K, ctx):
+    """Seeded fuzz over shapes the tile kernel's bookkeeping could trip on: fewer rows than one group, one row, a row count that
+    is no multiple of 32, empty rows (also at the end), a single column, every entry in one column, banded patterns that do
+    and do not reach the reuse threshold, 2-D grids of awkward extents.  Whatever kernel the handle ends up with (tile_info
+    state 1 or -1), Y equals the direct kernel's and the serial loop's, bit for bit."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2024)
+    cases = []
+    for m, n, dens in [(1, 1, 1.0), (1, 50, 0.5), (5, 5, 0.6), (31, 31, 0.3), (33, 40, 0.2), (64, 64, 0.05), (95, 200, 0.04), (129, 17, 0.5),
+                       (300, 300, 0.01), (1000, 1000, 0.003)]:
+        S = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="lil")
+        if m > 4:
+            S[m - 1, :] = 0                                   # empty last row
+            S[m // 2, :] = 0                                  # and one in the middle
+        cases.append((f"random {m}x{n}", S.tocsr()))
+    cases.append(("single column", sp.csr_matrix((np.ones(70), (np.arange(70), np.zeros(70, dtype=int))), shape=(70, 9))))
+    for w in (1, 3, 9):
+        k = 500
+        cases.append((f"band {w}", sp.diags([rng.standard_normal(k - abs(d)) for d in range(-w, w + 1)], list(range(-w, w + 1)), format="csr")))
+    for a, b in ((7, 5), (4, 4), (13, 3), (50, 9)):          # 5-point grids of awkward extents (8 x 4 x 1 tiles, partial ones)
+        T = lambda q: sp.diags([-np.ones(q - 1), 2 * np.ones(q), -np.ones(q - 1)], [-1, 0, 1])
+        cases.append((f"grid {a}x{b}", (sp.kron(sp.eye(b), T(a)) + sp.kron(T(b), sp.eye(a))).tocsr()))
+    for tag, S in cases:
+        S = S.tocsr()
+        S.eliminate_zeros()
+        S.sort_indices()
+        m, n = S.shape
+        dA = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data.astype(np.float64), (m, n))
+        X = rng.standard_normal((n, 16))
+        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
+        assert np.array_equal(Yt, Yd) and np.array_equal(Yw, Yd), (tag, dA.tile_info)
+        assert np.array_equal(Yt, _serial_spmm(S, X)), (tag, dA.tile_info)
+
+
 def test_block_gmres_same_history_with_and_without_tile_kernel(K, ctx, oracle):
     A = oracle.stencil27_unsym(12)
     S = A.to_scipy()
