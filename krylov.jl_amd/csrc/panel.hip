@@ -25,6 +25,13 @@ namespace khip {
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
+// Panels far larger than the caches are streams: non-temporal accesses lift a streaming kernel here from ~5.7 to 6.3-6.7 TB/s
+// (DESIGN.md 3.1).  `nt` is wave-uniform (a launch parameter): the branch costs a scalar compare.
+template <typename T>
+__device__ __forceinline__ T pld(const T *p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+template <typename T>
+__device__ __forceinline__ void pst(T *p, T v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+
 constexpr int kRowsPerWaveTN = 256;   // rows folded by one wave of the V^T Q kernel (64 MFMAs per tile pair)
 
 // ---------------------------------------------------------------- layout conversion ------
@@ -206,7 +213,8 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
   const int i = lane & 15, k = lane >> 4;
   constexpr int KK = NT * 4;
   __shared__ __attribute__((aligned(16))) char a_lds[NT == 1 ? kWavesPerBlock * UNT * 2048 : 16];
-  const bool a_via_lds = NT == 1 && p == 16 && a_stage != 0;
+  const bool a_via_lds = NT == 1 && p == 16 && (a_stage & 1) != 0;
+  const bool snt = (a_stage & 2) != 0;                    // streaming (non-temporal) accesses to the panels
   dbl4 tn[NT][NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a)
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               const int c16 = lane + 64 * h, row = c16 >> 3, c = c16 & 7;
-              const dbl2 piece = *reinterpret_cast<const dbl2 *>(Vi + (r0 + row) * 16 + 2 * c);
+              const dbl2 piece = pld(reinterpret_cast<const dbl2 *>(Vi + (r0 + row) * 16 + 2 * c), snt);
               *reinterpret_cast<dbl2 *>(slice + row * 128 + ((c ^ (row & 7)) << 4)) = piece;
             }
           }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk) {
             const int vcol = 4 * kk + k;
-            af[t][kk] = (tok && vcol < p) ? Vi[(r0 + i) * p + vcol] : 0.0;
+            af[t][kk] = (tok && vcol < p) ? pld(Vi + (r0 + i) * p + vcol, snt) : 0.0;
           }
         }
 #pragma unroll
@@ -261,14 +269,14 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int col = 16 * b + i;
-            cin[t][b][g] = (tok && beta != 0.0 && col < p) ? Q[(r0 + k + 4 * g) * p + col] : 0.0;
+            cin[t][b][g] = (tok && beta != 0.0 && col < p) ? pld(Q + (r0 + k + 4 * g) * p + col, snt) : 0.0;
           }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int a = 0; a < NT; ++a) {
             const int col = 16 * a + i;
-            va[t][u][a] = (!SELF && tok && col < p) ? Vn[(r0 + 4 * u + k) * p + col] : 0.0;
+            va[t][u][a] = (!SELF && tok && col < p) ? pld(Vn + (r0 + 4 * u + k) * p + col, snt) : 0.0;
           }
       }
 #pragma unroll
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
           for (int g = 0; g < 4; ++g) {
             const int col = 16 * b + i;
             wnew[b][g] = col < p ? fma(alpha, acc[b][g], beta * cin[t][b][g]) : 0.0;
-            if (col < p) Q[(r0 + k + 4 * g) * p + col] = wnew[b][g];
+            if (col < p) pst(Q + (r0 + k + 4 * g) * p + col, wnew[b][g], snt);
           }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -481,6 +489,13 @@ struct PanelScratch {            // scratch for the V^T Q partial tiles and the 
 };
 // scratch is owned by the context (khip_ctx::panel_scratch, freed by khip_ctx_destroy)
 #define g_ps (*static_cast<PanelScratch *>(ctx->panel_scratch))
+
+// streaming accesses for panels of at least tune.nt_min_elems doubles (the BLAS-1 kernels' threshold); panel_nt = 0 / 2 force off / on
+bool panel_nt(khip_ctx *ctx, int64_t np, int p) {
+  if (ctx->tune.panel_nt == 0) return false;
+  if (ctx->tune.panel_nt >= 2) return true;
+  return np * (int64_t)p >= (int64_t)ctx->tune.nt_min_elems;
+}
 
 int ensure_panel_scratch(khip_ctx *ctx, size_t elems) {
   if (!ctx->panel_scratch) ctx->panel_scratch = new PanelScratch();
@@ -729,8 +744,8 @@ int khip::panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const dou
   double *psi_h = g_ps.psi_pinned + (size_t)slot * 1024, *psi_d = g_ps.psi_dev + (size_t)slot * 1024;
   memcpy(psi_h, Ri_host, sizeof(double) * (size_t)p * p);
   KHIP_CHECK_HIP(hipMemcpyAsync(psi_d, psi_h, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, ctx->stream));
-  if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, ctx->tune.panel_a_lds);
-  else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, ctx->tune.panel_a_lds);
+  if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
+  else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
   tn_reduce(ctx, t, p, g_ps.psi_dev);
   KHIP_CHECK_HIP(hipGetLastError());
   KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned, g_ps.psi_dev, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -815,8 +830,8 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
     double *psi_i = g_ps.psi_dev + (size_t)(i + 1) * 1024;
     if (i + 1 < k) {
       double *psi_n = g_ps.psi_dev + (size_t)(i + 2) * 1024;
-      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, ctx->tune.panel_a_lds);
-      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, ctx->tune.panel_a_lds);
+      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
+      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
       tn_reduce(ctx, t, p, psi_n);
     } else if (tiles > 0) {
       launch_gemm_nn(ctx, np, p, -1.0, V_host[i], psi_i, 1.0, Q);

@@ -15,6 +15,7 @@ for n, p, k in [(1000, 16, 1), (4099, 16, 3), (100000, 16, 4), (257, 16, 2)]:
     res = []
     for a in (1, 0):
         ctx.set_option("panel_a_lds", a)
+        ctx.set_option("panel_nt", 2 * a)
         V = [K.Panel.from_host(ctx, v) for v in Vh]
         Q = K.Panel.from_host(ctx, Qh)
         blocks = K.panel_mgs_(V, Q)
@@ -27,14 +28,15 @@ n, p = 216 ** 3, 16
 V = [K.Panel(ctx, n, p) for _ in range(4)]
 Q = K.Panel(ctx, n, p)
 for v in V: K.kfill_(v.buf, 1e-4)
+ctx.set_option("panel_a_lds", 1)
 for k in (1, 3):
-    for a in (0, 1, 0, 1):
-        ctx.set_option("panel_a_lds", a)
+    for a in (0, 2, 0, 2):
+        ctx.set_option("panel_nt", a)
         K.kfill_(Q.buf, 1.0); K.panel_mgs_(V[:k], Q); ctx.sync()
         t0 = time.perf_counter()
         for _ in range(10): K.panel_mgs_(V[:k], Q)
         ctx.sync()
         dt = (time.perf_counter() - t0) / 10
-        print(json.dumps(dict(sweep_panels=k, panel_a_lds=a, ms=round(dt * 1e3, 4))), flush=True)
+        print(json.dumps(dict(sweep_panels=k, panel_nt=a, ms=round(dt * 1e3, 4))), flush=True)
 print("ALL EQUAL" if ok else "MISMATCH")
 ctx.close()
