@@ -365,7 +365,11 @@ typedef struct {
                                * work vectors.  Opt-in, own parity budget; same requirements as variant 1.
                                * gmres: 1 = CGS2, classical Gram-Schmidt applied twice instead of the modified Gram-Schmidt cascade of
                                * src/gmres.jl:259-271: h = V_k' q as one reduction per four basis vectors, q -= V_k h in one pass, twice:
-                               * three all-reduces per inner iteration on N GPUs instead of k + 1.  Opt-in, own parity budget. */
+                               * three all-reduces per inner iteration on N GPUs instead of k + 1.  Opt-in, own parity budget.
+                               * gmres: 2 = s-step GMRES (monomial basis, s = ctx option "gmres_sstep", 1..8, default 4): s products, one batched
+                               * CGS2 against the basis and a CholeskyQR2 of the block per s inner iterations -- four reductions per s
+                               * iterations; Hessenberg columns, Givens rotations and the stopping test on the host, column by column.
+                               * Needs restart = true, a CSR operator, M = N = I, memory x s <= 256.  Opt-in, own parity budget. */
   int    verbose;             /* > 0: the reference's log on stdout, one row every `verbose` iterations (src/cg.jl:132,182-183,224,
                                * 267-269; src/gmres.jl:131,191-192,315,364; src/bicgstab.jl:135,193-194,255-257;
                                * src/block_gmres.jl:120,181-182,297,340; kdisplay: src/krylov_utils.jl:301).  The rows need the scalars

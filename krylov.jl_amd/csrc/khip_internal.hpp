@@ -77,6 +77,7 @@ struct Tuning {
   int red_u = 0;            // reductions: 16-byte accesses per lane (0 auto: 4 for long vectors, else 1)
   int ilu_blocks = 1;        // ILU(0) solves: block schedule where the pattern is a structured grid (0: level scheduling always; 2: block schedule on packed entry lists only, no row records; 3: blocks from the level-sorted row sequence even where a grid is recognised)
   int panel_multi_tiles = 2; // X += sum V_i Y_i: factor blocks in LDS, this many 16-row tiles per wave (0 = the one-tile kernel that re-reads the factors per tile)
+  int gmres_sstep = 4;      // gmres! variant 2: inner iterations per block of the s-step form (1..8)
   int panel_nt = 0;         // fused Gram-Schmidt kernel: non-temporal accesses to the panels (1: panels of at least nt_min_elems doubles, 2: always); measured no effect (3.263 vs 3.263 ms per three-panel sweep), off
   int panel_a_lds = 1;      // fused Gram-Schmidt step at p = 16: the A operand (V_i tile) by two coalesced loads per lane + an LDS transpose instead of four loads that each touch all 16 lines of the tile
   int panel_qr_tsqr = 0;    // panel QR: R factor by TSQR (block Householder QRs out of LDS, tree of triangles) instead of the Cholesky of the Gram matrix: any conditioning, no shifted pass (block.cpp)

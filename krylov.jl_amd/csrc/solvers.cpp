@@ -904,8 +904,10 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
   if (verbose > 0) printf("GMRES: system of size %lld\n", (long long)n);                                          // src/gmres.jl:131
 
-  if (o.variant != 0 && o.variant != 1)
-    return ws->box.fail(KHIP_ERR_INVALID, "gmres: options.variant must be 0 (gmres! recurrence, modified Gram-Schmidt) or 1 (CGS2)");
+  if (o.variant != 0 && o.variant != 1 && o.variant != 2)
+    return ws->box.fail(KHIP_ERR_INVALID, "gmres: options.variant must be 0 (gmres! recurrence, modified Gram-Schmidt), 1 (CGS2) or 2 (s-step)");
+  if (o.variant == 2 && (!restart || M || N || reorth || o.callback || A->apply || !A->csr))
+    return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 2 (s-step) needs restart = true, a CSR operator, M = N = I, no reorthogonalization / callback");
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
   const bool look = o.variant == 0 && fused && o.fused >= 2 && MisI && NisI && !reorth && !o.callback && !A->apply && A->csr;
   if (!MisI && !ws->q) K(alloc_vec(ctx, n, &ws->q));                               // src/gmres.jl:142-144
@@ -964,7 +966,194 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   bool user_requested_exit = false, overtimed = false;
   const char *status = "unknown";
 
-  while (!(solved || tired || breakdown || user_requested_exit || overtimed)) {
+  // ---------------------------------------------------------------------------------------------------------------------
+  // variant 2: s-step (communication-avoiding) GMRES, opt-in (Hoemmen 2010, monomial basis).  Per block of s
+  // inner iterations: the s products z_j = A z_{j-1} / theta (z_0 = the last basis vector), ONE batched classical Gram-Schmidt
+  // pass of all s vectors against the k basis vectors, repeated once (CGS2), and a CholeskyQR2 of the block -- 2 + 2
+  // reductions per s iterations on N GPUs (each one all-reduce per 64 scalars) instead of 3 per iteration (variant 1) or k + 1
+  // (the reference's modified Gram-Schmidt).  With z_j = Q+ g_j (g_j = the Gram-Schmidt and QR coefficients, g_0 = e_k) and
+  // A z_j = theta z_{j+1}, the Hessenberg columns follow on the host: h_c = (theta g_{j+1} - sum_{i<c} g_j[i] h_i) / g_j[c],
+  // c = k + j; Givens rotations, the residual estimate and the stopping test column by column as in gmres!.  The residual at
+  // a restart is the true one (no Givens estimate in the normalisation).  Same Krylov spaces as gmres!, different rounding
+  // and a basis whose conditioning grows with s (s <= 8): own parity budget in the tests.
+  if (o.variant == 2 && !(solved || tired)) {
+    const int sblk = ctx->tune.gmres_sstep < 1 ? 4 : (ctx->tune.gmres_sstep > 8 ? 8 : ctx->tune.gmres_sstep);
+    const bool multi = comm_nranks(ctx) > 1;
+    auto allreduce_slots = [&](int slot, int count) -> int {            // device-side all-reduce of a slot range, 64 scalars at a time
+      for (int b0 = 0; b0 < count; b0 += kMaxRedOut) {
+        const int cnt = count - b0 < kMaxRedOut ? count - b0 : kMaxRedOut;
+        KHIP_TRY(comm_allreduce_dd_device(ctx, slot + b0, cnt));
+      }
+      return KHIP_OK;
+    };
+    double theta = 0.0;
+    std::vector<std::vector<double>> Hc;       // Hc[c-1]: column c of the Hessenberg matrix of this cycle (c + 1 entries), unrotated
+    std::vector<std::vector<double>> Rr;       // rotated columns (upper triangular part)
+    std::vector<double> cs, sn, zr, tmp;
+    while (!(solved || tired || overtimed)) {
+      // cycle start: w holds the residual b - A x, beta its norm (first cycle: computed above)
+      if (npass >= 1) {
+        K(apply_op(ctx, A, x, w));
+        K(khip_axpby(ctx, n, 1.0, b, -1.0, w));
+        K(khip_nrm2(ctx, n, w, &beta));
+        if (beta == 0.0) { solved = true; rNorm = 0.0; break; }
+      }
+      npass = npass + 1;
+      K(khip_fill(ctx, n, xr, 0.0));
+      K(khip_divcopy(ctx, n, V[0], w, beta));
+      Hc.clear(); Rr.clear(); cs.clear(); sn.clear();
+      zr.assign(1, beta);
+      int k = 1, cols = 0;                     // basis vectors held, Hessenberg columns processed in this cycle
+      const int64_t lim = (int64_t)mem < inner_itmax ? (int64_t)mem : inner_itmax;
+      bool block_failed = false;
+      while (cols < lim && !solved && !overtimed) {
+        int sb = (int)std::min<int64_t>(sblk, lim - cols);
+        if (block_failed) sb = 1;
+        if ((int)V.size() < k + sb) K(gmres_grow_basis(ws, k + sb - (int)V.size()));
+        // (1) matrix powers
+        for (int j = 1; j <= sb; ++j) {
+          K(apply_op(ctx, A, V[k - 2 + j], V[k - 1 + j]));
+          if (theta == 0.0) {                  // once per solve: ||A v_1|| as the scale of the monomial basis
+            K(khip_nrm2(ctx, n, V[k - 1 + j], &theta));
+            if (!(theta > 0.0)) theta = 1.0;
+          }
+          K(khip_scal(ctx, n, 1.0 / theta, V[k - 1 + j]));
+        }
+        // (2) block CGS2 against V[0 .. k-1]: all dots of a pass first (one reduction), then all updates
+        const int kpad = (k + 3) & ~3;
+        if (kpad * sb > kResultSlots) return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 2: memory x s too large for the device scalar ring (memory x s <= 256)");
+        std::vector<double> Cm((size_t)k * sb, 0.0);                       // C[i + k j], both passes accumulated
+        for (int pass = 0; pass < 2; ++pass) {
+          const int sp = take_slots(ctx, kpad * sb);
+          for (int j = 0; j < sb; ++j) K(launch_multi_dot(ctx, n, k, V.data(), V[k + j], sp + j * kpad));
+          if (multi) K(allreduce_slots(sp, kpad * sb));
+          for (int j = 0; j < sb; ++j) K(launch_multi_axpy_dev(ctx, n, k, ctx->results + sp + j * kpad, V.data(), V[k + j]));
+          tmp.resize((size_t)(kpad * sb));
+          K(fetch_results(ctx, sp, kpad * sb, tmp.data(), /*already_global=*/multi));
+          for (int j = 0; j < sb; ++j)
+            for (int i = 0; i < k; ++i) Cm[(size_t)i + (size_t)k * j] += tmp[(size_t)j * kpad + i];
+        }
+        // (3) CholeskyQR2 of the block Z = V[k .. k+sb-1]
+        const int spad = (sb + 3) & ~3;
+        std::vector<double> Racc((size_t)sb * sb, 0.0), Rk((size_t)sb * sb), Gm((size_t)sb * sb), Rt((size_t)sb * sb);
+        for (int i = 0; i < sb; ++i) Racc[(size_t)i * sb + i] = 1.0;       // row-major upper triangular
+        bool qr_ok = true;
+        for (int round = 0; round < 2 && qr_ok; ++round) {
+          const int slotG = take_slots(ctx, spad * sb);
+          for (int j = 0; j < sb; ++j) K(launch_multi_dot(ctx, n, sb, V.data() + k, V[k + j], slotG + j * spad));
+          if (multi) K(allreduce_slots(slotG, spad * sb));
+          tmp.resize((size_t)(spad * sb));
+          K(fetch_results(ctx, slotG, spad * sb, tmp.data(), /*already_global=*/multi));
+          for (int j = 0; j < sb; ++j)
+            for (int i = 0; i < sb; ++i) Gm[(size_t)i * sb + j] = tmp[(size_t)j * spad + i];
+          // Cholesky G = R' R, R upper (row-major)
+          for (int i = 0; i < sb && qr_ok; ++i)
+            for (int j = i; j < sb; ++j) {
+              double sum = Gm[(size_t)i * sb + j];
+              for (int l = 0; l < i; ++l) sum -= Rk[(size_t)l * sb + i] * Rk[(size_t)l * sb + j];
+              if (j == i) {
+                if (!(sum > 0.0) || !std::isfinite(sum) || (round == 0 && sum <= 1e-14 * Gm[(size_t)i * sb + i])) { qr_ok = false; break; }
+                Rk[(size_t)i * sb + i] = std::sqrt(sum);
+              } else {
+                Rk[(size_t)i * sb + j] = sum / Rk[(size_t)i * sb + i];
+              }
+            }
+          if (!qr_ok) break;
+          for (int i = 0; i < sb; ++i) for (int j = 0; j < i; ++j) Rk[(size_t)i * sb + j] = 0.0;
+          // Z <- Z R^-1, column by column: z_j <- (z_j - sum_{i<j} R_ij z_i') / R_jj
+          for (int j = 0; j < sb; ++j) {
+            if (j > 0) {
+              std::vector<double> coef((size_t)j);
+              for (int i = 0; i < j; ++i) coef[(size_t)i] = -Rk[(size_t)i * sb + j];
+              K(khip_multi_axpy(ctx, n, j, coef.data(), V.data() + k, V[k + j]));
+            }
+            K(khip_scal(ctx, n, 1.0 / Rk[(size_t)j * sb + j], V[k + j]));
+          }
+          for (int i = 0; i < sb; ++i)                                      // Racc <- Rk * Racc
+            for (int j = 0; j < sb; ++j) {
+              double sum = 0.0;
+              for (int l = i; l <= j; ++l) sum += Rk[(size_t)i * sb + l] * Racc[(size_t)l * sb + j];
+              Rt[(size_t)i * sb + j] = sum;
+            }
+          Racc = Rt;
+        }
+        if (!qr_ok) {
+          // the block lost rank (an exhausted Krylov space, or a monomial basis too ill-conditioned for this s): redo from
+          // here one vector at a time; a single vector that cannot be normalised is a (lucky) breakdown
+          if (sb == 1) { breakdown = true; break; }
+          block_failed = true;
+          continue;
+        }
+        // (4) Hessenberg columns, Givens rotations, residual estimates
+        auto gcoef = [&](int j, int i) -> double {       // g_j[i], i 1-based basis index, j = 0 .. sb (j = 0: e_k)
+          if (j == 0) return i == k ? 1.0 : 0.0;
+          if (i <= k) return Cm[(size_t)(i - 1) + (size_t)k * (j - 1)];
+          const int r = i - k - 1;                        // row of Racc
+          return r <= j - 1 ? Racc[(size_t)r * sb + (j - 1)] : 0.0;
+        };
+        for (int j = 0; j < sb && !solved; ++j) {
+          const int c = k + j;                            // column: A q_c in terms of q_1 .. q_{c+1}
+          std::vector<double> h((size_t)c + 1, 0.0);
+          for (int i = 1; i <= c + 1; ++i) h[(size_t)i - 1] = theta * gcoef(j + 1, i);
+          for (int i = 1; i < c; ++i) {
+            const double gi = gcoef(j, i);
+            if (gi == 0.0) continue;
+            const std::vector<double> &hi = Hc[(size_t)i - 1];
+            for (size_t l = 0; l < hi.size(); ++l) h[l] -= gi * hi[l];
+          }
+          const double gc = gcoef(j, c);
+          for (double &v : h) v /= gc;
+          Hc.push_back(h);
+          // rotate
+          std::vector<double> rcol(h);
+          for (int i = 0; i < c - 1; ++i) {
+            const double t1 = cs[(size_t)i] * rcol[(size_t)i] + sn[(size_t)i] * rcol[(size_t)i + 1];
+            rcol[(size_t)i + 1] = sn[(size_t)i] * rcol[(size_t)i] - cs[(size_t)i] * rcol[(size_t)i + 1];
+            rcol[(size_t)i] = t1;
+          }
+          double cc, ss, rho;
+          sym_givens(rcol[(size_t)c - 1], rcol[(size_t)c], cc, ss, rho);
+          rcol[(size_t)c - 1] = rho;
+          rcol.resize((size_t)c);
+          Rr.push_back(rcol);
+          cs.push_back(cc); sn.push_back(ss);
+          const double zeta_next = ss * zr[(size_t)c - 1];
+          zr[(size_t)c - 1] = cc * zr[(size_t)c - 1];
+          zr.push_back(zeta_next);
+          rNorm = std::fabs(zeta_next);
+          if (o.history) ws->box.push(rNorm);
+          cols = cols + 1;
+          solved = (rNorm <= eps_tol) || (rNorm + 1.0 <= 1.0);
+          if (kdisplay(iter + cols, verbose))
+            printf("%5d  %5lld  %7.1e  %7.1e  %.2fs\n", npass, (long long)(iter + cols), rNorm, h[(size_t)c], now_s() - t0);
+          if (iter + cols >= itmax) break;
+        }
+        k += sb;
+        block_failed = false;
+        overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
+        if (iter + cols >= itmax) break;
+      }
+      // (5) y from the rotated triangular system, x += sum y_i q_i
+      if (cols > 0) {
+        std::vector<double> y(zr.begin(), zr.begin() + cols);
+        for (int i = cols - 1; i >= 0; --i) {
+          for (int j = i + 1; j < cols; ++j) y[(size_t)i] -= Rr[(size_t)j][(size_t)i] * y[(size_t)j];
+          const double d = Rr[(size_t)i][(size_t)i];
+          if (std::fabs(d) <= btol) { y[(size_t)i] = 0.0; inconsistent = true; } else y[(size_t)i] /= d;
+        }
+        K(khip_multi_axpy(ctx, n, cols, y.data(), V.data(), xr));
+        K(khip_axpy(ctx, n, 1.0, xr, x));
+      }
+      inner_itmax = inner_itmax - cols;
+      iter = iter + cols;
+      tired = iter >= itmax;
+      if (breakdown) break;
+      if (!overtimed) overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
+    }
+    if (breakdown && !solved) { solved = rNorm <= eps_tol; }
+  }
+
+  while (o.variant != 2 && !(solved || tired || breakdown || user_requested_exit || overtimed)) {
     int nr = 0;
     // :211-213 zero-fills the mem basis vectors here (8 n mem bytes of writes per cycle).  Every V[k] is written by
     // the kdivcopy! of :231 / :325 before anything reads it and this ABI has no accessor for the basis, so the fill is

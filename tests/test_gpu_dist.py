@@ -445,3 +445,30 @@ def test_pipelined_cg_on_partitioned_operators(K, ctx, dctx, oracle):
         assert solved and niter == stp.niter and np.max(np.abs(hist - stp.residuals) / stp.residuals) <= 1e-10
         assert np.array_equal(hist, res[0][1])
         assert np.allclose(xs, ref.x[r0:r1], rtol=0, atol=1e-6 * np.abs(ref.x).max())
+
+
+def test_sstep_gmres_on_partitioned_operators(K, ctx, oracle):
+    """gmres! variant 2 (s-step) on three in-process ranks: the batched Gram-Schmidt and Gram reductions go through the device
+    all-reduce 64 scalars at a time; same iteration count and history (1e-9) as the single-GPU run of the variant, identical on
+    every rank."""
+    n1, memory = 12, 12
+    A_cpu = oracle.kron_unsymmetric(n1)
+    n = A_cpu.n
+    bh = A_cpu.matvec(np.ones(n))
+    Ap = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", n1)
+    _, stp, _ = K.gmres(Ap, ctx.array(bh), memory=memory, restart=True, history=True, variant=2)
+    assert stp.solved
+    world = 3
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+        x, st, _ = K.gmres(A, c.array(bh[r0:r1]), memory=memory, restart=True, history=True, variant=2)
+        return st.niter, st.residuals.copy(), x.to_host(), st.solved
+
+    res = _run_ranks(K, world, 939393, body)
+    for rank, (niter, hist, xs, solved) in enumerate(res):
+        assert solved and niter == stp.niter and np.max(np.abs(hist - stp.residuals) / stp.residuals) <= 1e-9
+        assert np.array_equal(hist, res[0][1])
+        assert np.allclose(xs, 1.0, atol=1e-6)

@@ -229,6 +229,42 @@ def test_cg_pipelined_variant_parity_budget(K, ctx, oracle, parity_log, n1):
     assert st4.solved and np.allclose(x4.to_host(), ref.x, rtol=0, atol=1e-6 * np.abs(ref.x).max())
 
 
+@pytest.mark.parametrize("n1,memory,sstep", [(12, 12, 4), (12, 10, 4), (16, 20, 1), (16, 20, 2), (16, 20, 5), (16, 24, 8), (20, 30, 4)])
+def test_gmres_sstep_variant_parity_budget(K, ctx, oracle, parity_log, n1, memory, sstep):
+    """options.variant = 2 of gmres!: s-step GMRES: blocks of s monomial-basis vectors,
+    batched CGS2 + CholeskyQR2, the Hessenberg columns recovered on the host.  The same Krylov spaces as gmres!(restart), so the
+    residual estimates agree with the oracle's up to rounding and the restart normalisation (the reference divides by the
+    Givens estimate, this variant by the true norm): iteration count within 2, history within 1e-6 while above 1e-7 r_0, the
+    TRUE residual within the tolerance."""
+    A = oracle.kron_unsymmetric(n1)
+    b = A.matvec(np.ones(A.n))
+    ref = oracle.gmres(A, b, memory=memory, restart=True, history=True)
+    dA = _upload(K, ctx, A)
+    ctx.set_option("gmres_sstep", sstep)
+    try:
+        x, st, _ = K.gmres(dA, ctx.array(b), memory=memory, restart=True, history=True, variant=2)
+    finally:
+        ctx.set_option("gmres_sstep", 4)
+    assert st.solved and st.status == ref.status, st.status
+    assert abs(st.niter - ref.niter) <= 2, (st.niter, ref.niter)
+    k = min(len(st.residuals), len(ref.residuals))
+    big = ref.residuals[:k] >= 1e-7 * ref.residuals[0]
+    dev = float(np.max(np.abs(st.residuals[:k] - ref.residuals[:k])[big] / ref.residuals[:k][big]))
+    xh = x.to_host()
+    res = np.linalg.norm(b - A.matvec(xh)) / np.linalg.norm(b)
+    parity_log(test="gmres_sstep", n1=n1, memory=memory, s=sstep, niter=st.niter, niter_ref=ref.niter, hist_max_rel=dev, res=res)
+    assert dev <= 1e-6, dev
+    assert res <= 3e-8
+    assert np.allclose(xh, 1.0, atol=1e-6)
+    # refusals
+    with pytest.raises(K.KhipError):
+        K.gmres(dA, ctx.array(b), memory=memory, restart=False, variant=2)
+    with pytest.raises(K.KhipError):
+        K.gmres(dA, ctx.array(b), memory=memory, restart=True, variant=2, M=K.Jacobi(dA))
+    _, st2, _ = K.gmres(dA, ctx.array(b), memory=memory, restart=True, variant=2, itmax=7)
+    assert st2.niter == 7 and not st2.solved and st2.status == "maximum number of iterations exceeded"
+
+
 def test_cg_edge_cases(K, ctx, oracle):
     A = oracle.tridiag(10, -1.0, 4.0, -1.0)                               # symmetric_definite(10)
     bh = A.matvec(np.arange(1.0, 11.0))
