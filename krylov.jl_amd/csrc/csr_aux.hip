@@ -583,7 +583,7 @@ namespace khip {
 #endif
 
 int spmm_window_build(khip_ctx *ctx, khip_csr *A, int L);   // below
-int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a);   // spmm_tile.hip
+int launch_spmm_tile(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p);   // spmm_tile.hip
 
 template <int L>
 static void launch_window(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p) {
@@ -677,11 +677,18 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
         if (K2 * Spad <= gcap) { a.sweep_s = (int)S2; a.sweep_w = W2; grid2 = (int)(K2 * Spad); }
       }
     }
-    if (ctx->tune.spmm_tile && p == 16 && A->m > 0 && A->nnz > 0) {  // wave-private windows, LDS-DMA, grid-tile row groups (spmm_tile.hip)
+    if (ctx->tune.spmm_tile && (p == 8 || p == 16 || p == 32) && A->m > 0 && A->nnz > 0) {
+      // wave-private windows, LDS-DMA, grid-tile row groups (spmm_tile.hip).  p = 16 always; p = 8 and 32 where it measures
+      // faster than the window / direct kernels (profiles/r03h_spmm_tile_p.log): grid operators, at p = 8 those with rows of
+      // 16 entries and more (27-point: 1.08 vs 1.41 ms; the 7-point operator and the banded + random one are 4 % slower);
+      // spmm_tile = 2 takes the tile kernel at all three widths.
       khip_csr *At = const_cast<khip_csr *>(A);
       if (At->tile_state == 0) KHIP_TRY(spmm_tile_build(ctx, At));
-      if (At->tile_state == 1) return launch_spmm_tile16(ctx, A, a);
+      const bool fits = (size_t)At->tile_cap * 8 * (size_t)p <= (size_t)160 * 1024;
+      const bool want = p == 16 || ctx->tune.spmm_tile >= 2 || (At->tile_grid == 1 && (p == 32 || A->nnz >= 16 * A->m));
+      if (At->tile_state == 1 && fits && want) return launch_spmm_tile(ctx, A, a, p);
     }
+
     if (ctx->tune.spmm_window && want2 <= gcap && A->m > 0) {      // panel-row window in LDS: one row group per workgroup
       khip_csr *Aw = const_cast<khip_csr *>(A);
       if (Aw->win_L != L && Aw->win_L != -L) KHIP_TRY(spmm_window_build(ctx, Aw, L));

@@ -1,6 +1,7 @@
-// spmm_tile.hip -- SpMM for p = 16 right-hand sides: wave-private panel-row windows filled by LDS-DMA.
+// spmm_tile.hip -- SpMM for p = 8, 16 or 32 right-hand sides: wave-private panel-row windows filled by LDS-DMA.
 //
-//   Y(m x 16, row-major) = A * X(n x 16, row-major)            (mul!(W, A, P), src/block_gmres.jl:242)
+//   Y(m x p, row-major) = A * X(n x p, row-major), p = 4 L, L = 2, 4, 8   (mul!(W, A, P), src/block_gmres.jl:242)
+// (numbers in this header: p = 16)
 //
 // Why another kernel.  spmm_window_kernel (csr_aux.hip) shares one 44 KB window between the four waves of a
 // persistent workgroup: two workgroups per CU, every row group one memory round trip behind a workgroup barrier, and a
@@ -47,74 +48,94 @@ struct TileArgs {
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ int quad_bcast(int v, int k) {      // value of lane k of every quad (k wave-uniform)
-  switch (k) {
-    case 0: return __builtin_amdgcn_update_dpp(0, v, 0x00, 0xF, 0xF, true);
-    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x55, 0xF, 0xF, true);
-    case 2: return __builtin_amdgcn_update_dpp(0, v, 0xAA, 0xF, 0xF, true);
-    default: return __builtin_amdgcn_update_dpp(0, v, 0xFF, 0xF, 0xF, true);
+// Value of lane K of every group of L consecutive lanes (L = 2, 4, 8) by DPP moves; old = 0 + bound_ctrl: no register to initialise.
+template <int L, int K>
+__device__ __forceinline__ int tile_bcast(int v) {
+  static_assert(L == 2 || L == 4 || L == 8, "tile_bcast: L = 2, 4, 8");
+  if (L == 2) {
+    constexpr int QP = K | (K << 2) | ((K + 2) << 4) | ((K + 2) << 6);                  // quad_perm [K, K, K+2, K+2]
+    return __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true);
   }
+  constexpr int Q = K & 3, QP = Q | (Q << 2) | (Q << 4) | (Q << 6);                     // quad_perm [Q, Q, Q, Q]
+  int t = __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true);
+  if (L == 8)       // the other quad of the octet takes the value across row_half_mirror (lane i <- lane 7 - i)
+    t = __builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, K < 4 ? 0xA : 0x5, false);
+  return t;
 }
-template <int K>
-__device__ __forceinline__ int quad_bcast_c(int v) {
-  constexpr int QP = K | (K << 2) | (K << 4) | (K << 6);
-  return __builtin_amdgcn_update_dpp(0, v, QP, 0xF, 0xF, true);
-}
-template <int K>
-__device__ __forceinline__ double quad_bcast_c(double v) {
-  return __hiloint2double(quad_bcast_c<K>(__double2hiint(v)), quad_bcast_c<K>(__double2loint(v)));
+template <int L, int K>
+__device__ __forceinline__ double tile_bcast(double v) {
+  return __hiloint2double(tile_bcast<L, K>(__double2hiint(v)), tile_bcast<L, K>(__double2loint(v)));
 }
 
-// One entry step of 16 rows: (val, slot) of entry 8 F + K spread over the quad, the two 16-byte pieces of the panel row
-// out of the window, four rounded products and four rounded adds.  xa / xb_: the lane's window base for its first and
-// second piece.  Which half of the 128-byte panel row a quad reads FIRST alternates with bit 1 of the quad number: a
-// ds_read_b128 is served in four groups of four quads, a quad touches 16 of the 64 banks, and which 16 is decided by (parity
-// of the slot, half of the row) -- with every quad reading the same half first, the four quads of a group share two bank
-// ranges (45 % of the LDS cycles were conflicts, profiles/r03_spmm_tile_pmc.log); alternating halves gives the four quads of
-// a group the four ranges whenever their slot parities alternate too (consecutive rows of a grid tile).
-template <int F, int K, bool MASK>
-__device__ __forceinline__ void tile_entry(const dbl2 (&v)[4], const int2v &s, const char *xa, const char *xb_, int len, double (&acc)[4]) {
-  const double vv = quad_bcast_c<K / 2>((K & 1) ? v[F].y : v[F].x);
-  const int sw = quad_bcast_c<F>((K & 4) ? s.y : s.x);
-  const int off = (int)(((unsigned)sw >> (8 * (K & 3))) & 0xffu) << 7;
+// Shapes for p = 4 L right-hand sides: L lanes per matrix row, FOUR panel columns per lane (pieces c and L + c of the 2 L
+// 16-byte pieces of a panel row), 64 / L rows per wave pass, 32 rows per group.
+template <int L>
+struct TileShape {
+  static constexpr int RP = 64 / L;            // rows per pass
+  static constexpr int NPASS = kTileR / RP;    // L = 2: 1, 4: 2, 8: 4
+  static constexpr int F = 16 / L;             // 16-byte val loads per lane and pass: entries 2 c, 2 c + 1 (+ 2 L f)
+  static constexpr int SW = 8 / L;             // slot words per lane and pass: bytes 4 SW c .. 4 SW (c + 1) - 1 of the row's 32
+  static constexpr int ROWB = 32 * L;          // bytes of a panel row
+  static constexpr int SHIFT = L == 2 ? 6 : (L == 4 ? 7 : 8);
+  static constexpr int EPI = 32 / L;           // list entries one LDS-DMA instruction copies (1 KiB)
+};
+
+// One entry step of a pass: (val, slot) of entry T spread over the row's L lanes, the two 16-byte pieces of the panel row out
+// of the window, four rounded products and four rounded adds.  xa / xb_: the lane's window base for its first and second
+// piece.  Which half of the panel row a lane group reads FIRST alternates with bit 1 of the group number: a ds_read_b128 is
+// served in four groups of 16 lanes, a row's lanes touch a quarter (L = 4) of the 64 banks, and which one is decided by
+// (parity of the slot, half of the row) -- with every group reading the same half first, the rows of a service group shared
+// two bank ranges (45 % of the LDS cycles were conflicts, profiles/r03_spmm_tile_pmc.log); alternating halves gives them the
+// four ranges whenever their slot parities alternate too (consecutive rows of a grid tile).
+template <int L, int T, bool MASK>
+__device__ __forceinline__ void tile_entry(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
+                                           const char *xb_, int len, double (&acc)[4]) {
+  using S = TileShape<L>;
+  constexpr int f = T / (2 * L), e = T % (2 * L);
+  const double vv = tile_bcast<L, e / 2>((e & 1) ? v[f].y : v[f].x);
+  constexpr int bpl = 4 * S::SW;                                     // slot bytes per lane
+  const int word = tile_bcast<L, T / bpl>(sw[(T % bpl) / 4]);
+  const int off = (int)(((unsigned)word >> (8 * (T & 3))) & 0xffu) << S::SHIFT;
   const dbl2 x0 = *reinterpret_cast<const dbl2 *>(xa + off);
   const dbl2 x1 = *reinterpret_cast<const dbl2 *>(xb_ + off);
   const double p0 = vv * x0.x, p1 = vv * x0.y, p2 = vv * x1.x, p3 = vv * x1.y;
-  if (!MASK || 8 * F + K < len) {
+  if (!MASK || T < len) {
     acc[0] = acc[0] + p0;
     acc[1] = acc[1] + p1;
     acc[2] = acc[2] + p2;
     acc[3] = acc[3] + p3;
   }
 }
-template <int F, bool MASK>
-__device__ __forceinline__ void tile_batch(const dbl2 (&v)[4], const int2v &s, const char *xa, const char *xb_, int len, int n, double (&acc)[4]) {
-  // n: wave-uniform number of entries of this batch that any row still has (1..8)
-  tile_entry<F, 0, MASK>(v, s, xa, xb_, len, acc);
-  if (n > 1) tile_entry<F, 1, MASK>(v, s, xa, xb_, len, acc);
-  if (n > 2) tile_entry<F, 2, MASK>(v, s, xa, xb_, len, acc);
-  if (n > 3) tile_entry<F, 3, MASK>(v, s, xa, xb_, len, acc);
-  if (n > 4) tile_entry<F, 4, MASK>(v, s, xa, xb_, len, acc);
-  if (n > 5) tile_entry<F, 5, MASK>(v, s, xa, xb_, len, acc);
-  if (n > 6) tile_entry<F, 6, MASK>(v, s, xa, xb_, len, acc);
-  if (n > 7) tile_entry<F, 7, MASK>(v, s, xa, xb_, len, acc);
+template <int L, int B, bool MASK>       // entries 8 B .. 8 B + 7; n: wave-uniform number of them that any row still has (1..8)
+__device__ __forceinline__ void tile_batch(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
+                                           const char *xb_, int len, int n, double (&acc)[4]) {
+  tile_entry<L, 8 * B + 0, MASK>(v, sw, xa, xb_, len, acc);
+  if (n > 1) tile_entry<L, 8 * B + 1, MASK>(v, sw, xa, xb_, len, acc);
+  if (n > 2) tile_entry<L, 8 * B + 2, MASK>(v, sw, xa, xb_, len, acc);
+  if (n > 3) tile_entry<L, 8 * B + 3, MASK>(v, sw, xa, xb_, len, acc);
+  if (n > 4) tile_entry<L, 8 * B + 4, MASK>(v, sw, xa, xb_, len, acc);
+  if (n > 5) tile_entry<L, 8 * B + 5, MASK>(v, sw, xa, xb_, len, acc);
+  if (n > 6) tile_entry<L, 8 * B + 6, MASK>(v, sw, xa, xb_, len, acc);
+  if (n > 7) tile_entry<L, 8 * B + 7, MASK>(v, sw, xa, xb_, len, acc);
 }
-template <bool MASK>
-__device__ __forceinline__ void tile_rows(const dbl2 (&v)[4], const int2v &s, const char *xa, const char *xb_, int len, int nmax, double (&acc)[4]) {
-  if (nmax > 0) tile_batch<0, MASK>(v, s, xa, xb_, len, nmax < 8 ? nmax : 8, acc);
-  if (nmax > 8) tile_batch<1, MASK>(v, s, xa, xb_, len, nmax < 16 ? nmax - 8 : 8, acc);
-  if (nmax > 16) tile_batch<2, MASK>(v, s, xa, xb_, len, nmax < 24 ? nmax - 16 : 8, acc);
-  if (nmax > 24) tile_batch<3, MASK>(v, s, xa, xb_, len, nmax - 24, acc);
+template <int L, bool MASK>
+__device__ __forceinline__ void tile_rows(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
+                                          const char *xb_, int len, int nmax, double (&acc)[4]) {
+  if (nmax > 0) tile_batch<L, 0, MASK>(v, sw, xa, xb_, len, nmax < 8 ? nmax : 8, acc);
+  if (nmax > 8) tile_batch<L, 1, MASK>(v, sw, xa, xb_, len, nmax < 16 ? nmax - 8 : 8, acc);
+  if (nmax > 16) tile_batch<L, 2, MASK>(v, sw, xa, xb_, len, nmax < 24 ? nmax - 16 : 8, acc);
+  if (nmax > 24) tile_batch<L, 3, MASK>(v, sw, xa, xb_, len, nmax - 24, acc);
 }
 
-template <int NL>
-struct TileRec {            // what a lane holds of a group's record: its two row descriptors and its share of the list
-  int4v d0, d1;
+template <int L, int NL>
+struct TileRec {            // what a lane holds of a group's record: its row descriptors (one per pass) and its share of the list
+  int4v d[TileShape<L>::NPASS];
   int lw[NL];
 };
-struct TileEnt {            // ... and of the (val, slot) stream of its two rows
-  dbl2 v0[4], v1[4];
-  int2v s0, s1;
+template <int L>
+struct TileEnt {            // ... and of the (val, slot) stream of its rows
+  dbl2 v[TileShape<L>::NPASS][TileShape<L>::F];
+  int sw[TileShape<L>::NPASS][TileShape<L>::SW];
 };
 
 // Persistent waves, one per workgroup, wave i takes the groups i, i + G, i + 2 G, ...  Three stages in flight per wave:
@@ -123,11 +144,12 @@ struct TileEnt {            // ... and of the (val, slot) stream of its two rows
 // group ONE latency -- that of panel rows, mostly L2 / Infinity-Cache hits -- is exposed, and the HBM streams (val, records)
 // run a whole group ahead.  (The one-shot form, one group per wave launch, spent 8.8 us per wave, 63 % of it waiting on
 // two dependent round trips: 1.35-1.5 ms; profiles/r03_spmm_tile_sweep.log.)
-template <bool DIST, int NL, bool NT>      // NL = ceil(cap / 64): list words per lane; NT: non-temporal hints on the streams
-__global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w) {
-  extern __shared__ dbl2 tile_win[];                 // [cap][8]: the group's distinct panel rows
+template <int L, bool DIST, int NL, bool NT>      // p = 4 L; NL = ceil(cap / 64): list words per lane; NT: non-temporal hints on the streams
+__global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
+  using S = TileShape<L>;
+  extern __shared__ dbl2 tile_win[];                 // [cap][2 L]: the group's distinct panel rows
   typedef __attribute__((address_space(3))) char lds_char;
-  const int lane = threadIdx.x, sub = lane >> 2, c = lane & 3;
+  const int lane = threadIdx.x, sub = lane / L, c = lane % L;
   // Wave b runs on XCD b % 8 (round-robin dispatch of the workgroups).  XCD x takes the x-th of eight contiguous runs of
   // groups and its waves walk that run side by side, so that the groups in flight on an XCD are neighbours and share
   // panel rows through its L2 (exp & 8: plain round-robin over all waves instead).
@@ -140,64 +162,77 @@ __global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w)
     gend = (x + 1) * w.per_xcd < w.groups ? (x + 1) * w.per_xcd : w.groups;
   }
   if (g >= gend) return;
-  const int hq = (lane & 8) ? 64 : 0;                // quads with bit 1 set read the second half of a panel row first
+  const int hq = (sub & 2) ? 16 * L : 0;             // lane groups with bit 1 set read the second half of a panel row first
   const char *xa = reinterpret_cast<const char *>(tile_win) + 16 * c + hq;
-  const char *xb_ = reinterpret_cast<const char *>(tile_win) + 16 * c + (64 - hq);
+  const char *xb_ = reinterpret_cast<const char *>(tile_win) + 16 * c + (16 * L - hq);
   const int64_t vlast = a.nnz_bound - 2;
+  const int slot_off = kTileDescBytes + 4 * w.cap;
 
-  auto load_rec = [&](int64_t gg, TileRec<NL> &r) {
+  auto load_rec = [&](int64_t gg, TileRec<L, NL> &r) {
     const char *rec = w.meta + (gg < last ? gg : last) * (int64_t)w.stride;
     const int4v *desc = reinterpret_cast<const int4v *>(rec);
     const int32_t *lst = reinterpret_cast<const int32_t *>(rec + kTileDescBytes);
-    r.d0 = ld<NT>(desc + sub);              // records, entries and Y are streams: they should not push
-    r.d1 = ld<NT>(desc + 16 + sub);         // the panel rows the neighbouring groups share out of the L2
+#pragma unroll
+    for (int q = 0; q < S::NPASS; ++q) r.d[q] = ld<NT>(desc + q * S::RP + sub);   // records, entries and Y are streams
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int q = lane + 64 * j;
       r.lw[j] = ld<NT>(lst + (q < w.cap ? q : w.cap - 1));
     }
   };
-  // the (val, slot) stream of the lane's two rows: entries 2 c, 2 c + 1 (+ 8 f) and the slot bytes 8 c .. 8 c + 7
-  auto load_ent = [&](int64_t gg, const TileRec<NL> &r, TileEnt &e) {
-    const char *slots = w.meta + (gg < last ? gg : last) * (int64_t)w.stride + kTileDescBytes + 4 * w.cap;
+  // the (val, slot) stream of the lane's rows: entries 2 c, 2 c + 1 (+ 2 L f) and the slot bytes 4 SW c .. 4 SW (c + 1) - 1
+  auto load_ent = [&](int64_t gg, const TileRec<L, NL> &r, TileEnt<L> &e) {
+    const char *slots = w.meta + (gg < last ? gg : last) * (int64_t)w.stride + slot_off;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      int64_t i0 = (int64_t)r.d0.y + 2 * c + 8 * f, i1 = (int64_t)r.d1.y + 2 * c + 8 * f;
-      i0 = i0 < vlast ? i0 : vlast;
-      i1 = i1 < vlast ? i1 : vlast;
-      if (w.exp & 4) { i0 = 2 * c + 8 * f; i1 = i0; }
-      e.v0[f] = NT ? __builtin_nontemporal_load(reinterpret_cast<const dbl2u *>(a.val + i0)) : *reinterpret_cast<const dbl2u *>(a.val + i0);
-      e.v1[f] = NT ? __builtin_nontemporal_load(reinterpret_cast<const dbl2u *>(a.val + i1)) : *reinterpret_cast<const dbl2u *>(a.val + i1);
+    for (int q = 0; q < S::NPASS; ++q) {
+#pragma unroll
+      for (int f = 0; f < S::F; ++f) {
+        int64_t i0 = (int64_t)r.d[q].y + 2 * c + 2 * L * f;
+        i0 = i0 < vlast ? i0 : vlast;
+        if (w.exp & 4) i0 = 2 * c + 2 * L * f;
+        e.v[q][f] = NT ? __builtin_nontemporal_load(reinterpret_cast<const dbl2u *>(a.val + i0)) : *reinterpret_cast<const dbl2u *>(a.val + i0);
+      }
+      const char *sp = slots + (q * S::RP + sub) * kTileLen + 4 * S::SW * c;
+      if (S::SW == 1) {
+        e.sw[q][0] = ld<NT>(reinterpret_cast<const int *>(sp));
+      } else if (S::SW == 2) {
+        const int2v t = ld<NT>(reinterpret_cast<const int2v *>(sp));
+        e.sw[q][0] = t.x; e.sw[q][S::SW - 1] = t.y;
+      } else {
+        const int4v t = ld<NT>(reinterpret_cast<const int4v *>(sp));
+        e.sw[q][0] = t.x; e.sw[q][1 % S::SW] = t.y; e.sw[q][2 % S::SW] = t.z; e.sw[q][3 % S::SW] = t.w;
+      }
     }
-    e.s0 = ld<NT>(reinterpret_cast<const int2v *>(slots + sub * kTileLen + 8 * c));
-    e.s1 = ld<NT>(reinterpret_cast<const int2v *>(slots + (16 + sub) * kTileLen + 8 * c));
   };
-  // panel rows -> LDS: instruction wq copies list entries 8 wq .. 8 wq + 7, lane i the 16-byte piece i % 8 of entry i / 8
-  // The copy is inline asm on purpose: with the builtin, hipcc tracks the LDS-DMA as a pending LDS write and puts a vmcnt
-  // wait that also drains the prefetches of the next groups behind every ds_read of the product loop (seen in the ISA);
-  // an asm VMEM instruction is outside its bookkeeping, which is safe here: the copies are OLDER than every load the
-  // compiler counts in this iteration, so its counted waits stay sufficient, and the wait for the copies themselves is
-  // the explicit vmcnt below.  M0 (the LDS destination base) is compiler-reserved: saved and restored per statement.
+  // panel rows -> LDS: instruction wq copies list entries EPI wq .. EPI (wq + 1) - 1, lane i the 16-byte piece i % (2 L) of
+  // entry i / (2 L).  The copy is inline asm on purpose: with the builtin, hipcc tracks the LDS-DMA as a pending LDS write and
+  // puts a vmcnt wait that also drains the prefetches of the next groups behind every ds_read of the product loop (seen in
+  // the ISA); an asm VMEM instruction is outside its bookkeeping, which is safe here: the copies are OLDER than every load the
+  // compiler counts in this iteration, so its counted waits stay sufficient, and the wait for the copies themselves is the
+  // explicit vmcnt below.  M0 (the LDS destination base) is compiler-reserved: saved and restored per statement.
   const unsigned win_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_char *)tile_win);
-  auto issue_dma = [&](const TileRec<NL> &r) {
-    int cols[8 * NL];
+  auto issue_dma = [&](const TileRec<L, NL> &r) {
+    constexpr int PER = 64 / S::EPI;                 // instructions per list word
+    int col[NL * PER];
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
+    for (int j = 0; j < NL; ++j) {                   // all the lane exchanges first: one lgkmcnt wait, then the copies back to back
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) cols[8 * j + w8] = __builtin_amdgcn_ds_bpermute(4 * (8 * w8 + (lane >> 3)), r.lw[j]);
+      for (int u = 0; u < PER; ++u) {
+        col[j * PER + u] = __builtin_amdgcn_ds_bpermute(4 * (u * S::EPI + lane / (2 * L)), r.lw[j]);
+        if (w.exp & 16) col[j * PER + u] = S::EPI * (j * PER + u) + lane / (2 * L);
+      }
     }
 #pragma unroll
-    for (int wq = 0; wq < 8 * NL; ++wq) {
-      if (8 * wq < w.cap && !(w.exp & 1)) {
-        const int col = (w.exp & 16) ? 8 * wq + (lane >> 3) : cols[wq];
+    for (int wq = 0; wq < NL * PER; ++wq) {
+      if (S::EPI * wq < w.cap && !(w.exp & 1)) {
         const char *src = reinterpret_cast<const char *>(a.x);
-        uint64_t rr = (unsigned)col;
+        uint64_t rr = (unsigned)col[wq];
         if (DIST) {
-          const bool own = (int64_t)col < a.n_owned;
+          const bool own = (int64_t)col[wq] < a.n_owned;
           src = own ? src : reinterpret_cast<const char *>(a.ghost);
           rr = own ? rr : rr - (uint64_t)a.n_owned;
         }
-        const char *gsrc = src + (rr << 7) + 16 * (lane & 7);
+        const char *gsrc = src + (rr << S::SHIFT) + 16 * (lane % (2 * L));
         const unsigned dst = win_lds + 1024u * (unsigned)wq;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -205,44 +240,46 @@ __global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w)
       }
     }
   };
-  auto products = [&](const TileRec<NL> &r, const TileEnt &e) {
+  auto products = [&](const TileRec<L, NL> &r, const TileEnt<L> &e) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int4v &d = q ? r.d1 : r.d0;
+    for (int q = 0; q < S::NPASS; ++q) {
+      const int4v &d = r.d[q];
       const int len = d.z;
       const int len0 = __builtin_amdgcn_readfirstlane(len);
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       if (w.exp & 2) {
-        acc[0] = (q ? e.v1 : e.v0)[0].x + (q ? e.v1 : e.v0)[1].x + (q ? e.v1 : e.v0)[2].x + (q ? e.v1 : e.v0)[3].y + (double)(q ? e.s1 : e.s0).x;
+        acc[0] = e.v[q][0].x + e.v[q][S::F - 1].y + (double)e.sw[q][0];
       } else if (__ballot(len != len0) == 0) {
-        tile_rows<false>(q ? e.v1 : e.v0, q ? e.s1 : e.s0, xa, xb_, len, len0, acc);
+        tile_rows<L, false>(e.v[q], e.sw[q], xa, xb_, len, len0, acc);
       } else {
         int nmax = len;
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(nmax, sft); nmax = o > nmax ? o : nmax; }
         nmax = __builtin_amdgcn_readfirstlane(nmax);
-        tile_rows<true>(q ? e.v1 : e.v0, q ? e.s1 : e.s0, xa, xb_, len, nmax, acc);
+        tile_rows<L, true>(e.v[q], e.sw[q], xa, xb_, len, nmax, acc);
       }
       if (d.x >= 0) {
-        double *yr = a.y + (int64_t)d.x * 16 + 2 * c;
+        double *yr = a.y + (int64_t)d.x * (4 * L) + 2 * c;
         if (NT) {
-          __builtin_nontemporal_store(dbl2{acc[0], acc[1]}, reinterpret_cast<dbl2 *>(yr + (hq >> 3)));          // the half this quad read first
-          __builtin_nontemporal_store(dbl2{acc[2], acc[3]}, reinterpret_cast<dbl2 *>(yr + 8 - (hq >> 3)));
+          __builtin_nontemporal_store(dbl2{acc[0], acc[1]}, reinterpret_cast<dbl2 *>(yr + (hq >> 3)));          // the half this lane group read first
+          __builtin_nontemporal_store(dbl2{acc[2], acc[3]}, reinterpret_cast<dbl2 *>(yr + 2 * L - (hq >> 3)));
         } else {
           *reinterpret_cast<dbl2 *>(yr + (hq >> 3)) = dbl2{acc[0], acc[1]};
-          *reinterpret_cast<dbl2 *>(yr + 8 - (hq >> 3)) = dbl2{acc[2], acc[3]};
+          *reinterpret_cast<dbl2 *>(yr + 2 * L - (hq >> 3)) = dbl2{acc[2], acc[3]};
         }
       }
     }
   };
-  TileRec<NL> r0, r1, r2;
-  TileEnt e0, e1;
+
+  TileRec<L, NL> r0, r1, r2;
+  TileEnt<L> e0, e1;
   load_rec(g, r0);
   load_rec(g + G, r1);
   load_ent(g, r0, e0);
   __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): the loop starts with nothing in flight
   for (;;) {
-    const bool direct = __builtin_amdgcn_readfirstlane(__shfl(r0.d0.w, 4)) != 0;      // aux of row slot 1 = the group's flag
+    // aux of row slot 1 = the group's flag (row slot 1 is lane L of pass 0)
+    const bool direct = __builtin_amdgcn_readfirstlane(__shfl(r0.d[0].w, L)) != 0;
     if (!direct) issue_dma(r0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -251,18 +288,16 @@ __global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (!direct) {
-      // the DMA is older than the 10 + 2 + NL loads just issued: wait for it alone (nothing but the issuing wave's vmcnt
-      // orders a ds_read behind an LDS-DMA)
-      // (the builtin, not inline asm: hipcc's own wait-count bookkeeping sees it and does not add vmcnt(0) at the first use
-      // of the entries loaded one iteration ago; gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8)
-      if (NL == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 13);
-      else if (NL == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 14);
-      else if (NL == 3) __builtin_amdgcn_s_waitcnt(0x0F70 | 15);
-      else __builtin_amdgcn_s_waitcnt(0x4F70 | 0);             // vmcnt(16)
+      // the DMA is older than the NPASS (F + 1) + NPASS + NL loads just issued: wait for it alone (nothing but the issuing
+      // wave's vmcnt orders a ds_read behind an LDS-DMA).  The builtin, not inline asm: hipcc's own wait-count bookkeeping sees
+      // it and does not add vmcnt(0) at the first use of the entries loaded one iteration ago; gfx9 encoding: vmcnt in bits
+      // 3:0 and 15:14, expcnt 6:4, lgkmcnt 11:8.
+      constexpr int N = S::NPASS * (S::F + 1) + S::NPASS + NL;
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       products(r0, e0);
-    }                                                        // (flagged groups: spmm_tile16_direct_kernel, launched next)
+    }                                                        // (flagged groups: spmm_tile_direct_kernel, launched next)
     g += G;
     if (g >= gend) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every window read of this group has returned before the next DMA
@@ -274,13 +309,14 @@ __global__ __launch_bounds__(64) void spmm_tile16_kernel(SpmvArgs a, TileArgs w)
 // order of operations.  One workgroup per flagged group, launched after the main kernel over the handle's list of such groups
 // (kept out of the main kernel: a second arm with loads of its own made hipcc's wait-count merging drain the prefetches there).
 // A row of thousands of entries must not be one serial chain of dependent gathers (four such rows cost 1.5 ms at 10 M rows,
-// profiles/r03_bench_irregular.jsonl): the 256 threads form the 4 x 16 products of 64 entries at a time in parallel (thread
-// t: entry t / 4, columns 4 (t % 4) .. + 3), park them in LDS, and ONE quad adds them up in stored order -- the same rounded
+// profiles/r03_bench_irregular.jsonl): the 256 threads form the products of 256 / L entries at a time in parallel (thread t:
+// entry t / L, columns 4 (t % L) .. + 3), park them in LDS, and L lanes add them up in stored order -- the same rounded
 // multiply and rounded add per entry and column as everywhere else.
-template <bool DIST>
-__global__ __launch_bounds__(kBlock) void spmm_tile16_direct_kernel(SpmvArgs a, TileArgs w, const int32_t *glist, int64_t count) {
-  __shared__ double prod[64][16];
-  const int tid = threadIdx.x, e = tid >> 2, c = tid & 3;
+template <int L, bool DIST>
+__global__ __launch_bounds__(kBlock) void spmm_tile_direct_kernel(SpmvArgs a, TileArgs w, const int32_t *glist, int64_t count) {
+  constexpr int CH = kBlock / L, P = 4 * L;
+  __shared__ double prod[CH][P];
+  const int tid = threadIdx.x, e = tid / L, c = tid % L;
   if ((int64_t)blockIdx.x >= count) return;
   const int64_t g = glist[blockIdx.x];
   const int4v *desc = reinterpret_cast<const int4v *>(w.meta + g * (int64_t)w.stride);
@@ -289,23 +325,23 @@ __global__ __launch_bounds__(kBlock) void spmm_tile16_direct_kernel(SpmvArgs a, 
     if (d.x < 0) continue;                                  // (uniform)
     const int64_t s = d.y, len = d.z;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t base = 0; base < len; base += 64) {
-      const int cnt = (int)((len - base) < 64 ? (len - base) : 64);
+    for (int64_t base = 0; base < len; base += CH) {
+      const int cnt = (int)((len - base) < CH ? (len - base) : CH);
       if (e < cnt) {
         const double vv = a.val[s + base + e];
         const int32_t cc = a.col[s + base + e];
         const bool own = !DIST || cc < a.n_owned;
         const double *src = own ? a.x : a.ghost;
         const int64_t rr = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
-        const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 4 * c);
-        const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + rr * 16 + 4 * c + 2);
+        const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + rr * P + 4 * c);
+        const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + rr * P + 4 * c + 2);
         prod[e][4 * c + 0] = vv * x0.x;
         prod[e][4 * c + 1] = vv * x0.y;
         prod[e][4 * c + 2] = vv * x1.x;
         prod[e][4 * c + 3] = vv * x1.y;
       }
       __syncthreads();
-      if (tid < 4) {
+      if (tid < L) {
         for (int k = 0; k < cnt; ++k) {
           acc[0] = acc[0] + prod[k][4 * c + 0];
           acc[1] = acc[1] + prod[k][4 * c + 1];
@@ -315,8 +351,8 @@ __global__ __launch_bounds__(kBlock) void spmm_tile16_direct_kernel(SpmvArgs a, 
       }
       __syncthreads();
     }
-    if (tid < 4) {
-      double *yr = a.y + (int64_t)d.x * 16 + 4 * c;
+    if (tid < L) {
+      double *yr = a.y + (int64_t)d.x * P + 4 * c;
       *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
       *reinterpret_cast<dbl2 *>(yr + 2) = dbl2{acc[2], acc[3]};
     }
@@ -596,10 +632,11 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
   return KHIP_OK;
 }
 
-int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
+template <int L>
+static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
   TileArgs w;
   w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride; w.exp = ctx->tune.spmm_tile_exp;
-  const size_t lds = (size_t)w.cap * 128;
+  const size_t lds = (size_t)w.cap * 32 * L;
   int per_cu = (int)((size_t)(160 * 1024) / lds);                    // LDS-limited residency of the one-wave workgroups
   if (per_cu >= 5) --per_cu;                                         // one wave short of the LDS limit measures 3 % faster (7 instead of 8 at 144 panel rows)
   if (per_cu > 16) per_cu = 16;
@@ -614,8 +651,8 @@ int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
 #define KHIP_TILE_LAUNCH1(D, N, T)                                                                                      \
   do {                                                                                                                  \
     if (lds > 64 * 1024)                                                                                                \
-      (void)hipFuncSetAttribute((const void *)spmm_tile16_kernel<D, N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL((spmm_tile16_kernel<D, N, T>), gd, bd, lds, ctx->stream, a, w);                                  \
+      (void)hipFuncSetAttribute((const void *)spmm_tile_kernel<L, D, N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((spmm_tile_kernel<L, D, N, T>), gd, bd, lds, ctx->stream, a, w);                                 \
   } while (0)
 #define KHIP_TILE_LAUNCH(D, N)                                                                                          \
   do {                                                                                                                  \
@@ -631,11 +668,22 @@ int launch_spmm_tile16(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
 #undef KHIP_TILE_LAUNCH1
   if (A->tile_direct > 0) {
     const dim3 gdd((unsigned)A->tile_direct), bdd(kBlock);
-    if (dist) hipLaunchKernelGGL((spmm_tile16_direct_kernel<true>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
-    else hipLaunchKernelGGL((spmm_tile16_direct_kernel<false>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+    if (dist) hipLaunchKernelGGL((spmm_tile_direct_kernel<L, true>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+    else hipLaunchKernelGGL((spmm_tile_direct_kernel<L, false>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
   }
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
+}
+
+// p = 8, 16 or 32 right-hand sides (L = p / 4 lanes per row); the group records do not depend on p
+int launch_spmm_tile(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p) {
+  if ((size_t)A->tile_cap * 8 * (size_t)p > (size_t)160 * 1024) { set_error("spmm_tile: window of %d panel rows x %d columns exceeds the LDS", A->tile_cap, p); return KHIP_ERR_UNSUPPORTED; }
+  switch (p) {
+    case 8: return launch_tile_L<2>(ctx, A, a);
+    case 16: return launch_tile_L<4>(ctx, A, a);
+    case 32: return launch_tile_L<8>(ctx, A, a);
+    default: set_error("spmm_tile: p = 8, 16 or 32"); return KHIP_ERR_INVALID;
+  }
 }
 
 }  // namespace khip

@@ -309,13 +309,13 @@ def test_spmm_window_mixed_groups_and_fallbacks(K, ctx, oracle):
 # ---- SpMM with 16 columns: wave-private windows filled by LDS-DMA, grid-tile row groups (spmm_tile.hip) ----------
 
 def _spmm_three(K, ctx, dA, X):
-    """Y (16 columns) with the tile kernel, the window kernel and the direct-gather kernel, as host arrays."""
+    """Y (8, 16 or 32 columns) with the tile kernel, the window kernel and the direct-gather kernel, as host arrays."""
     dX = K.Panel.from_host(ctx, X)
     out = []
-    for tile, window in ((1, 1), (0, 1), (0, 0)):
+    for tile, window in ((2, 1), (0, 1), (0, 0)):            # 2: the tile kernel at every width it has
         ctx.set_option("spmm_tile", tile)
         ctx.set_option("spmm_window", window)
-        dY = K.Panel(ctx, dA.m, 16)
+        dY = K.Panel(ctx, dA.m, X.shape[1])
         K.spmm_(dA, dX, dY)
         out.append(dY.to_host())
     ctx.set_option("spmm_tile", 1)
@@ -444,6 +444,57 @@ def test_spmm_tile_fuzz_small_and_odd_shapes(K, ctx):
         Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
         assert np.array_equal(Yt, Yd) and np.array_equal(Yw, Yd), (tag, dA.tile_info)
         assert np.array_equal(Yt, _serial_spmm(S, X)), (tag, dA.tile_info)
+
+
+@pytest.mark.parametrize("p", [8, 32])
+def test_spmm_tile_other_widths_bit_identical(K, ctx, oracle, p):
+    """The tile kernel with 2 and 8 lanes per row (p = 8, 32): grid operators (one and two descriptor passes differ from
+    p = 16), band + long-range columns, band + dense rows (flagged groups: the direct kernel at that width), ragged rows with
+    Inf / NaN in X, odd small shapes.  Same records as p = 16; Y == window kernel == direct kernel == serial loop."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(100 + p)
+    for kind, dims in (("stencil27", (13, 11, 9)), ("poisson", (20, 17, 6)), ("poisson", (37, 9, 1))):
+        dA = K.CsrMatrix.stencil(ctx, kind, *dims)
+        X = rng.standard_normal((dA.n, p))
+        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
+        assert dA.tile_info["state"] == 1 and dA.tile_info["grid_tiles"] == 1
+        assert np.array_equal(Yt, Yd) and np.array_equal(Yw, Yd), (kind, dims)
+        if kind == "poisson":
+            A = oracle.poisson3d(*dims)
+            assert np.array_equal(Yt, np.stack([A.matvec(np.ascontiguousarray(X[:, j])) for j in range(p)], axis=1))
+    n = 3000
+    band = sp.diags([rng.standard_normal(n - abs(k)) for k in range(-10, 11)], list(range(-10, 11)), format="lil")
+    far = sp.random(n, n, density=3.0 / n, random_state=5, format="lil")
+    dense = sp.diags([rng.standard_normal(n - abs(k)) for k in range(-6, 7)], list(range(-6, 7)), format="lil")
+    for r in (100, 101, 2222):
+        dense[r, :] = rng.standard_normal(n) * (rng.random(n) < 0.3)
+    ragged = sp.lil_matrix((n, n))
+    for i in range(n):
+        k = (i * 7) % 23
+        cols = np.unique((i + np.arange(k) * 3 - k) % n)
+        if cols.size:
+            ragged[i, cols] = rng.standard_normal(cols.size)
+    edge = sp.lil_matrix((400, 400))                          # rows of exactly 32 entries (every entry step of a pass) and one of 33
+    for i in range(400):
+        k = 32 if i % 2 == 0 else (33 if i == 201 else 5)
+        edge[i, (i + np.arange(k)) % 400] = rng.standard_normal(k)
+    small = sp.random(95, 200, density=0.04, random_state=3, format="lil")
+    for tag, S, special in (("band + random", band + far, False), ("dense rows", dense, False), ("ragged", ragged, True), ("rows of 32 / 33", edge, False),
+                            ("small", small, False)):
+        S = S.tocsr()
+        S.sort_indices()
+        dA = K.CsrMatrix.from_host(ctx, S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data.copy(), S.shape)
+        X = rng.standard_normal((S.shape[1], p))
+        if special:
+            X[::97, 3] = np.inf
+            X[5::131, p - 1] = np.nan
+        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
+        if tag == "dense rows":
+            assert dA.tile_info["state"] == 1 and dA.tile_info["direct_groups"] >= 2, dA.tile_info
+        with np.errstate(invalid="ignore", over="ignore"):
+            ref = _serial_spmm(S, X)
+        assert np.array_equal(Yt, Yd, equal_nan=True) and np.array_equal(Yw, Yd, equal_nan=True), tag
+        assert np.array_equal(Yt, ref, equal_nan=True), tag
 
 
 def test_block_gmres_same_history_with_and_without_tile_kernel(K, ctx, oracle):

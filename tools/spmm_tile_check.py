@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""spmm_tile16_kernel (spmm_tile.hip) vs the window and direct kernels at p = 16: bit-equality, then timing on the
+"""spmm_tile_kernel (spmm_tile.hip) vs the window and direct kernels at p = 16: bit-equality, then timing on the
 27-point 216^3 operator (cfg 5) and on a banded + random operator.  Usage: python tools/spmm_tile_check.py [n1] [reps]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
