@@ -634,7 +634,7 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
     KHIP_TRY(comm_halo_exchange_end(ctx, A));
     if (A->n_ghost > 0) { a.ghost = A->ghost_w; a.n_owned = A->m; }
   }
-  a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.fake_gather = 0; a.tiles_per_block = 1;
+  a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.dot_early = 0; a.fake_gather = 0; a.tiles_per_block = 1;
   a.nnz_bound = A->nnz + kPad;
   int P = 4;
   while (P < p) P <<= 1;

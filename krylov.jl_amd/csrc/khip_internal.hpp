@@ -59,6 +59,7 @@ struct Tuning {
   int spmv_sweep_s = 0;     // plane sweep (spmv_xcd = -2): tiles per grid plane (0 = from the handle's band width)
   int spmv_sweep_w = 16;    // plane sweep: consecutive tiles per XCD column
   int spmv_nty = 0;         // non-temporal store of y
+  int spmv_dot_early = 0;   // staged kernels with a fused dot: load dotw[row] before the row block's windows
   int spmv_fake_gather = 0; // tuning experiment (wrong results): coalesced x reads
   int spmv_tiles = 1;       // staged kernel: consecutive row blocks per workgroup
   int spmv_template = 1;    // use the row-template kernel on handles that khip_csr_compress compressed

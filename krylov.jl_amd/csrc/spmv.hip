@@ -210,7 +210,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
     const int64_t s = a.rowptr[r0], e = a.rowptr[r0 + nr];
     const int my_a = (tid < nr) ? a.rowptr[r0 + tid] : 0;
     const int my_b = (tid < nr) ? a.rowptr[r0 + tid + 1] : 0;
-    double acc = 0.0;
+    double acc = 0.0, wv = 0.0;
+    if (DOT && a.dot_early && tid < nr) wv = a.dotw[r0 + tid];       // in flight beside the window, not behind the row walk
     // windows start on a multiple of 4 entries so that every lane moves aligned 16-byte vectors:
     // 4 val loads (2 entries each) + 2 col loads (4 entries each) per lane and window -- the
     // vector-memory instruction count, not HBM, is what bounds this kernel
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
     if (tid < nr) {
       if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
       if (DOT) {
-        const double wv = a.dotw[r0 + tid];
+        if (!a.dot_early) wv = a.dotw[r0 + tid];
         acc_prod<COMP>(dacc[0], wv, acc);
         if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);        // y . y
         else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);     // w . w (single-reduction CG: r.r beside r.(A r))
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
     const int my_a = (tid < nr) ? a.rowptr[r0 + tid] : 0;
     const int my_b = (tid < nr) ? a.rowptr[r0 + tid + 1] : 0;
     const int32_t row = (int32_t)(r0 + tid);
-    double acc = 0.0;
+    double acc = 0.0, wv = 0.0;
+    if (DOT && a.dot_early && tid < nr) wv = a.dotw[r0 + tid];       // in flight beside the window, not behind the row walk
     for (int64_t c0 = s & ~(int64_t)3; c0 < e; c0 += CAP) {
       const int lim = (int)((e - c0) < (int64_t)CAP ? (e - c0) : (int64_t)CAP);
       const int lim4 = (lim + 3) & ~3;
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
     if (tid < nr) {
       if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
       if (DOT) {
-        const double wv = a.dotw[r0 + tid];
+        if (!a.dot_early) wv = a.dotw[r0 + tid];
         acc_prod<COMP>(dacc[0], wv, acc);
         if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
         else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);
@@ -887,6 +889,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.sweep_s = ctx->tune.spmv_sweep_s;
   a.sweep_w = ctx->tune.spmv_sweep_w;
   a.nt_y = ctx->tune.spmv_nty;
+  a.dot_early = ctx->tune.spmv_dot_early;
   a.tiles_per_block = 1;
   a.stage_cap = 2048;
   a.stop_seq = ctx->ctl.stop_seq;

@@ -37,6 +37,7 @@ struct SpmvArgs {
   int tmpl_T, tmpl_K;
   const double *dotw;    // left vector of the fused dot: results[slot] = dotw . y   (x for p.Ap; another vector for c.(A p))
   int dot_sq;            // staged kernel: also results[slot + 1] = y . y
+  int dot_early;         // staged kernels: load dotw[row] before the row block's windows instead of after the row walk
   const long long *stop_seq;   // device-resident loop control (solver_device.hpp); null outside such loops
   long long seq;
   int fake_gather;       // experiment: coalesced x reads instead of x[col] (WRONG results)
