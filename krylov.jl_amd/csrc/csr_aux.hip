@@ -583,7 +583,7 @@ namespace khip {
 #endif
 
 int spmm_window_build(khip_ctx *ctx, khip_csr *A, int L);   // below
-int launch_spmm_tile(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p);   // spmm_tile.hip
+int launch_spmm_tile(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p, bool slices);   // spmm_tile.hip
 
 template <int L>
 static void launch_window(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p) {
@@ -677,17 +677,25 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
         if (K2 * Spad <= gcap) { a.sweep_s = (int)S2; a.sweep_w = W2; grid2 = (int)(K2 * Spad); }
       }
     }
-    if (ctx->tune.spmm_tile && (p == 8 || p == 16 || p == 32) && A->m > 0 && A->nnz > 0) {
-      // wave-private windows, LDS-DMA, grid-tile row groups (spmm_tile.hip).  p = 16 always; p = 8 and 32 where it measures
-      // faster than the window / direct kernels (profiles/r03h_spmm_tile_p.log): grid operators, at p = 8 those with rows of
-      // 16 entries and more (27-point: 1.08 vs 1.41 ms; the 7-point operator and the banded + random one are 4 % slower);
-      // spmm_tile = 2 takes the tile kernel at all three widths.
+    const bool pow2 = (p & (p - 1)) == 0;
+    if (ctx->tune.spmm_tile && pow2 && p >= 8 && A->m > 0 && A->nnz > 0) {
+      // wave-private windows, LDS-DMA, grid-tile row groups (spmm_tile.hip).  p = 16 always; p = 8 on grid operators with rows
+      // of 16 entries and more (27-point: 1.08 vs 1.41 ms; the 7-point and the banded + random operators are 4 % slower); p = 32
+      // and wider either as ONE launch with p / 4 lanes per row (7-point: 1.51 vs 2.33 ms) or as p / 16 launches of the
+      // 16-column kernel over column slices (p = 32 with rows of 16 entries and more, 27-point: 2.52 vs 3.23 ms in one launch --
+      // the window reads of wide panels load the LDS pipes and halve the residency; p >= 64 always: 5.0 vs 13.0 ms;
+      // profiles/r03h_spmm_tile_p.log, r03i_spmm_tile_slices.log).  spmm_tile = 2 takes the tile kernel at every width
+      // it has; spmm_tile_slices = 1 / -1 forces / forbids the slices.
       khip_csr *At = const_cast<khip_csr *>(A);
       if (At->tile_state == 0) KHIP_TRY(spmm_tile_build(ctx, At));
-      const bool fits = (size_t)At->tile_cap * 8 * (size_t)p <= (size_t)160 * 1024;
-      const bool want = p == 16 || ctx->tune.spmm_tile >= 2 || (At->tile_grid == 1 && (p == 32 || A->nnz >= 16 * A->m));
-      if (At->tile_state == 1 && fits && want) return launch_spmm_tile(ctx, A, a, p);
+      const bool long_rows = A->nnz >= 16 * A->m;
+      const bool slices = p >= 32 && ctx->tune.spmm_tile_slices >= 0 && (p > 32 || ctx->tune.spmm_tile_slices > 0 || long_rows);
+      const bool fits = slices || (size_t)At->tile_cap * 8 * (size_t)p <= (size_t)160 * 1024;
+      const bool want = p == 16 || p > 32 || ctx->tune.spmm_tile >= 2 || (p == 8 && At->tile_grid == 1 && long_rows) ||
+                        (p == 32 && (slices ? long_rows : At->tile_grid == 1));
+      if (At->tile_state == 1 && fits && want && (p <= 32 || slices)) return launch_spmm_tile(ctx, A, a, p, slices);
     }
+
 
     if (ctx->tune.spmm_window && want2 <= gcap && A->m > 0) {      // panel-row window in LDS: one row group per workgroup
       khip_csr *Aw = const_cast<khip_csr *>(A);

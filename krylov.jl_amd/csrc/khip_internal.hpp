@@ -91,6 +91,7 @@ struct Tuning {
   int spmm_tile_waves = 0;  // persistent waves of the tile kernel = this multiple of the LDS-limited residency (0 = 1)
   int spmm_tile_grid = 0;   // ... or this many waves outright
   int spmm_tile_pencil = 0; // tile rows per pencil in the group order of grid operators (0 = 4)
+  int spmm_tile_slices = 0; // panels of 32 columns and more as 16-column slices through the p = 16 tile kernel: 0 = where it measures faster, 1 = always, -1 = never
   int spmm_tile_nt = 0;     // non-temporal hints on the record / entry / Y streams of the tile kernel
   int spmm_tile_shape = 0;  // grid tile of a 32-row group at build time: 0 = 4x4x2, 1 = 8x2x2, 2 = 2x4x4, 3 = 4x2x4, 4 = 8x4x1, 5 = 32x1x1
   int spmm_window = 1;      // SpMM: stage the distinct panel rows of a row group in LDS (csr_aux.hip, spmm_window_kernel)

@@ -43,6 +43,8 @@ struct TileArgs {
   int cap;                // list entries per group (multiple of 8)
   int stride;             // bytes per record
   int exp;                // tuning experiments, WRONG results: 1 no panel-row copies, 2 no products, 4 no (val, slot) loads, 8 groups dealt round-robin to the XCDs
+  int gshift;             // log2 of the bytes of a panel row in HBM: 5 + log2 L, or more when the launch covers a column slice of wider panels
+  int coff;               // byte offset of that slice in a panel row
 };
 
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
           src = own ? src : reinterpret_cast<const char *>(a.ghost);
           rr = own ? rr : rr - (uint64_t)a.n_owned;
         }
-        const char *gsrc = src + (rr << S::SHIFT) + 16 * (lane % (2 * L));
+        const char *gsrc = src + (rr << w.gshift) + w.coff + 16 * (lane % (2 * L));
         const unsigned dst = win_lds + 1024u * (unsigned)wq;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
         tile_rows<L, true>(e.v[q], e.sw[q], xa, xb_, len, nmax, acc);
       }
       if (d.x >= 0) {
-        double *yr = a.y + (int64_t)d.x * (4 * L) + 2 * c;
+        double *yr = a.y + ((int64_t)d.x << (w.gshift - 3)) + (w.coff >> 3) + 2 * c;
         if (NT) {
           __builtin_nontemporal_store(dbl2{acc[0], acc[1]}, reinterpret_cast<dbl2 *>(yr + (hq >> 3)));          // the half this lane group read first
           __builtin_nontemporal_store(dbl2{acc[2], acc[3]}, reinterpret_cast<dbl2 *>(yr + 2 * L - (hq >> 3)));
@@ -333,8 +335,9 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_direct_kernel(SpmvArgs a, Ti
         const bool own = !DIST || cc < a.n_owned;
         const double *src = own ? a.x : a.ghost;
         const int64_t rr = own ? (int64_t)cc : (int64_t)cc - a.n_owned;
-        const dbl2 x0 = *reinterpret_cast<const dbl2 *>(src + rr * P + 4 * c);
-        const dbl2 x1 = *reinterpret_cast<const dbl2 *>(src + rr * P + 4 * c + 2);
+        const double *xr = src + (rr << (w.gshift - 3)) + (w.coff >> 3) + 4 * c;
+        const dbl2 x0 = *reinterpret_cast<const dbl2 *>(xr);
+        const dbl2 x1 = *reinterpret_cast<const dbl2 *>(xr + 2);
         prod[e][4 * c + 0] = vv * x0.x;
         prod[e][4 * c + 1] = vv * x0.y;
         prod[e][4 * c + 2] = vv * x1.x;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_direct_kernel(SpmvArgs a, Ti
       __syncthreads();
     }
     if (tid < L) {
-      double *yr = a.y + (int64_t)d.x * P + 4 * c;
+      double *yr = a.y + ((int64_t)d.x << (w.gshift - 3)) + (w.coff >> 3) + 4 * c;
       *reinterpret_cast<dbl2 *>(yr) = dbl2{acc[0], acc[1]};
       *reinterpret_cast<dbl2 *>(yr + 2) = dbl2{acc[2], acc[3]};
     }
@@ -633,9 +636,9 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
 }
 
 template <int L>
-static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
+static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int gshift, int coff) {
   TileArgs w;
-  w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride; w.exp = ctx->tune.spmm_tile_exp;
+  w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride; w.exp = ctx->tune.spmm_tile_exp; w.gshift = gshift; w.coff = coff;
   const size_t lds = (size_t)w.cap * 32 * L;
   int per_cu = (int)((size_t)(160 * 1024) / lds);                    // LDS-limited residency of the one-wave workgroups
   if (per_cu >= 5) --per_cu;                                         // one wave short of the LDS limit measures 3 % faster (7 instead of 8 at 144 panel rows)
@@ -675,14 +678,22 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a) {
   return KHIP_OK;
 }
 
-// p = 8, 16 or 32 right-hand sides (L = p / 4 lanes per row); the group records do not depend on p
-int launch_spmm_tile(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p) {
+// p = 8, 16 or 32 right-hand sides in one launch (L = p / 4 lanes per row), or any multiple of 16 as p / 16 launches of the
+// 16-column kernel over column slices of the panels (tune.spmm_tile_slices; the matrix stream is read once per slice, the
+// window reads and the residency are those of p = 16).  The group records do not depend on p.
+int launch_spmm_tile(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int p, bool slices) {
+  if (slices && p % 16 == 0 && (p & (p - 1)) == 0 && p > 16) {
+    int gshift = 3;
+    while ((1 << gshift) < 8 * p) ++gshift;                    // 8 p bytes per panel row
+    for (int c = 0; c < p / 16; ++c) KHIP_TRY(launch_tile_L<4>(ctx, A, a, gshift, 128 * c));
+    return KHIP_OK;
+  }
   if ((size_t)A->tile_cap * 8 * (size_t)p > (size_t)160 * 1024) { set_error("spmm_tile: window of %d panel rows x %d columns exceeds the LDS", A->tile_cap, p); return KHIP_ERR_UNSUPPORTED; }
   switch (p) {
-    case 8: return launch_tile_L<2>(ctx, A, a);
-    case 16: return launch_tile_L<4>(ctx, A, a);
-    case 32: return launch_tile_L<8>(ctx, A, a);
-    default: set_error("spmm_tile: p = 8, 16 or 32"); return KHIP_ERR_INVALID;
+    case 8: return launch_tile_L<2>(ctx, A, a, 6, 0);
+    case 16: return launch_tile_L<4>(ctx, A, a, 7, 0);
+    case 32: return launch_tile_L<8>(ctx, A, a, 8, 0);
+    default: set_error("spmm_tile: p = 8, 16, 32 or a power of two above"); return KHIP_ERR_INVALID;
   }
 }
 

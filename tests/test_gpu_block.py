@@ -308,17 +308,27 @@ def test_spmm_window_mixed_groups_and_fallbacks(K, ctx, oracle):
 
 # ---- SpMM with 16 columns: wave-private windows filled by LDS-DMA, grid-tile row groups (spmm_tile.hip) ----------
 
-def _spmm_three(K, ctx, dA, X):
-    """Y (8, 16 or 32 columns) with the tile kernel, the window kernel and the direct-gather kernel, as host arrays."""
-    dX = K.Panel.from_host(ctx, X)
+def _spmm_three(K, ctx, dA, X, slices=0):
+    """Y (8, 16, 32, 64 columns) with the tile kernel, the window kernel and the direct-gather kernel, as host arrays.
+    slices: panels of 32 columns and more as 16-column slices (1), in one launch (-1), as the library decides (0)."""
+    p = X.shape[1]
+    if p <= 32:
+        dX = K.Panel.from_host(ctx, X)
+    else:                                                    # wider than the panel kernels go: the row-major buffer directly
+        dX = K.Panel(ctx, X.shape[0], p)
+        h = np.zeros((K.panel_rows(X.shape[0]), p))
+        h[:X.shape[0]] = X
+        dX.buf.copy_from_host(h.ravel())
     out = []
     for tile, window in ((2, 1), (0, 1), (0, 0)):            # 2: the tile kernel at every width it has
         ctx.set_option("spmm_tile", tile)
+        ctx.set_option("spmm_tile_slices", slices)
         ctx.set_option("spmm_window", window)
-        dY = K.Panel(ctx, dA.m, X.shape[1])
+        dY = K.Panel(ctx, dA.m, p)
         K.spmm_(dA, dX, dY)
-        out.append(dY.to_host())
+        out.append(dY.to_host() if p <= 32 else dY.buf.to_host().reshape(-1, p)[:dA.m].copy())
     ctx.set_option("spmm_tile", 1)
+    ctx.set_option("spmm_tile_slices", 0)
     ctx.set_option("spmm_window", 1)
     return out
 
@@ -446,17 +456,18 @@ def test_spmm_tile_fuzz_small_and_odd_shapes(K, ctx):
         assert np.array_equal(Yt, _serial_spmm(S, X)), (tag, dA.tile_info)
 
 
-@pytest.mark.parametrize("p", [8, 32])
-def test_spmm_tile_other_widths_bit_identical(K, ctx, oracle, p):
-    """The tile kernel with 2 and 8 lanes per row (p = 8, 32): grid operators (one and two descriptor passes differ from
-    p = 16), band + long-range columns, band + dense rows (flagged groups: the direct kernel at that width), ragged rows with
-    Inf / NaN in X, odd small shapes.  Same records as p = 16; Y == window kernel == direct kernel == serial loop."""
+@pytest.mark.parametrize("p,slices", [(8, 0), (32, -1), (32, 1), (64, 1)])
+def test_spmm_tile_other_widths_bit_identical(K, ctx, oracle, p, slices):
+    """The tile kernel with 2 and 8 lanes per row (p = 8, 32 in one launch) and the 16-column kernel over column slices of
+    wider panels (p = 32, 64): grid operators, band + long-range columns, band + dense rows (flagged groups: the direct kernel
+    at that width / slice), ragged rows with Inf / NaN in X, odd small shapes.  Same records as p = 16; Y == window kernel ==
+    direct kernel == serial loop."""
     import scipy.sparse as sp
     rng = np.random.default_rng(100 + p)
     for kind, dims in (("stencil27", (13, 11, 9)), ("poisson", (20, 17, 6)), ("poisson", (37, 9, 1))):
         dA = K.CsrMatrix.stencil(ctx, kind, *dims)
         X = rng.standard_normal((dA.n, p))
-        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
+        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X, slices)
         assert dA.tile_info["state"] == 1 and dA.tile_info["grid_tiles"] == 1
         assert np.array_equal(Yt, Yd) and np.array_equal(Yw, Yd), (kind, dims)
         if kind == "poisson":
@@ -488,7 +499,7 @@ def test_spmm_tile_other_widths_bit_identical(K, ctx, oracle, p):
         if special:
             X[::97, 3] = np.inf
             X[5::131, p - 1] = np.nan
-        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X)
+        Yt, Yw, Yd = _spmm_three(K, ctx, dA, X, slices)
         if tag == "dense rows":
             assert dA.tile_info["state"] == 1 and dA.tile_info["direct_groups"] >= 2, dA.tile_info
         with np.errstate(invalid="ignore", over="ignore"):

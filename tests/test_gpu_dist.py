@@ -229,10 +229,12 @@ def test_distributed_krylov_processes_local_ranks(K, oracle):
         assert np.array_equal(H, res[0][1]) and np.array_equal(Tnz, res[0][4])      # identical on every rank
 
 
-def test_distributed_spmm_window_local_ranks(K, oracle):
-    """SpMM on row slabs with ghost panel rows: the window kernel (owned / ghost select, DIST instantiation) gives the
-    same bits as the direct-gather kernel and as the single-GPU product."""
-    world, n1, p = 3, 12, 16
+@pytest.mark.parametrize("p,slices", [(16, 0), (8, 0), (32, -1), (32, 1)])
+def test_distributed_spmm_window_local_ranks(K, oracle, p, slices):
+    """SpMM on row slabs with ghost panel rows: the tile and window kernels (owned / ghost select, DIST instantiations; the tile
+    kernel with 2, 4 and 8 lanes per row and over 16-column slices of 32-column panels) give the same bits as the
+    direct-gather kernel and as the single-GPU product."""
+    world, n1 = 3, 12
     A_cpu = oracle.stencil27_unsym(n1)
     n = A_cpu.n
     Xh = np.random.default_rng(2).standard_normal((n, p))
@@ -244,8 +246,9 @@ def test_distributed_spmm_window_local_ranks(K, oracle):
         A = K.CsrMatrix.stencil(c, "stencil27", n1, rows=(r0, r1), distributed=True)
         X = K.Panel.from_host(c, Xh[r0:r1])
         out = []
-        for tile, window in ((1, 1), (0, 1), (0, 0)):     # p = 16: spmm_tile.hip's DIST instantiation, then the window and direct kernels
+        for tile, window in ((2, 1), (0, 1), (0, 0)):     # spmm_tile.hip's DIST instantiations, then the window and direct kernels
             c.set_option("spmm_tile", tile)
+            c.set_option("spmm_tile_slices", slices)
             c.set_option("spmm_window", window)
             Y = K.Panel(c, r1 - r0, p)
             K.spmm_(A, X, Y)

@@ -12,8 +12,12 @@ n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 216
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 
 
-def timed(A, X, Y, tile, window):
-    ctx.set_option("spmm_tile", tile); ctx.set_option("spmm_window", window)
+def setopts(tile, window, slices):
+    ctx.set_option("spmm_tile", tile); ctx.set_option("spmm_window", window); ctx.set_option("spmm_tile_slices", slices)
+
+
+def timed(A, X, Y, tile, window, slices):
+    setopts(tile, window, slices)
     for _ in range(3 * reps): K.spmm_(A, X, Y)      # the first few dozen launches of a process run at ramping clocks
     ctx.sync()
     t0 = time.perf_counter()
@@ -34,17 +38,19 @@ for kind, A in operators():
         h = np.zeros((K.panel_rows(A.n), p)); h[:A.n] = np.random.default_rng(p).standard_normal((A.n, p))
         X.buf.copy_from_host(h.ravel())
         outs = []
-        for tile, window in ((2, 1), (0, 1), (0, 0)):
-            ctx.set_option("spmm_tile", tile); ctx.set_option("spmm_window", window)
+        variants = [(2, 1, -1), (0, 1, 0), (0, 0, 0)] + ([(2, 1, 1)] if p >= 32 else [])     # slices: -1 one launch, 1 column slices of 16
+        if p > 32: variants = variants[1:]
+        for tile, window, slices in variants:
+            setopts(tile, window, slices)
             K.spmm_(A, X, Y); ctx.sync()
             outs.append(Y.buf.to_host())
-        same = bool(np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[2]))
+        same = bool(all(np.array_equal(o, outs[-2 if p >= 32 else -1]) for o in outs))
         alg = 12 * A.nnz + 4 * A.n + 16 * A.n * p
-        for tile, window in ((2, 1), (0, 1), (0, 0)):
-            dt = timed(A, X, Y, tile, window)
-            print(json.dumps(dict(op=kind, n1=n1, p=p, tile=tile, window=window, ms=round(dt * 1e3, 4), alg_gbps=round(alg / dt / 1e9, 1),
+        for tile, window, slices in variants:
+            dt = timed(A, X, Y, tile, window, slices)
+            print(json.dumps(dict(op=kind, n1=n1, p=p, tile=tile, window=window, slices=slices, ms=round(dt * 1e3, 4), alg_gbps=round(alg / dt / 1e9, 1),
                                   frac=round(alg / dt / 8e12, 4), same=same, window_rows=A.tile_info["window"], direct=A.tile_info["direct_groups"])), flush=True)
         del X, Y
     del A
-ctx.set_option("spmm_tile", 1); ctx.set_option("spmm_window", 1)
+setopts(1, 1, 0)
 ctx.close()
