@@ -68,9 +68,36 @@ __global__ __launch_bounds__(kBlock) void panel_to_colmajor_kernel(int64_t n, in
   }
 }
 
+// The NT x NT accumulator tiles of a workgroup's four waves -> ONE partial tile per workgroup: the waves park their tiles in
+// LDS and thread t adds element t of the four in wave order (a fixed order: deterministic), then stores it.  A quarter of the
+// partial traffic and of the first level of panel_tn_reduce_kernel (per-wave tiles were 80 MB per product at 10 M rows, 46 us
+// of reduction behind every 0.3-0.9 ms kernel).  Every thread of the workgroup must call it (barrier).
+template <int NT>
+__device__ __forceinline__ void tn_publish(const dbl4 (&tn)[NT][NT], double *partials) {
+  __shared__ double s_tn[kWavesPerBlock][NT * NT * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // tile (a, b), register g of lane l holds Psi[16a + (l >> 4) + 4g][16b + (l & 15)]
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s_tn[w][(a * NT + b) * 256 + g * 64 + lane] = tn[a][b][g];
+  __syncthreads();
+  double *out = partials + (size_t)blockIdx.x * (NT * NT * 256);
+#pragma unroll
+  for (int q = 0; q < NT * NT; ++q) {
+    const int e = q * 256 + threadIdx.x;
+    double sum = s_tn[0][e];
+#pragma unroll
+    for (int v = 1; v < kWavesPerBlock; ++v) sum = sum + s_tn[v][e];
+    out[e] = sum;
+  }
+}
+
 // ---------------------------------------------------------------- Psi = V^T Q -------------
-// Each wave folds kRowsPerWaveTN consecutive rows into NT x NT accumulator tiles and writes them to
-// partials[wave][NT*NT][256]; panel_tn_finish_kernel sums the per-wave tiles in wave order.
+// Each wave folds kRowsPerWaveTN consecutive rows into NT x NT accumulator tiles; the workgroup's four are added in wave order
+// (tn_publish) into partials[workgroup][NT*NT][256]; panel_tn_reduce_kernel sums those in workgroup order.
 template <int NT>
 __global__ __launch_bounds__(kBlock) void panel_gemm_tn_kernel(int64_t n_pad, int p, const double *V, const double *Q,
                                                                double *partials) {
@@ -109,17 +136,10 @@ __global__ __launch_bounds__(kBlock) void panel_gemm_tn_kernel(int64_t n_pad, in
             acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u][a], qb[u][b], acc[a][b], 0, 0, 0);
     }
   }
-  // tile (a, b), register g of lane l holds Psi[16a + (l >> 4) + 4g][16b + (l & 15)]
-  double *out = partials + (size_t)wid * (NT * NT * 256);
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) out[(a * NT + b) * 256 + g * 64 + lane] = acc[a][b][g];
+  tn_publish<NT>(acc, partials);
 }
 
-// Fixed-order tree over the per-wave tiles: each workgroup (x = group, y = tile pair) sums up to
+// Fixed-order tree over the per-workgroup tiles: each workgroup (x = group, y = tile pair) sums up to
 // kTnFan consecutive tiles; repeated until one is left, which is scattered into Psi_dev
 // (p x p column-major).  The order depends only on the wave count: deterministic.
 constexpr int kTnFan = 64;
@@ -308,13 +328,7 @@ __global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int 
       }
     }
   }
-  double *out = partials + (size_t)wid * (NT * NT * 256);
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) out[(a * NT + b) * 256 + g * 64 + lane] = tn[a][b][g];
+  tn_publish<NT>(tn, partials);
 }
 
 // ---------------------------------------------------------------- X = beta X + sum_i V_i Y_i ----
@@ -694,8 +708,8 @@ static TnPlan tn_plan(int64_t np, int p) {
   return t;
 }
 static void tn_reduce(khip_ctx *ctx, const TnPlan &t, int p, double *psi_out) {
-  double *ping = g_ps.partials, *pong = g_ps.partials + (size_t)t.nwaves * t.tile_elems;
-  int64_t count = t.nwaves;
+  double *ping = g_ps.partials, *pong = g_ps.partials + (size_t)t.blocks * t.tile_elems;
+  int64_t count = t.blocks;
   while (true) {
     const int64_t groups = (count + kTnFan - 1) / kTnFan;
     double *out = groups == 1 ? psi_out : nullptr;
@@ -709,7 +723,7 @@ static void tn_reduce(khip_ctx *ctx, const TnPlan &t, int p, double *psi_out) {
 // Psi = V^T Q into psi_out (device), no host synchronisation
 static int tn_enqueue(khip_ctx *ctx, int64_t np, int p, const double *V, const double *Q, double *psi_out) {
   const TnPlan t = tn_plan(np, p);
-  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.nwaves * t.tile_elems));
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.blocks * t.tile_elems));
   if (t.NT == 1) hipLaunchKernelGGL((panel_gemm_tn_kernel<1>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, V, Q, g_ps.partials);
   else hipLaunchKernelGGL((panel_gemm_tn_kernel<2>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, V, Q, g_ps.partials);
   tn_reduce(ctx, t, p, psi_out);
@@ -735,7 +749,7 @@ int khip_panel_gemm_tn(khip_ctx *ctx, int64_t n, int p, const double *V, const d
 int khip::panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const double *Ri_host, double *G_host) {
   const int64_t np = pad16(n);
   const TnPlan t = tn_plan(np, p);
-  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.nwaves * t.tile_elems));
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.blocks * t.tile_elems));
   if (g_ps.next_slot == kPsiSlots || g_ps.next_slot == 0) {
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     g_ps.next_slot = 1;
@@ -821,7 +835,7 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
   }
   const int64_t np = pad16(n);
   const TnPlan t = tn_plan(np, p);
-  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.nwaves * t.tile_elems));
+  KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.blocks * t.tile_elems));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));       // the Psi staging ring is ours from slot 1 on
   g_ps.next_slot = 1;
   const int64_t tiles = np / 16;
