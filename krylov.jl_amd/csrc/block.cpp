@@ -102,6 +102,34 @@ bool chol_upper(int p, const double *G, double *R) {
   }
   return true;
 }
+// Cholesky of a Gram matrix G (column-major p x p) that leaves out the columns lying, to working accuracy, in the span of the
+// columns before them.  detect: column j joins the set D when its pivot -- its squared distance from that span -- is at most
+// tol^2 times the largest diagonal entry; otherwise D = preset and a vanishing pivot elsewhere is a failure (*ok = false).
+// Rhat (upper, column-major) is the factor of the other columns, with R_jj = 1 and a zero row j for j in D and, above the
+// diagonal of such a column, its coefficients along the columns kept: Q <- Q Rhat^-1 orthonormalises the kept columns (as far
+// as one Cholesky round does) and turns column j in D into its own remainder outside their span -- rounding dust.
+unsigned deflating_chol(int p, const double *G, double tol, bool detect, unsigned preset, double *Rhat, bool *ok) {
+  double gmax = 0.0;
+  for (int j = 0; j < p; ++j) gmax = std::fmax(gmax, G[(size_t)j * p + j]);
+  unsigned mask = detect ? 0u : preset;
+  *ok = std::isfinite(gmax) && gmax > 0;
+  for (int j = 0; j < p; ++j) {
+    for (int i = 0; i < p; ++i) Rhat[(size_t)j * p + i] = 0.0;
+    for (int i = 0; i <= j; ++i) {
+      if (i < j && ((mask >> i) & 1u)) continue;                       // row of a column left out: zero
+      double s = G[(size_t)j * p + i];
+      for (int l = 0; l < i; ++l)
+        if (!((mask >> l) & 1u)) s -= Rhat[(size_t)i * p + l] * Rhat[(size_t)j * p + l];
+      if (i < j) { Rhat[(size_t)j * p + i] = s / Rhat[(size_t)i * p + i]; continue; }
+      const bool vanishing = !(s > tol * tol * gmax) || !std::isfinite(s);
+      if ((mask >> j) & 1u) Rhat[(size_t)j * p + j] = 1.0;
+      else if (vanishing && detect) { mask |= 1u << j; Rhat[(size_t)j * p + j] = 1.0; }
+      else if (vanishing) { *ok = false; Rhat[(size_t)j * p + j] = 1.0; }
+      else Rhat[(size_t)j * p + j] = std::sqrt(s);
+    }
+  }
+  return mask;
+}
 void inv_upper(int p, const double *R, double *Ri) {   // Ri = R^-1, both upper, column-major
   for (int j = 0; j < p; ++j) {
     for (int i = 0; i < p; ++i) Ri[(size_t)j * p + i] = 0;
@@ -204,7 +232,17 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
   // SISC 2020): chol(G + s I) with s = 11 (n p + p (p + 1)) eps ||Q||^2 always exists and brings cond(Q) down to
   // ~eps^-1/2, after which the two ordinary rounds converge.  Everything touching the n x p panel stays on the
   // device; only p x p matrices visit the host, as in the reference (src/block_gmres.jl:250-283).
-  bool shifted_done = false;
+  // rows of the whole panel: the shift of the shifted pass and DLARFG's single-entry case depend on it, and every rank of a
+  // row-partitioned panel must apply the SAME factors to its rows
+  int64_t n_global_rows = n;
+  if (comm_nranks(ctx) > 1) {
+    double v = (double)n;
+    KHIP_TRY(comm_allreduce_sum_host(ctx, &v, 1));
+    n_global_rows = (int64_t)v;
+  }
+  bool shifted_done = false, deflated = false;
+  unsigned pending = 0;                   // columns to be replaced by stand-in directions after this round's scaling
+  double fill_scale = 0.0;
   bool have_G = false;                    // G of this round came out of the kernel that applied the previous R^-1
   const bool tsqr = ctx->tune.panel_qr_tsqr != 0;
   for (int pass = 0; pass < 2; ++pass) {
@@ -228,13 +266,31 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
         const double d = std::fabs(Rrow[(size_t)i * p + i]);
         dmax = std::fmax(dmax, d); dmin = std::fmin(dmin, d);
       }
-      if (!(dmin > 16.0 * (double)p * std::numeric_limits<double>::epsilon() * dmax) || !std::isfinite(dmax)) {
-        set_error("panel_qr: the block is numerically rank deficient (block_gmres! needs full column rank)");
-        return KHIP_ERR_NUMERIC;
+      const double thr = 16.0 * (double)p * std::numeric_limits<double>::epsilon() * dmax;
+      if (!(dmin > thr) || !std::isfinite(dmax)) {
+        // |R_jj| is the distance of column j from the span of the columns before it: those at rounding level are deflated as in
+        // the Cholesky path below (the factor that isolates their remainders comes from the Gram matrix of the other columns)
+        unsigned D = 0;
+        if (!deflated && std::isfinite(dmax) && dmax > 0)
+          for (int i = 0; i < p; ++i)
+            if (!(std::fabs(Rrow[(size_t)i * p + i]) > thr)) D |= 1u << i;
+        bool fac_ok = false;
+        if (D != 0u) {
+          KHIP_TRY(khip_panel_gemm_tn(ctx, n, p, Q, Q, G.data()));
+          (void)deflating_chol(p, G.data(), 0.0, false, D, R.data(), &fac_ok);
+        }
+        if (D == 0u || !fac_ok) {
+          set_error("panel_qr: the block is numerically rank deficient (block_gmres! needs full column rank)");
+          return KHIP_ERR_NUMERIC;
+        }
+        pending = D;
+        fill_scale = dmax / std::sqrt((double)(n_global_rows > 0 ? n_global_rows : 1));
       }
-      for (int i = 0; i < p; ++i) {                                        // row-major -> upper, column-major, positive diagonal
-        const double sgn = Rrow[(size_t)i * p + i] < 0 ? -1.0 : 1.0;
-        for (int j = 0; j < p; ++j) R[(size_t)j * p + i] = j >= i ? sgn * Rrow[(size_t)i * p + j] : 0.0;
+      if (pending == 0u) {
+        for (int i = 0; i < p; ++i) {                                      // row-major -> upper, column-major, positive diagonal
+          const double sgn = Rrow[(size_t)i * p + i] < 0 ? -1.0 : 1.0;
+          for (int j = 0; j < p; ++j) R[(size_t)j * p + i] = j >= i ? sgn * Rrow[(size_t)i * p + j] : 0.0;
+        }
       }
       have_G = false;
     }
@@ -246,18 +302,34 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
       for (int i = 0; i < p; ++i) { dmax = std::fmax(dmax, R[(size_t)i * p + i]); dmin = std::fmin(dmin, R[(size_t)i * p + i]); }
       if (!(dmin > 1e-7 * dmax)) ok = false;                             // cond(Q)^2 would exceed 1/eps
     }
-    if (!ok) {
-      if (shifted_done || pass != 0) {
+    if (!ok && (shifted_done || pass != 0)) {
+      // Still no factor after the shifted pass: some columns lie in the span of the columns before them (equal or dependent
+      // right-hand sides, a zero column, a block Krylov space that is exhausted in some directions).  The reference's
+      // Householder QR goes on with a zero on R's diagonal and whatever unit vectors its reflectors complete the basis with
+      // (src/block_gmres.jl:250-283 calls householder! on such blocks like on any other).  Same here: the columns D whose
+      // Cholesky pivots vanish are left out of the factor; this round's scaling Q <- Q Rhat^-1 turns them into their own
+      // remainders outside the span of the others (rounding dust), which are then replaced by fixed pseudo-random directions
+      // while rows D of the accumulated R are zeroed -- W = Q' (Z Racc) up to that dust -- and the rounds start over on Q'.
+      bool fac_ok = false;
+      const unsigned D = deflated ? 0u : deflating_chol(p, G.data(), 1e-7, true, 0u, R.data(), &fac_ok);
+      double gmax = 0.0;
+      for (int i = 0; i < p; ++i) gmax = std::fmax(gmax, G[(size_t)i * p + i]);
+      if (D == 0u || !fac_ok) {
         set_error("panel_qr: the block is numerically rank deficient (block_gmres! needs full column rank)");
         return KHIP_ERR_NUMERIC;
       }
+      pending = D;
+      fill_scale = std::sqrt(gmax / (double)(n_global_rows > 0 ? n_global_rows : 1));
+      ok = true;
+    }
+    if (!ok) {
       double tr = 0;
       for (int i = 0; i < p; ++i) tr += G[(size_t)i * p + i];             // ||Q||_F^2 >= ||Q||_2^2
       if (!(tr > 0) || !std::isfinite(tr)) {
         set_error("panel_qr: the block is zero or not finite");
         return KHIP_ERR_NUMERIC;
       }
-      const double shift = 11.0 * ((double)n * p + (double)p * (p + 1)) * std::numeric_limits<double>::epsilon() * tr;
+      const double shift = 11.0 * ((double)n_global_rows * p + (double)p * (p + 1)) * std::numeric_limits<double>::epsilon() * tr;
       for (int i = 0; i < p; ++i) G[(size_t)i * p + i] += shift;
       if (!chol_upper(p, G.data(), R.data())) {
         set_error("panel_qr: shifted Cholesky broke down");
@@ -267,17 +339,11 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
       pass = -1;                                                          // two ordinary rounds follow
     }
     inv_upper(p, R.data(), Ri.data());
-    if (pass == 1 && ctx->tune.panel_signs != 0) {
+    if (pass == 1 && ctx->tune.panel_signs != 0 && pending == 0u) {
       // last scaling: LAPACK's column signs from the top block of the result, Q1 = (top block of Q) R^-1, folded into R^-1.
       // Row-partitioned panels: the top block is rank 0's; the other ranks contribute zeros to the rank sum.
       std::vector<double> top(pp, 0.0), Q1(pp, 0.0);
       const int64_t have = n < p ? n : p;              // local rows of the top block
-      int64_t n_global_rows = n;
-      if (comm_nranks(ctx) > 1) {
-        double v = (double)n;
-        KHIP_TRY(comm_allreduce_sum_host(ctx, &v, 1));
-        n_global_rows = (int64_t)v;
-      }
       const bool mine = comm_nranks(ctx) == 1 || comm_rank_of(ctx) == 0;
       if (mine && have > 0) {
         KHIP_CHECK_HIP(hipMemcpyAsync(top.data(), Q, sizeof(double) * (size_t)have * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -295,7 +361,7 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
         if (S[j] < 0)
           for (int i = 0; i < p; ++i) Ri[(size_t)j * p + i] = -Ri[(size_t)j * p + i];
     }
-    if (pass == 0 && ctx->tune.panel_fuse != 0 && !tsqr) {
+    if (pass == 0 && ctx->tune.panel_fuse != 0 && !tsqr && pending == 0u) {
       // first ordinary round: Q <- Q R^-1 and the Gram matrix of the second round in one pass (same bits)
       KHIP_TRY(panel_scale_gram(ctx, n, p, Q, Ri.data(), G.data()));
       have_G = true;
@@ -304,6 +370,17 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
     }
     matmul_pp(p, R.data(), Racc.data(), tmp.data());                      // Racc <- R * Racc
     Racc = tmp;
+    if (pending != 0u) {
+      KHIP_TRY(panel_fill_columns(ctx, n, p, Q, pending, fill_scale, 0x6b68697051520000ull + (unsigned long long)comm_rank_of(ctx)));
+      for (int i = 0; i < p; ++i)
+        if ((pending >> i) & 1u)
+          for (int j = 0; j < p; ++j) Racc[(size_t)j * p + i] = 0.0;      // row i (column-major)
+      pending = 0u;
+      deflated = true;
+      shifted_done = false;
+      have_G = false;
+      pass = -1;                                                          // the rounds start over on the completed panel
+    }
   }
   memcpy(R_host, Racc.data(), sizeof(double) * pp);
   for (int j = 0; j < p; ++j)

@@ -645,6 +645,28 @@ int panel_tsqr_r_impl(khip_ctx *ctx, int64_t n, int p, const double *Q, double *
 }  // namespace
 
 namespace khip {
+// Columns `mask` of the n x p row-major panel <- scale * u(row, column), u a fixed hash into [-1, 1): the stand-in directions
+// of khip_panel_qr_tau for columns that lie in the span of the columns before them (what LAPACK's reflectors complete the
+// basis with is just as arbitrary).  Rows past n (the panel's padding) stay as they are.
+__global__ __launch_bounds__(kBlock) void panel_fill_columns_kernel(int64_t n, int p, double *Q, unsigned mask, double scale,
+                                                                    unsigned long long seed) {
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n * p) return;
+  const int c = (int)(idx % p);
+  if (!((mask >> c) & 1u)) return;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(idx + 1);       // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  Q[idx] = scale * ((double)(long long)(z >> 11) * (1.0 / 4503599627370496.0) - 1.0);         // 53 bits -> [-1, 1)
+}
+int panel_fill_columns(khip_ctx *ctx, int64_t n, int p, double *Q, unsigned mask, double scale, unsigned long long seed) {
+  if (n <= 0 || mask == 0) return KHIP_OK;
+  const int64_t blocks = (n * p + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(panel_fill_columns_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, n, p, Q, mask, scale, seed);
+  KHIP_CHECK_HIP(hipGetLastError());
+  return KHIP_OK;
+}
 int panel_tsqr_r(khip_ctx *ctx, int64_t n, int p, const double *Q, double *R_host_rowmajor) {
   return panel_tsqr_r_impl(ctx, n, p, Q, R_host_rowmajor);
 }

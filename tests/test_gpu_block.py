@@ -165,6 +165,65 @@ def test_panel_qr_rank_deficient_block(K, ctx):
         K.panel_qr_(K.Panel.from_host(ctx, np.zeros((64, 3))))
 
 
+@pytest.mark.parametrize("tsqr", [0, 1])
+def test_panel_qr_dependent_columns_get_stand_in_directions(K, ctx, tsqr):
+    """Tall panels whose dependent columns survive even the shifted pass (its shift grows with n): an equal column, a linear
+    combination, a zero column.  As with LAPACK's Householder QR (src/block_gmres.jl:250-283 calls householder! on whatever
+    block it gets) the factorisation goes on: A = Q R, Q orthonormal, R upper triangular with a zero where the dependent
+    column is, and a unit vector in Q there."""
+    rng = np.random.default_rng(41)
+    n, p = 200_000, 8
+    A = rng.standard_normal((n, p))
+    A[:, 3] = A[:, 1]
+    A[:, 5] = 2.0 * A[:, 0] - 0.5 * A[:, 2]
+    A[:, 6] = 0.0
+    ctx.set_option("panel_qr_tsqr", tsqr)
+    try:
+        dQ = K.Panel.from_host(ctx, A)
+        R = K.panel_qr_(dQ)
+        Qh = dQ.to_host()
+    finally:
+        ctx.set_option("panel_qr_tsqr", 0)
+    assert np.allclose(np.tril(R, -1), 0)
+    assert np.max(np.abs(Qh.T @ Qh - np.eye(p))) <= 1e-10
+    assert np.max(np.abs(Qh @ R - A)) <= 1e-9 * np.sqrt(n)
+    d = np.abs(np.diag(R))
+    assert np.all(d[[3, 5, 6]] <= 1e-6 * d[0]) and np.all(d[[0, 1, 2, 4, 7]] >= 1e-3 * d[0])
+
+
+@pytest.mark.parametrize("case", ["equal columns", "linear combination", "zero column", "equal + zero, memory 3"])
+def test_block_gmres_with_dependent_right_hand_sides(K, ctx, oracle, case):
+    """block_gmres! on right-hand sides without full column rank: the reference's Householder QR of the residual block does not
+    care and the solve converges (the oracle, which restates it, takes 20-24 iterations here).  Same on the device: solved, the
+    same status, an iteration count within 2 of the oracle's, true residuals as small as the oracle's."""
+    A = oracle.stencil27_unsym(10)
+    S = A.to_scipy()
+    n = A.n
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((n, 6))
+    memory = 5
+    if case == "equal columns":
+        B[:, 3] = B[:, 1]
+    elif case == "linear combination":
+        B[:, 5] = 2.0 * B[:, 0] - B[:, 2]
+    elif case == "zero column":
+        B[:, 4] = 0.0
+    else:
+        B[:, 3] = B[:, 1]
+        B[:, 5] = 0.0
+        memory = 3
+    ref = oracle.block_gmres(A, B, memory=memory, restart=True, rtol=1e-8, atol=0.0, history=True, itmax=200)
+    dA = K.CsrMatrix.from_host(ctx, A.rowptr, A.col, A.val, (n, n))
+    X, st, ws = K.block_gmres(dA, B, memory=memory, restart=True, rtol=1e-8, atol=0.0, history=True, itmax=200)
+    Xh = np.asarray(X)
+    assert st.solved and ref.solved and st.status == ref.status
+    assert abs(st.niter - ref.niter) <= 2, (st.niter, ref.niter)
+    res_gpu = np.linalg.norm(B - S @ Xh, axis=0).max()
+    res_ref = np.linalg.norm(B - S @ ref.x, axis=0).max()
+    assert res_gpu <= 10.0 * res_ref + 1e-12, (res_gpu, res_ref)
+    assert np.max(np.abs(Xh - ref.x)) <= 1e-5 * np.max(np.abs(ref.x))
+
+
 def test_spmm_panel(K, ctx, oracle):
     A = oracle.stencil27_unsym(10)
     rng = np.random.default_rng(5)

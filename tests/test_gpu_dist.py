@@ -197,6 +197,66 @@ def test_distributed_block_gmres_local_ranks(K, oracle):
         assert np.array_equal(out["hist"], res[0]["hist"])            # identical on every rank
 
 
+@pytest.mark.parametrize("kind", ["ill-conditioned", "dependent"])
+def test_distributed_panel_qr_same_factors_on_all_ranks(K, kind):
+    """The panel QR on unequal row slabs (333 / 333 / 334 rows) when it leaves the plain CholeskyQR2 route: the shifted pass
+    (a column 1e-9 away from another) and the deflation of dependent columns.  Every rank must apply the same p x p factors
+    to its rows -- the shift depends on the row count of the WHOLE panel: R identical on the ranks, the stacked Q orthonormal,
+    Q R = A."""
+    world, n, p = 3, 1000, 6
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((n, p))
+    if kind == "ill-conditioned":
+        A[:, 5] = A[:, 0] + 1e-9 * rng.standard_normal(n)
+    else:
+        A = np.repeat(A, 300, axis=0)[: 300 * n]              # tall enough for the shifted pass to flatten the dependent columns
+        A = A + 0.0
+        A[:, 4] = A[:, 1]
+        A[:, 2] = 0.0
+    starts = K.row_partition(A.shape[0], world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        Q = K.Panel.from_host(c, A[r0:r1])
+        R = K.panel_qr_(Q)
+        return dict(R=R, Q=Q.to_host())
+
+    res = _run_ranks(K, world, 31337, body)
+    for out in res[1:]:
+        assert np.array_equal(out["R"], res[0]["R"])
+    Qs, R = np.concatenate([o["Q"] for o in res], axis=0), res[0]["R"]
+    assert np.max(np.abs(Qs.T @ Qs - np.eye(p))) <= 1e-9
+    assert np.max(np.abs(Qs @ R - A)) <= 1e-9 * np.sqrt(A.shape[0])
+
+
+def test_distributed_block_gmres_with_dependent_right_hand_sides(K, oracle):
+    """The deflating panel QR on row slabs: an equal and a zero right-hand side column, 3 ranks.  The Gram matrices are
+    rank-summed, so every rank deflates the same columns; solved, the oracle's status, an iteration count within 2 of the
+    oracle's global solve, identical histories on the ranks."""
+    n1, world = 10, 3
+    A_cpu = oracle.stencil27_unsym(n1)
+    n = A_cpu.n
+    S = A_cpu.to_scipy()
+    B = np.random.default_rng(0).standard_normal((n, 6))
+    B[:, 3] = B[:, 1]
+    B[:, 5] = 0.0
+    ref = oracle.block_gmres(A_cpu, B, memory=3, restart=True, rtol=1e-8, atol=0.0, history=True, itmax=200)
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = K.CsrMatrix.stencil(c, "stencil27", n1, rows=(r0, r1), distributed=True)
+        X, st, _ = K.block_gmres(A, B[r0:r1], memory=3, restart=True, rtol=1e-8, atol=0.0, history=True, itmax=200, ctx=c)
+        return dict(X=np.asarray(X), niter=st.niter, solved=st.solved, hist=st.residuals.copy(), status=st.status)
+
+    res = _run_ranks(K, world, 424242, body)
+    X = np.concatenate([out["X"] for out in res], axis=0)
+    for out in res:
+        assert out["solved"] and out["status"] == ref.status and abs(out["niter"] - ref.niter) <= 2, (out["niter"], ref.niter)
+        assert np.array_equal(out["hist"], res[0]["hist"])
+    assert np.linalg.norm(B - S @ X, axis=0).max() <= 10.0 * np.linalg.norm(B - S @ ref.x, axis=0).max() + 1e-12
+
+
 def test_distributed_krylov_processes_local_ranks(K, oracle):
     """arnoldi / hermitian_lanczos on a row-partitioned operator (3 in-process ranks): every rank gets the same H / T
     as the oracle's serial run, and the row slabs of V stack to the oracle's basis."""
