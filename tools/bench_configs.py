@@ -100,5 +100,6 @@ M = np.eye(p) * 1e-3
 tt = timeit(lambda: K.panel_gemm_nn_(-1.0, V, M, 1.0, Q)); emit(kernel="panel_gemm_nn", ms=tt * 1e3, gbps=3 * panel / tt / 1e9)
 Y = K.Panel(ctx, n, p)
 tt = timeit(lambda: K.spmm_(A, V, Y)); emit(kernel="spmm p=16", ms=tt * 1e3, gbps=(12 * A.nnz + 4 * n + 2 * panel) / tt / 1e9)
-tt = timeit(lambda: K.panel_qr_(Q), reps=3); emit(kernel="panel_qr (CholQR2)", ms=tt * 1e3, gbps=(2 * 2 * panel + 2 * 2 * panel) / tt / 1e9)
+tt = timeit(lambda: K.panel_qr_(Q), reps=3); emit(kernel="panel_qr (CholQR2)", ms=tt * 1e3, gbps=5 * panel / tt / 1e9,
+                                                           bytes_note="5 panel passes: Gram | scale + Gram fused (read, write) | scale (read, write)")
 ctx.close()
