@@ -220,7 +220,12 @@ extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double 
   return khip_panel_qr_tau(ctx, n, p, Q, R_host, nullptr);
 }
 
+static int panel_qr_tau_impl(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host, double *tau_host, const double *G0);
 extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host, double *tau_host) {
+  return panel_qr_tau_impl(ctx, n, p, Q, R_host, tau_host, nullptr);
+}
+// G0: the Gram matrix Q^T Q of the panel as it comes in, when the caller already has it (khip::panel_mgs_gram), else null
+static int panel_qr_tau_impl(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host, double *tau_host, const double *G0) {
   KHIP_REQUIRE(ctx && Q && R_host && p >= 1 && p <= 32, "panel_qr: bad argument (1 <= p <= 32)");
   const size_t pp = (size_t)p * p;
   std::vector<double> S((size_t)p, 1.0), tauv((size_t)p, 0.0);
@@ -243,8 +248,9 @@ extern "C" int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, dou
   bool shifted_done = false, deflated = false;
   unsigned pending = 0;                   // columns to be replaced by stand-in directions after this round's scaling
   double fill_scale = 0.0;
-  bool have_G = false;                    // G of this round came out of the kernel that applied the previous R^-1
+  bool have_G = false;                    // G of this round came out of the kernel that applied the previous R^-1 (or of the caller's sweep)
   const bool tsqr = ctx->tune.panel_qr_tsqr != 0;
+  if (G0 && !tsqr) { memcpy(G.data(), G0, sizeof(double) * pp); have_G = true; }
   for (int pass = 0; pass < 2; ++pass) {
     if (tsqr) {
       // R by TSQR (panel.hip: block Householder QRs out of LDS, tree of triangles) instead of chol(Q'Q): backward
@@ -403,6 +409,7 @@ struct khip_block_gmres_workspace {
   std::vector<double *> V;
   std::vector<std::vector<double>> Z, R, H, tau;               // host p x p, p x p, 2p x p, p
   std::vector<double> C, D;                                    // host p x p, 2p x p (src/block_krylov_workspaces.jl:126-127)
+  std::vector<double> gram;                                    // p x p: Gram matrix of the swept panel, from the sweep's last pass
   std::vector<double> sweep, Yall, tmp;                        // staging of the fused sweeps: mem p x p each (grown with the basis), p x p
   std::vector<const double *> Vp;
   bool warm_start = false;
@@ -536,7 +543,8 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   double *dX = ws->dX, *X = ws->X, *W = ws->W, *Bp = ws->Bp;
   std::vector<double *> &V = ws->V;
   auto &Z = ws->Z; auto &R = ws->R; auto &H = ws->H; auto &tau = ws->tau;
-  std::vector<double> &C = ws->C, &D = ws->D, &sweep = ws->sweep;      // in-place solve: no allocation per call (test/test_allocations.jl:752)
+  std::vector<double> &C = ws->C, &D = ws->D, &sweep = ws->sweep, &gram = ws->gram;      // in-place solve: no allocation per call (test/test_allocations.jl:752)
+  bool have_gram = false;
   const bool warm_start = ws->warm_start;
   ws->box.reset();
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
@@ -627,16 +635,19 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
         for (int i = 0; i < inner_iter; ++i) Vp[i] = V[i];
         if (sweep.size() < (size_t)inner_iter * pp) sweep.resize((size_t)inner_iter * pp);
         std::fill(sweep.begin(), sweep.begin() + (size_t)inner_iter * pp, 0.0);
-        KB(khip_panel_mgs(ctx, n, p, inner_iter, Vp.data(), Q, sweep.data(), 0));
+        // the LAST sweep also returns the Gram matrix of the swept panel (same pass as its last update): the QR's first round
+        const bool gram_wanted = ctx->tune.panel_qr_tsqr == 0;
+        if (gram.size() < pp) gram.resize(pp);
+        KB(khip::panel_mgs_gram(ctx, n, p, inner_iter, Vp.data(), Q, sweep.data(), 0, (gram_wanted && !reorth) ? gram.data() : nullptr, &have_gram));
         for (int i = 0; i < inner_iter; ++i) std::copy(sweep.begin() + (size_t)i * pp, sweep.begin() + (size_t)(i + 1) * pp, R[nr + i].begin());
         if (reorth) {
-          KB(khip_panel_mgs(ctx, n, p, inner_iter, Vp.data(), Q, sweep.data(), 0));
+          KB(khip::panel_mgs_gram(ctx, n, p, inner_iter, Vp.data(), Q, sweep.data(), 0, gram_wanted ? gram.data() : nullptr, &have_gram));
           for (int i = 0; i < inner_iter; ++i)
             for (size_t l = 0; l < pp; ++l) R[nr + i][l] += sweep[(size_t)i * pp + l];
         }
       }
 
-      KB(khip_panel_qr(ctx, n, p, Q, C.data()));                                   // :259 householder!(Q, C, ..)
+      KB(panel_qr_tau_impl(ctx, n, p, Q, C.data(), nullptr, have_gram ? gram.data() : nullptr));   // :259 householder!(Q, C, ..)
 
       for (int i = 0; i < inner_iter - 1; ++i) {                                   // :263-269
         for (int j = 0; j < p; ++j)

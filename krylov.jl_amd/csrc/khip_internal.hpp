@@ -292,6 +292,8 @@ int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
                    double *X);   // panel.hip
 int panel_tsqr_r(khip_ctx *ctx, int64_t n, int p, const double *Q, double *R_host_rowmajor);   // panel.hip: R factor by TSQR
 int panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const double *Ri_host, double *G_host);   // panel.hip
+int panel_mgs_gram(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, double *Q, double *Psi_host, int accumulate,
+                   double *G_host, bool *have_gram);   // panel.hip: khip_panel_mgs that also returns Q^T Q of the swept panel
 int panel_fill_columns(khip_ctx *ctx, int64_t n, int p, double *Q, unsigned mask, double scale, unsigned long long seed);   // panel.hip
 
 // api.cpp: the MGS cascade of khip_mgs in two halves (enqueue: launches only; the k coefficients and ||q||^2 end up in

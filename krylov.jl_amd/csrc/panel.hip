@@ -854,9 +854,21 @@ extern "C" {
 // applied, which goes through the host: the two-kernel sequence per step.  Either way the same bits.
 int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, double *Q, double *Psi_host,
                    int accumulate) {
+  return khip::panel_mgs_gram(ctx, n, p, k, V_host, Q, Psi_host, accumulate, nullptr, nullptr);
+}
+}  // extern "C"
+
+// The sweep, and on request the Gram matrix G = Q^T Q of the swept panel with it: the last update Q -= V_k Psi_k and G come out
+// of one pass (the SELF form of panel_nn_tn_kernel, as in panel_scale_gram), so the CholeskyQR that follows in block_gmres!
+// (src/block_gmres.jl:259) starts without its own pass over the panel.  Same bits as khip_panel_gemm_tn(Q, Q) after the sweep.
+// *have_gram says whether G_host was filled (single GPU, fused sweeps only).
+int khip::panel_mgs_gram(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, double *Q, double *Psi_host,
+                         int accumulate, double *G_host, bool *have_gram) {
   KHIP_REQUIRE(ctx && Q && p >= 1 && p <= 32 && k >= 0 && (k == 0 || (V_host && Psi_host)), "panel_mgs: bad argument (1 <= p <= 32)");
+  if (have_gram) *have_gram = false;
   const size_t pp = (size_t)p * p;
-  const bool fuse = ctx->tune.panel_fuse != 0 && comm_nranks(ctx) == 1 && k >= 1 && k + 1 < kPsiSlots;   // Psi_i lives in slot i + 1 of the ring (one spare)
+  const bool fuse = ctx->tune.panel_fuse != 0 && comm_nranks(ctx) == 1 && k >= 1 && k + 2 < kPsiSlots;   // Psi_i lives in slot i + 1 of the ring, G in slot k + 1
+  const bool want_gram = fuse && G_host != nullptr && have_gram != nullptr;
   if (!fuse) {
     std::vector<double> psi(pp);
     for (int i = 0; i < k; ++i) {
@@ -880,21 +892,33 @@ int khip_panel_mgs(khip_ctx *ctx, int64_t n, int p, int k, const double *const *
       if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
       else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
       tn_reduce(ctx, t, p, psi_n);
+    } else if (tiles > 0 && want_gram) {
+      double *psi_g = g_ps.psi_dev + (size_t)(k + 1) * 1024;
+      const int flags = (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0);
+      if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, nullptr, Q, g_ps.partials, flags);
+      else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, nullptr, Q, g_ps.partials, flags);
+      tn_reduce(ctx, t, p, psi_g);
     } else if (tiles > 0) {
       launch_gemm_nn(ctx, np, p, -1.0, V_host[i], psi_i, 1.0, Q);
     }
   }
   KHIP_CHECK_HIP(hipGetLastError());
-  KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned + 1024, g_ps.psi_dev + 1024, sizeof(double) * 1024 * (size_t)k, hipMemcpyDeviceToHost, ctx->stream));
+  const int nslots = k + ((want_gram && tiles > 0) ? 1 : 0);
+  KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned + 1024, g_ps.psi_dev + 1024, sizeof(double) * 1024 * (size_t)nslots, hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < k; ++i) {
     const double *src = g_ps.psi_pinned + (size_t)(i + 1) * 1024;
     double *dst = Psi_host + (size_t)i * pp;
     for (size_t l = 0; l < pp; ++l) dst[l] = accumulate ? dst[l] + src[l] : src[l];
   }
-  g_ps.next_slot = k + 1;
+  if (want_gram && tiles > 0) {
+    memcpy(G_host, g_ps.psi_pinned + (size_t)(k + 1) * 1024, sizeof(double) * pp);
+    *have_gram = true;
+  }
+  g_ps.next_slot = nslots + 1;
   return KHIP_OK;
 }
+extern "C" {
 
 int khip_panel_gemm_nn(khip_ctx *ctx, int64_t n, int p, double alpha, const double *V, const double *Psi_host, double beta,
                        double *Q) {
