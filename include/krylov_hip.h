@@ -337,6 +337,17 @@ int khip_ilu0_block_info(const khip_operator *op, int64_t *dims3, int64_t *block
  * largest row, rows of the largest block rounded up to the wave. */
 int khip_test_ilu_blocks_host(int64_t n, const int64_t *rowptr, const int32_t *col, int mode, int64_t *out10);
 
+/* test-only, host-only: the p x p host steps of khip_panel_qr (no device).  deflating_chol: G = Gram matrix (column-major); detect
+ * != 0: columns whose Cholesky pivot is <= tol^2 max_j G_jj are left out of the factor and returned as a bit mask, else the
+ * columns `preset` are; Rhat (column-major, upper) = the factor of the other columns with R_jj = 1 and a zero row for those left
+ * out; *ok = 0 when a column that is not left out has a vanishing pivot.  householder_r: R (row-major, upper) of a rows x p
+ * row-major matrix by unblocked Householder QR (the last TSQR level across ranks); A is overwritten.
+ * householder_signs: LAPACK's column signs S and tau of the Householder QR of an n x p panel with orthonormal columns from its
+ * top p x p block Q1 (row-major; overwritten). */
+int khip_test_deflating_chol(int p, const double *G, double tol, int detect, unsigned preset, double *Rhat, int *ok, unsigned *mask);
+int khip_test_householder_r(int rows, int p, double *A, double *R);
+int khip_test_householder_signs(int p, int64_t n, double *Q1, double *S, double *tau);
+
 typedef int (*khip_callback_fn)(void *workspace, void *userdata);       /* callback(workspace)::Bool */
 
 typedef struct {

@@ -216,6 +216,24 @@ struct StatsBoxB {
 
 }  // namespace
 
+extern "C" int khip_test_deflating_chol(int p, const double *G, double tol, int detect, unsigned preset, double *Rhat, int *ok, unsigned *mask) {
+  KHIP_REQUIRE(p >= 1 && p <= 32 && G && Rhat && ok && mask, "test_deflating_chol: bad argument");
+  bool good = false;
+  *mask = deflating_chol(p, G, tol, detect != 0, preset, Rhat, &good);
+  *ok = good ? 1 : 0;
+  return KHIP_OK;
+}
+extern "C" int khip_test_householder_r(int rows, int p, double *A, double *R) {
+  KHIP_REQUIRE(rows >= 1 && p >= 1 && A && R, "test_householder_r: bad argument");
+  householder_r_host(rows, p, A, R);
+  return KHIP_OK;
+}
+extern "C" int khip_test_householder_signs(int p, int64_t n, double *Q1, double *S, double *tau) {
+  KHIP_REQUIRE(p >= 1 && n >= 1 && Q1 && S && tau, "test_householder_signs: bad argument");
+  householder_signs(p, n, Q1, S, tau);
+  return KHIP_OK;
+}
+
 extern "C" int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host) {
   return khip_panel_qr_tau(ctx, n, p, Q, R_host, nullptr);
 }

@@ -197,7 +197,7 @@ def test_distributed_block_gmres_local_ranks(K, oracle):
         assert np.array_equal(out["hist"], res[0]["hist"])            # identical on every rank
 
 
-@pytest.mark.parametrize("kind", ["ill-conditioned", "dependent"])
+@pytest.mark.parametrize("kind", ["ill-conditioned", "dependent", "tsqr", "tsqr dependent"])
 def test_distributed_panel_qr_same_factors_on_all_ranks(K, kind):
     """The panel QR on unequal row slabs (333 / 333 / 334 rows) when it leaves the plain CholeskyQR2 route: the shifted pass
     (a column 1e-9 away from another) and the deflation of dependent columns.  Every rank must apply the same p x p factors
@@ -206,7 +206,7 @@ def test_distributed_panel_qr_same_factors_on_all_ranks(K, kind):
     world, n, p = 3, 1000, 6
     rng = np.random.default_rng(8)
     A = rng.standard_normal((n, p))
-    if kind == "ill-conditioned":
+    if kind in ("ill-conditioned", "tsqr"):                   # "tsqr...": R by TSQR, one triangle per rank, finished on the host
         A[:, 5] = A[:, 0] + 1e-9 * rng.standard_normal(n)
     else:
         A = np.repeat(A, 300, axis=0)[: 300 * n]              # tall enough for the shifted pass to flatten the dependent columns
@@ -218,6 +218,7 @@ def test_distributed_panel_qr_same_factors_on_all_ranks(K, kind):
     def body(c, rank):
         r0, r1 = starts[rank], starts[rank + 1]
         Q = K.Panel.from_host(c, A[r0:r1])
+        c.set_option("panel_qr_tsqr", 1 if kind.startswith("tsqr") else 0)
         R = K.panel_qr_(Q)
         return dict(R=R, Q=Q.to_host())
 
