@@ -261,7 +261,10 @@ int khip_panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *co
  * :230-236, :254-262): Q overwritten by the orthonormal factor, R_host (p-by-p column-major, upper triangular) and
  * tau_host (p, may be null) with LAPACK's sign convention (R_jj = -sign(alpha_j) |x_j|, tau_j in [1, 2]).  Computed on the
  * device by CholeskyQR2 (shifted CholeskyQR3 for ill-conditioned blocks); the signs and tau come from the top p-by-p block
- * of Q (csrc/block.cpp).  ctx option "panel_signs" = 0 leaves the positive diagonal of the Cholesky factor. */
+ * of Q (csrc/block.cpp).  ctx option "panel_signs" = 0 leaves the positive diagonal of the Cholesky factor.  A block without
+ * full column rank (equal, dependent or zero columns) is factored as LAPACK factors it: A = Q R with orthonormal Q, zeros on
+ * R's diagonal where a column lies in the span of the columns before it and an arbitrary unit vector in Q there; only a
+ * block that is zero or not finite altogether is KHIP_ERR_NUMERIC. */
 int khip_panel_qr(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host);
 int khip_panel_qr_tau(khip_ctx *ctx, int64_t n, int p, double *Q, double *R_host, double *tau_host);
 int khip_panel_norm(khip_ctx *ctx, int64_t n, int p, const double *Q, double *result_host);

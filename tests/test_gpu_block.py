@@ -151,8 +151,8 @@ def test_panel_qr_ill_conditioned_takes_the_shifted_pass(K, ctx, eps_col):
 
 def test_panel_qr_rank_deficient_block(K, ctx):
     """An exactly dependent column behaves as with LAPACK's Householder QR: A = Q R still holds, the dependent
-    direction shows up as a (relatively) tiny diagonal entry of R and an arbitrary unit column of Q.  (block_gmres!
-    itself requires full column rank, docs/src/interfaces/reference.md:236.)  A zero block is an error."""
+    direction shows up as a (relatively) tiny diagonal entry of R and an arbitrary unit column of Q (here the shifted
+    pass alone copes; taller panels: test_panel_qr_dependent_columns_get_stand_in_directions).  A zero block is an error."""
     rng = np.random.default_rng(4)
     A = rng.standard_normal((300, 4))
     A[:, 3] = 2.0 * A[:, 1]
