@@ -453,7 +453,13 @@ int comm_transpose_dist(khip_ctx *ctx, const khip_csr *A, khip_csr **out) {
   std::vector<int64_t> recv_off((size_t)G + 1, 0);
   for (int r = 0; r < G; ++r) recv_off[(size_t)r + 1] = recv_off[(size_t)r] + all[(size_t)r * G + me];
   const int64_t nnzT = recv_off[(size_t)G];
-  if (nnzT >= (1ll << 31) - 64) { set_error("csr_transpose: the transposed shard has %lld entries (int32 row pointers)", (long long)nnzT); return KHIP_ERR_UNSUPPORTED; }
+  // every rank sees every rank's counts: a shard too large for int32 row pointers fails the call on ALL ranks, before the
+  // exchange (a rank leaving alone would leave the others in it for good)
+  for (int r = 0; r < G; ++r) {
+    int64_t tot = 0;
+    for (int q = 0; q < G; ++q) tot += all[(size_t)q * G + r];
+    if (tot >= (1ll << 31) - 64) { set_error("csr_transpose: the transposed shard of rank %d has %lld entries (int32 row pointers)", r, (long long)tot); return KHIP_ERR_UNSUPPORTED; }
+  }
   DevScratch scratch;
   char *d_send = nullptr, *d_recv = nullptr;
   KHIP_TRY(scratch.alloc(&d_send, sizeof(Trip) * (size_t)std::max<int64_t>(nnz, 1)));
@@ -468,7 +474,10 @@ int comm_transpose_dist(khip_ctx *ctx, const khip_csr *A, khip_csr **out) {
   std::vector<int64_t> rpT((size_t)m + 1, 0);
   for (const Trip &t : got) {
     const int64_t lr = (int64_t)t.col - row0;
-    if (lr < 0 || lr >= m) { set_error("csr_transpose: received an entry of column %d outside [%lld, %lld)", t.col, (long long)row0, (long long)(row0 + m)); return KHIP_ERR_INVALID; }
+    if (lr < 0 || lr >= m) {                                 // (internal) -- fail on all ranks through the next collective
+      set_error("csr_transpose: received an entry of column %d outside [%lld, %lld)", t.col, (long long)row0, (long long)(row0 + m));
+      return comm_build_plan(ctx, nullptr, KHIP_ERR_INVALID);
+    }
     rpT[(size_t)lr + 1]++;
   }
   for (int64_t i = 0; i < m; ++i) rpT[(size_t)i + 1] += rpT[(size_t)i];
