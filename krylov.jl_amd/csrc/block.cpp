@@ -257,11 +257,16 @@ static int panel_qr_tau_impl(khip_ctx *ctx, int64_t n, int p, double *Q, double 
   // device; only p x p matrices visit the host, as in the reference (src/block_gmres.jl:250-283).
   // rows of the whole panel: the shift of the shifted pass and DLARFG's single-entry case depend on it, and every rank of a
   // row-partitioned panel must apply the SAME factors to its rows
-  int64_t n_global_rows = n;
+  int64_t n_global_rows = n, row_offset = 0;          // row_offset: global number of this rank's first panel row
   if (comm_nranks(ctx) > 1) {
-    double v = (double)n;
-    KHIP_TRY(comm_allreduce_sum_host(ctx, &v, 1));
-    n_global_rows = (int64_t)v;
+    std::vector<double> counts((size_t)comm_nranks(ctx), 0.0);
+    counts[(size_t)comm_rank_of(ctx)] = (double)n;
+    KHIP_TRY(comm_allreduce_sum_host(ctx, counts.data(), (int)counts.size()));
+    n_global_rows = 0;
+    for (int r = 0; r < comm_nranks(ctx); ++r) {
+      if (r == comm_rank_of(ctx)) row_offset = n_global_rows;
+      n_global_rows += (int64_t)counts[(size_t)r];
+    }
   }
   bool shifted_done = false, deflated = false;
   unsigned pending = 0;                   // columns to be replaced by stand-in directions after this round's scaling
@@ -365,12 +370,13 @@ static int panel_qr_tau_impl(khip_ctx *ctx, int64_t n, int p, double *Q, double 
     inv_upper(p, R.data(), Ri.data());
     if (pass == 1 && ctx->tune.panel_signs != 0 && pending == 0u) {
       // last scaling: LAPACK's column signs from the top block of the result, Q1 = (top block of Q) R^-1, folded into R^-1.
-      // Row-partitioned panels: the top block is rank 0's; the other ranks contribute zeros to the rank sum.
+      // Row-partitioned panels: every rank contributes the rows of the top block it owns (normally all of them are rank 0's;
+      // a rank with fewer than p rows leaves the rest to its successors), zeros elsewhere, and the block is the rank sum.
       std::vector<double> top(pp, 0.0), Q1(pp, 0.0);
-      const int64_t have = n < p ? n : p;              // local rows of the top block
-      const bool mine = comm_nranks(ctx) == 1 || comm_rank_of(ctx) == 0;
-      if (mine && have > 0) {
-        KHIP_CHECK_HIP(hipMemcpyAsync(top.data(), Q, sizeof(double) * (size_t)have * p, hipMemcpyDeviceToHost, ctx->stream));
+      const int64_t first = row_offset < p ? row_offset : p;                              // global rows [first, first + have) of the top block
+      const int64_t have = row_offset < p ? std::min<int64_t>(n, p - row_offset) : 0;
+      if (have > 0) {
+        KHIP_CHECK_HIP(hipMemcpyAsync(top.data() + (size_t)first * p, Q, sizeof(double) * (size_t)have * p, hipMemcpyDeviceToHost, ctx->stream));
         KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
       }
       if (comm_nranks(ctx) > 1) KHIP_TRY(comm_allreduce_sum_host(ctx, top.data(), (int)pp));

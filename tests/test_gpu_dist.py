@@ -230,6 +230,34 @@ def test_distributed_panel_qr_same_factors_on_all_ranks(K, kind):
     assert np.max(np.abs(Qs @ R - A)) <= 1e-9 * np.sqrt(A.shape[0])
 
 
+@pytest.mark.parametrize("n,p,world", [(20, 6, 4), (1000, 16, 3), (9, 4, 3)])
+def test_distributed_panel_qr_is_lapacks_also_when_rank0_owns_few_rows(K, n, p, world):
+    """householder!(Q, R, tau) on row slabs equals LAPACK's geqrf + orgqr without sign normalisation -- the signs and tau come
+    from the top p x p block of the panel, which spans several ranks when rank 0 owns fewer than p rows (20 rows over 4 ranks,
+    p = 6: rows 0-4 | 5 of rank 1)."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(7 * n + p)
+    A = rng.standard_normal((n, p)) @ (np.eye(p) + 0.3 * rng.standard_normal((p, p)))
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        Q = K.Panel.from_host(c, A[r0:r1])
+        R, tau = K.panel_qr_tau_(Q)
+        return dict(R=R, tau=tau, Q=Q.to_host())
+
+    res = _run_ranks(K, world, 5150 + n, body)
+    (_, tau_l), _ = sl.qr(A, mode="raw")
+    Ql, Rl = sl.qr(A, mode="economic")
+    Qs = np.concatenate([o["Q"] for o in res], axis=0)
+    for o in res:
+        assert np.array_equal(o["R"], res[0]["R"]) and np.array_equal(o["tau"], res[0]["tau"])
+    R, tau = res[0]["R"], res[0]["tau"]
+    assert np.array_equal(np.sign(np.diag(R)), np.sign(np.diag(Rl)))
+    assert np.allclose(Qs, Ql, atol=1e-10) and np.allclose(R, Rl, atol=1e-10 * np.abs(Rl).max())
+    assert np.allclose(tau, tau_l, atol=1e-10)
+
+
 def test_distributed_block_gmres_with_dependent_right_hand_sides(K, oracle):
     """The deflating panel QR on row slabs: an equal and a zero right-hand side column, 3 ranks.  The Gram matrices are
     rank-summed, so every rank deflates the same columns; solved, the oracle's status, an iteration count within 2 of the
