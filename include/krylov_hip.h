@@ -340,6 +340,10 @@ int khip_ilu0_block_info(const khip_operator *op, int64_t *dims3, int64_t *block
  * largest row, rows of the largest block rounded up to the wave. */
 int khip_test_ilu_blocks_host(int64_t n, const int64_t *rowptr, const int32_t *col, int mode, int64_t *out10);
 
+/* test-only, host-only: the rows [row0, row0 + m) of khip_gen_banded_random into host arrays (no device): rowptr_out has m + 1
+ * entries; col_out / val_out may be null on a first call that only asks for the row pointers and *nnz_out. */
+int khip_test_gen_banded_random_host(int64_t n, int half_band, int links, uint64_t seed, int flags, int dense_rows, int64_t row0,
+                                     int64_t m, int32_t *rowptr_out, int32_t *col_out, double *val_out, int64_t *nnz_out);
 /* test-only, host-only: the p x p host steps of khip_panel_qr (no device).  deflating_chol: G = Gram matrix (column-major); detect
  * != 0: columns whose Cholesky pivot is <= tol^2 max_j G_jj are left out of the factor and returned as a bit mask, else the
  * columns `preset` are; Rhat (column-major, upper) = the factor of the other columns with R_jj = 1 and a zero row for those left

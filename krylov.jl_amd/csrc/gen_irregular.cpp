@@ -157,10 +157,9 @@ void parallel_rows(int64_t m, F f) {
 
 using namespace khip;
 
-extern "C" int khip_gen_banded_random(khip_ctx *ctx, int64_t n, int half_band, int links, uint64_t seed, int flags, int dense_rows,
-                                      int64_t row0, int64_t m, int32_t **rowptr_dev, int32_t **col_dev, double **val_dev,
-                                      int64_t *nnz_out) {
-  KHIP_REQUIRE(ctx && rowptr_dev && col_dev && val_dev && nnz_out, "gen_banded_random: null argument");
+// the rows [row0, row0 + m) of the operator in host memory (col / val padded by kPad zeros, as every CSR handle's arrays are)
+static int build_banded_random_host(int64_t n, int half_band, int links, uint64_t seed, int flags, int dense_rows, int64_t row0, int64_t m,
+                                    std::vector<int32_t> &rp32, std::vector<int32_t> &col, std::vector<double> &val, int64_t *nnz_out) {
   KHIP_REQUIRE(n >= 2 && n < (1ll << 31) && half_band >= 0 && half_band <= 64 && links >= 0 && links <= 16 && dense_rows >= 0 && dense_rows <= 64,
                "gen_banded_random: n in [2, 2^31), half_band <= 64, links <= 16, dense_rows <= 64 required");
   KHIP_REQUIRE(row0 >= 0 && m >= 0 && row0 + m <= n, "gen_banded_random: bad row range");
@@ -186,8 +185,9 @@ extern "C" int khip_gen_banded_random(khip_ctx *ctx, int64_t n, int half_band, i
   for (int64_t i = 0; i < m; ++i) rp[(size_t)i + 1] += rp[(size_t)i];
   const int64_t total = rp[(size_t)m];
   if (total >= (1ll << 31) - 64) { set_error("gen_banded_random: shard nnz %lld does not fit int32 row pointers", (long long)total); return KHIP_ERR_INVALID; }
-  std::vector<int32_t> rp32((size_t)m + 1), col((size_t)total + kPad, 0);
-  std::vector<double> val((size_t)total + kPad, 0.0);
+  rp32.assign((size_t)m + 1, 0);
+  col.assign((size_t)total + kPad, 0);
+  val.assign((size_t)total + kPad, 0.0);
   for (int64_t i = 0; i <= m; ++i) rp32[(size_t)i] = (int32_t)rp[(size_t)i];
   parallel_rows(m, [&](int64_t lo, int64_t hi) {
     std::vector<int32_t> c; std::vector<double> v;
@@ -197,6 +197,18 @@ extern "C" int khip_gen_banded_random(khip_ctx *ctx, int64_t n, int half_band, i
       std::copy(v.begin(), v.end(), val.begin() + rp[(size_t)i]);
     }
   });
+  *nnz_out = total;
+  return KHIP_OK;
+}
+
+extern "C" int khip_gen_banded_random(khip_ctx *ctx, int64_t n, int half_band, int links, uint64_t seed, int flags, int dense_rows,
+                                      int64_t row0, int64_t m, int32_t **rowptr_dev, int32_t **col_dev, double **val_dev,
+                                      int64_t *nnz_out) {
+  KHIP_REQUIRE(ctx && rowptr_dev && col_dev && val_dev && nnz_out, "gen_banded_random: null argument");
+  std::vector<int32_t> rp32, col;
+  std::vector<double> val;
+  int64_t total = 0;
+  KHIP_TRY(build_banded_random_host(n, half_band, links, seed, flags, dense_rows, row0, m, rp32, col, val, &total));
   KHIP_CHECK_HIP(hipSetDevice(ctx->device));
   int32_t *d_rp = nullptr, *d_cl = nullptr;
   double *d_vl = nullptr;
@@ -207,5 +219,21 @@ extern "C" int khip_gen_banded_random(khip_ctx *ctx, int64_t n, int half_band, i
   KHIP_CHECK_HIP(hipMemcpy(d_cl, col.data(), sizeof(int32_t) * (size_t)(total + kPad), hipMemcpyHostToDevice));
   KHIP_CHECK_HIP(hipMemcpy(d_vl, val.data(), sizeof(double) * (size_t)(total + kPad), hipMemcpyHostToDevice));
   *rowptr_dev = d_rp; *col_dev = d_cl; *val_dev = d_vl; *nnz_out = total;
+  return KHIP_OK;
+}
+
+// test-only, host-only: the same rows into caller-provided host arrays (no device).  Call with col_out = val_out = null to get
+// the row pointers (m + 1 entries) and the entry count, then with arrays of that size.
+extern "C" int khip_test_gen_banded_random_host(int64_t n, int half_band, int links, uint64_t seed, int flags, int dense_rows, int64_t row0,
+                                                int64_t m, int32_t *rowptr_out, int32_t *col_out, double *val_out, int64_t *nnz_out) {
+  KHIP_REQUIRE(rowptr_out && nnz_out, "test_gen_banded_random_host: null argument");
+  std::vector<int32_t> rp32, col;
+  std::vector<double> val;
+  int64_t total = 0;
+  KHIP_TRY(build_banded_random_host(n, half_band, links, seed, flags, dense_rows, row0, m, rp32, col, val, &total));
+  std::copy(rp32.begin(), rp32.end(), rowptr_out);
+  if (col_out) std::copy(col.begin(), col.begin() + total, col_out);
+  if (val_out) std::copy(val.begin(), val.begin() + total, val_out);
+  *nnz_out = total;
   return KHIP_OK;
 }

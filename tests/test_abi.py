@@ -296,3 +296,26 @@ def test_integration_md_ccalls_match_header():
             else:
                 ok = ct in want
             assert ok, f"{sym}: argument {pos + 1} is {jt} in the ccall but `{ct}` in the header"
+
+
+@pytest.mark.parametrize("n,half_band,links,seed,unsym,dense_rows", [(20000, 13, 3, 3, False, 0), (70001, 13, 3, 5, True, 4),
+                                                                    (5000, 4, 1, 9, False, 2), (1 << 15, 20, 5, 2, True, 0)])
+def test_products_irregular_generator_equals_the_oracles_on_the_host(K, oracle, n, half_band, links, seed, unsym, dense_rows):
+    """khip_gen_banded_random's host build (csrc/gen_irregular.cpp, through the host-only test export) against the oracle's
+    independent restatement of the definition (oracle/krylov_oracle.c ko_csr_banded_random): row pointers, columns and values
+    equal entry for entry -- for the whole operator and for a row slab as a rank of a partition would ask for it."""
+    L = K.lib()
+    A = oracle.banded_random(n, half_band=half_band, links=links, seed=seed, unsym=unsym, dense_rows=dense_rows)
+    for r0, r1 in ((0, n), (n // 3, n // 3 + n // 5)):
+        m = r1 - r0
+        rp = np.zeros(m + 1, dtype=np.int32)
+        nnz = C.c_int64()
+        args = (n, half_band, links, seed, 1 if unsym else 0, dense_rows, r0, m)
+        assert L.khip_test_gen_banded_random_host(*args, rp.ctypes.data_as(C.POINTER(C.c_int32)), None, None, C.byref(nnz)) == 0
+        col, val = np.zeros(nnz.value, dtype=np.int32), np.zeros(nnz.value)
+        assert L.khip_test_gen_banded_random_host(*args, rp.ctypes.data_as(C.POINTER(C.c_int32)), col.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  val.ctypes.data_as(C.POINTER(C.c_double)), C.byref(nnz)) == 0
+        a, b = int(A.rowptr[r0]), int(A.rowptr[r1])
+        assert nnz.value == b - a
+        assert np.array_equal(rp, (np.asarray(A.rowptr[r0:r1 + 1]) - a).astype(np.int32))
+        assert np.array_equal(col, A.col[a:b]) and np.array_equal(val, A.val[a:b])
