@@ -354,6 +354,10 @@ int khip_test_gen_banded_random_host(int64_t n, int half_band, int links, uint64
 int khip_test_deflating_chol(int p, const double *G, double tol, int detect, unsigned preset, double *Rhat, int *ok, unsigned *mask);
 int khip_test_householder_r(int rows, int p, double *A, double *R);
 int khip_test_householder_signs(int p, int64_t n, double *Q1, double *S, double *tau);
+/* ... and the small dense routines block_gmres! runs on the host for its 2p x p blocks (column-major, LAPACK semantics): which = 0
+ * DGEQR2 (A m x n in place, tau), 1 DORG2R (first n columns of Q in place of DGEQR2's output), 2 DORM2R('L', 'T') on C (m x nc),
+ * 3 the inverse of an upper triangular n x n matrix into C. */
+int khip_test_small_dense(int which, int m, int n, int nc, double *A, double *tau, double *Cmat);
 
 typedef int (*khip_callback_fn)(void *workspace, void *userdata);       /* callback(workspace)::Bool */
 

@@ -183,6 +183,7 @@ SIGNATURES = {
     "khip_bicgstab_workspace_bytes": (_sz, [_vp]),
     "khip_block_gmres_workspace_bytes": (_sz, [_vp, C.POINTER(C.c_size_t)]),
     "khip_test_gen_banded_random_host": (_int, [_i64, _int, _int, C.c_uint64, _int, _int, _i64, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_double_p, C.POINTER(_i64)]),
+    "khip_test_small_dense": (_int, [_int, _int, _int, _int, c_double_p, c_double_p, c_double_p]),
     "khip_test_deflating_chol": (_int, [_int, c_double_p, C.c_double, _int, C.c_uint, c_double_p, C.POINTER(_int), C.POINTER(C.c_uint)]),
     "khip_test_householder_r": (_int, [_int, _int, c_double_p, c_double_p]),
     "khip_test_householder_signs": (_int, [_int, _i64, c_double_p, c_double_p, c_double_p]),

@@ -223,6 +223,18 @@ extern "C" int khip_test_deflating_chol(int p, const double *G, double tol, int 
   *ok = good ? 1 : 0;
   return KHIP_OK;
 }
+// which: 0 = geqr2 (A m x n column-major in place, tau), 1 = org2r (the first n columns of Q from geqr2's output, k = n),
+// 2 = orm2r_LT (C <- Q^T C with Q = the k = n reflectors in A; C is m x nc), 3 = inv_upper (A n x n upper -> C = A^-1)
+extern "C" int khip_test_small_dense(int which, int m, int n, int nc, double *A, double *tau, double *Cmat) {
+  KHIP_REQUIRE(m >= 1 && n >= 1 && A, "test_small_dense: bad argument");
+  switch (which) {
+    case 0: KHIP_REQUIRE(tau, "test_small_dense: tau"); geqr2(m, n, A, m, tau); return KHIP_OK;
+    case 1: KHIP_REQUIRE(tau && m >= n, "test_small_dense: tau"); org2r(m, n, n, A, m, tau); return KHIP_OK;
+    case 2: KHIP_REQUIRE(tau && Cmat && nc >= 1, "test_small_dense: C"); orm2r_LT(m, nc, n < m ? n : m, A, m, tau, Cmat, m); return KHIP_OK;
+    case 3: KHIP_REQUIRE(Cmat && m == n, "test_small_dense: C"); inv_upper(n, A, Cmat); return KHIP_OK;
+    default: set_error("test_small_dense: which = 0 .. 3"); return KHIP_ERR_INVALID;
+  }
+}
 extern "C" int khip_test_householder_r(int rows, int p, double *A, double *R) {
   KHIP_REQUIRE(rows >= 1 && p >= 1 && A && R, "test_householder_r: bad argument");
   householder_r_host(rows, p, A, R);

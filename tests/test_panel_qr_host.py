@@ -104,3 +104,30 @@ def test_householder_signs_and_tau_are_dgeqrfs(n, p):
     assert _lib().khip_test_householder_signs(p, n, _dp(Q1), _dp(S), _dp(tau)) == 0
     assert np.array_equal(S, np.sign(np.diag(R_l)) + (np.diag(R_l) == 0))
     assert np.allclose(tau, tau_l, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("m,n", [(32, 16), (8, 4), (64, 32), (2, 1), (6, 6)])
+def test_small_dense_routines_are_lapacks(m, n):
+    """DGEQR2 / DORG2R / DORM2R('L', 'T') and the triangular inverse as block_gmres! uses them on its 2p x p Hessenberg blocks
+    (src/block_gmres.jl:263-284 = householder!(H, R, tau; compact = true) and kormqr!('L', 'T', H, tau, D)): equal to LAPACK's
+    geqrf / orgqr / ormqr to rounding, same signs, same tau."""
+    rng = np.random.default_rng(100 * m + n)
+    A = rng.standard_normal((m, n))
+    L = _lib()
+    a = np.array(A, order="F")
+    tau = np.zeros(n)
+    assert L.khip_test_small_dense(0, m, n, 0, _dp(a), _dp(tau), None) == 0
+    (qr_l, tau_l), _ = sla.qr(A, mode="raw")
+    assert np.allclose(a, qr_l, rtol=1e-12, atol=1e-12) and np.allclose(tau, tau_l, rtol=1e-12, atol=1e-14)
+    Cm = rng.standard_normal((m, 5))
+    c = np.array(Cm, order="F")
+    assert L.khip_test_small_dense(2, m, n, 5, _dp(a), _dp(tau), _dp(c)) == 0
+    Qfull = sla.qr(A, mode="full")[0]
+    assert np.allclose(c, Qfull.T @ Cm, rtol=1e-11, atol=1e-12)
+    q = a.copy(order="F")
+    assert L.khip_test_small_dense(1, m, n, 0, _dp(q), _dp(tau), None) == 0
+    assert np.allclose(q, sla.qr(A, mode="economic")[0], rtol=1e-11, atol=1e-12)
+    U = np.triu(rng.standard_normal((n, n))) + 3.0 * np.eye(n)
+    u, ui = np.array(U, order="F"), np.zeros((n, n), order="F")
+    assert L.khip_test_small_dense(3, n, n, 0, _dp(u), None, _dp(ui)) == 0
+    assert np.allclose(ui, np.linalg.inv(U), rtol=1e-11, atol=1e-12) and np.allclose(np.tril(ui, -1), 0)
