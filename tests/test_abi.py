@@ -319,3 +319,42 @@ def test_products_irregular_generator_equals_the_oracles_on_the_host(K, oracle, 
         assert nnz.value == b - a
         assert np.array_equal(rp, (np.asarray(A.rowptr[r0:r1 + 1]) - a).astype(np.int32))
         assert np.array_equal(col, A.col[a:b]) and np.array_equal(val, A.val[a:b])
+
+
+REFERENCE_SRC = "/root/reference/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_SRC), reason="the reference tree is only present in the build container")
+def test_julia_glue_defines_what_the_reference_solvers_call():
+    """The drop-in promise of INTEGRATION.md, checked mechanically where the reference sources are at hand: every Krylov.k*
+    primitive that cg! / gmres! / bicgstab! call on the workspace's vector type (src/cg.jl, gmres.jl, bicgstab.jl) has a method for
+    HIPVector in the glue, and every operation block_gmres! applies to its matrix type (src/block_gmres.jl) has one for
+    HIPMatrix.  (ktypeof is defined for both; kdisplay is host-only bookkeeping and not a primitive of the vector type.)"""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    glue = "\n".join(re.findall(r"```julia\n(.*?)```", md, flags=re.S))
+    used = set()
+    for f in ("cg.jl", "gmres.jl", "bicgstab.jl"):
+        src = re.sub(r"#.*", "", open(os.path.join(REFERENCE_SRC, f)).read())
+        used |= set(re.findall(r"\b(k[a-z_]+!?)\(", src))
+    used -= {"kdisplay", "ktimer", "ktypeof"}
+    assert {"kdot", "knorm", "kaxpy!", "kaxpby!", "kcopy!", "kfill!", "kmul!", "kdivcopy!"} <= used, sorted(used)
+    for name in sorted(used):
+        pat = r"(?m)^\s*(?:function\s+)?(?:Krylov\.)?" + re.escape(name) + r"\((?:[^)]*HIPVector)"
+        assert re.search(pat, glue), f"no HIPVector method of {name} in INTEGRATION.md"
+    assert re.search(r"Krylov\.ktypeof\(::HIPVector\)", glue) and re.search(r"Krylov\.ktypeof\(::HIPMatrix\)", glue)
+    # block_gmres!: the calls made on SM objects
+    bsrc = re.sub(r"#.*", "", open(os.path.join(REFERENCE_SRC, "block_gmres.jl")).read())
+    wanted = {"mul!": r"LinearAlgebra\.mul!\(\w+::HIPMatrix", "copyto!": r"Base\.copyto!\(\w+::HIPMatrix", "fill!": r"Base\.fill!\(\w+::HIPMatrix",
+              "norm": r"LinearAlgebra\.norm\(\w+::HIPMatrix", "ldiv!": r"LinearAlgebra\.ldiv!\(\w+::UpperTriangular\{Float64,HIPMatrix\}",
+              "householder!": r"Krylov\.householder!\(\w+::HIPMatrix", "kormqr!": r"Krylov\.kormqr!\([^)]*::HIPMatrix", "view": r"Base\.view\(\w+::HIPMatrix"}
+    for call, pat in wanted.items():
+        assert re.search(r"\b" + re.escape(call) + r"\(", bsrc), f"{call} is not called by block_gmres.jl (test out of date)"
+        assert re.search(pat, glue), f"no HIPMatrix method of {call} in INTEGRATION.md"
+    # the three forms of mul! the solver uses: A * P, V' * Q, and the 5-argument update
+    assert re.search(r"mul!\(\w+::HIPMatrix, \w+::HIPCsr, \w+::HIPMatrix\)", glue)
+    assert re.search(r"mul!\(\w+::HIPMatrix, \w+::Adjoint\{Float64,HIPMatrix\}, \w+::HIPMatrix\)", glue)
+    assert re.search(r"mul!\(\w+::HIPMatrix, \w+::HIPMatrix, \w+::HIPMatrix, \w+::Number, \w+::Number\)", glue)
+    # the workspace constructor is called as the reference defines it: (m, n, p, SV, SM; memory)
+    ws = open(os.path.join(REFERENCE_SRC, "block_krylov_workspaces.jl")).read()
+    assert re.search(r"function BlockGmresWorkspace\(m::Integer, n::Integer, p::Integer, SV::Type, SM::Type; memory", ws)
+    assert re.search(r"BlockGmresWorkspace\(n, n, p, Vector\{Float64\}, HIPMatrix; memory = \d+\)", md)
