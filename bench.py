@@ -134,7 +134,7 @@ def cpu_baseline(n1, budget_s=30.0):
     A = ok.poisson3d(sample_n1)
     t_gen = time.time() - t0
     r = C.c_double()
-    iters = 2 if sample_n1 >= 512 else 6
+    iters = 5 if sample_n1 >= 512 else 8          # timed iterations, after ko_cg_bench's one untimed warm-up iteration
     # The box may cap CPU time below the visible core count (cgroup quota), where 256 OpenMP threads
     # thrash: time a ladder of thread counts and report the best.  1 thread = the reference's own
     # serial SparseMatrixCSC mul!.
@@ -143,18 +143,97 @@ def cpu_baseline(n1, budget_s=30.0):
         quota_cpus = None if quota[0] == "max" else float(quota[0]) / float(quota[1])
     except Exception:
         quota_cpus = None
-    ladder = sorted({ncores, min(ncores, 64), min(ncores, 16), min(ncores, 4), 1}, reverse=True)
+    # most promising first (the quota when there is one), the serial reference mode last if the budget allows
+    first = int(min(ncores, max(1.0, round(quota_cpus)))) if quota_cpus else ncores
+    ladder = [first] + [t for t in sorted({ncores, min(ncores, 64), min(ncores, 16), min(ncores, 4)}, reverse=True) if t != first and t != 1] + [1]
+    ladder = list(dict.fromkeys(ladder))
     trials = {}
     for th in ladder:
         if trials and time.time() - t0 > budget_s:
             break
         trials[th] = ok.lib().ko_cg_bench(C.byref(A.c), iters, th, C.byref(r))
     cores, best = min(trials.items(), key=lambda kv: kv[1])
-    sample = (f"{iters} CG iterations of the oracle loop (cg! recurrence, OpenMP SpMV/dot/axpy) on get_div_grad({sample_n1}^3); "
+    sample = (f"1 untimed warm-up + {iters} timed CG iterations of the oracle loop (cg! recurrence, OpenMP SpMV/dot/axpy) on get_div_grad({sample_n1}^3); "
               + "it/s by thread count: " + ", ".join(f"{th}: {1.0 / v:.3f}" for th, v in trials.items())
               + f"; visible cores {ncores}, cgroup cpu quota {quota_cpus}; matrix generation {t_gen:.1f} s excluded")
     return {"value": 1.0 / best, "unit": "iter/s", "cores": cores, "kind": "port", "sample": sample,
             "sample_n1": sample_n1}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside a launcher: become the launcher.  Spawns N children of this very script,
+    one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment -- exactly what
+    `python -m torch.distributed.run --nproc-per-node N` would set, which keeps working: a process that already has
+    WORLD_SIZE never comes here).  Rank 0 inherits this process's stdout (the one JSON line); the other ranks' stdout
+    goes to stderr.  Refuses (rc 2) when fewer than N devices are visible: N ranks never silently share a GPU or
+    shrink to one.  Returns the worst child return code.  ref: docs/src/custom_workspaces.md:583-637 (mpiexecjl -n 4)."""
+    import subprocess
+    n = args.gpus
+    if not args.dry_launch:
+        import krylov_jl_amd as K
+        ndev = K.device_count() if K.gpu_available() else 0
+        if ndev < n:
+            log(f"bench.py: --gpus {n} asked for, {ndev} HIP device(s) visible: refusing to run "
+                f"(no fallback to fewer ranks, no sharing of a GPU between ranks)")
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   KHIP_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rcs = [None] * n
+    deadline = time.time() + float(os.environ.get("KHIP_BENCH_LAUNCH_TIMEOUT", "3600"))
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        failed = [rc for rc in rcs if rc not in (None, 0)]
+        if (failed or time.time() > deadline) and any(rc is None for rc in rcs):
+            time.sleep(5.0)                       # let the others notice (gloo errors out when a peer is gone)
+            for i, p in enumerate(procs):         # then stop exactly the processes started here
+                if p.poll() is None:
+                    p.kill()
+                rcs[i] = p.wait()
+            if not failed:
+                log("bench.py: launch timed out")
+                return 124
+            break
+        time.sleep(0.05)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        log(f"bench.py: rank return codes {rcs}")
+    return worst
+
+
+def dry_launch(rank, world, json_fd):
+    """--dry-launch: the launch path without the GPU -- every rank joins the gloo group (the control plane of the real run)
+    and the ranks are counted by an all-reduce; rank 0 prints the one JSON line."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    t = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(t)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid()))
+    dist.barrier()
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"dry_launch": True, "n_gpus": world, "ranks_rendezvoused": int(t.item()),
+                                       "ranks": [list(r) for r in ranks],
+                                       "launcher": "bench.py" if os.environ.get("KHIP_BENCH_SELF_LAUNCHED") else "external"}) + "\n").encode())
+    dist.destroy_process_group()
 
 
 def main():
@@ -172,9 +251,14 @@ def main():
                     help="NOT the headline: 1 = single-reduction CG (one all-reduce per iteration; different rounding)")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (khip_ctx_set_option)")
     ap.add_argument("--no-full-parity", action="store_true", help="skip the (untimed) full solve to rtol 1e-8 of the parity leg")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="exercise only the N-rank launch + rendezvous (gloo), no GPU work: tests/test_bench_launch.py")
     ap.add_argument("--also-variant1", action="store_true",
                     help="also time single-reduction CG and report it as the nested entry single_reduction_cg (always done with --gpus > 1)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))      # no launcher around us: be the launcher (one rank per GPU)
 
     # stdout carries exactly one JSON line: anything a library prints there (RCCL writes a version banner to stdout at
     # communicator creation) is sent to stderr by pointing fd 1 at fd 2 for the life of the process.
@@ -185,6 +269,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        log(f"bench.py: WARNING --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks; "
+            f"running (and reporting n_gpus =) {world}")
+    if args.dry_launch:
+        dry_launch(rank, world, json_fd)
+        return
     dist = None
     force_comm = os.environ.get("KHIP_FORCE_COMM") == "1"      # exercise the distributed path with one rank
     if world > 1 or "RANK" in os.environ:
@@ -195,10 +285,19 @@ def main():
     import numpy as np
     import krylov_jl_amd as K
 
-    try:
+    # one rank per GPU, never two ranks on one device: device = LOCAL_RANK, unless the launcher restricted this
+    # process to ONE visible device (then that device is this rank's).  KHIP_FORCE_COMM / KHIP_ALLOW_SHARED_GPU are
+    # the explicit test switches for running the distributed path on a 1-GPU box.
+    ndev = K.device_count() if K.gpu_available() else 0
+    restricted = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    if local_rank < ndev:
         ctx = K.Context(local_rank)
-    except K.KhipError:
-        ctx = K.Context(0)          # the launcher restricted this rank to one visible device
+    elif ndev == 1 and (restricted or os.environ.get("KHIP_ALLOW_SHARED_GPU") == "1"):
+        ctx = K.Context(0)
+    else:
+        log(f"bench.py: rank {rank} (local rank {local_rank}) has no device of its own: {ndev} HIP device(s) visible, "
+            f"{world} ranks; refusing to share a GPU between ranks")
+        sys.exit(2)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))

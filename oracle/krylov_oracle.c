@@ -421,6 +421,41 @@ void ko_spmv_omp(const ko_csr *A, const double *x, double *y) {
   }
 }
 
+/* matrix-free get_div_grad (test/get_div_grad.jl:8-25): see krylov_oracle.h.  One row = the loop body of ko_spmv
+ * over the entries csr_stencil3d would have stored for it: offsets in ascending column order, value 6 on the
+ * diagonal and -1 on the six face neighbours, absent across a Dirichlet face. */
+static inline double stencil7_row(const double *x, int64_t row, int i1, int i2, int i3, int n1, int n2, int n3) {
+  const int64_t s2 = n1, s3 = (int64_t)n1 * n2;
+  double acc = 0.0, prod;
+  if (i3 > 0)      { prod = -1.0 * x[row - s3]; acc = acc + prod; }
+  if (i2 > 0)      { prod = -1.0 * x[row - s2]; acc = acc + prod; }
+  if (i1 > 0)      { prod = -1.0 * x[row - 1];  acc = acc + prod; }
+                   { prod =  6.0 * x[row];      acc = acc + prod; }
+  if (i1 < n1 - 1) { prod = -1.0 * x[row + 1];  acc = acc + prod; }
+  if (i2 < n2 - 1) { prod = -1.0 * x[row + s2]; acc = acc + prod; }
+  if (i3 < n3 - 1) { prod = -1.0 * x[row + s3]; acc = acc + prod; }
+  return acc;
+}
+void ko_stencil7_matvec(const double *x, double *y, void *ud) {
+  const ko_stencil7 *S = (const ko_stencil7 *)ud;
+  const int n1 = S->n1, n2 = S->n2, n3 = S->n3;
+  for (int i3 = 0; i3 < n3; i3++)
+    for (int i2 = 0; i2 < n2; i2++) {
+      const int64_t base = (int64_t)n1 * i2 + (int64_t)n1 * n2 * i3;
+      for (int i1 = 0; i1 < n1; i1++) y[base + i1] = stencil7_row(x, base + i1, i1, i2, i3, n1, n2, n3);
+    }
+}
+void ko_stencil7_matvec_omp(const double *x, double *y, void *ud) {
+  const ko_stencil7 *S = (const ko_stencil7 *)ud;
+  const int n1 = S->n1, n2 = S->n2, n3 = S->n3;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int i3 = 0; i3 < n3; i3++)
+    for (int i2 = 0; i2 < n2; i2++) {
+      const int64_t base = (int64_t)n1 * i2 + (int64_t)n1 * n2 * i3;
+      for (int i1 = 0; i1 < n1; i1++) y[base + i1] = stencil7_row(x, base + i1, i1, i2, i3, n1, n2, n3);
+    }
+}
+
 void ko_spmm(const ko_csr *A, const double *X, double *Y, int p) {
   int64_t n = A->n;
   for (int j = 0; j < p; j++) ko_spmv(A, X + (size_t)j * n, Y + (size_t)j * n);
@@ -469,7 +504,11 @@ void ko_scalcopy(int64_t n, double *y, double s, const double *x) {
 void ko_divcopy(int64_t n, double *y, const double *x, double s) {
   for (int64_t i = 0; i < n; i++) y[i] = x[i] / s;
 }
+/* The elementwise loops below run on g_threads threads once the vector is long (ko_set_threads; default 1 = the
+ * reference's serial BLAS calls): elements are independent, so no value depends on the thread count. */
+#define KO_PAR_MIN ((int64_t)1 << 22)
 void ko_axpy(int64_t n, double s, const double *x, double *y) {
+#pragma omp parallel for schedule(static) if (g_threads > 1 && n >= KO_PAR_MIN)
   for (int64_t i = 0; i < n; i++) y[i] = fma(s, x[i], y[i]);
 }
 void ko_axpy_omp(int64_t n, double s, const double *x, double *y) {
@@ -477,6 +516,7 @@ void ko_axpy_omp(int64_t n, double s, const double *x, double *y) {
   for (int64_t i = 0; i < n; i++) y[i] = fma(s, x[i], y[i]);
 }
 void ko_axpby(int64_t n, double s, const double *x, double t, double *y) {
+#pragma omp parallel for schedule(static) if (g_threads > 1 && n >= KO_PAR_MIN)
   for (int64_t i = 0; i < n; i++) y[i] = fma(s, x[i], t * y[i]);
 }
 void ko_axpby_omp(int64_t n, double s, const double *x, double t, double *y) {
@@ -484,6 +524,7 @@ void ko_axpby_omp(int64_t n, double s, const double *x, double t, double *y) {
   for (int64_t i = 0; i < n; i++) y[i] = fma(s, x[i], t * y[i]);
 }
 void ko_fill(int64_t n, double *x, double val) {
+#pragma omp parallel for schedule(static) if (g_threads > 1 && n >= KO_PAR_MIN)
   for (int64_t i = 0; i < n; i++) x[i] = val;
 }
 /* reflect!(x, y, c, s): x_i <- c x_i + s y_i ; y_i <- s x_i - c y_i  (conj(s) = s for reals) */
@@ -784,6 +825,27 @@ int ko_cg(ko_cg_workspace *ws, ko_matvec A, ko_matvec M, void *ud, const double 
   st->timer = now_s() - t0;
   snprintf(st->status, sizeof(st->status), "%s", status);
   return 0;
+}
+
+/* cfg-4 oracle: ko_cg itself on the matrix-free operator, b = ones (krylov_oracle.h) */
+int ko_cg_stencil7(int n1, int n2, int n3, const ko_options *opts, ko_stats *st,
+                   int nsample, const int64_t *x_idx, double *x_out) {
+  const int64_t n = (int64_t)n1 * n2 * n3;
+  ko_stencil7 S = {n1, n2, n3};
+  ko_cg_workspace *ws = ko_cg_workspace_create(n, n);
+  double *b = (double *)malloc(sizeof(double) * (size_t)n);
+  if (!ws || !b) { free(b); if (ws) ko_cg_workspace_free(ws); return -2; }
+  ko_fill(n, b, 1.0);
+  int rc = ko_cg(ws, g_threads > 1 ? ko_stencil7_matvec_omp : ko_stencil7_matvec, NULL, &S, b, opts);
+  for (int i = 0; i < nsample; i++) x_out[i] = ws->x[x_idx[i]];
+  if (st) {            /* hand the statistics (history included) to the caller */
+    ko_stats_free(st);
+    *st = ws->stats;
+    ws->stats.residuals = NULL; ws->stats.nres = ws->stats.cap = 0;
+  }
+  free(b);
+  ko_cg_workspace_free(ws);
+  return rc;
 }
 
 /* ===================================================================== *
@@ -1597,10 +1659,10 @@ double ko_cg_bench(const ko_csr *A, int iters, int threads, double *rnorm_out) {
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) { x[i] = 0.0; r[i] = 1.0; p[i] = 1.0; Ap[i] = 0.0; }   /* b = ones */
   double gamma = ko_dot_omp(n, r, r);
-  /* one untimed warm-up product */
-  ko_spmv_omp(A, p, Ap);
-  double t0 = now_s();
-  for (int it = 0; it < iters; it++) {
+  /* one untimed warm-up ITERATION (it = -1: pages touched by every loop, threads spun up), then `iters` timed ones */
+  double t0 = 0.0;
+  for (int it = -1; it < iters; it++) {
+    if (it == 0) t0 = now_s();
     ko_spmv_omp(A, p, Ap);
     double pAp = ko_dot_omp(n, p, Ap);
     double alpha = gamma / pAp;

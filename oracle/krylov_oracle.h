@@ -68,6 +68,15 @@ void ko_csr_matvec_omp(const double *x, double *y, void *csr);
 void ko_csr_block_matvec(const double *X, double *Y, int p, void *csr);
 void ko_csr_block_matvec_omp(const double *X, double *Y, int p, void *csr);   /* same values, row-parallel */
 
+/* Matrix-free get_div_grad(n1,n2,n3) (test/get_div_grad.jl:8-25): the 7-point product computed from the grid
+ * indices, no CSR arrays.  Per row: the entries ko_csr_poisson3d stores, in its (ascending column) order
+ * (-n1 n2, -n1, -1, 0, +1, +n1, +n1 n2 where the neighbour exists), accumulator +0.0, rounded product then
+ * rounded add: every y value is bit-identical to ko_spmv on the CSR operator.  BASELINE cfg 4 (1024^3) needs
+ * it: the CSR arrays alone would be 94 GB.  ud = a ko_stencil7. */
+typedef struct { int n1, n2, n3; } ko_stencil7;
+void ko_stencil7_matvec(const double *x, double *y, void *ud);       /* serial            */
+void ko_stencil7_matvec_omp(const double *x, double *y, void *ud);   /* row-parallel: same values */
+
 /* ---- ILU(0) / IC(0) preconditioner -------------------------
  * The reference gets these from the vendor library (ic02 / ilu02 of CUSPARSE resp. rocSPARSE,
  * docs/src/gpu.md:74-163, test/gpu/nvidia.jl:37-100) -- an un-vendored dependency.  Restated from the
@@ -199,6 +208,14 @@ int ko_bicgstab(ko_bicgstab_workspace *ws, ko_matvec A, ko_matvec M, ko_matvec N
 /* block_gmres!  src/block_gmres.jl:110-358 */
 int ko_block_gmres(ko_block_gmres_workspace *ws, ko_block_matvec A, ko_block_matvec M,
                    ko_block_matvec N, void *ud, const double *B, const ko_options *opts);
+
+/* cg! (ko_cg, unchanged) on the matrix-free get_div_grad(n1,n2,n3) with b = ones: the cfg-4 oracle
+ * ("matrix-free stencil oracle", 5 vectors = 43 GB at 1024^3).  Products run row-parallel when
+ * ko_set_threads(>1) (values unchanged); the dots stay ko_dot's serial extended-precision sums.
+ * x_idx / x_out: nsample entries of the solution copied out (the vector itself is freed).  The history is in st
+ * (caller: ko_stats_init before, ko_stats_free after). */
+int ko_cg_stencil7(int n1, int n2, int n3, const ko_options *opts, ko_stats *st,
+                   int nsample, const int64_t *x_idx, double *x_out);
 
 /* CPU-baseline loop for bench.py: seconds per CG iteration with `threads` OpenMP threads */
 double ko_cg_bench(const ko_csr *A, int iters, int threads, double *rnorm_out);

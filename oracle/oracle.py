@@ -140,6 +140,10 @@ def lib():
                                   C.POINTER(Options)]),
         "ko_block_gmres": (C.c_int, [C.POINTER(BlockGmresWs), BLOCK_MATVEC, BLOCK_MATVEC, BLOCK_MATVEC,
                                      C.c_void_p, dp, C.POINTER(Options)]),
+        "ko_cg_stencil7": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(Options), C.POINTER(Stats), C.c_int,
+                                     C.POINTER(C.c_int64), dp]),
+        "ko_stats_init": (None, [C.POINTER(Stats)]),
+        "ko_stats_free": (None, [C.POINTER(Stats)]),
         "ko_cg_bench": (C.c_double, [C.POINTER(Csr), C.c_int, C.c_int, dp]),
         "ko_geqrf": (None, [C.c_int, C.c_int, dp, C.c_int, dp]),
         "ko_orgqr": (None, [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]),
@@ -153,6 +157,8 @@ def lib():
     # expose the C matvec adaptors as raw function pointers usable as MATVEC arguments
     L.csr_matvec = C.cast(L.ko_csr_matvec, MATVEC)
     L.csr_matvec_omp = C.cast(L.ko_csr_matvec_omp, MATVEC)
+    L.stencil7_matvec = C.cast(L.ko_stencil7_matvec, MATVEC)
+    L.stencil7_matvec_omp = C.cast(L.ko_stencil7_matvec_omp, MATVEC)
     L.csr_block_matvec = C.cast(L.ko_csr_block_matvec, BLOCK_MATVEC)
     L.csr_block_matvec_omp = C.cast(L.ko_csr_block_matvec_omp, BLOCK_MATVEC)
     _lib = L
@@ -355,6 +361,44 @@ def cg(A, b, M=None, x0=None, **kw):
     x = np.ctypeslib.as_array(ws.contents.x, shape=(n,)).copy()
     res = Result(x, ws.contents.stats, rc)
     L.ko_cg_workspace_free(ws)
+    return res
+
+
+class Stencil7(C.Structure):
+    """ko_stencil7: the matrix-free get_div_grad(n1,n2,n3) operator (test/get_div_grad.jl:8-25)."""
+    _fields_ = [("n1", C.c_int), ("n2", C.c_int), ("n3", C.c_int)]
+
+    def matvec(self, x, parallel=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        (lib().ko_stencil7_matvec_omp if parallel else lib().ko_stencil7_matvec)(_dp(x), _dp(y), C.cast(C.pointer(self), C.c_void_p))
+        return y
+
+
+def cg_stencil7(n1, n2=None, n3=None, x_index=(), progress=None, **kw):
+    """cg! on the MATRIX-FREE get_div_grad(n1,n2,n3), b = ones (ko_cg_stencil7: ko_cg itself, the operator computed
+    from the grid indices) -- the cfg-4 oracle.  Returns a Result whose .x holds only the entries x_index.
+    progress: callable(iteration) invoked once per iteration (through the solver's callback)."""
+    L = lib()
+    o = make_options(**kw)
+    keep = None
+    if progress is not None:
+        count = [0]
+
+        def cb(_ws, _data):
+            count[0] += 1
+            progress(count[0])
+            return 0
+        keep = CALLBACK(cb)
+        o.callback = keep
+    st = Stats()
+    L.ko_stats_init(C.byref(st))
+    idx = np.ascontiguousarray(x_index, dtype=np.int64)
+    xs = np.zeros(max(idx.size, 1))
+    rc = L.ko_cg_stencil7(n1, n2 or n1, n3 or n1, C.byref(o), C.byref(st), idx.size,
+                          idx.ctypes.data_as(C.POINTER(C.c_int64)), _dp(xs))
+    res = Result(xs[: idx.size], st, rc)
+    L.ko_stats_free(C.byref(st))
     return res
 
 

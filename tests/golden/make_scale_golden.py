@@ -181,3 +181,31 @@ if 15 in which:
         n=A.n, nnz=A.nnz, p=p, memory=mem, atol=0.0, rtol=FULL_RTOL, niter=res.niter, solved=bool(res.solved),
         status=res.status, residuals=[float(v) for v in res.residuals], x_index=idx,
         x_sample=[[float(v) for v in res.x[i]] for i in idx], seconds=time.time() - t0))
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE cfg 4: cg! on get_div_grad(1024,1024,1024), b = ones, the config that is row-partitioned
+# over 8 GPUs.  The CSR arrays alone would be 94 GB, so the oracle's cg! (ko_cg, unchanged) runs on the MATRIX-FREE
+# operator ko_stencil7_matvec (oracle/krylov_oracle.c; tests/test_oracle.py pins it bit for bit to the CSR operator at
+# 32^3 / 64^3 and on non-cubic grids).  Leg 40: the first 100 iterations (atol = rtol = 0), x samples included.
+# 5 vectors = 43 GB of host memory, ~10 s per iteration on 8 cores (the dots are serial extended-precision sums).
+# ---------------------------------------------------------------------------------------------------------------------
+if 40 in which:
+    t0 = time.time()
+    n1 = int(os.environ.get("CFG4_N1", "1024"))
+    iters = int(os.environ.get("CFG4_ITERS", "100"))
+    n = n1 ** 3
+    idx = sample_idx(n)
+
+    def tick(k):
+        if k % 5 == 0:
+            print(f"  cfg 4: iteration {k}  ({time.time() - t0:.0f} s)", flush=True)
+    res = ok.cg_stencil7(n1, x_index=idx, progress=tick, atol=0.0, rtol=0.0, itmax=iters, history=True)
+    assert res.rc == 0 and res.niter == iters, (res.rc, res.niter, res.status)
+    dump("oracle_cfg4_cg1024.json" if n1 == 1024 else f"oracle_cfg4_cg{n1}.json", dict(
+        generator="tests/golden/make_scale_golden.py 40",
+        oracle="oracle/krylov_oracle.c ko_cg_stencil7 = ko_cg (src/cg.jl:120-291) on the matrix-free get_div_grad "
+               "(test/get_div_grad.jl:8-25), bit-identical to the CSR operator (tests/test_oracle.py)",
+        config=f"BASELINE cfg 4: cg! on get_div_grad({n1},{n1},{n1}), b = ones, x0 = 0, atol = rtol = 0",
+        n=n, nnz=7 * n - 6 * n1 * n1, niter=res.niter, status=res.status,
+        residuals=[float(v) for v in res.residuals], x_index=idx, x_sample=[float(v) for v in res.x],
+        seconds=time.time() - t0))

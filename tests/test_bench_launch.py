@@ -1,0 +1,86 @@
+"""bench.py's N-rank launch path: `python bench.py --gpus N` must itself start N ranks (one per GPU),
+keep working under `python -m torch.distributed.run`, and REFUSE when fewer than N devices are visible -- never shrink to
+one rank or let ranks share a GPU silently.  --dry-launch runs only the launch + gloo rendezvous, so the path is covered
+here without a GPU.  ref: docs/src/custom_workspaces.md:583-637 (the reference's `mpiexecjl -n 4` recipe)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update(extra)
+    return env
+
+
+def _json_line(stdout: bytes):
+    lines = [l for l in stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines          # stdout carries exactly one line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_gpus_n_launches_n_ranks_itself(n):
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-launch"], env=_clean_env(), capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    d = _json_line(p.stdout)
+    assert d["dry_launch"] and d["n_gpus"] == n and d["ranks_rendezvoused"] == n and d["launcher"] == "bench.py"
+    assert sorted(r[0] for r in d["ranks"]) == list(range(n))              # ranks 0..n-1, each once
+    assert [r[1] for r in sorted(d["ranks"])] == list(range(n))            # LOCAL_RANK = rank: one device each
+    assert len({r[2] for r in d["ranks"]}) == n                            # n distinct processes
+
+
+def test_bench_under_torch_distributed_run_still_works():
+    """The driver's launch: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ..."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--dry-launch"], env=_clean_env(), capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    d = _json_line(p.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_rendezvoused"] == 2 and d["launcher"] == "external"
+
+
+def test_single_rank_default_does_not_spawn():
+    p = subprocess.run([sys.executable, BENCH, "--dry-launch"], env=_clean_env(), capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    d = _json_line(p.stdout)
+    assert d["n_gpus"] == 1 and d["ranks_rendezvoused"] == 1 and d["launcher"] == "external"
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-box form of the refusal (the GPU form is test_refuses_more_ranks_than_devices)")
+def test_refuses_without_devices():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=_clean_env(), capture_output=True, timeout=300)
+    assert p.returncode == 2 and p.stdout.strip() == b""
+    assert b"refusing" in p.stderr
+
+
+@pytest.mark.gpu
+def test_refuses_more_ranks_than_devices():
+    sys.path.insert(0, ROOT)
+    import krylov_jl_amd as K
+    ndev = K.device_count()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(ndev + 1), "--steps", "2", "--warmup", "1"], env=_clean_env(),
+                       capture_output=True, timeout=300)
+    assert p.returncode == 2 and p.stdout.strip() == b"", (p.returncode, p.stdout)
+    assert f"--gpus {ndev + 1} asked for, {ndev} HIP device(s) visible".encode() in p.stderr
+    # ... and a rank started by an external launcher without a device of its own refuses as well (no silent sharing)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = _clean_env(RANK="0", LOCAL_RANK=str(ndev), WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "KHIP_ALLOW_SHARED_GPU"):
+        env.pop(v, None)
+    if ndev > 1 or True:
+        p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--n1", "32", "--no-cpu-baseline"],
+                           env=env, capture_output=True, timeout=300)
+        assert p.returncode == 2 and b"refusing to share a GPU" in p.stderr, (p.returncode, p.stderr[-400:])

@@ -122,3 +122,27 @@ def test_bench_with_one_rank_communicator_equals_the_plain_path():
         sr = o["single_reduction_cg"]
         assert sr is not None and "NOT_THE_HEADLINE" in sr and sr["steps"] == 30 and sr["value"] > 0
         assert o["roofline"]["frac"] > 0 and o["metric"] == "cg_iters_per_sec_poisson3d_csr_512cubed"
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_gpus_n_runs_n_rccl_ranks(world):
+    """`python bench.py --gpus N` as the driver types it at N = 1 (no launcher around it): N ranks over real RCCL, one per
+    GPU, n_gpus = N in the line, RCCL saw N ranks, and the partitioned 512^3 history equals the 1-GPU golden bit for bit
+    (self_consistency) and the CPU oracle's within 1e-12 (parity).  Skips below N GPUs (tests/test_bench_launch.py covers
+    the launch itself on CPU and the refusal on a 1-GPU box)."""
+    import json
+    ngpu = _ngpu()
+    if ngpu < world:
+        pytest.skip(f"bench.py --gpus {world} needs {world} GPUs in one box ({ngpu} visible)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5",
+                        "--no-full-parity"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == world and o["rccl_ranks_seen"] == world and o["steps"] == 20 and o["scaling"] == "strong"
+    assert o["self_consistency"]["max_rel_dev"] == 0.0 and o["self_consistency"]["iterations_compared"] == 100
+    assert o["parity"]["ok"] and o["parity"]["max_rel_dev"] <= 1e-12
+    assert o["value"] > 0 and o["config"]["partition"] == f"1-D rows over {world} GPU(s)"
