@@ -49,7 +49,7 @@ class COptions(C.Structure):
     _fields_ = [("atol", C.c_double), ("rtol", C.c_double), ("itmax", C.c_int), ("timemax", C.c_double),
                 ("history", C.c_int), ("radius", C.c_double), ("linesearch", C.c_int), ("restart", C.c_int),
                 ("reorthogonalization", C.c_int), ("fused", C.c_int), ("callback", CALLBACK_FN),
-                ("callback_data", C.c_void_p), ("variant", C.c_int), ("verbose", C.c_int)]
+                ("callback_data", C.c_void_p), ("variant", C.c_int), ("verbose", C.c_int), ("log_fd", C.c_int)]
 
 
 class CStats(C.Structure):
@@ -890,7 +890,7 @@ def _make_operator(ctx, op, n, keep):
 
 
 def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, radius=0.0, linesearch=False,
-                  restart=False, reorthogonalization=False, fused=True, callback=None, keep=None, ws=None, variant=0, verbose=0):
+                  restart=False, reorthogonalization=False, fused=True, callback=None, keep=None, ws=None, variant=0, verbose=0, log_fd=0):
     o = lib().khip_default_options()
     if atol is not None:
         o.atol = atol
@@ -907,6 +907,7 @@ def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, ra
     o.fused = 2 if fused is True else int(fused)     # True = everything that is bit-identical: fused kernels + device-resident scalars
     o.variant = int(variant)
     o.verbose = int(verbose)
+    o.log_fd = int(log_fd)          # the reference's `iostream`: 0 = stdout, else a file descriptor
     if callback is not None:
         def cb(_ws, _ud):
             try:

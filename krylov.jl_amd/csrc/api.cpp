@@ -355,7 +355,10 @@ int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y,
     int rc = spmv_any(ctx, A, x, y, dot_slot, dotw, 0);
     if (rc == KHIP_OK) rc = launch_nrm2sq(ctx, A->m, dot_sq == 1 ? y : (dotw ? dotw : x), dot_slot + 1);
     ctx->ctl.epi = epi;
-    if (rc == KHIP_OK && epi != 0) rc = launch_epilogue_only(ctx, dot_slot);
+    // with a communicator the cross-rank combine (comm_allreduce_dd_device) owns the epilogue and runs it ONCE on the
+    // global values, exactly as launch_finish leaves it to it; running it here too applied it twice, first on rank-local
+    // scalars
+    if (rc == KHIP_OK && epi != 0 && !ctx->comm) rc = launch_epilogue_only(ctx, dot_slot);
     return rc;
   }
   if (!A->dist || !ctx->comm) return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m, nullptr, true, dotw, dot_sq);

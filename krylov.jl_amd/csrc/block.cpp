@@ -572,7 +572,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   const double atol = std::isnan(o.atol) ? std::sqrt(kEps) : o.atol, rtol = std::isnan(o.rtol) ? std::sqrt(kEps) : o.rtol;
   const bool restart = o.restart != 0, reorth = o.reorthogonalization != 0;
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
-  if (o.verbose > 0) printf("BLOCK-GMRES: system of size %lld with %d right-hand sides\n", (long long)ws->n, ws->p);   // src/block_gmres.jl:120
+  if (o.verbose > 0) klogf(o.log_fd, "BLOCK-GMRES: system of size %lld with %d right-hand sides\n", (long long)ws->n, ws->p);   // src/block_gmres.jl:120
   if (o.variant != 0) return ws->box.fail(KHIP_ERR_INVALID, "block_gmres: options.variant must be 0 (there is no other recurrence)");
 
   if (restart && !ws->dX) KB(alloc_panel(ctx, np, p, &ws->dX));
@@ -611,8 +611,8 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   const int64_t itmax = o.itmax == 0 ? 2 * (global_rows(ctx, A, n) / p) : o.itmax;
   int64_t inner_itmax = itmax;
   const int verbose = o.verbose;                                                   // :181-182   pass  k  ‖Rₖ‖  timer
-  if (verbose > 0) printf(" pass      k     \xe2\x80\x96R\xe2\x82\x96\xe2\x80\x96  timer\n");
-  if (verbose > 0 && iter % verbose == 0) printf("%5d  %5lld  %7.1e  %.2fs\n", npass, (long long)iter, RNorm, now_s() - t0);
+  if (verbose > 0) klogf(o.log_fd, " pass      k     \xe2\x80\x96R\xe2\x82\x96\xe2\x80\x96  timer\n");
+  if (verbose > 0 && iter % verbose == 0) klogf(o.log_fd, "%5d  %5lld  %7.1e  %.2fs\n", npass, (long long)iter, RNorm, now_s() - t0);
 
   bool solved = RNorm <= eps_tol;
   bool tired = iter >= itmax;
@@ -738,7 +738,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
       }
       overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
       if (verbose > 0 && (iter + inner_iter) % verbose == 0)                       // :297
-        printf("%5d  %5lld  %7.1e  %.2fs\n", npass, (long long)(iter + inner_iter), RNorm, now_s() - t0);
+        klogf(o.log_fd, "%5d  %5lld  %7.1e  %.2fs\n", npass, (long long)(iter + inner_iter), RNorm, now_s() - t0);
 
       if (!(solved || inner_tired || user_requested_exit || overtimed)) {
         if (!restart && (inner_iter >= mem)) {                                     // :300-305
@@ -806,7 +806,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
-  if (verbose > 0) { printf("\n"); fflush(stdout); }                              // :340
+  if (verbose > 0) { klogf(o.log_fd, "\n"); klog_flush(o.log_fd); }                              // :340
   if (tired) status = "maximum number of iterations exceeded";
   if (solved) status = "solution good enough given atol and rtol";
   if (overtimed) status = "time limit exceeded";

@@ -667,10 +667,9 @@ int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count) {
   return launch_combine(ctx, c->gather_dev, c->nranks, count, slot);
 }
 
-static thread_local bool g_allreduce_pending = false;
 int comm_allreduce_dd_device_begin(khip_ctx *ctx, int slot, int count) {
   Comm *c = ctx->comm;
-  g_allreduce_pending = false;
+  ctx->allreduce_pending = false;
   if (!c || c->hub || c->halo_comm == c->comm || !ctx->tune.overlap_halo) return comm_allreduce_dd_device(ctx, slot, count);
   if (count > kMaxRedOut) { set_error("allreduce: too many scalars"); return KHIP_ERR_INVALID; }
   // The (hi, lo) partials are final on the main stream; everything from here to the epilogue runs on the communication
@@ -684,12 +683,12 @@ int comm_allreduce_dd_device_begin(khip_ctx *ctx, int slot, int count) {
   KHIP_TRY(launch_combine(ctx, c->gather_dev, c->nranks, count, slot, cs));
   if (!ctx->ev_red) KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_red, hipEventDisableTiming));
   KHIP_CHECK_HIP(hipEventRecord(ctx->ev_red, cs));
-  g_allreduce_pending = true;
+  ctx->allreduce_pending = true;      // state of THIS context, next to ev_red
   return KHIP_OK;
 }
 int comm_allreduce_dd_device_end(khip_ctx *ctx) {
-  if (!g_allreduce_pending) return KHIP_OK;
-  g_allreduce_pending = false;
+  if (!ctx->allreduce_pending) return KHIP_OK;
+  ctx->allreduce_pending = false;
   KHIP_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_red, 0));
   return KHIP_OK;
 }

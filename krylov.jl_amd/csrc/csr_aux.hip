@@ -687,7 +687,7 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
       // profiles/r03h_spmm_tile_p.log, r03i_spmm_tile_slices.log).  spmm_tile = 2 takes the tile kernel at every width
       // it has; spmm_tile_slices = 1 / -1 forces / forbids the slices.
       khip_csr *At = const_cast<khip_csr *>(A);
-      if (At->tile_state == 0) KHIP_TRY(spmm_tile_build(ctx, At));
+      if (At->tile_state == 0) optional_build(spmm_tile_build(ctx, At));
       const bool long_rows = A->nnz >= 16 * A->m;
       const bool slices = p >= 32 && ctx->tune.spmm_tile_slices >= 0 && (p > 32 || ctx->tune.spmm_tile_slices > 0 || long_rows);
       const bool fits = slices || (size_t)At->tile_cap * 8 * (size_t)p <= (size_t)160 * 1024;

@@ -3,6 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
+#include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -14,6 +17,19 @@
 namespace khip {
 
 void set_error(const char *fmt, ...);
+
+// options.verbose rows: stdout (log_fd = 0) or the caller's file descriptor (the reference's `iostream`, src/cg.jl:24)
+inline void klogf(int fd, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  if (fd <= 0) vprintf(fmt, ap); else vdprintf(fd, fmt, ap);
+  va_end(ap);
+}
+// Lazily built optional accelerators (coded column stream, SpMM tiles) set their state to -1 ("not usable") before they
+// start: a build that fails -- typically hipMalloc on a full device -- must not fail the user's product, the other kernels
+// are still there.  The sticky HIP error of the failed call is cleared.
+inline void optional_build(int rc) { if (rc != KHIP_OK) (void)hipGetLastError(); }
+inline void klog_flush(int fd) { if (fd <= 0) fflush(stdout); }
 
 #define KHIP_CHECK_HIP(expr)                                                              \
   do {                                                                                    \
@@ -128,6 +144,7 @@ struct khip_ctx {
   unsigned ev_cur = 0;
   hipEvent_t ev_fetch = nullptr;       // results_copy_begin / _end (look-ahead fetch of device scalars)
   hipEvent_t ev_red = nullptr;         // comm_allreduce_dd_device_begin / _end (all-reduce on the communication stream)
+  bool allreduce_pending = false;      // a _begin on this context still waits for its _end
   int num_cu = 256;
   // reduction scratch (grown on demand by ensure_reduction_scratch)
   khip::dd *partials = nullptr;        // [kMaxNout][red_cap1]  one per wave of the streaming kernel

@@ -541,9 +541,10 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
   (void)take_alloc_seconds();
 
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
-  if (verbose > 0) printf("CG: system of %lld equations in %lld variables\n", (long long)n, (long long)n);      // src/cg.jl:132
   if (o.variant != 0 && o.variant != 1 && o.variant != 2)
     return ws->box.fail(KHIP_ERR_INVALID, "cg: options.variant must be 0 (cg! recurrence), 1 (single-reduction CG) or 2 (pipelined CG)");
+  if (o.variant != 0 && verbose > 0)       // the log's pAp / alpha / sigma columns belong to cg!'s own recurrence
+    return ws->box.fail(KHIP_ERR_UNSUPPORTED, "cg: verbose > 0 prints the rows of the reference recurrence: use variant = 0");
   if (A->csr && !A->apply) {
     int64_t am, an;
     khip_csr_shape(A->csr, &am, &an, nullptr);
@@ -553,6 +554,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     return ws->box.fail(KHIP_ERR_INVALID, "`linesearch` set to `true` but trust-region radius > 0");
   if (ws->warm_start && linesearch)
     return ws->box.fail(KHIP_ERR_INVALID, "warm_start and linesearch cannot be used together");
+  if (verbose > 0) klogf(o.log_fd, "CG: system of %lld equations in %lld variables\n", (long long)n, (long long)n);      // src/cg.jl:132, after the argument checks as there
   const bool MisI = (M == nullptr);
   if (!MisI && radius > 0)
     return ws->box.fail(KHIP_ERR_UNSUPPORTED, "radius > 0 with a preconditioner needs ldiv!(M): not available through a callback");
@@ -597,8 +599,8 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
   double pNorm2 = gamma;
   const double eps_tol = atol + rtol * rNorm;
 
-  if (verbose > 0) printf("    k      \xe2\x80\x96r\xe2\x80\x96       pAp         \xce\xb1         \xcf\x83  timer\n");   // :182  k ‖r‖ pAp α σ timer
-  if (kdisplay(iter, verbose)) printf("%5lld  %7.1e", (long long)iter, rNorm);                                   // :183
+  if (verbose > 0) klogf(o.log_fd, "    k      \xe2\x80\x96r\xe2\x80\x96       pAp         \xce\xb1         \xcf\x83  timer\n");   // :182  k ‖r‖ pAp α σ timer
+  if (kdisplay(iter, verbose)) klogf(o.log_fd, "%5lld  %7.1e", (long long)iter, rNorm);                                   // :183
 
   bool solved = rNorm <= eps_tol;
   bool tired = iter >= itmax;
@@ -706,7 +708,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
       if (rcb > 0) return ws->box.fail_rc(rcb);
       sigma = s1 > s2 ? s1 : s2;
     }
-    if (kdisplay(iter, verbose)) printf("  %8.1e  %8.1e  %8.1e  %.2fs\n", pAp, alpha, sigma, now_s() - t0);        // :224
+    if (kdisplay(iter, verbose)) klogf(o.log_fd, "  %8.1e  %8.1e  %8.1e  %.2fs\n", pAp, alpha, sigma, now_s() - t0);        // :224
     if ((radius > 0) && ((pAp <= 0) || (alpha > sigma))) {                         // :229-237
       alpha = sigma;
       if (pAp <= 0) {
@@ -754,9 +756,9 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     tired = iter >= itmax;
     if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;    // :264
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
-    if (kdisplay(iter, verbose)) printf("%5lld  %7.1e", (long long)iter, rNorm);                                 // :267
+    if (kdisplay(iter, verbose)) klogf(o.log_fd, "%5lld  %7.1e", (long long)iter, rNorm);                                 // :267
   }
-  if (verbose > 0) { printf("\n\n"); fflush(stdout); }                                                         // :269
+  if (verbose > 0) { klogf(o.log_fd, "\n\n"); klog_flush(o.log_fd); }                                                         // :269
 
   if (solved && on_boundary) status = "on trust-region boundary";
   if (solved && st->indefinite) status = "nonpositive curvature";
@@ -902,14 +904,15 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   const int verbose = o.verbose;
   (void)take_alloc_seconds();
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
-  if (verbose > 0) printf("GMRES: system of size %lld\n", (long long)n);                                          // src/gmres.jl:131
 
   if (o.variant != 0 && o.variant != 1 && o.variant != 2)
     return ws->box.fail(KHIP_ERR_INVALID, "gmres: options.variant must be 0 (gmres! recurrence, modified Gram-Schmidt), 1 (CGS2) or 2 (s-step)");
   if (o.variant == 2 && (!restart || M || N || reorth || o.callback || A->apply || !A->csr))
     return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 2 (s-step) needs restart = true, a CSR operator, M = N = I, no reorthogonalization / callback");
+  if (verbose > 0) klogf(o.log_fd, "GMRES: system of size %lld\n", (long long)n);                                          // src/gmres.jl:131, after the argument checks
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
-  const bool look = o.variant == 0 && fused && o.fused >= 2 && MisI && NisI && !reorth && !o.callback && !A->apply && A->csr;
+  // (a verbose solve keeps the host in step with every inner iteration, like the cg! / bicgstab! device loops)
+  const bool look = o.variant == 0 && fused && o.fused >= 2 && MisI && NisI && !reorth && !o.callback && !A->apply && A->csr && verbose <= 0;
   if (!MisI && !ws->q) K(alloc_vec(ctx, n, &ws->q));                               // src/gmres.jl:142-144
   if (!NisI && !ws->p) K(alloc_vec(ctx, n, &ws->p));
   if (restart && !ws->dx) K(alloc_vec(ctx, n, &ws->dx));
@@ -957,8 +960,8 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
 
   bool breakdown = false, inconsistent = false;
   // :191-192   pass  k  ‖rₖ‖  hₖ₊₁.ₖ  timer ; the first row shows "✗ ✗ ✗ ✗" in the h column
-  if (verbose > 0) printf(" pass      k     \xe2\x80\x96r\xe2\x82\x96\xe2\x80\x96   h\xe2\x82\x96\xe2\x82\x8a\xe2\x82\x81.\xe2\x82\x96  timer\n");
-  if (kdisplay(iter, verbose)) printf("%5d  %5lld  %7.1e  \xe2\x9c\x97 \xe2\x9c\x97 \xe2\x9c\x97 \xe2\x9c\x97  %.2fs\n", npass, (long long)iter, rNorm, now_s() - t0);
+  if (verbose > 0) klogf(o.log_fd, " pass      k     \xe2\x80\x96r\xe2\x82\x96\xe2\x80\x96   h\xe2\x82\x96\xe2\x82\x8a\xe2\x82\x81.\xe2\x82\x96  timer\n");
+  if (kdisplay(iter, verbose)) klogf(o.log_fd, "%5d  %5lld  %7.1e  \xe2\x9c\x97 \xe2\x9c\x97 \xe2\x9c\x97 \xe2\x9c\x97  %.2fs\n", npass, (long long)iter, rNorm, now_s() - t0);
 
   bool solved = rNorm <= eps_tol;
   bool tired = iter >= itmax;
@@ -979,6 +982,15 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   if (o.variant == 2 && !(solved || tired)) {
     const int sblk = ctx->tune.gmres_sstep < 1 ? 4 : (ctx->tune.gmres_sstep > 8 ? 8 : ctx->tune.gmres_sstep);
     const bool multi = comm_nranks(ctx) > 1;
+    // checked BEFORE the first cycle (k never exceeds mem): a solve must not fail after x was already updated
+    if (((mem + 3) & ~3) * sblk > kResultSlots)
+      return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 2: memory x s too large for the device scalar ring (memory x s <= 256)");
+    // the padding slots between the columns of a batch are shipped by the all-reduce as well: keep them zero, not stale
+    auto zero_slots = [&](int slot, int count) -> int {
+      if (!multi) return KHIP_OK;
+      KHIP_CHECK_HIP(hipMemsetAsync(ctx->results_dd + slot, 0, sizeof(dd) * (size_t)count, ctx->stream));
+      return KHIP_OK;
+    };
     auto allreduce_slots = [&](int slot, int count) -> int {            // device-side all-reduce of a slot range, 64 scalars at a time
       for (int b0 = 0; b0 < count; b0 += kMaxRedOut) {
         const int cnt = count - b0 < kMaxRedOut ? count - b0 : kMaxRedOut;
@@ -1021,10 +1033,10 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
         }
         // (2) block CGS2 against V[0 .. k-1]: all dots of a pass first (one reduction), then all updates
         const int kpad = (k + 3) & ~3;
-        if (kpad * sb > kResultSlots) return ws->box.fail(KHIP_ERR_UNSUPPORTED, "gmres variant 2: memory x s too large for the device scalar ring (memory x s <= 256)");
         std::vector<double> Cm((size_t)k * sb, 0.0);                       // C[i + k j], both passes accumulated
         for (int pass = 0; pass < 2; ++pass) {
           const int sp = take_slots(ctx, kpad * sb);
+          K(zero_slots(sp, kpad * sb));
           for (int j = 0; j < sb; ++j) K(launch_multi_dot(ctx, n, k, V.data(), V[k + j], sp + j * kpad));
           if (multi) K(allreduce_slots(sp, kpad * sb));
           for (int j = 0; j < sb; ++j) K(launch_multi_axpy_dev(ctx, n, k, ctx->results + sp + j * kpad, V.data(), V[k + j]));
@@ -1040,6 +1052,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
         bool qr_ok = true;
         for (int round = 0; round < 2 && qr_ok; ++round) {
           const int slotG = take_slots(ctx, spad * sb);
+          K(zero_slots(slotG, spad * sb));
           for (int j = 0; j < sb; ++j) K(launch_multi_dot(ctx, n, sb, V.data() + k, V[k + j], slotG + j * spad));
           if (multi) K(allreduce_slots(slotG, spad * sb));
           tmp.resize((size_t)(spad * sb));
@@ -1125,7 +1138,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
           cols = cols + 1;
           solved = (rNorm <= eps_tol) || (rNorm + 1.0 <= 1.0);
           if (kdisplay(iter + cols, verbose))
-            printf("%5d  %5lld  %7.1e  %7.1e  %.2fs\n", npass, (long long)(iter + cols), rNorm, h[(size_t)c], now_s() - t0);
+            klogf(o.log_fd, "%5d  %5lld  %7.1e  %7.1e  %.2fs\n", npass, (long long)(iter + cols), rNorm, h[(size_t)c], now_s() - t0);
           if (iter + cols >= itmax) break;
         }
         k += sb;
@@ -1296,7 +1309,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
       }
       overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
       if (kdisplay(iter + inner_iter, verbose))                                     // :315
-        printf("%5d  %5lld  %7.1e  %7.1e  %.2fs\n", npass, (long long)(iter + inner_iter), rNorm, Hbis, now_s() - t0);
+        klogf(o.log_fd, "%5d  %5lld  %7.1e  %7.1e  %.2fs\n", npass, (long long)(iter + inner_iter), rNorm, Hbis, now_s() - t0);
 
       if (!(solved || inner_tired || breakdown || user_requested_exit || overtimed)) {
         if (!restart && (inner_iter >= mem)) {                                     // :319-324
@@ -1343,7 +1356,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
   }
 
-  if (verbose > 0) { printf("\n"); fflush(stdout); }                                                           // src/gmres.jl:364
+  if (verbose > 0) { klogf(o.log_fd, "\n"); klog_flush(o.log_fd); }                                                           // src/gmres.jl:364
   if (tired) status = "maximum number of iterations exceeded";
   if (solved) status = "solution good enough given atol and rtol";
   if (inconsistent) status = "found approximate least-squares solution";
@@ -1535,7 +1548,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   const bool fused = o.fused != 0;
   const int verbose = o.verbose;
   (void)take_alloc_seconds();
-  if (verbose > 0) printf("BICGSTAB: system of size %lld\n", (long long)n);                                       // src/bicgstab.jl:135
+  if (verbose > 0) klogf(o.log_fd, "BICGSTAB: system of size %lld\n", (long long)n);                                       // src/bicgstab.jl:135
   if (ws->m != ws->n) return ws->box.fail(KHIP_ERR_INVALID, "System must be square");
   if (o.variant != 0) return ws->box.fail(KHIP_ERR_INVALID, "bicgstab: options.variant must be 0 (there is no other recurrence)");
   if (!c) c = b;                                                                   // src/bicgstab.jl:105
@@ -1582,8 +1595,8 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
   const int64_t itmax = o.itmax == 0 ? 2 * global_rows(ctx, A, n) : o.itmax;   // 2n of the GLOBAL system on every rank
   const double eps_tol = atol + rtol * rNorm;
   // :193-194   k  ‖rₖ‖  |αₖ|  |ωₖ|  timer
-  if (verbose > 0) printf("    k     \xe2\x80\x96r\xe2\x82\x96\xe2\x80\x96      |\xce\xb1\xe2\x82\x96|      |\xcf\x89\xe2\x82\x96|  timer\n");
-  if (kdisplay(iter, verbose)) printf("%5lld  %7.1e  %8.1e  %8.1e  %.2fs\n", (long long)iter, rNorm, std::fabs(alpha), std::fabs(omega), now_s() - t0);
+  if (verbose > 0) klogf(o.log_fd, "    k     \xe2\x80\x96r\xe2\x82\x96\xe2\x80\x96      |\xce\xb1\xe2\x82\x96|      |\xcf\x89\xe2\x82\x96|  timer\n");
+  if (kdisplay(iter, verbose)) klogf(o.log_fd, "%5lld  %7.1e  %8.1e  %8.1e  %.2fs\n", (long long)iter, rNorm, std::fabs(alpha), std::fabs(omega), now_s() - t0);
 
   double next_rho;
   K(khip_dot(ctx, n, c, r, &next_rho));                                            // :196
@@ -1696,10 +1709,10 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
     tired = iter >= itmax;
     breakdown = (alpha == 0 || std::isnan(alpha));
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
-    if (kdisplay(iter, verbose)) printf("%5lld  %7.1e  %8.1e  %8.1e  %.2fs\n", (long long)iter, rNorm, std::fabs(alpha), std::fabs(omega), now_s() - t0);   // :255
+    if (kdisplay(iter, verbose)) klogf(o.log_fd, "%5lld  %7.1e  %8.1e  %8.1e  %.2fs\n", (long long)iter, rNorm, std::fabs(alpha), std::fabs(omega), now_s() - t0);   // :255
   }
 
-  if (verbose > 0) { printf("\n"); fflush(stdout); }                                                           // src/bicgstab.jl:257
+  if (verbose > 0) { klogf(o.log_fd, "\n"); klog_flush(o.log_fd); }                                                           // src/bicgstab.jl:257
   if (tired) status = "maximum number of iterations exceeded";
   if (breakdown) status = "breakdown \xce\xb1\xe2\x82\x96 == 0";
   if (solved) status = "solution good enough given atol and rtol";

@@ -925,7 +925,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   // and the stream kernel (spmv_kernel_choice)
   if (ctx->tune.spmv_kernel == 0 && A->code_state == 0 && A->mean_row_nnz > 12.0 && A->mean_row_nnz <= 64.0 && A->max_row_nnz <= 64 &&
       ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && !nt && !a.fake_gather && !(A->tmpl_id && ctx->tune.spmv_template))
-    KHIP_TRY(csr_build_codes(ctx, const_cast<khip_csr *>(A)));
+    optional_build(csr_build_codes(ctx, const_cast<khip_csr *>(A)));
   const int kernel = spmv_kernel_choice(ctx, A);
   unsigned grid = 1;
   RedArgs ra;
@@ -983,7 +983,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     // 16 = two-byte codes, 0 = never
     const bool try_codes = ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && !nt && !a.fake_gather;
     // coded column stream (colcode.hip): built once per handle, at the first product that gets here
-    if (try_codes && Am->code_state == 0) KHIP_TRY(csr_build_codes(ctx, Am));
+    if (try_codes && Am->code_state == 0) optional_build(csr_build_codes(ctx, Am));
     const bool coded = try_codes && Am->code_state == 1;
     if (coded) { a.code = Am->code; a.code_tab = Am->code_tab; a.code_T = Am->code_T; }
     a.stage_rows = rows;

@@ -20,10 +20,23 @@ def K():
     return K
 
 
-def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "krylov_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(khip_[a-z0-9_]+)\s*\(", src)))
+def _declared_symbols(headers=("krylov_hip.h", "krylov_hip_test.h")):
+    out = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(khip_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_test_hooks_are_not_in_the_public_header():
+    """khip_test_* are test exports, declared in include/krylov_hip_test.h, not in the shipped ABI."""
+    pub = _declared_symbols(("krylov_hip.h", "krylov_hip_ext.h"))
+    assert not [s for s in pub if s.startswith("khip_test_")]
+    hooks = _declared_symbols(("krylov_hip_test.h",))
+    assert len([s for s in hooks if s.startswith("khip_test_")]) >= 9
+    glue = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "khip_test_" not in glue
 
 
 def test_library_exports_every_declared_symbol(K):

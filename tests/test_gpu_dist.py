@@ -564,3 +564,52 @@ def test_sstep_gmres_on_partitioned_operators(K, ctx, oracle):
         assert solved and niter == stp.niter and np.max(np.abs(hist - stp.residuals) / stp.residuals) <= 1e-9
         assert np.array_equal(hist, res[0][1])
         assert np.allclose(xs, 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_device_loops_with_the_two_reduction_fallback_on_partitioned_operators(K, ctx, oracle, kernel):
+    """with a forced ordered / vector SpMV kernel (spmv_kernel = 2 / 3) the product cannot carry the second
+    reduction, so spmv_any issues two reductions and a stand-alone scalar epilogue -- which under a communicator belongs to
+    the cross-rank combine alone (it was applied twice: iter advanced by two, alpha and gamma corrupted, ranks could diverge).
+    Single-reduction CG (variant 1) and bicgstab!(fused = 2) on three in-process ranks against the same runs on one GPU."""
+    n1 = 14
+    A_cpu = oracle.poisson3d(n1)
+    n = A_cpu.n
+    ref = oracle.cg(A_cpu, np.ones(n), history=True)
+    B_cpu = oracle.kron_unsymmetric(n1)
+    bb = B_cpu.matvec(np.ones(n))
+    refb = oracle.bicgstab(B_cpu, bb, history=True)
+    prev = ctx.get_option("spmv_kernel")
+    ctx.set_option("spmv_kernel", kernel)
+    try:
+        Ap = K.CsrMatrix.stencil(ctx, "poisson", n1)
+        bp = ctx.empty(n); K.kfill_(bp, 1.0)
+        _, stp, _ = K.cg(Ap, bp, history=True, variant=1)
+        Bp = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", n1)
+        _, stb, _ = K.bicgstab(Bp, ctx.array(bb), history=True, fused=2)
+    finally:
+        ctx.set_option("spmv_kernel", prev)
+    assert stp.solved and abs(stp.niter - ref.niter) <= 2 and stb.solved and stb.niter == refb.niter
+    world = 3
+    starts = K.row_partition(n, world)
+
+    def body(c, rank):
+        c.set_option("spmv_kernel", kernel)
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = K.CsrMatrix.stencil(c, "poisson", n1, rows=(r0, r1), distributed=True)
+        b = c.empty(r1 - r0); K.kfill_(b, 1.0)
+        x, st, _ = K.cg(A, b, history=True, variant=1)
+        B = K.CsrMatrix.stencil(c, "kron_unsymmetric", n1, rows=(r0, r1), distributed=True)
+        xb, sb, _ = K.bicgstab(B, c.array(bb[r0:r1]), history=True, fused=2)
+        return st.niter, st.residuals.copy(), x.to_host(), st.solved, sb.niter, sb.residuals.copy(), xb.to_host(), sb.solved
+
+    res = _run_ranks(K, world, 929200 + kernel, body)
+    for rank, (niter, hist, xs, solved, nb, hb, xb, sb) in enumerate(res):
+        r0, r1 = starts[rank], starts[rank + 1]
+        assert solved and niter == stp.niter and len(hist) == len(stp.residuals)
+        assert np.max(np.abs(hist - stp.residuals) / stp.residuals) <= 1e-10
+        assert np.array_equal(hist, res[0][1])
+        assert np.allclose(xs, ref.x[r0:r1], rtol=0, atol=1e-6 * np.abs(ref.x).max())
+        assert sb and nb == stb.niter and np.max(np.abs(hb - stb.residuals) / stb.residuals) <= 1e-7
+        assert np.array_equal(hb, res[0][5])
+        assert np.allclose(xb, refb.x[r0:r1], rtol=0, atol=1e-6 * np.abs(refb.x).max())

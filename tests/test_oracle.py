@@ -645,6 +645,35 @@ def test_parallel_matvec_changes_no_value(oracle):
         assert s_.niter == p_.niter and np.array_equal(s_.residuals, p_.residuals) and np.array_equal(s_.x, p_.x)
 
 
+def test_matrix_free_stencil_oracle_equals_the_csr_oracle_bit_for_bit(oracle):
+    """The cfg-4 oracle: ko_cg on the MATRIX-FREE get_div_grad (ko_stencil7_matvec, the 7-point product
+    from the grid indices; test/get_div_grad.jl:8-25) -- the CSR arrays of 1024^3 would be 94 GB.  It must be the CSR oracle
+    bit for bit: products on cubic and non-cubic grids (incl. degenerate 1-wide ones), then whole cg! histories, solutions and
+    status at 32^3 and 64^3, serial and threaded."""
+    ok = oracle
+    rng = np.random.default_rng(7)
+    for dims in ((1, 1, 1), (1, 5, 1), (4, 1, 3), (5, 7, 9), (16, 16, 16), (3, 33, 2)):
+        A = ok.poisson3d(*dims)
+        S = ok.Stencil7(*dims)
+        for x in (rng.standard_normal(A.n), np.ones(A.n), -np.abs(rng.standard_normal(A.n))):
+            y = A.matvec(x)
+            assert np.array_equal(y, S.matvec(x)) and np.array_equal(np.signbit(y), np.signbit(S.matvec(x))), dims
+            assert np.array_equal(y, S.matvec(x, parallel=True)), dims
+    for threads in (1, 4):
+        ok.lib().ko_set_threads(threads)
+        try:
+            for n1, kw in ((32, dict(atol=0.0, rtol=0.0, itmax=70)), (32, {}), (64, dict(atol=0.0, rtol=1e-8, itmax=64 ** 3))):
+                A = ok.poisson3d(n1)
+                ref = ok.cg(A, np.ones(A.n), history=True, **kw)
+                idx = np.linspace(0, A.n - 1, 64).astype(np.int64)
+                got = ok.cg_stencil7(n1, x_index=idx, history=True, **kw)
+                assert got.rc == 0 and got.niter == ref.niter and got.status == ref.status and got.solved == ref.solved
+                assert np.array_equal(got.residuals, ref.residuals), (n1, threads)
+                assert np.array_equal(got.x, ref.x[idx]), (n1, threads)
+        finally:
+            ok.lib().ko_set_threads(1)
+
+
 def test_scale_goldens_are_well_formed():
     """The BASELINE-size oracle histories the GPU parity tests and bench.py compare with."""
     for name, n, niter in (("oracle_cfg2_cg512.json", 512 ** 3, 100), ("oracle_cfg3_gmres256.json", 256 ** 3, 45),
@@ -652,6 +681,9 @@ def test_scale_goldens_are_well_formed():
         g = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
         assert g["n"] == n and g["niter"] == niter and len(g["residuals"]) == niter + 1
         assert all(np.isfinite(g["residuals"])) and len(g["x_sample"]) == len(g["x_index"]) == 16
+    g4 = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg4_cg1024.json")))          # BASELINE cfg 4 (matrix-free oracle)
+    assert g4["n"] == 1024 ** 3 and g4["nnz"] == 7 * 1024 ** 3 - 6 * 1024 ** 2 and g4["niter"] == 100 and len(g4["residuals"]) == 101
+    assert g4["residuals"][0] == 32768.0 and all(np.isfinite(g4["residuals"])) and len(g4["x_sample"]) == len(g4["x_index"]) == 16
     g2 = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg2_cg512.json")))
     assert g2["residuals"][0] == math.sqrt(512 ** 3) and g2["nnz"] == 7 * 512 ** 3 - 6 * 512 ** 2      # ||ones||, SURVEY 8
 
