@@ -107,6 +107,10 @@ int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
  * codes operators of at least 4 M entries (smaller ones are latency bound and keep the int32 stream), 2 codes whatever the
  * size, 16 forces two-byte codes, 0 keeps the int32 stream (environment variable KHIP_SPMV_CODES sets the initial value).  ref: the product is kmul!(y, A, x), src/krylov_utils.jl:305. */
 int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
+/* Block-delta column stream of the stream SpMV (operators that are not stencils: more than 2048 diagonals; built at the first
+ * product that can use it, ctx option "spmv_delta"): bits = 8 / 16 (32: not in use), rows = rows per block, escapes = entries
+ * that stay int32 (6 B each).  khip_spmv_bytes_stored counts what that kernel streams. */
+int khip_csr_delta_info(const khip_csr *A, int *bits, int *rows, int64_t *escapes);
 /* Which SpMM kernel a product with 16 right-hand sides runs on this handle (csrc/spmm_tile.hip): *state = 1 when the handle
  * keeps group records for the wave-private-window kernel (built by the first khip_spmm with p = 16; 0 before that, -1 when
  * the operator lacks the locality and the other SpMM kernels are used); *window = distinct panel rows a group's LDS window

@@ -90,6 +90,7 @@ SIGNATURES = {
     "khip_spmm": (_int, [_vp, _vp, _vp, _vp, _int]),
     "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
     "khip_csr_code_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "khip_csr_delta_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "khip_csr_tile_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "khip_csr_halo_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
@@ -636,6 +637,14 @@ class CsrMatrix:
         b, t = C.c_int(), C.c_int()
         _ck(lib().khip_csr_code_info(self._h, C.byref(b), C.byref(t)))
         return b.value, t.value
+
+    @property
+    def delta_info(self):
+        """(bits, rows_per_block, escapes) of the block-delta column stream the stream SpMV reads (csrc/coldelta.hip):
+        (32, 0, 0) = plain int32 columns."""
+        b, r, e = C.c_int(), C.c_int(), C.c_int64()
+        _ck(lib().khip_csr_delta_info(self._h, C.byref(b), C.byref(r), C.byref(e)))
+        return b.value, r.value, e.value
 
     @property
     def tile_info(self):

@@ -11,7 +11,7 @@ BUILD="${KHIP_BUILD_DIR:-$HERE/build}"
 mkdir -p "$BUILD"
 objs=""
 pids=""
-for f in blas1.hip spmv.hip csr_aux.hip spmm_tile.hip panel.hip ilu.hip template.hip colcode.hip comm.cpp gen_irregular.cpp api.cpp solvers.cpp block.cpp processes.cpp; do
+for f in blas1.hip spmv.hip csr_aux.hip spmm_tile.hip panel.hip ilu.hip template.hip colcode.hip coldelta.hip comm.cpp gen_irregular.cpp api.cpp solvers.cpp block.cpp processes.cpp; do
   [ -f "$SRC/$f" ] || continue
   o="$BUILD/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ -n "$(find "$SRC" "$HERE/../include" -name '*.h*' -newer "$o" | head -1)" ]; then

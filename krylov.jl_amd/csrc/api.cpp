@@ -52,6 +52,7 @@ int khip_ctx_create(int device, void *stream, khip_ctx **out) {
     KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_a[i], hipEventDisableTiming));
     KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_b[i], hipEventDisableTiming));
   }
+  if (const char *e = getenv("KHIP_SPMV_DELTA")) ctx->tune.spmv_delta = atoi(e);   // likewise for the block-delta column stream
   if (const char *e = getenv("KHIP_SPMV_CODES")) ctx->tune.spmv_codes = atoi(e);   // tests force the coded column stream on small operators too (tests/conftest.py)
   hipDeviceProp_t prop;
   KHIP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
@@ -106,7 +107,7 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
       {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
+      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_delta", &t.spmv_delta}, {"spmv_wide", &t.spmv_wide}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;
@@ -292,6 +293,7 @@ int khip_csr_destroy(khip_csr *A) {
   csr_free_templates(A);
   csr_free_window(A);
   csr_free_tiles(A);
+  csr_free_delta(A);
   csr_free_codes(A);
   delete A;
   return KHIP_OK;
@@ -317,6 +319,15 @@ int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals) {
   KHIP_REQUIRE(A, "csr_code_info: null handle");
   if (bits) *bits = A->code_state == 1 ? A->code_bits : 32;
   if (diagonals) *diagonals = A->code_state == 1 ? A->code_T : 0;
+  return KHIP_OK;
+}
+
+int khip_csr_delta_info(const khip_csr *A, int *bits, int *rows, int64_t *escapes) {
+  KHIP_REQUIRE(A, "csr_delta_info: null handle");
+  const bool on = A->delta_state == 1;
+  if (bits) *bits = on ? A->delta_bits : 32;
+  if (rows) *rows = on ? A->delta_rows : 0;
+  if (escapes) *escapes = on ? A->delta_esc : 0;
   return KHIP_OK;
 }
 
@@ -413,6 +424,9 @@ int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes) {
   if (A->tmpl_id) *bytes = 2 * A->m + 8 * ncols_read + 8 * A->m;        // template id + x + y
   else if (A->code_state == 1)                                          // coded columns (colcode.hip): 1 or 2 B per entry
     *bytes = (8 + A->code_bits / 8) * A->nnz + 4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
+  else if (A->delta_state == 1)                                         // block-delta columns (coldelta.hip): codes + 6 B per escape + 8 B per block
+    *bytes = (8 + A->delta_bits / 8) * A->nnz + 6 * A->delta_esc + 8 * ((A->m + A->delta_rows - 1) / A->delta_rows) +
+             4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
   else *bytes = 12 * A->nnz + 4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
   return KHIP_OK;
 }

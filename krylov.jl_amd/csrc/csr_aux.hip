@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(kBlock) void col_remap_kernel(int32_t *col, int64_t
 
 int launch_col_remap(khip_ctx *ctx, khip_csr *A, const int32_t *ghost_sorted_dev, int64_t n_ghost) {
   csr_free_codes(A);        // the coded column stream (colcode.hip) is rebuilt from the renumbered columns
+  csr_free_delta(A);        // ... and so is the block-delta stream (coldelta.hip)
   if (A->nnz == 0) return KHIP_OK;
   int64_t want = (A->nnz + kBlock - 1) / kBlock;
   int grid = (int)(want < 4096 ? want : 4096);
@@ -1050,6 +1051,7 @@ __global__ __launch_bounds__(kBlock) void col_remap_gather_kernel(int32_t *col, 
 
 int launch_col_remap_gather(khip_ctx *ctx, khip_csr *A, const int64_t *row_starts_dev, int nranks, int64_t maxm) {
   csr_free_codes(A);
+  csr_free_delta(A);
   if (A->nnz == 0) return KHIP_OK;
   int64_t want = (A->nnz + kBlock - 1) / kBlock;
   int grid = (int)(want < 4096 ? want : 4096);

@@ -84,6 +84,8 @@ struct Tuning {
   int spmv_lds_pad = 0;     // experiment: extra dynamic LDS bytes per workgroup (lowers occupancy)
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
   int spmv_pipe = 0;        // staged kernel: software-pipelined form with this many consecutive row blocks per workgroup (0 = one block per workgroup, no pipeline; measured no faster: profiles/r02b_sweep_pipe.log)
+  int spmv_delta = 1;       // stream kernel: block-delta column stream (coldelta.hip: 1 or 2 B per entry + 6 B per escape) -- 1: operators of >= 4 M entries where it saves at least a sixth of the column bytes; 2: whatever the size; 8 / 16: that width, always; 0: never
+  int spmv_wide = 1;        // stream kernel: the 16-byte-load form (spmv_delta_kernel<int32_t>) where the delta stream is not used; 0: the 8 + 4 byte loads of spmv_stream_kernel
   int spmv_codes = 1;       // staged kernel: stream dictionary-coded columns (1 or 2 B per entry) when the operator has <= 2048 diagonals -- 1: for operators of >= 4 M entries; 2: whatever the size; 16: two-byte codes; 0: plain int32 columns
   int spmv_lanes = 0;       // vector kernel lanes per row (0 = auto)
   int spmv_persist = 0;     // 1 = persistent grid (<= 8 workgroups per CU) instead of one row block per workgroup
@@ -219,6 +221,16 @@ struct khip_csr {
   int code_T = 0;                      // distinct (column - row) offsets
   void *code = nullptr;                // uint8_t / uint16_t [nnz + pad]
   int32_t *code_tab = nullptr;         // [code_T], ascending
+  // optional block-delta column stream of the stream SpMV (coldelta.hip, built on the first product that can use it)
+  int delta_state = 0;                 // 0 = not tried, 1 = built, -1 = tried, not usable / not worth it
+  int delta_bits = 0;                  // 8 or 16
+  int delta_rows = 0;                  // rows per block (the kernel's row block)
+  int64_t delta_esc = 0;               // escapes (entries kept as int32 columns)
+  void *dcode = nullptr;               // uint8_t / uint16_t [nnz + pad]
+  int32_t *dbase = nullptr;            // [blocks]
+  int32_t *desc_ptr = nullptr;         // [blocks + 1]
+  uint16_t *desc_pos = nullptr;        // [delta_esc]
+  int32_t *desc_col = nullptr;         // [delta_esc]
 };
 
 namespace khip {
@@ -303,6 +315,8 @@ void csr_free_templates(khip_csr *A);
 void csr_free_window(khip_csr *A);
 void csr_free_tiles(khip_csr *A);                  // spmm_tile.hip
 int spmm_tile_build(khip_ctx *ctx, khip_csr *A);   // spmm_tile.hip: sets A->tile_state to 1 or -1
+void csr_free_delta(khip_csr *A);                  // coldelta.hip
+int csr_build_delta(khip_ctx *ctx, khip_csr *A, int rows);   // coldelta.hip: sets A->delta_state to 1 or -1
 void csr_free_codes(khip_csr *A);                  // colcode.hip
 int csr_build_codes(khip_ctx *ctx, khip_csr *A);   // colcode.hip: sets A->code_state to 1 or -1
 int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,

@@ -600,6 +600,161 @@ __global__ __launch_bounds__(kBlock) void spmv_pipe_kernel(SpmvArgs a, RedArgs r
   }
 }
 
+// ---------------------------------------------------------------- stream, wide loads, block-delta columns ----
+// The stream kernel (products in nnz order into LDS, then one lane per row sums its segment in stored order) for
+// mid-length rows, rebuilt around two measurements: (1) a wave's vector-memory instruction costs the CU about the same
+// whatever its width (profiles/r02_l2bench.log), so the val / column window is moved as 16-byte buffer loads with the
+// block's extent in the descriptor (4 + 2 instructions per lane and 2048 entries instead of 16 of 8 and 4 bytes);
+// (2) the bytes are what is left to cut: with CODE = uint8_t / uint16_t the columns come as block-delta codes
+// (coldelta.hip: col = base[block] + code, 1 or 2 bytes per entry), the entries that do not fit (code = all ones: long-range
+// links, dense rows) from the block's escape list -- (position, int32 column) pairs patched into the product window by
+// the first lanes after the main pass.  CODE = int32_t reads the plain CSR columns (no escapes).  A lane holds four
+// consecutive entries; its four gathers are issued together.  Arithmetic per row is unchanged -- one rounded multiply per
+// entry, rounded adds in stored order -- so y is bit-identical to every other kernel and to the serial loop.
+// Requires row_lo to be a multiple of the row block (launch_spmv checks).
+template <typename CODE, bool DOT, bool COMP, bool DIST>
+__global__ __launch_bounds__(kBlock) void spmv_delta_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
+  typedef typename code_load<CODE>::vec cvec;
+  constexpr bool PLAIN = sizeof(CODE) == 4;
+  constexpr unsigned ESC = PLAIN ? 0xffffffffu : ((1u << (8 * (sizeof(CODE) & 3))) - 1u);
+  constexpr int CAP = 2048;                  // products per window (16 KB)
+  __shared__ __attribute__((aligned(16))) double s_prod[CAP + 8];
+  const int ROWS = a.stage_rows;
+  const int tid = threadIdx.x;
+  const CODE *code = reinterpret_cast<const CODE *>(PLAIN ? (const void *)a.col : a.dcode);
+  const int64_t nrows = a.row_hi - a.row_lo;
+  const int64_t nrb = (nrows + ROWS - 1) / ROWS;
+  const int G = gridDim.x;
+  const int cid = chunk_id(blockIdx.x, G, a.xcd_remap);
+  const int64_t rb_begin = nrb * cid / G;
+  const int64_t rb_end = nrb * (cid + 1) / G;
+  dd dacc[2];
+  dacc[0] = dd{0.0, 0.0};
+  dacc[1] = dd{0.0, 0.0};
+
+  for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
+    const int64_t r0 = a.row_lo + rb * ROWS;
+    const int nr = (int)((a.row_hi - r0) < ROWS ? (a.row_hi - r0) : ROWS);
+    const int64_t s = a.rowptr[r0], e = a.rowptr[r0 + nr];
+    const int my_a = (tid < nr) ? a.rowptr[r0 + tid] : 0;
+    const int my_b = (tid < nr) ? a.rowptr[r0 + tid + 1] : 0;
+    int32_t base = 0, E0 = 0, E1 = 0;
+    if (!PLAIN) {
+      const int64_t bi = r0 / ROWS;
+      base = a.dbase[bi];
+      E0 = a.desc_ptr[bi];
+      E1 = a.desc_ptr[bi + 1];
+    }
+    double acc = 0.0, wv = 0.0;
+    if (DOT && a.dot_early && tid < nr) wv = a.dotw[r0 + tid];
+    for (int64_t c0 = s & ~(int64_t)3; c0 < e; c0 += CAP) {
+      const int lim = (int)((e - c0) < (int64_t)CAP ? (e - c0) : (int64_t)CAP);
+      const int lim4 = (lim + 3) & ~3;
+      const int first = (int)(s - c0) > 0 ? (int)(s - c0) : 0;      // entries below it belong to the previous block (other base)
+      const __amdgpu_buffer_rsrc_t rv =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(a.val + c0), 0, lim4 * 8, kBufRsrcWord3);
+      const __amdgpu_buffer_rsrc_t rc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<CODE *>(code + c0), 0, lim4 * (int)sizeof(CODE), kBufRsrcWord3);
+      u32x4 v[4];
+      cvec c[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int o = q * (4 * kBlock) + 4 * tid;
+        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 0);
+        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 0);
+        c[q] = code_load<CODE>::ld(rc, o * (int)sizeof(CODE));
+      }
+      // this lane's escape of the block (blocks with more than 256 escapes: the loop behind the barrier takes the rest)
+      int epos = 0;
+      int32_t ecol = 0;
+      const int eb = E0 + tid;
+      const bool has_esc = !PLAIN && eb < E1;
+      if (has_esc) { epos = a.desc_pos[eb]; ecol = a.desc_col[eb]; }
+      // columns of this lane's 8 entries
+      int32_t cc[8];
+      bool ok[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int o = q * (4 * kBlock) + 4 * tid;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned cd;
+          if (PLAIN) cd = ((const unsigned *)&c[q])[j];
+          else if (sizeof(CODE) == 1) cd = (((const unsigned *)&c[q])[0] >> (8 * j)) & 0xffu;
+          else cd = (((const unsigned *)&c[q])[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+          ok[4 * q + j] = (o + j >= first) && (o + j < lim) && (PLAIN || cd != ESC);
+          cc[4 * q + j] = base + (int32_t)cd;
+        }
+      }
+      double xx[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xx[u] = 0.0;
+        if (ok[u]) xx[u] = gather_x<DIST>(a, cc[u]);
+      }
+      // second level of the escape: its value (an L2 hit: this workgroup has just streamed it) and its x entry
+      double ev = 0.0, ex = 0.0;
+      int eidx = -1;
+      if (has_esc) {
+        eidx = (int)(s - c0) + epos;
+        if (eidx < lim) { ev = a.val[s + epos]; ex = gather_x<DIST>(a, ecol); } else eidx = -1;
+        if (eidx >= CAP || eidx < 0) eidx = -1;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int o = q * (4 * kBlock) + 4 * tid;
+        const double *vv = reinterpret_cast<const double *>(&v[2 * q]);
+        dbl2 p01, p23;
+        p01.x = vv[0] * xx[4 * q];
+        p01.y = vv[1] * xx[4 * q + 1];
+        p23.x = vv[2] * xx[4 * q + 2];
+        p23.y = vv[3] * xx[4 * q + 3];
+        if (o < CAP) {
+          *reinterpret_cast<dbl2 *>(s_prod + o) = p01;
+          *reinterpret_cast<dbl2 *>(s_prod + o + 2) = p23;
+        }
+      }
+      if (!PLAIN) {
+        __syncthreads();
+        if (eidx >= 0) s_prod[eidx] = ev * ex;
+        for (int eb2 = eb + kBlock; eb2 < E1; eb2 += kBlock) {
+          const int ep = a.desc_pos[eb2];
+          const int ei = (int)(s - c0) + ep;
+          if (ei >= 0 && ei < lim) s_prod[ei] = a.val[s + ep] * gather_x<DIST>(a, a.desc_col[eb2]);
+        }
+      }
+      __syncthreads();
+      if (tid < nr) {
+        const int rel_a = (int)(my_a - c0), rel_b = (int)(my_b - c0);
+        const int lo = rel_a > 0 ? rel_a : 0;
+        const int hi = rel_b < lim ? rel_b : lim;
+        int k = lo;
+        for (; k + 4 <= hi; k += 4) {
+          const double p0 = s_prod[k], p1 = s_prod[k + 1], p2 = s_prod[k + 2], p3 = s_prod[k + 3];
+          acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+        }
+        for (; k < hi; ++k) acc = acc + s_prod[k];
+      }
+      if (c0 + CAP < e) __syncthreads();
+    }
+    if (rb + 1 < rb_end) __syncthreads();
+    if (tid < nr) {
+      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+      if (DOT) {
+        if (!a.dot_early) wv = a.dotw[r0 + tid];
+        acc_prod<COMP>(dacc[0], wv, acc);
+        if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
+        else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);
+      }
+    }
+  }
+  if (DOT) {
+    if (a.dot_sq) wave_publish<2>(dacc, ra);
+    else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
+  }
+}
+
 // ---------------------------------------------------------------- row templates ----------
 // Compressed handles (template.hip): a row is a 16-bit id into a table of (column - row, value) sequences
 // held in LDS.  One lane per row; lanes of a wave mostly share the template (LDS broadcast), and at step k
@@ -804,6 +959,15 @@ static void launch_pipe_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra,
 #undef KHIP_L
 }
 
+template <typename CODE>
+static void launch_delta_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
+                             bool dist) {
+#define KHIP_L(DOT, COMP, DIST) \
+  hipLaunchKernelGGL((spmv_delta_kernel<CODE, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, ra)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
 template <int L, int RPG, bool NT>
 static void launch_ordered_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                                bool dist) {
@@ -901,6 +1065,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256; a.max_row = 0;
+  a.dcode = nullptr; a.dbase = nullptr; a.desc_ptr = nullptr; a.desc_pos = nullptr; a.desc_col = nullptr;
   a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;
   const bool dot = dot_slot >= 0, comp = ctx->tune.compensated != 0, dist = A->dist;
   const bool persist = ctx->tune.spmv_persist != 0;
@@ -946,6 +1111,25 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
     ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
     const int vec = ctx->tune.spmv_vec == 2 ? 2 : 1;
+    // 16-byte-load form (spmv_delta_kernel): with the block-delta column stream (coldelta.hip, built once per handle at the
+    // first product that gets here) where that saves bytes, else on the plain int32 columns
+    khip_csr *Am = const_cast<khip_csr *>(A);
+    const int dl = ctx->tune.spmv_delta;
+    const bool wide_ok = !nt && !a.fake_gather && vec != 2 && !persist && A->nnz > 0;
+    if (wide_ok && dl && (dl != 1 || A->nnz >= ((int64_t)1 << 22)) && Am->delta_state == 0)
+      optional_build(csr_build_delta(ctx, Am, rows));
+    const bool delta = wide_ok && dl && Am->delta_state == 1 && row_lo % Am->delta_rows == 0;
+    if (delta || (wide_ok && ctx->tune.spmv_wide)) {
+      a.stage_rows = delta ? Am->delta_rows : rows;
+      if (delta) { a.dcode = Am->dcode; a.dbase = Am->dbase; a.desc_ptr = Am->desc_ptr; a.desc_pos = Am->desc_pos; a.desc_col = Am->desc_col; }
+      grid = pick_grid(ctx, (nrows + a.stage_rows - 1) / a.stage_rows, false);
+      if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
+      ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
+      if (!delta) launch_delta_cfg<int32_t>(ctx, a, ra, grid, dot, comp, dist);
+      else if (Am->delta_bits == 8) launch_delta_cfg<uint8_t>(ctx, a, ra, grid, dot, comp, dist);
+      else launch_delta_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
+      rows = 0;        // launched
+    }
 #define KHIP_ROWS(R)                                                                              \
   do {                                                                                            \
     if (vec == 2) { if (nt) launch_stream_cfg<R, 2, true>(ctx, a, ra, grid, dot, comp, dist);     \
@@ -954,6 +1138,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
                     else    launch_stream_cfg<R, 1, false>(ctx, a, ra, grid, dot, comp, dist); }  \
   } while (0)
     switch (rows) {
+      case 0: break;
       case 256: KHIP_ROWS(256); break;
       case 128: KHIP_ROWS(128); break;
       case 64: KHIP_ROWS(64); break;

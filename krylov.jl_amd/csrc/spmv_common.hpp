@@ -45,7 +45,13 @@ struct SpmvArgs {
   const void *code;          // uint8_t[nnz + pad] or uint16_t[nnz + pad]
   const int32_t *code_tab;   // sorted distinct (column - row) offsets, code_T entries
   int code_T;
-  int stage_rows;            // coded / pipelined kernels: rows per block (256, 128, 64 or 32)
+  // block-delta column stream (coldelta.hip): col = dbase[block] + dcode[k]; all-ones code = escape
+  const void *dcode;         // uint8_t[nnz + pad] or uint16_t[nnz + pad]
+  const int32_t *dbase;      // base column of every row block
+  const int32_t *desc_ptr;   // [blocks + 1] first escape of every row block
+  const uint16_t *desc_pos;  // escape: entry position inside its block
+  const int32_t *desc_col;   // escape: column
+  int stage_rows;            // coded / pipelined / delta kernels: rows per block (256, 128, 64 or 32)
   int max_row;               // pipelined kernel: longest row of the operator (uniform trip count of the row walk)
 };
 

@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 # iteration is latency bound); the tests' operators are small, so every context of the test session (and of the processes
 # it spawns) forces the coded stream wherever an operator qualifies.  tests/test_gpu_primitives.py checks the default too.
 os.environ.setdefault("KHIP_SPMV_CODES", "2")
+# ... and likewise the block-delta column stream of the stream kernel (csrc/coldelta.hip): whatever the operator's size
+os.environ.setdefault("KHIP_SPMV_DELTA", "2")
 
 
 def pytest_configure(config):

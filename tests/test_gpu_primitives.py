@@ -689,6 +689,79 @@ def test_spmv_fuzz_all_kernels_bit_exact(K, ctx, oracle):
             ctx.set_option(k, v)
 
 
+def test_spmv_block_delta_columns_bit_exact(K, ctx, oracle):
+    """The stream kernel's block-delta column stream (csrc/coldelta.hip: col = base[block] + 1- or 2-byte code, the entries that
+    do not fit as (position, int32 column) escapes) and its 16-byte-load form on plain int32 columns: y equals the oracle's
+    serial loop bit for bit on the non-stencil operators -- the banded + random operator (3 long-range links per row: escapes
+    with 8 and with 16 bits), its nonsymmetric variant with rows of 3000 entries (blocks of several windows, more than 256
+    escapes per block), random matrices (nearly everything escapes), empty rows, a rectangular operator -- with and without
+    the fused dots; the bytes the kernel streams are what khip_spmv_bytes_stored reports."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(4242)
+    cases = []
+    for kw in (dict(n=20000, seed=3), dict(n=30000, seed=5, unsym=True, dense_rows=3), dict(n=5000, half_band=40, links=1, seed=9)):
+        A = oracle.banded_random(**kw)
+        cases.append((A.rowptr.copy(), A.col.copy(), A.val.copy(), (A.n, A.n), "banded_random %r" % kw))
+    for (m, n, dens) in ((3000, 3000, 0.006), (2500, 4100, 0.008), (700, 90000, 0.0004)):
+        S = sp.random(m, n, density=dens, random_state=int(rng.integers(1 << 30)), format="csr")
+        S.sort_indices()
+        cases.append((S.indptr.astype(np.int64), S.indices.astype(np.int32), S.data.copy(), (m, n), "random %dx%d" % (m, n)))
+    saved = {k: ctx.get_option(k) for k in ("spmv_kernel", "spmv_delta", "spmv_wide", "spmv_codes")}
+    try:
+        ctx.set_option("spmv_kernel", 1)
+        ctx.set_option("spmv_codes", 0)
+        for rp, ci, va, (m, n), name in cases:
+            nnz = int(rp[-1])
+            x = _vec(rng, n)
+            y_ref = oracle.CsrMatrix.from_arrays(rp, ci, va).matvec(x) if m == n else None
+            if y_ref is None:
+                y_ref = np.zeros(m)
+                for i in range(m):
+                    acc = 0.0
+                    for q in range(rp[i], rp[i + 1]):
+                        acc = acc + va[q] * x[ci[q]]
+                    y_ref[i] = acc
+            dx = ctx.array(x)
+            seen = set()
+            for delta, wide in ((0, 0), (0, 1), (8, 1), (16, 1), (2, 1), (1, 1)):
+                ctx.set_option("spmv_delta", delta)
+                ctx.set_option("spmv_wide", wide)
+                dA = K.CsrMatrix.from_host(ctx, rp, ci, va, (m, n))
+                assert dA.delta_info == (32, 0, 0)                                     # nothing is built before the first product
+                dy = ctx.zeros(m)
+                dA.matvec(dx, dy)
+                assert np.array_equal(dy.to_host(), y_ref), (name, delta, wide)
+                bits, rows, esc = dA.delta_info
+                seen.add(bits)
+                if delta in (8, 16):
+                    assert bits == delta and rows in (32, 64, 128, 256) and 0 <= esc <= nnz, (name, dA.delta_info)
+                    blocks = (m + rows - 1) // rows
+                    assert dA.spmv_bytes_stored == (8 + bits // 8) * nnz + 6 * esc + 8 * blocks + 4 * (m + 1) + 8 * n + 8 * m
+                    # the escapes are exactly the entries outside [base, base + 2^bits - 2] of their block
+                    r_of = np.repeat(np.arange(m), np.diff(rp))
+                    base = np.maximum(0, (r_of // rows) * rows - ((1 << bits) - 1 - rows) // 2)
+                    assert esc == int(np.count_nonzero((ci < base) | (ci - base >= (1 << bits) - 1))), name
+                elif delta in (0, 1):
+                    assert bits == 32                                                  # 1: only operators of >= 4 M entries
+                    assert dA.spmv_bytes_stored == 12 * nnz + 4 * (m + 1) + 8 * n + 8 * m
+                if m == n:
+                    dy2 = ctx.zeros(m)
+                    d = K.spmv_dot(dA, dx, dy2)
+                    assert np.array_equal(dy2.to_host(), y_ref), (name, delta, "fused dot")
+                    d_cpu = oracle.dot(x, y_ref)
+                    assert abs(d - d_cpu) <= 2 * EPS * abs(d_cpu) + 1e-16 * float(np.abs(x * y_ref).sum())
+                    dy3 = ctx.zeros(m)
+                    d2 = K.spmv_dot2(dA, dx, dy3)                                      # x.y and y.y from one product
+                    assert np.array_equal(dy3.to_host(), y_ref)
+                    yy = oracle.dot(y_ref, y_ref)
+                    assert abs(d2[0] - d_cpu) <= 2 * EPS * abs(d_cpu) + 1e-16 * float(np.abs(x * y_ref).sum())
+                    assert abs(d2[1] - yy) <= 4 * EPS * yy
+            assert 8 in seen and 16 in seen and 32 in seen
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+
+
 @pytest.mark.parametrize("kind,n1,bits,diags", [("poisson", 20, 8, 7), ("kron_unsymmetric", 12, 8, 7), ("stencil27", 9, 8, 27)])
 def test_spmv_coded_columns_bit_exact(K, ctx, oracle, kind, n1, bits, diags):
     """The staged kernel's dictionary-coded column stream (csrc/colcode.hip: one byte per entry = the rank of the

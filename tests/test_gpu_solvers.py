@@ -736,6 +736,43 @@ def test_verbose_prints_the_reference_log_and_changes_nothing(K, ctx, oracle, ca
     assert out[0] == f"BLOCK-GMRES: system of size {nu} with 4 right-hand sides" and out[1].split() == ["pass", "k", "‖Rₖ‖", "timer"]
 
 
+def test_verbose_log_goes_to_the_callers_iostream(K, ctx, capfd, tmp_path):
+    """options.log_fd = the reference's `iostream` keyword (src/cg.jl:24,182-183): the same rows, written to the caller's file
+    descriptor instead of stdout; variants with another recurrence have no such rows and refuse verbose."""
+    n1 = 12
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "poisson", n1)
+    b = ctx.empty(n)
+    K.kfill_(b, 1.0)
+    capfd.readouterr()
+    _, st0, _ = K.cg(A, b, history=True, verbose=5)
+    on_stdout = capfd.readouterr().out
+    on_stdout = on_stdout[on_stdout.index("CG: system"):]
+    path = tmp_path / "cg.log"
+    with open(path, "wb") as f:
+        _, st1, _ = K.cg(A, b, history=True, verbose=5, log_fd=f.fileno())
+    assert "CG: system" not in capfd.readouterr().out                  # nothing on stdout this time
+    text = path.read_text()
+    strip = lambda t: [" ".join(l.split()[:-1]) for l in t.split("\n")]   # drop the timer column
+    assert strip(text) == strip(on_stdout) and text.startswith(f"CG: system of {n} equations in {n} variables\n")
+    assert st1.niter == st0.niter and np.array_equal(st1.residuals, st0.residuals)
+    Au = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", 8)
+    ones = ctx.empty(512)
+    K.kfill_(ones, 1.0)
+    bu = Au.matvec(ones)
+    with open(tmp_path / "rest.log", "wb") as f:
+        K.gmres(Au, bu, memory=10, restart=True, verbose=3, log_fd=f.fileno())
+        K.bicgstab(Au, bu, verbose=3, log_fd=f.fileno())
+        K.block_gmres(Au, np.random.default_rng(5).standard_normal((512, 2)), memory=4, ctx=ctx, verbose=2, log_fd=f.fileno())
+    rest = (tmp_path / "rest.log").read_text()
+    assert rest.index("GMRES: system of size 512") < rest.index("BICGSTAB: system of size 512") < rest.index("BLOCK-GMRES: system of size 512 with 2")
+    assert "system of size" not in capfd.readouterr().out
+    for variant in (1, 2):
+        with pytest.raises(K.KhipError) as e:
+            K.cg(A, b, variant=variant, verbose=1)
+        assert "variant = 0" in str(e.value)
+
+
 def test_allocation_timer_counts_creation_and_lazy_allocations(K, ctx):
     """stats.allocation_timer (src/krylov_workspaces.jl:288-289; allocate_if, src/krylov_utils.jl:281-288): set when the
     workspace allocates its vectors, increased by the lazy ones (z for a preconditioned cg!, Δx for a warm start), not by
