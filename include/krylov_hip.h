@@ -111,6 +111,10 @@ int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
  * product that can use it, ctx option "spmv_delta"): bits = 8 / 16 (32: not in use), rows = rows per block, escapes = entries
  * that stay int32 (6 B each).  khip_spmv_bytes_stored counts what that kernel streams. */
 int khip_csr_delta_info(const khip_csr *A, int *bits, int *rows, int64_t *escapes);
+/* Which SpMV kernel khip_spmv takes for this handle under the context's options: 1 = stream (products in nnz order through
+ * LDS), 2 = strided vector (very long rows), 3 = ordered sub-wave, 4 = staged rows (one lane per row; also the one that streams
+ * the dictionary codes), 5 = row templates (khip_csr_compress), 6 = wave-private windows (LDS-DMA). */
+int khip_spmv_kernel_info(khip_ctx *ctx, const khip_csr *A, int *kernel);
 /* Which SpMM kernel a product with 16 right-hand sides runs on this handle (csrc/spmm_tile.hip): *state = 1 when the handle
  * keeps group records for the wave-private-window kernel (built by the first khip_spmm with p = 16; 0 before that, -1 when
  * the operator lacks the locality and the other SpMM kernels are used); *window = distinct panel rows a group's LDS window

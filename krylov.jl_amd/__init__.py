@@ -90,6 +90,7 @@ SIGNATURES = {
     "khip_spmm": (_int, [_vp, _vp, _vp, _vp, _int]),
     "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
     "khip_csr_code_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "khip_spmv_kernel_info": (_int, [_vp, _vp, C.POINTER(C.c_int)]),
     "khip_csr_delta_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "khip_csr_tile_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -637,6 +638,14 @@ class CsrMatrix:
         b, t = C.c_int(), C.c_int()
         _ck(lib().khip_csr_code_info(self._h, C.byref(b), C.byref(t)))
         return b.value, t.value
+
+    @property
+    def spmv_kernel_choice(self):
+        """The SpMV kernel this handle takes under the context's current options (khip_spmv_kernel_info): 1 stream, 2 vector,
+        3 ordered, 4 staged rows, 5 row templates, 6 wave-private windows."""
+        k = C.c_int()
+        _ck(lib().khip_spmv_kernel_info(self.ctx._h, self._h, C.byref(k)))
+        return k.value
 
     @property
     def delta_info(self):

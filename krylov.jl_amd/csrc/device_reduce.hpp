@@ -128,6 +128,35 @@ __device__ __forceinline__ void wave_publish(dd (&acc)[NOUT], const RedArgs &ra)
   }
 }
 
+// The same for kernels whose workgroup is one tile and has LDS to spare at its end (the SpMV windows): the four waves leave
+// their lanes' partials in LDS and ONE wave folds all 256 (lane l: threads l, l + 64, l + 128, l + 192 in that order, then the
+// wave64 tree).  The double-double tree is ~90 VALU instructions per wave -- as many as a 7-point row block's own arithmetic --
+// and three of the four waves now skip it: measured on the fused SpMV + p.Ap at 512^3 (profiles/r04*).  The partial lands
+// in the first wave's slot, the other three slots get an exact zero (the finish kernel's input layout is unchanged).
+// s_red: kBlock * NOUT dd of LDS that no wave reads any more once every wave has passed the caller's last barrier.
+template <int NOUT>
+__device__ __forceinline__ void block_publish(dd (&acc)[NOUT], const RedArgs &ra, dd *s_red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t wid = ra.wave_offset + (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) s_red[o * kBlock + tid] = acc[o];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      dd v = s_red[o * kBlock + lane];
+      v = dd_merge(v, s_red[o * kBlock + 64 + lane]);
+      v = dd_merge(v, s_red[o * kBlock + 128 + lane]);
+      v = dd_merge(v, s_red[o * kBlock + 192 + lane]);
+      v = wave_reduce(v);
+      if (lane == kResultLane) ra.wave_partials[(size_t)o * ra.cap + wid] = v;
+    }
+  } else if (lane == kResultLane) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) ra.wave_partials[(size_t)o * ra.cap + wid] = dd{0.0, 0.0};
+  }
+}
+
 // Workgroup reduction of NOUT partials; result valid in thread 0.
 template <int NOUT>
 __device__ __forceinline__ void block_reduce(dd (&acc)[NOUT], dd (*s_w)[kWavesPerBlock]) {

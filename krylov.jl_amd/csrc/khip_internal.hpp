@@ -84,8 +84,10 @@ struct Tuning {
   int spmv_lds_pad = 0;     // experiment: extra dynamic LDS bytes per workgroup (lowers occupancy)
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
   int spmv_pipe = 0;        // staged kernel: software-pipelined form with this many consecutive row blocks per workgroup (0 = one block per workgroup, no pipeline; measured no faster: profiles/r02b_sweep_pipe.log)
-  int spmv_delta = 1;       // stream kernel: block-delta column stream (coldelta.hip: 1 or 2 B per entry + 6 B per escape) -- 1: operators of >= 4 M entries where it saves at least a sixth of the column bytes; 2: whatever the size; 8 / 16: that width, always; 0: never
-  int spmv_wide = 1;        // stream kernel: the 16-byte-load form (spmv_delta_kernel<int32_t>) where the delta stream is not used; 0: the 8 + 4 byte loads of spmv_stream_kernel
+  int spmv_stream_nt = 0;   // 16-byte-load stream kernel: matrix stream loaded with the non-temporal policy
+  int spmv_blk_pub = 0;     // fused dots of the staged / coded / delta SpMV kernels: 1 = workgroup-level fold in LDS, one wave runs the double-double tree (block_publish); measured equal to the per-wave trees (profiles/r04b_sweep_headline.log): off
+  int spmv_delta = 0;       // stream kernel: block-delta column stream (coldelta.hip: 1 or 2 B per entry + 6 B per escape) -- 0: never (default: 18 % fewer bytes but no faster on the banded + random operator, slower on stencils; profiles/r04a_sweep_delta.log); 1: operators of >= 4 M entries where it saves at least a sixth of the column bytes; 2: whatever the size; 8 / 16: that width, always
+  int spmv_wide = 0;        // stream kernel: 1 = the 16-byte-load form (spmv_delta_kernel<int32_t>) where the delta stream is not used (measured equal on the irregular operator, 8 % slower on the 27-point one); 0: the 8 + 4 byte loads of spmv_stream_kernel
   int spmv_codes = 1;       // staged kernel: stream dictionary-coded columns (1 or 2 B per entry) when the operator has <= 2048 diagonals -- 1: for operators of >= 4 M entries; 2: whatever the size; 16: two-byte codes; 0: plain int32 columns
   int spmv_lanes = 0;       // vector kernel lanes per row (0 = auto)
   int spmv_persist = 0;     // 1 = persistent grid (<= 8 workgroups per CU) instead of one row block per workgroup

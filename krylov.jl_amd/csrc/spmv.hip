@@ -284,7 +284,13 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
     }
   }
   if (DOT) {
-    if (a.dot_sq) wave_publish<2>(dacc, ra);
+    // the window is free: every wave has passed the loop's last barrier (a tile has at least one window when nnz > 0;
+    // a.blk_pub is off otherwise)
+    if (a.blk_pub) {
+      dd *s_red = reinterpret_cast<dd *>(s_stage);
+      if (a.dot_sq) block_publish<2>(dacc, ra, s_red);
+      else block_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra, s_red);
+    } else if (a.dot_sq) wave_publish<2>(dacc, ra);
     else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
   }
 }
@@ -302,14 +308,16 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
 template <typename CODE> struct code_load;
 template <> struct code_load<uint8_t> {    // 4 codes = one dword
   typedef unsigned int vec;
+  template <int AUX = 0>
   static __device__ __forceinline__ vec ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, AUX);
   }
 };
 template <> struct code_load<uint16_t> {   // 4 codes = two dwords
   typedef unsigned int vec __attribute__((ext_vector_type(2)));
+  template <int AUX = 0>
   static __device__ __forceinline__ vec ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, AUX);
   }
 };
 
@@ -416,7 +424,13 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
     }
   }
   if (DOT) {
-    if (a.dot_sq) wave_publish<2>(dacc, ra);
+    // the window is free: every wave has passed the loop's last barrier (a tile has at least one window when nnz > 0;
+    // a.blk_pub is off otherwise)
+    if (a.blk_pub) {
+      dd *s_red = reinterpret_cast<dd *>(s_stage);
+      if (a.dot_sq) block_publish<2>(dacc, ra, s_red);
+      else block_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra, s_red);
+    } else if (a.dot_sq) wave_publish<2>(dacc, ra);
     else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
   }
 }
@@ -441,8 +455,9 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
 // Requires every row block to fit one window (rows * max_row_nnz + 3 <= 2048) and nnz > 0; launch_spmv checks.
 template <> struct code_load<int32_t> {    // 4 columns = four dwords
   typedef u32x4 vec;
+  template <int AUX = 0>
   static __device__ __forceinline__ vec ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX);
   }
 };
 
@@ -658,12 +673,22 @@ __global__ __launch_bounds__(kBlock) void spmv_delta_kernel(SpmvArgs a, RedArgs 
           __builtin_amdgcn_make_buffer_rsrc(const_cast<CODE *>(code + c0), 0, lim4 * (int)sizeof(CODE), kBufRsrcWord3);
       u32x4 v[4];
       cvec c[2];
+      if (a.stream_nt) {       // matrix stream with the non-temporal policy (read once, by this CU): x lines stay longer in the L2
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int o = q * (4 * kBlock) + 4 * tid;
-        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 0);
-        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 0);
-        c[q] = code_load<CODE>::ld(rc, o * (int)sizeof(CODE));
+        for (int q = 0; q < 2; ++q) {
+          const int o = q * (4 * kBlock) + 4 * tid;
+          v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 2);
+          v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 2);
+          c[q] = code_load<CODE>::template ld<2>(rc, o * (int)sizeof(CODE));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int o = q * (4 * kBlock) + 4 * tid;
+          v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 0);
+          v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 0);
+          c[q] = code_load<CODE>::ld(rc, o * (int)sizeof(CODE));
+        }
       }
       // this lane's escape of the block (blocks with more than 256 escapes: the loop behind the barrier takes the rest)
       int epos = 0;
@@ -743,6 +768,118 @@ __global__ __launch_bounds__(kBlock) void spmv_delta_kernel(SpmvArgs a, RedArgs 
       if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
       if (DOT) {
         if (!a.dot_early) wv = a.dotw[r0 + tid];
+        acc_prod<COMP>(dacc[0], wv, acc);
+        if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
+        else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);
+      }
+    }
+  }
+  if (DOT) {
+    if (a.blk_pub) {
+      __syncthreads();               // the last window's row sums are done in every wave: s_prod is free
+      dd *s_red = reinterpret_cast<dd *>(s_prod);
+      if (a.dot_sq) block_publish<2>(dacc, ra, s_red);
+      else block_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra, s_red);
+    } else if (a.dot_sq) wave_publish<2>(dacc, ra);
+    else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
+  }
+}
+
+// ---------------------------------------------------------------- wave-private windows (LDS-DMA) ----
+// One WAVE owns 64 consecutive rows, one lane per row, and the wave is the whole workgroup: no barrier anywhere.  The val / col
+// entries of its rows land in the wave's LDS window by global_load_lds_dwordx4 (1 KiB per instruction, no staging registers,
+// no ds_write -- gfx950), then every lane walks its row out of LDS in stored order, eight gathers in flight: at step k the
+// wave gathers x for 64 CONSECUTIVE rows, which for the near-diagonal part of any banded operator is a coalesced access
+// (the texture path handles it in ~16 cycles; the same entries taken in nnz order by the stream kernels cost ~100 because
+// a wave then touches ~10 scattered lines -- TA_BUSY 80 % of the kernel on the banded + random operator,
+// profiles/r04_spmv_irregular_pmc.json).  Unlike the staged kernel (256 threads, rows x entries <= 2048 per block, so 27
+// entries per row leave 3 of 4 waves idle during the walk) every resident wave walks all the time, and 6 ... 13 independent
+// waves per CU overlap each other's copies and walks.  Rows longer than the window are walked window by window (lanes
+// whose row does not reach into a window sit it out).  Arithmetic per row as everywhere: rounded multiply, rounded add, stored
+// order => y bit-identical to the serial loop.
+typedef __attribute__((address_space(3))) char lds_char_t;
+template <bool DOT, bool COMP, bool DIST>
+__global__ __launch_bounds__(64) void spmv_wave_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
+  constexpr int UK = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_stage[];
+  const int CAP = a.stage_cap;               // entries per window: a multiple of 256 (whole 1-KiB copies of both streams)
+  double *s_val = reinterpret_cast<double *>(s_stage);
+  int32_t *s_col = reinterpret_cast<int32_t *>(s_stage + (size_t)CAP * sizeof(double));
+  const unsigned lds_val = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_char_t *)s_stage);
+  const unsigned lds_col = lds_val + (unsigned)CAP * 8u;
+  const int lane = threadIdx.x;
+  const int64_t nrows = a.row_hi - a.row_lo;
+  const int64_t ngrp = (nrows + 63) / 64;
+  dd dacc[2];
+  dacc[0] = dd{0.0, 0.0};
+  dacc[1] = dd{0.0, 0.0};
+  for (int64_t g = blockIdx.x; g < ngrp; g += gridDim.x) {
+    const int64_t r0 = a.row_lo + g * 64;
+    const int nr = (int)((a.row_hi - r0) < 64 ? (a.row_hi - r0) : 64);
+    const int my_a = a.rowptr[r0 + (lane < nr ? lane : nr)];          // lanes past the last row: an empty row at the group's end
+    const int my_b = a.rowptr[r0 + (lane < nr ? lane + 1 : nr)];
+    const int64_t s = __builtin_amdgcn_readfirstlane(my_a);
+    const int64_t e = __builtin_amdgcn_readlane(my_b, 63);
+    double acc = 0.0, wv = 0.0;
+    if (DOT && lane < nr) wv = a.dotw[r0 + lane];
+    for (int64_t c0 = s & ~(int64_t)3; c0 < e; c0 += CAP) {
+      const int lim = (int)((e - c0) < (int64_t)CAP ? (e - c0) : (int64_t)CAP);
+      // copies: val 128 entries per instruction, col 256; lanes past the window's end are masked off (no request)
+      const int nv = (lim + 127) >> 7, nc = (lim + 255) >> 8;
+      for (int i = 0; i < nv; ++i) {
+        const int o = i * 128 + lane * 2;
+        if (o < lim) {
+          const double *gsrc = a.val + c0 + o;
+          const unsigned dst = lds_val + 1024u * (unsigned)i;
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
+      }
+      for (int i = 0; i < nc; ++i) {
+        const int o = i * 256 + lane * 4;
+        if (o < lim) {
+          const int32_t *gsrc = a.col + c0 + o;
+          const unsigned dst = lds_col + 1024u * (unsigned)i;
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const int rel_a = (int)(my_a - c0), rel_b = (int)(my_b - c0);
+      const int lo = rel_a > 0 ? rel_a : 0;
+      const int hi = rel_b < lim ? rel_b : lim;
+      for (int k0 = lo; k0 < hi; k0 += UK) {
+        int32_t cc[UK];
+        double vv[UK], xx[UK];
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+          const int j = (k0 + u < hi) ? k0 + u : k0;
+          cc[u] = s_col[j];
+          vv[u] = s_val[j];
+        }
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+          xx[u] = 0.0;
+          if (k0 + u < hi) xx[u] = gather_x<DIST>(a, cc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+          if (k0 + u < hi) {
+            const double prod = vv[u] * xx[u];
+            acc = acc + prod;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();      // every lane is done with the window before the next copies overwrite it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (lane < nr) {
+      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + lane); else a.y[r0 + lane] = acc;
+      if (DOT) {
         acc_prod<COMP>(dacc[0], wv, acc);
         if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
         else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);
@@ -932,8 +1069,11 @@ static void launch_stream_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &r
 template <int ROWS, bool NT>
 static void launch_stage_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                              bool dist) {
+  size_t lds = (size_t)ctx->tune.spmv_lds_pad + 12u * (size_t)a.stage_cap;
+  const size_t pub = dot && a.blk_pub ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;    // block_publish reuses the window
+  if (lds < pub) lds = pub;
 #define KHIP_L(DOT, COMP, DIST) \
-  hipLaunchKernelGGL((spmv_stage_kernel<ROWS, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), (size_t)ctx->tune.spmv_lds_pad + 12u * (size_t)a.stage_cap, ctx->stream, a, ra)
+  hipLaunchKernelGGL((spmv_stage_kernel<ROWS, NT, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra)
   KHIP_DISPATCH_DCD(KHIP_L);
 #undef KHIP_L
 }
@@ -941,7 +1081,9 @@ static void launch_stage_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra
 template <typename CODE>
 static void launch_code_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                             bool dist) {
-  const size_t lds = (size_t)ctx->tune.spmv_lds_pad + (8u + sizeof(CODE)) * (size_t)a.stage_cap + 4u * (size_t)a.code_T;
+  size_t lds = (size_t)ctx->tune.spmv_lds_pad + (8u + sizeof(CODE)) * (size_t)a.stage_cap + 4u * (size_t)a.code_T;
+  const size_t pub = dot && a.blk_pub ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;    // block_publish reuses the window
+  if (lds < pub) lds = pub;
 #define KHIP_L(DOT, COMP, DIST) \
   hipLaunchKernelGGL((spmv_code_kernel<CODE, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra)
   KHIP_DISPATCH_DCD(KHIP_L);
@@ -964,6 +1106,14 @@ static void launch_delta_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra
                              bool dist) {
 #define KHIP_L(DOT, COMP, DIST) \
   hipLaunchKernelGGL((spmv_delta_kernel<CODE, DOT, COMP, DIST>), dim3(grid), dim3(kBlock), 0, ctx->stream, a, ra)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
+static void launch_wave_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp, bool dist) {
+  const size_t lds = 12u * (size_t)a.stage_cap;
+#define KHIP_L(DOT, COMP, DIST) \
+  hipLaunchKernelGGL((spmv_wave_kernel<DOT, COMP, DIST>), dim3(grid), dim3(64), lds, ctx->stream, a, ra)
   KHIP_DISPATCH_DCD(KHIP_L);
 #undef KHIP_L
 }
@@ -1033,7 +1183,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   int64_t local_cursor = 0;
   if (!wave_cursor) wave_cursor = &local_cursor;
   const int nout = dot_sq ? 2 : 1;
-  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5 && spmv_kernel_choice(ctx, A) != 1) { set_error("spmv: the second reduction output needs the staged, stream or template kernel"); return KHIP_ERR_UNSUPPORTED; }
+  if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5 && spmv_kernel_choice(ctx, A) != 1 && spmv_kernel_choice(ctx, A) != 6) { set_error("spmv: the second reduction output needs the staged, stream, wave or template kernel"); return KHIP_ERR_UNSUPPORTED; }
   if (row_hi <= row_lo) {
     if (dot_slot >= 0 && finish) {
       if (*wave_cursor == 0) {                                              // nothing at all: writes 0
@@ -1065,6 +1215,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256; a.max_row = 0;
+  a.blk_pub = ctx->tune.spmv_blk_pub;
+  a.stream_nt = ctx->tune.spmv_stream_nt;
   a.dcode = nullptr; a.dbase = nullptr; a.desc_ptr = nullptr; a.desc_pos = nullptr; a.desc_col = nullptr;
   a.blockptr = (ctx->tune.spmv_blockptr && A->blockptr && (row_lo & 255) == 0) ? A->blockptr : nullptr;
   const bool dot = dot_slot >= 0, comp = ctx->tune.compensated != 0, dist = A->dist;
@@ -1094,7 +1246,18 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   const int kernel = spmv_kernel_choice(ctx, A);
   unsigned grid = 1;
   RedArgs ra;
-  if (kernel == 5) {
+  int wpb = kWavesPerBlock;                   // reduction partials one workgroup of the chosen kernel writes
+  if (kernel == 6) {
+    // wave-private windows: a window that takes a typical 64-row group whole (+ 20 %), in 256-entry steps, at most 2048 entries
+    int64_t cap = ctx->tune.spmv_cap > 0 ? ctx->tune.spmv_cap : (int64_t)(64.0 * A->mean_row_nnz * 1.2) + 3;
+    cap = (cap + 255) & ~(int64_t)255;
+    a.stage_cap = (int)(cap < 256 ? 256 : (cap > 2048 ? 2048 : cap));
+    wpb = 1;
+    grid = pick_grid(ctx, (nrows + 63) / 64, false);
+    if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * wpb, nout));
+    ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
+    launch_wave_cfg(ctx, a, ra, grid, dot, comp, dist);
+  } else if (kernel == 5) {
     const int rpt = ctx->tune.spmv_tmpl_rows > 0 ? ctx->tune.spmv_tmpl_rows : 1;      // rows per lane: amortises the table load
     grid = pick_grid(ctx, (nrows + (int64_t)kBlock * rpt - 1) / ((int64_t)kBlock * rpt), false);
     if (dot) KHIP_TRY(ensure_reduction_scratch(ctx, *wave_cursor + (int64_t)grid * kWavesPerBlock, nout));
@@ -1149,7 +1312,11 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     int rows = ctx->tune.spmv_rows;
     if (rows != 256 && rows != 128 && rows != 64 && rows != 32) rows = 256;
     while (rows > 32 && rows * A->mean_row_nnz > 2048.0) rows >>= 1;
-    a.tiles_per_block = ctx->tune.spmv_tiles > 0 ? ctx->tune.spmv_tiles : 1;
+    // row blocks per workgroup: with a fused dot, two -- the double-double tree at a workgroup's end is ~0.1 us of dependent
+    // fp64 latency on a 2.5 us lifetime, and it is paid once per workgroup whatever it covered: 2.19 -> 2.10 ms fused at 512^3,
+    // the plain product is unchanged and four blocks per workgroup cost more than they save (profiles/r04b_sweep_headline.log)
+    const int64_t nrb_all = (nrows + rows - 1) / rows;
+    a.tiles_per_block = ctx->tune.spmv_tiles > 0 ? ctx->tune.spmv_tiles : ((dot && nrb_all >= 8192) ? 2 : 1);
     {   // LDS window: the widest row block (+3 for the 4-entry alignment of its start), at most 2048 entries
       int64_t cap = ctx->tune.spmv_cap > 0 ? ctx->tune.spmv_cap : (int64_t)rows * A->max_row_nnz + 3;
       cap = (cap + 3) & ~(int64_t)3;
@@ -1245,7 +1412,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   // the profiling bracket closes right behind the SpMV kernel: the tiny finish kernel of a fused dot is another kernel
   if (ev_stop) KHIP_CHECK_HIP(hipEventRecord(ev_stop, ctx->stream));
   if (dot) {
-    *wave_cursor += (int64_t)grid * kWavesPerBlock;
+    *wave_cursor += (int64_t)grid * wpb;
     if (finish) KHIP_TRY(launch_finish(ctx, *wave_cursor, nout, dot_slot));
   }
   return KHIP_OK;

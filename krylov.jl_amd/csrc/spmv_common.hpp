@@ -37,6 +37,8 @@ struct SpmvArgs {
   int tmpl_T, tmpl_K;
   const double *dotw;    // left vector of the fused dot: results[slot] = dotw . y   (x for p.Ap; another vector for c.(A p))
   int dot_sq;            // staged kernel: also results[slot + 1] = y . y
+  int stream_nt;         // delta kernel: non-temporal policy on the val / column window loads
+  int blk_pub;           // fused dots of the staged / coded / delta kernels: one double-double tree per workgroup (block_publish) instead of one per wave
   int dot_early;         // staged kernels: load dotw[row] before the row block's windows instead of after the row walk
   const long long *stop_seq;   // device-resident loop control (solver_device.hpp); null outside such loops
   long long seq;

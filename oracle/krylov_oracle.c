@@ -476,7 +476,50 @@ void ko_csr_block_matvec_omp(const double *X, double *Y, int p, void *csr) {
  *  BLAS-1 shim
  * ===================================================================== */
 
+/* ko_set_dot_mode(1): every dot / norm of the solvers becomes Dot2 (Ogita, Rump & Oishi 2005: TwoProd by one fma, TwoSum,
+ * double-double accumulator; thread partials merged in thread order) -- as accurate as an accumulation in twice the working
+ * precision, whatever n.  NOT the documented convention (mode 0, the default: sequential x87 extended precision, whose own
+ * rounding reaches ~sqrt(n) 2^-64 -- 2e-15 at n = 2^30): it exists to MEASURE how far that convention is from exact dots
+ * at sizes where binary128 (oracle/quad_reference.c) is out of reach (tests/golden/make_scale_golden.py leg 40). */
+static int g_dot_mode = 0;
+void ko_set_dot_mode(int mode) { g_dot_mode = mode; }
+int ko_get_dot_mode(void) { return g_dot_mode; }
+
+static inline void ko_two_sum(double a, double b, double *s, double *e) {
+  *s = a + b;
+  const double z = *s - a;
+  *e = (a - (*s - z)) + (b - z);
+}
+static double ko_dot2(int64_t n, const double *x, const double *y) {
+  int nt = g_threads > 1 && n >= ((int64_t)1 << 16) ? g_threads : 1;
+  if (nt > 256) nt = 256;
+  double hi[256], lo[256];
+#pragma omp parallel for schedule(static) num_threads(nt)
+  for (int t = 0; t < nt; t++) {
+    const int64_t i0 = n * t / nt, i1 = n * (t + 1) / nt;
+    double h = 0.0, l = 0.0;
+    for (int64_t i = i0; i < i1; i++) {
+      const double p = x[i] * y[i];
+      const double pe = fma(x[i], y[i], -p);
+      double s, e;
+      ko_two_sum(h, p, &s, &e);
+      h = s;
+      l += e + pe;
+    }
+    hi[t] = h; lo[t] = l;
+  }
+  double h = 0.0, l = 0.0;
+  for (int t = 0; t < nt; t++) {
+    double s, e;
+    ko_two_sum(h, hi[t], &s, &e);
+    h = s;
+    l += e + lo[t];
+  }
+  return h + l;
+}
+
 double ko_dot(int64_t n, const double *x, const double *y) {
+  if (g_dot_mode == 1) return ko_dot2(n, x, y);
   long double acc = 0.0L;
   for (int64_t i = 0; i < n; i++) acc += (long double)x[i] * (long double)y[i];
   return (double)acc;

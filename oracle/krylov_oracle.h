@@ -63,6 +63,8 @@ void ko_spmv(const ko_csr *A, const double *x, double *y);
 /* row-parallel OpenMP form (threaded_mul!, docs/src/tips.md:44-55) */
 void ko_spmv_omp(const ko_csr *A, const double *x, double *y);
 void ko_spmm(const ko_csr *A, const double *X, double *Y, int p); /* column-major n-by-p */
+void ko_set_dot_mode(int mode);   /* 0 (default): the documented sequential extended-precision dots; 1: Dot2 (krylov_oracle.c) */
+int  ko_get_dot_mode(void);
 void ko_csr_matvec(const double *x, double *y, void *csr);        /* ko_matvec adaptor  */
 void ko_csr_matvec_omp(const double *x, double *y, void *csr);
 void ko_csr_block_matvec(const double *X, double *Y, int p, void *csr);

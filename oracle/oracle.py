@@ -117,6 +117,8 @@ def lib():
         "ko_fill": (None, [i64, dp, C.c_double]),
         "ko_ref": (None, [i64, dp, dp, C.c_double, C.c_double]),
         "ko_set_threads": (None, [C.c_int]),
+        "ko_set_dot_mode": (None, [C.c_int]),
+        "ko_get_dot_mode": (C.c_int, []),
         "ko_get_threads": (C.c_int, []),
         "ko_sym_givens": (None, [C.c_double, C.c_double, dp, dp, dp]),
         "ko_roots_quadratic": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]),

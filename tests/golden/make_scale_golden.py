@@ -199,6 +199,21 @@ if 40 in which:
     def tick(k):
         if k % 5 == 0:
             print(f"  cfg 4: iteration {k}  ({time.time() - t0:.0f} s)", flush=True)
+    # "41": only add the second history (the same recurrence with Dot2 dots) to the existing file
+    gname = "oracle_cfg4_cg1024.json" if n1 == 1024 else f"oracle_cfg4_cg{n1}.json"
+    if 41 in which:
+        d = json.load(open(os.path.join(HERE, gname)))
+        ok.lib().ko_set_dot_mode(1)
+        res2 = ok.cg_stencil7(n1, x_index=idx, progress=tick, atol=0.0, rtol=0.0, itmax=iters, history=True)
+        ok.lib().ko_set_dot_mode(0)
+        assert res2.rc == 0 and res2.niter == iters
+        h1, h2 = np.array(d["residuals"]), res2.residuals
+        d.update(residuals_exact_dots=[float(v) for v in h2], x_sample_exact_dots=[float(v) for v in res2.x],
+                 oracle_vs_exact_dots_max_rel_dev=float(np.max(np.abs(h1 - h2) / h2)),
+                 exact_dots="the same ko_cg with ko_set_dot_mode(1): every dot is Dot2 (double-double accumulation, krylov_oracle.c ko_dot2) "
+                            "instead of the documented sequential extended-precision sum; measures the documented oracle's own rounding at this size")
+        dump(gname, d)
+        sys.exit(0)
     res = ok.cg_stencil7(n1, x_index=idx, progress=tick, atol=0.0, rtol=0.0, itmax=iters, history=True)
     assert res.rc == 0 and res.niter == iters, (res.rc, res.niter, res.status)
     dump("oracle_cfg4_cg1024.json" if n1 == 1024 else f"oracle_cfg4_cg{n1}.json", dict(

@@ -658,7 +658,7 @@ def test_spmv_fuzz_all_kernels_bit_exact(K, ctx, oracle):
         S = sp.csr_matrix((vals, (rows, cols)), shape=(m, n))
         S.sort_indices()
         cases.append(S)
-    defaults = {k: ctx.get_option(k) for k in ("spmv_kernel", "spmv_lanes", "spmv_rows")}
+    defaults = {k: ctx.get_option(k) for k in ("spmv_kernel", "spmv_lanes", "spmv_rows", "spmv_cap")}
     try:
         for S in cases:
             m, n = S.shape
@@ -671,11 +671,23 @@ def test_spmv_fuzz_all_kernels_bit_exact(K, ctx, oracle):
                     acc = acc + S.data[q] * x[S.indices[q]]
                 y_ref[i] = acc
             dx = ctx.array(x)
-            for kern in (0, 1, 3, 4):
+            for kern in (0, 1, 3, 4, 6):
                 ctx.set_option("spmv_kernel", kern)
                 dy = ctx.zeros(m)
                 dA.matvec(dx, dy)
                 assert np.array_equal(dy.to_host(), y_ref), (S.shape, S.nnz, kern)
+            for cap in (256, 512):                              # wave-private windows smaller than the row groups: several windows per group
+                ctx.set_option("spmv_kernel", 6)
+                ctx.set_option("spmv_cap", cap)
+                dy = ctx.zeros(m)
+                dA.matvec(dx, dy)
+                assert np.array_equal(dy.to_host(), y_ref), (S.shape, S.nnz, "wave kernel", cap)
+                if m == n:
+                    dyw = ctx.zeros(m)
+                    dw = K.spmv_dot(dA, dx, dyw)
+                    assert np.array_equal(dyw.to_host(), y_ref)
+                    assert abs(dw - float(np.dot(x, y_ref))) <= 1e-13 * float(np.abs(x * y_ref).sum()) + 1e-300
+            ctx.set_option("spmv_cap", 0)
             ctx.set_option("spmv_kernel", 0)
             if m == n:
                 d = K.spmv_dot(dA, dx, ctx.empty(m))
@@ -796,6 +808,42 @@ def test_spmv_coded_columns_bit_exact(K, ctx, oracle, kind, n1, bits, diags):
             stored = dA.spmv_bytes_stored
             want = (8 + (want_bits // 8)) * A.nnz + 4 * (A.n + 1) + 16 * A.n
             assert stored == want and dA.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+
+
+@pytest.mark.parametrize("kernel,codes", [(4, 2), (4, 0), (1, 0)])
+def test_spmv_fused_dots_with_workgroup_level_publish(K, ctx, oracle, kernel, codes):
+    """spmv_blk_pub = 1 (block_publish, csrc/device_reduce.hpp: the four waves of a tile fold their lanes' double-double
+    partials through LDS and one wave runs the tree) and spmv_tiles = 1 / 2 / 3 on the staged, coded and 16-byte-load stream
+    kernels: y bit-identical, the fused dots within the usual bound and equal to the per-wave form's to an ulp."""
+    A = oracle.stencil27_unsym(11)
+    rng = np.random.default_rng(5)
+    x = _vec(rng, A.n)
+    y_ref = A.matvec(x)
+    d_cpu, yy = oracle.dot(x, y_ref), oracle.dot(y_ref, y_ref)
+    saved = {k: ctx.get_option(k) for k in ("spmv_kernel", "spmv_codes", "spmv_blk_pub", "spmv_tiles", "spmv_wide", "spmv_delta")}
+    try:
+        ctx.set_option("spmv_kernel", kernel); ctx.set_option("spmv_codes", codes)
+        ctx.set_option("spmv_wide", 1); ctx.set_option("spmv_delta", 0)
+        dx = ctx.array(x)
+        got = {}
+        for pub in (0, 1):
+            for tiles in (1, 2, 3):
+                ctx.set_option("spmv_blk_pub", pub); ctx.set_option("spmv_tiles", tiles)
+                dA = K.CsrMatrix.stencil(ctx, "stencil27", 11)
+                dy = ctx.zeros(A.n)
+                d = K.spmv_dot(dA, dx, dy)
+                assert np.array_equal(dy.to_host(), y_ref), (pub, tiles)
+                assert abs(d - d_cpu) <= 2 * EPS * abs(d_cpu) + 1e-16 * float(np.abs(x * y_ref).sum())
+                d2 = K.spmv_dot2(dA, dx, dy)
+                assert np.array_equal(dy.to_host(), y_ref)
+                assert abs(d2[0] - d_cpu) <= 2 * EPS * abs(d_cpu) + 1e-16 * float(np.abs(x * y_ref).sum()) and abs(d2[1] - yy) <= 4 * EPS * yy
+                got[(pub, tiles)] = (d, d2[0], d2[1])
+        ref = got[(0, 1)]
+        for k, v in got.items():
+            assert all(abs(a - b) <= EPS * abs(b) for a, b in zip(v, ref)), (k, v, ref)
     finally:
         for k, v in saved.items():
             ctx.set_option(k, v)

@@ -156,11 +156,12 @@ def test_bicgstab_256_matches_oracle_within_the_derived_tolerance(K, ctx, parity
 # iterations -> 1e-8 leaves four orders for the 1225 iterations at 512^3 (measured against the oracle: 7.7e-11).
 # gmres!(30, restart): 7.7e-10 / 1.6e-9 / 7.4e-9 after 97 / 180 / 209 iterations -- the restarts feed the Givens estimate of
 # the residual back into the basis (src/gmres.jl:229-231) and the drift grows about tenfold per 110 iterations; at 940
-# iterations two correct double implementations are therefore expected up to ~1e-2 apart (measured: 4.0e-4).  The bound 5e-3
-# is a quarter of the 2 % margin by which the oracle's last iterates clear the stopping threshold, i.e. equal iteration
-# counts are implied by it, not luck.  block_gmres!: 2e-6 / 6e-5 / 4e-7 at 10^3 / 14^3 / 18^3 x 16 over 20-27 iterations (the restart re-orthogonalises a residual block that
+# iterations two correct double implementations are therefore expected up to ~1e-2 apart (measured: 4.0e-4 in rounds 3 and 4).
+# The derivation bounds what CAN be asserted (anything below a quarter of the 2 % margin by which the oracle's last iterates
+# clear the stopping threshold implies equal iteration counts); the bound itself is set to 3 x the measured gap, 1.2e-3, so
+# that a regression of one order cannot hide under it.  block_gmres!: 2e-6 / 6e-5 / 4e-7 at 10^3 / 14^3 / 18^3 x 16 over 20-27 iterations (the restart re-orthogonalises a residual block that
 # loses conditioning as columns converge); at 216^3 the two implementations stay 1e-11 apart over 35 iterations, bound 1e-6.
-FULL_TOL = {"cg": 1e-8, "gmres": 5e-3, "block_gmres": 1e-6}
+FULL_TOL = {"cg": 1e-8, "gmres": 1.2e-3, "block_gmres": 1e-6}
 
 
 def _full_check(g, st, parity_log, name, extra):
@@ -237,6 +238,14 @@ def test_block_gmres_cfg5_full_solve_equal_iteration_count(K, ctx, parity_log):
 # atol = rtol = 0.  The HIP side is the distributed path at full size on ONE GPU: 8 in-process ranks (khip_comm_init_local),
 # each with its 128-plane slab of the CSR operator (global columns up to 2^30, 8 MiB halo planes), 155 GB of HBM in total --
 # the same code the 8-GPU run executes except for the transport under the collectives (tests/test_gpu_rccl_multi.py covers RCCL).
+#
+# Tolerance.  At n = 2^30 the DOCUMENTED oracle dot -- a sequential sum in x87 extended precision, 64-bit mantissa -- carries a
+# rounding of its own of ~sqrt(n) 2^-64 = 2e-15 per dot, which cg! amplifies: the golden holds a second history of the same
+# ko_cg with every dot computed by Dot2 (double-double accumulation, error ~1e-31; ko_set_dot_mode(1), make_scale_golden.py
+# leg 41), and the documented oracle is d = oracle_vs_exact_dots_max_rel_dev (5e-12 over the 100 iterations) away from it.
+# binary128 (the yardstick at the smaller sizes) is out of reach here.  Asserted: the HIP path within the north
+# star's 1e-12 of the exact-dot oracle history, and within d + 1e-12 of the documented one (512^3: 4e-13 against the documented
+# oracle, whose own rounding is three times smaller there).
 def _cfg4_ranks(K, n1, world, iters, x_index, halo_mode=0):
     import threading
     n = n1 ** 3
@@ -297,13 +306,20 @@ def test_cg_1024_over_8_ranks_matches_oracle_prefix(K, ctx, parity_log, halo_mod
     assert all(np.array_equal(x["hist"], o["hist"]) for x in out), "ranks disagree on the history"
     assert o["niter"] == g["niter"] and o["status"] == g["status"]
     assert len(o["hist"]) == len(href)
+    hex_ = np.array(g["residuals_exact_dots"])
+    d_oracle = float(g["oracle_vs_exact_dots_max_rel_dev"])
     dev = _rel(o["hist"], href)
+    dev_exact = _rel(o["hist"], hex_)
     xs = {}
     for x in out:
         xs.update(x["xs"])
-    xg = np.array(g["x_sample"])
-    xdev = float(np.max(np.abs(np.array([xs[k] for k in range(len(xg))]) - xg)) / np.max(np.abs(xg)))
-    parity_log(test="cg_1024_8ranks_vs_oracle", halo_mode=halo_mode, iterations=o["niter"], hist_max_rel=dev, x_sample_rel=xdev,
+    xv = np.array([xs[k] for k in range(len(g["x_index"]))])
+    xg, xe = np.array(g["x_sample"]), np.array(g["x_sample_exact_dots"])
+    xdev = float(np.max(np.abs(xv - xg)) / np.max(np.abs(xg)))
+    xdev_exact = float(np.max(np.abs(xv - xe)) / np.max(np.abs(xe)))
+    parity_log(test="cg_1024_8ranks_vs_oracle", halo_mode=halo_mode, iterations=o["niter"], hist_max_rel=dev, hist_max_rel_vs_exact_dot_oracle=dev_exact,
+               documented_oracle_vs_exact_dot_oracle=d_oracle, x_sample_rel=xdev, x_sample_rel_vs_exact_dot_oracle=xdev_exact,
                halo_info_rank0=o["halo"], code_info_rank0=o["code"])
-    assert dev <= 1e-12, dev
-    assert xdev <= 1e-12, xdev
+    assert dev_exact <= 1e-12, dev_exact
+    assert dev <= d_oracle + 1e-12, (dev, d_oracle)
+    assert xdev_exact <= 1e-12 and xdev <= d_oracle + 1e-12, (xdev_exact, xdev)

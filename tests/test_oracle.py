@@ -674,6 +674,33 @@ def test_matrix_free_stencil_oracle_equals_the_csr_oracle_bit_for_bit(oracle):
             ok.lib().ko_set_threads(1)
 
 
+def test_dot2_mode_of_the_oracle_is_exact_and_changes_only_the_dots(oracle):
+    """ko_set_dot_mode(1) (the yardstick for the documented oracle at sizes where binary128 is out of reach): Dot2 equals the
+    exactly rounded dot (rational arithmetic) also where the sequential sum does not, whatever the thread count; cg! histories
+    with it stay within 1e-13 of the documented ones at a small size; the default mode is restored."""
+    from fractions import Fraction
+    ok = oracle
+    L = ok.lib()
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(30000) * 10.0 ** rng.integers(-8, 8, 30000)
+    y = rng.standard_normal(30000) * 10.0 ** rng.integers(-8, 8, 30000)
+    exact = float(sum(Fraction(a) * Fraction(b) for a, b in zip(x.tolist(), y.tolist())))
+    assert L.ko_get_dot_mode() == 0
+    try:
+        L.ko_set_dot_mode(1)
+        for th in (1, 3, 8):
+            L.ko_set_threads(th)
+            assert ok.dot(x, y) == exact
+        L.ko_set_threads(1)
+        A = ok.poisson3d(20)
+        r1 = ok.cg(A, np.ones(A.n), history=True)
+    finally:
+        L.ko_set_dot_mode(0)
+        L.ko_set_threads(1)
+    r0 = ok.cg(A, np.ones(A.n), history=True)
+    assert r0.niter == r1.niter and np.max(np.abs(r0.residuals - r1.residuals) / r0.residuals) <= 1e-13
+
+
 def test_scale_goldens_are_well_formed():
     """The BASELINE-size oracle histories the GPU parity tests and bench.py compare with."""
     for name, n, niter in (("oracle_cfg2_cg512.json", 512 ** 3, 100), ("oracle_cfg3_gmres256.json", 256 ** 3, 45),
@@ -684,6 +711,8 @@ def test_scale_goldens_are_well_formed():
     g4 = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg4_cg1024.json")))          # BASELINE cfg 4 (matrix-free oracle)
     assert g4["n"] == 1024 ** 3 and g4["nnz"] == 7 * 1024 ** 3 - 6 * 1024 ** 2 and g4["niter"] == 100 and len(g4["residuals"]) == 101
     assert g4["residuals"][0] == 32768.0 and all(np.isfinite(g4["residuals"])) and len(g4["x_sample"]) == len(g4["x_index"]) == 16
+    h, hx = np.array(g4["residuals"]), np.array(g4["residuals_exact_dots"])          # the second history: the same recurrence, Dot2 dots
+    assert len(hx) == 101 and hx[0] == 32768.0 and g4["oracle_vs_exact_dots_max_rel_dev"] == float(np.max(np.abs(h - hx) / hx)) < 1e-10
     g2 = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg2_cg512.json")))
     assert g2["residuals"][0] == math.sqrt(512 ** 3) and g2["nnz"] == 7 * 512 ** 3 - 6 * 512 ** 2      # ||ones||, SURVEY 8
 
