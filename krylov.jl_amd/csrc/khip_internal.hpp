@@ -110,6 +110,7 @@ struct Tuning {
   int spmm_tile_exp = 0;    // experiments on the tile kernel (WRONG results): 1 no panel-row copies, 2 no products, 4 no (val, slot) loads, 8 round-robin XCD order
   int spmm_tile_waves = 0;  // persistent waves of the tile kernel = this multiple of the LDS-limited residency (0 = 1)
   int spmm_tile_grid = 0;   // ... or this many waves outright
+  int spmm_tile_slide = 0;  // sliding windows (opt-in: bit-identical, L2 -> LDS copies halved, but no faster at cfg 5 -- 1.35-1.71 vs 1.39 ms, profiles/r04e_spmm_slide2.log; 10 % faster on 7-point grids): a wave walks a run of groups along the slowest grid direction and copies only the panel rows its window does not hold yet (0: every group fills its window anew; > 1: run length on operators without a grid)
   int spmm_tile_pencil = 0; // tile rows per pencil in the group order of grid operators (0 = 4)
   int spmm_tile_slices = 0; // panels of 32 columns and more as 16-column slices through the p = 16 tile kernel: 0 = where it measures faster, 1 = always, -1 = never
   int spmm_tile_nt = 0;     // non-temporal hints on the record / entry / Y streams of the tile kernel
@@ -215,6 +216,8 @@ struct khip_csr {
   char *tile_meta = nullptr;           // [tile_groups] records of tile_stride bytes
   int32_t *tile_direct_list = nullptr; // [tile_direct] groups on the direct-gather path
   int tile_cap = 0, tile_stride = 0, tile_grid = 0;   // window size (panel rows); tile_grid: 1 = groups are grid tiles, 0 = consecutive rows
+  int tile_run_len = 0;                // sliding windows: groups per run (0: every group fills its window anew)
+  int64_t tile_runs = 0;
   int64_t tile_groups = 0, tile_direct = 0;           // tile_direct: groups on the direct-gather path
   double tile_reuse = 0;               // references per distinct column of a group
   // optional dictionary-coded column stream of the staged SpMV (colcode.hip, built on the first product that can use it)

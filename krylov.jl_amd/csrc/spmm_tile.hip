@@ -40,6 +40,8 @@ constexpr int kTileSlotBytes = kTileR * kTileLen;
 struct TileArgs {
   const char *meta;       // [groups] records: int4 {row, start, len, aux}[32] | int32 list[cap] | uint8 slot[32][32]
   int64_t groups, per_xcd;
+  int64_t runs, runs_per_xcd;   // sliding windows (run_len > 0): the groups form runs of run_len consecutive records, a wave walks whole runs
+  int run_len;
   int cap;                // list entries per group (multiple of 8)
   int stride;             // bytes per record
   int exp;                // tuning experiments, WRONG results: 1 no panel-row copies, 2 no products, 4 no (val, slot) loads, 8 groups dealt round-robin to the XCDs
@@ -163,6 +165,29 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
     g = x * w.per_xcd + (blockIdx.x >> 3);
     gend = (x + 1) * w.per_xcd < w.groups ? (x + 1) * w.per_xcd : w.groups;
   }
+  // SLIDING WINDOWS (w.run_len > 0): the records form runs of run_len groups that follow each other along the slowest grid
+  // direction (or are consecutive row blocks); a wave walks a whole run and KEEPS its window from one group to the next -- the
+  // record of a group assigns the panel rows it shares with its predecessor the slots they already sit in and lists in a bit
+  // mask the octets of slots that hold new rows: only those are copied.  4 x 4 x 2 tiles of a 27-point grid share two of
+  // their four planes with the next tile: 72 instead of 144 panel rows per group cross L2 -> LDS.  XCD x takes the x-th
+  // eighth of the runs; its waves walk neighbouring runs side by side.
+  const bool slide = w.run_len > 0;
+  int64_t run = 0, run_end = 0;
+  int tpos = 0;
+  if (slide) {
+    const int64_t x = blockIdx.x & 7;
+    G = (gridDim.x & 7) == 0 ? (gridDim.x >> 3) : gridDim.x;
+    run = (gridDim.x & 7) == 0 ? x * w.runs_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    run_end = (gridDim.x & 7) == 0 ? ((x + 1) * w.runs_per_xcd < w.runs ? (x + 1) * w.runs_per_xcd : w.runs) : w.runs;
+    g = run * w.run_len;
+    gend = run_end * w.run_len;
+  }
+  // the group after (rr, tt) in this wave's sequence
+  auto next_of = [&](int64_t &rr, int &tt) -> int64_t {
+    if (!slide) return 0;
+    if (++tt == w.run_len) { tt = 0; rr += G; }
+    return rr * w.run_len + tt;
+  };
   if (g >= gend) return;
   const int hq = (sub & 2) ? 16 * L : 0;             // lane groups with bit 1 set read the second half of a panel row first
   const char *xa = reinterpret_cast<const char *>(tile_win) + 16 * c + hq;
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
   // compiler counts in this iteration, so its counted waits stay sufficient, and the wait for the copies themselves is the
   // explicit vmcnt below.  M0 (the LDS destination base) is compiler-reserved: saved and restored per statement.
   const unsigned win_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_char *)tile_win);
-  auto issue_dma = [&](const TileRec<L, NL> &r) {
+  auto issue_dma = [&](const TileRec<L, NL> &r, unsigned mask) {     // mask: bit o set = the slots 8 o .. 8 o + 7 hold rows that are not in the window yet
     constexpr int PER = 64 / S::EPI;                 // instructions per list word
     int col[NL * PER];
 #pragma unroll
@@ -226,7 +251,8 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
     }
 #pragma unroll
     for (int wq = 0; wq < NL * PER; ++wq) {
-      if (S::EPI * wq < w.cap && !(w.exp & 1)) {
+      constexpr unsigned OCT = S::EPI >= 8 ? (1u << (S::EPI / 8)) - 1u : 1u;      // octets one instruction covers (a part of one when EPI = 4)
+      if (S::EPI * wq < w.cap && !(w.exp & 1) && ((mask >> ((S::EPI * wq) >> 3)) & OCT) != 0) {
         const char *src = reinterpret_cast<const char *>(a.x);
         uint64_t rr = (unsigned)col[wq];
         if (DIST) {
@@ -275,18 +301,24 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
 
   TileRec<L, NL> r0, r1, r2;
   TileEnt<L> e0, e1;
+  int64_t run1 = run, run2;
+  int t1 = tpos, t2;
+  int64_t g1 = slide ? next_of(run1, t1) : g + G;
+  run2 = run1; t2 = t1;
+  int64_t g2 = slide ? next_of(run2, t2) : g + 2 * G;
   load_rec(g, r0);
-  load_rec(g + G, r1);
+  load_rec(g1, r1);
   load_ent(g, r0, e0);
   __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): the loop starts with nothing in flight
   for (;;) {
-    // aux of row slot 1 = the group's flag (row slot 1 is lane L of pass 0)
+    // aux of row slot 1 = the group's flag (row slot 1 is lane L of pass 0), of row slot 2 = the octets to copy
     const bool direct = __builtin_amdgcn_readfirstlane(__shfl(r0.d[0].w, L)) != 0;
-    if (!direct) issue_dma(r0);
+    const unsigned mask = slide ? (unsigned)__builtin_amdgcn_readfirstlane(__shfl(r0.d[0].w, 2 * L)) : 0xffffffffu;
+    if (!direct) issue_dma(r0, mask);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    load_ent(g + G, r1, e1);
-    load_rec(g + 2 * G, r2);
+    load_ent(g1, r1, e1);
+    load_rec(g2, r2);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (!direct) {
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
       __builtin_amdgcn_sched_barrier(0);
       products(r0, e0);
     }                                                        // (flagged groups: spmm_tile_direct_kernel, launched next)
-    g += G;
+    if (slide) { g = g1; g1 = g2; g2 = next_of(run2, t2); } else { g += G; g1 = g + G; g2 = g + 2 * G; }
     if (g >= gend) break;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // every window read of this group has returned before the next DMA
     r0 = r1; e0 = e1; r1 = r2;
@@ -381,9 +413,25 @@ struct TileOrder {
   int bi, bj, bk;       // tile extents (bi * bj * bk == 32)
   int gi, gj, gk;       // tiles along i, j, k
   int pj;               // pencil width in tiles along j (group order: i fastest, then j inside a pencil, then k, then the pencils)
+  int run_pieces;       // runs per line of tiles along the sliding direction (1: whole lines)
+  int run_len;          // > 0: sliding windows -- the groups are numbered in runs of run_len along the slowest tile direction
+                        // (k; j on a single plane), run r = (ti, tj) with ti fastest; identity order: runs of consecutive groups
 };
 __device__ __forceinline__ int64_t tile_row_of(const TileOrder &o, int64_t g, int t) {
   if (o.s1 == 0) { const int64_t r = g * kTileR + t; return r < o.m ? r : -1; }
+  if (o.run_len > 0) {
+    const int64_t rid0 = g / o.run_len, nlines = o.gk > 1 ? (int64_t)o.gi * o.gj : (int64_t)o.gi;
+    const int64_t rid = rid0 % nlines, pos = (rid0 / nlines) * o.run_len + g % o.run_len;      // pieces of a line: slowest, so that consecutive runs are neighbouring lines
+    int64_t ti, tj, tk;
+    if (o.gk > 1) { ti = rid % o.gi; tj = rid / o.gi; tk = pos; }
+    else { ti = rid; tj = pos; tk = 0; }
+    if (ti >= o.gi || tj >= o.gj || tk >= o.gk) return -1;
+    const int di = t % o.bi, dj = (t / o.bi) % o.bj, dk = t / (o.bi * o.bj);
+    const int64_t i = ti * o.bi + di, j = tj * o.bj + dj, k = tk * o.bk + dk;
+    if (i >= o.n1 || j >= o.n2 || k >= o.n3) return -1;
+    const int64_t r = i + o.s1 * j + o.s2 * k;
+    return r < o.m ? r : -1;
+  }
   // pencil order: the groups of pj tile rows are walked through ALL planes before the next pj tile rows, so that the
   // k-neighbours of a tile are pj * gi groups away (inside the set of groups an XCD has in flight) instead of gi * gj
   const int64_t per_pencil = (int64_t)o.gi * o.pj * o.gk;          // groups of a full-width pencil
@@ -403,76 +451,89 @@ __device__ __forceinline__ int64_t tile_row_of(const TileOrder &o, int64_t g, in
 constexpr int kTileKeys = kTileR * kTileLen;   // 1024 column indices of a group at most
 constexpr int kTileEmpty = 0x7fffffff;
 
-// One workgroup per group: the group's column indices sorted (bitonic, LDS), made unique, counted.  FILL = false:
-// cnt[g] = number of distinct columns, or -1 when a row has more than 32 entries; statistics for the choice of the order
-// and of the window size.  FILL = true: the group's record.
-template <bool FILL>
-__global__ __launch_bounds__(kBlock) void spmm_tile_build_kernel(const int32_t *rowptr, const int32_t *col, TileOrder o, int cap,
-                                                                  int stride, char *meta, int32_t *cnt,
-                                                                  unsigned long long *stat /* [0] long-row groups, [1] sum cnt, [2..34] histogram of ceil(cnt / 8) */) {
-  __shared__ int keys[kTileKeys];
-  __shared__ int uniq[kTileKeys];
-  __shared__ int scan[kBlock];
-  __shared__ int rrow[kTileR], rstart[kTileR], rlen[kTileR];
-  __shared__ int too_long;
+struct TileBuildShared {
+  int keys[kTileKeys];
+  int uniq[kTileKeys];
+  int scan[kBlock];
+  int rrow[kTileR], rstart[kTileR], rlen[kTileR];
+  int too_long;
+};
+
+// The distinct columns of group g, ascending, in S.uniq[0 .. n); returns n, or -1 when a row has more than 32 entries.  Fills
+// S.rrow / rstart / rlen.  Called by all threads of the workgroup; ends with a barrier.
+__device__ int tile_group_unique(TileBuildShared &S, const int32_t *rowptr, const int32_t *col, const TileOrder &o, int64_t g) {
   const int tid = threadIdx.x;
-  const int64_t g = blockIdx.x;
-  if (tid == 0) too_long = 0;
+  __syncthreads();                     // the previous group's arrays are no longer read
+  if (tid == 0) S.too_long = 0;
   __syncthreads();
   if (tid < kTileR) {
     const int64_t r = tile_row_of(o, g, tid);
     int s = 0, len = 0;
     if (r >= 0) { s = rowptr[r]; len = rowptr[r + 1] - s; }
-    rrow[tid] = (int)r; rstart[tid] = s; rlen[tid] = len;
-    if (len > kTileLen) too_long = 1;
+    S.rrow[tid] = (int)r; S.rstart[tid] = s; S.rlen[tid] = len;
+    if (len > kTileLen) S.too_long = 1;
   }
   __syncthreads();
-  const bool longrow = too_long != 0;
+  const bool longrow = S.too_long != 0;
   for (int q = tid; q < kTileKeys; q += kBlock) {
     const int t = q / kTileLen, k = q % kTileLen;
-    keys[q] = (!longrow && k < rlen[t]) ? col[(int64_t)rstart[t] + k] : kTileEmpty;
+    S.keys[q] = (!longrow && k < S.rlen[t]) ? col[(int64_t)S.rstart[t] + k] : kTileEmpty;
   }
   __syncthreads();
-  int n_uniq = 0;
-  if (!longrow) {
-    for (int size = 2; size <= kTileKeys; size <<= 1) {
-      for (int strd = size >> 1; strd > 0; strd >>= 1) {
-        for (int q = tid; q < kTileKeys / 2; q += kBlock) {
-          const int lo = 2 * q - (q & (strd - 1));      // index with bit `strd` clear
-          const int hi = lo + strd;
-          const bool up = (lo & size) == 0;
-          const int x = keys[lo], y = keys[hi];
-          if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
-        }
-        __syncthreads();
+  if (longrow) return -1;
+  for (int size = 2; size <= kTileKeys; size <<= 1) {
+    for (int strd = size >> 1; strd > 0; strd >>= 1) {
+      for (int q = tid; q < kTileKeys / 2; q += kBlock) {
+        const int lo = 2 * q - (q & (strd - 1));      // index with bit `strd` clear
+        const int hi = lo + strd;
+        const bool up = (lo & size) == 0;
+        const int x = S.keys[lo], y = S.keys[hi];
+        if ((x > y) == up) { S.keys[lo] = y; S.keys[hi] = x; }
       }
+      __syncthreads();
     }
-    // unique: thread t owns keys 4 t .. 4 t + 3
-    int mine = 0;
+  }
+  // unique: thread t owns keys 4 t .. 4 t + 3
+  int mine = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = 4 * tid + j;
-      const int k = keys[q];
-      mine += (k != kTileEmpty && (q == 0 || keys[q - 1] != k)) ? 1 : 0;
-    }
-    scan[tid] = mine;
+  for (int j = 0; j < 4; ++j) {
+    const int q = 4 * tid + j;
+    const int k = S.keys[q];
+    mine += (k != kTileEmpty && (q == 0 || S.keys[q - 1] != k)) ? 1 : 0;
+  }
+  S.scan[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < kBlock; d <<= 1) {
+    const int add = tid >= d ? S.scan[tid - d] : 0;
     __syncthreads();
-    for (int d = 1; d < kBlock; d <<= 1) {
-      const int add = tid >= d ? scan[tid - d] : 0;
-      __syncthreads();
-      scan[tid] += add;
-      __syncthreads();
-    }
-    n_uniq = scan[kBlock - 1];
-    int pos = scan[tid] - mine;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = 4 * tid + j;
-      const int k = keys[q];
-      if (k != kTileEmpty && (q == 0 || keys[q - 1] != k)) uniq[pos++] = k;
-    }
+    S.scan[tid] += add;
     __syncthreads();
   }
+  const int n_uniq = S.scan[kBlock - 1];
+  int pos = S.scan[tid] - mine;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = 4 * tid + j;
+    const int k = S.keys[q];
+    if (k != kTileEmpty && (q == 0 || S.keys[q - 1] != k)) S.uniq[pos++] = k;
+  }
+  __syncthreads();
+  return n_uniq;
+}
+
+// One workgroup per group: the group's column indices sorted (bitonic, LDS), made unique, counted.  FILL = false:
+// cnt[g] = number of distinct columns, or -1 when a row has more than 32 entries; statistics for the choice of the order
+// and of the window size.  FILL = true: the group's record (slots = ranks of the columns: every group fills its window anew).
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void spmm_tile_build_kernel(const int32_t *rowptr, const int32_t *col, TileOrder o, int cap,
+                                                                  int stride, char *meta, int32_t *cnt,
+                                                                  unsigned long long *stat /* [0] long-row groups, [1] sum cnt, [2..34] histogram of ceil(cnt / 8) */) {
+  __shared__ TileBuildShared S;
+  const int tid = threadIdx.x;
+  const int64_t g = blockIdx.x;
+  const int n_uniq0 = tile_group_unique(S, rowptr, col, o, g);
+  const bool longrow = n_uniq0 < 0;
+  const int n_uniq = longrow ? 0 : n_uniq0;
   if (!FILL) {
     if (tid == 0) {
       cnt[g] = longrow ? -1 : n_uniq;
@@ -488,8 +549,8 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_kernel(const int32_t *
   const bool direct = longrow || n_uniq > cap;
   if (tid < kTileR) {
     int4v d;
-    d.x = rrow[tid]; d.y = rstart[tid]; d.z = rlen[tid];
-    d.w = tid == 0 ? n_uniq : (tid == 1 ? (direct ? 1 : 0) : 0);
+    d.x = S.rrow[tid]; d.y = S.rstart[tid]; d.z = S.rlen[tid];
+    d.w = tid == 0 ? n_uniq : (tid == 1 ? (direct ? 1 : 0) : (tid == 2 ? -1 : 0));
     reinterpret_cast<int4v *>(rec)[tid] = d;
   }
   int32_t *lst = reinterpret_cast<int32_t *>(rec + kTileDescBytes);
@@ -499,20 +560,119 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_kernel(const int32_t *
     for (int q = tid; q < kTileSlotBytes; q += kBlock) slots[q] = 0;
     return;
   }
-  for (int q = tid; q < cap; q += kBlock) lst[q] = n_uniq > 0 ? uniq[q < n_uniq ? q : n_uniq - 1] : 0;   // padding: the last column again
+  for (int q = tid; q < cap; q += kBlock) lst[q] = n_uniq > 0 ? S.uniq[q < n_uniq ? q : n_uniq - 1] : 0;   // padding: the last column again
   for (int q = tid; q < kTileKeys; q += kBlock) {
     const int t = q / kTileLen, k = q % kTileLen;
     int sl = 0;
-    if (k < rlen[t]) {
-      const int key = col[(int64_t)rstart[t] + k];
+    if (k < S.rlen[t]) {
+      const int key = col[(int64_t)S.rstart[t] + k];
       int lo = 0, hi = n_uniq - 1;
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (uniq[mid] < key) lo = mid + 1; else hi = mid;
+        if (S.uniq[mid] < key) lo = mid + 1; else hi = mid;
       }
       sl = lo;
     }
     slots[q] = (uint8_t)sl;
+  }
+}
+
+// Sliding windows: one workgroup per RUN, its groups one after the other.  slot_col[s] = the column whose panel row sits in
+// slot s of the wave's window once the group's copies have landed.  A column the group shares with what the window holds
+// keeps its slot; the others take, in ascending order, the slots of columns the group does not need (ascending too), and the
+// octets of slots that received one are the group's copy mask (aux word of row slot 2).  The list keeps naming, for EVERY
+// slot, the column that sits there, so an octet that is copied again for one new row rewrites its other seven rows with
+// themselves.  A group on the direct-gather path (or an empty one) ends the chain: the next group fills the window anew.
+__global__ __launch_bounds__(kBlock) void spmm_tile_build_run_kernel(const int32_t *rowptr, const int32_t *col, TileOrder o, int cap,
+                                                                      int stride, char *meta, int run_len) {
+  __shared__ TileBuildShared S;
+  __shared__ int slot_col[kTileCapMax], uslot[kTileCapMax], freelist[kTileCapMax], flag[kBlock];
+  __shared__ unsigned mask_sh;
+  const int tid = threadIdx.x;
+  for (int q = tid; q < kTileCapMax; q += kBlock) slot_col[q] = kTileEmpty;
+  for (int t = 0; t < run_len; ++t) {
+    const int64_t g = (int64_t)blockIdx.x * run_len + t;
+    const int n_uniq0 = tile_group_unique(S, rowptr, col, o, g);
+    const bool longrow = n_uniq0 < 0;
+    const int n_uniq = longrow ? 0 : n_uniq0;
+    char *rec = meta + g * (int64_t)stride;
+    const bool direct = longrow || n_uniq > cap;
+    int32_t *lst = reinterpret_cast<int32_t *>(rec + kTileDescBytes);
+    uint8_t *slots = reinterpret_cast<uint8_t *>(rec + kTileDescBytes + 4 * cap);
+    if (tid == 0) mask_sh = 0u;
+    if (direct) {
+      for (int q = tid; q < cap; q += kBlock) lst[q] = 0;
+      for (int q = tid; q < kTileSlotBytes; q += kBlock) slots[q] = 0;
+      for (int q = tid; q < kTileCapMax; q += kBlock) slot_col[q] = kTileEmpty;       // the chain ends here
+      __syncthreads();
+    } else {
+      // (a) slots whose column the group needs again keep it
+      for (int q = tid; q < kTileCapMax; q += kBlock) uslot[q] = -1;
+      __syncthreads();
+      int keep = 0;
+      if (tid < cap) {
+        const int c = slot_col[tid];
+        if (c != kTileEmpty && n_uniq > 0) {
+          int lo = 0, hi = n_uniq - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (S.uniq[mid] < c) lo = mid + 1; else hi = mid;
+          }
+          if (S.uniq[lo] == c) { uslot[lo] = tid; keep = 1; }
+        }
+      }
+      // (b) the free slots, ascending
+      flag[tid] = (tid < cap && !keep) ? 1 : 0;
+      __syncthreads();
+      for (int d = 1; d < kBlock; d <<= 1) {
+        const int add = tid >= d ? flag[tid - d] : 0;
+        __syncthreads();
+        flag[tid] += add;
+        __syncthreads();
+      }
+      if (tid < cap && !keep) freelist[flag[tid] - 1] = tid;
+      __syncthreads();
+      // (c) the new columns, ascending, into them
+      const int isnew = (tid < n_uniq && uslot[tid] < 0) ? 1 : 0;
+      flag[tid] = isnew;
+      __syncthreads();
+      for (int d = 1; d < kBlock; d <<= 1) {
+        const int add = tid >= d ? flag[tid - d] : 0;
+        __syncthreads();
+        flag[tid] += add;
+        __syncthreads();
+      }
+      if (isnew) {
+        const int sl = freelist[flag[tid] - 1];
+        uslot[tid] = sl;
+        slot_col[sl] = S.uniq[tid];
+        atomicOr(&mask_sh, 1u << (sl >> 3));
+      }
+      __syncthreads();
+      // (d) the record: list in slot order (an empty slot names the group's last column: any valid row will do), slot bytes
+      for (int q = tid; q < cap; q += kBlock) lst[q] = slot_col[q] != kTileEmpty ? slot_col[q] : (n_uniq > 0 ? S.uniq[n_uniq - 1] : 0);
+      for (int q = tid; q < kTileKeys; q += kBlock) {
+        const int tt = q / kTileLen, k = q % kTileLen;
+        int sl = 0;
+        if (k < S.rlen[tt]) {
+          const int key = col[(int64_t)S.rstart[tt] + k];
+          int lo = 0, hi = n_uniq - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (S.uniq[mid] < key) lo = mid + 1; else hi = mid;
+          }
+          sl = uslot[lo];
+        }
+        slots[q] = (uint8_t)sl;
+      }
+      __syncthreads();
+    }
+    if (tid < kTileR) {
+      int4v d;
+      d.x = S.rrow[tid]; d.y = S.rstart[tid]; d.z = S.rlen[tid];
+      d.w = tid == 0 ? n_uniq : (tid == 1 ? (direct ? 1 : 0) : (tid == 2 ? (int)mask_sh : 0));
+      reinterpret_cast<int4v *>(rec)[tid] = d;
+    }
   }
 }
 
@@ -549,7 +709,30 @@ static TileOrder tile_order_for(const khip_csr *A, bool tiles) {
   if (o.pj > o.gj) o.pj = o.gj;
   return o;
 }
+// sliding windows (ctx option spmm_tile_slide): runs along k (along j on a single plane); identity order: 64 consecutive groups
+static void tile_order_set_runs(const khip_csr *A, TileOrder &o) {
+  const int slide = A->ctx ? A->ctx->tune.spmm_tile_slide : 0;
+  o.run_len = 0;
+  if (!slide) return;
+  if (o.s1 == 0) o.run_len = slide > 1 ? slide : 64;
+  else {
+    const int full = o.gk > 1 ? o.gk : o.gj;
+    o.run_len = full;
+    if (slide > 1 && slide < full) {           // shorter runs: pieces of (nearly) equal length
+      const int pieces = (full + slide - 1) / slide;
+      o.run_len = (full + pieces - 1) / pieces;
+    }
+    o.run_pieces = (full + o.run_len - 1) / o.run_len;
+  }
+  if (o.run_len < 2) o.run_len = 0;
+}
+static int64_t tile_runs_for(const TileOrder &o) {
+  if (o.run_len <= 0) return 0;
+  if (o.s1 == 0) return ((o.m + kTileR - 1) / kTileR + o.run_len - 1) / o.run_len;
+  return (o.gk > 1 ? (int64_t)o.gi * o.gj : (int64_t)o.gi) * o.run_pieces;
+}
 static int64_t tile_groups_for(const TileOrder &o) {
+  if (o.run_len > 0) return tile_runs_for(o) * o.run_len;        // padded to whole runs (rows past the end: -1)
   if (o.s1 == 0) return (o.m + kTileR - 1) / kTileR;
   return (int64_t)o.gi * o.gj * o.gk;
 }
@@ -572,7 +755,8 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
   std::vector<unsigned long long> best_st;
   double best_score = -1.0;
   for (int cand = 0; cand < (grid_ok ? 2 : 1); ++cand) {
-    const TileOrder o = tile_order_for(A, cand == 1);
+    TileOrder o = tile_order_for(A, cand == 1);
+    tile_order_set_runs(A, o);
     const int64_t groups = tile_groups_for(o);
     if (groups <= 0 || groups > ((int64_t)1 << 30)) continue;
     (void)hipFree(cnt); cnt = nullptr;
@@ -607,8 +791,12 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
   KHIP_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
   if ((size_t)groups * (size_t)stride + ((size_t)1 << 30) > free_b) return KHIP_OK;
   KHIP_CHECK_HIP(hipMalloc(&A->tile_meta, (size_t)groups * (size_t)stride));
-  hipLaunchKernelGGL((spmm_tile_build_kernel<true>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, best, cap, stride,
-                     A->tile_meta, (int32_t *)nullptr, (unsigned long long *)nullptr);
+  if (best.run_len > 0)
+    hipLaunchKernelGGL(spmm_tile_build_run_kernel, dim3((unsigned)tile_runs_for(best)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, best, cap,
+                       stride, A->tile_meta, best.run_len);
+  else
+    hipLaunchKernelGGL((spmm_tile_build_kernel<true>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, best, cap, stride,
+                       A->tile_meta, (int32_t *)nullptr, (unsigned long long *)nullptr);
   KHIP_CHECK_HIP(hipGetLastError());
   unsigned long long over = 0;
   for (size_t bin = (size_t)cap / 8 + 1; bin + 2 < best_st.size(); ++bin) over += best_st[2 + bin];
@@ -629,6 +817,8 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
   A->tile_cap = cap;
   A->tile_stride = stride;
   A->tile_groups = groups;
+  A->tile_run_len = best.run_len;
+  A->tile_runs = tile_runs_for(best);
   A->tile_grid = best.s1 != 0 ? 1 : 0;
   A->tile_direct = n_direct;
   A->tile_reuse = best_score;
@@ -638,6 +828,7 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
 template <int L>
 static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, int gshift, int coff) {
   TileArgs w;
+  w.run_len = A->tile_run_len; w.runs = A->tile_runs; w.runs_per_xcd = (A->tile_runs + 7) / 8;
   w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride; w.exp = ctx->tune.spmm_tile_exp; w.gshift = gshift; w.coff = coff;
   const size_t lds = (size_t)w.cap * 32 * L;
   int per_cu = (int)((size_t)(160 * 1024) / lds);                    // LDS-limited residency of the one-wave workgroups
@@ -647,6 +838,14 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   int64_t grid = (int64_t)ctx->num_cu * per_cu * (ctx->tune.spmm_tile_waves > 0 ? ctx->tune.spmm_tile_waves : 1);
   if (ctx->tune.spmm_tile_grid > 0) grid = ctx->tune.spmm_tile_grid;
   if (grid > w.groups) grid = w.groups;
+  if (w.run_len > 0 && ctx->tune.spmm_tile_grid <= 0) {
+    // sliding windows: a wave takes whole runs, so the waves must get equally many -- the largest grid below the residency
+    // limit that gives every wave of an XCD ceil(runs per XCD / waves per XCD) runs with no wave left half empty
+    const int64_t per_x = w.runs_per_xcd, max_wx = grid / 8 > 0 ? grid / 8 : 1;
+    const int64_t k = (per_x + max_wx - 1) / max_wx;                 // runs per wave
+    grid = 8 * ((per_x + k - 1) / k);
+  }
+  if (w.run_len > 0 && grid > w.runs) grid = w.runs;
   if (grid >= 64) grid &= ~(int64_t)7;                               // whole waves per XCD
   const bool dist = a.ghost != a.x;
   const int NL = (w.cap + 63) / 64;
