@@ -224,3 +224,28 @@ if 40 in which:
         n=n, nnz=7 * n - 6 * n1 * n1, niter=res.niter, status=res.status,
         residuals=[float(v) for v in res.residuals], x_index=idx, x_sample=[float(v) for v in res.x],
         seconds=time.time() - t0))
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Leg 22: cfg 2 (512^3) once more with EXACT DOTS (ko_set_dot_mode(1): Dot2, krylov_oracle.c) -- the full solve of the benchmark
+# definition (atol = 0, rtol = 1e-8) and the 100-iteration prefix (atol = rtol = 0).  Everything else of ko_cg is unchanged
+# (serial-order products, fma axpys).  Measures how much of the HIP path's distance to the documented oracle is the documented
+# oracle's own extended-precision summation (tests/test_gpu_scale_parity.py).  ~10 minutes on 8 cores.
+# ---------------------------------------------------------------------------------------------------------------------
+if 22 in which:
+    t0 = time.time()
+    ok.lib().ko_set_dot_mode(1)
+    try:
+        A = ok.poisson3d(512)
+        b = np.ones(A.n)
+        idx = sample_idx(A.n)
+        pre = ok.cg(A, b, atol=0.0, rtol=0.0, itmax=100, history=True)
+        full = ok.cg(A, b, atol=0.0, rtol=FULL_RTOL, itmax=A.n, history=True)
+    finally:
+        ok.lib().ko_set_dot_mode(0)
+    dump("oracle_cfg2_cg512_exact_dots.json", dict(
+        generator="tests/golden/make_scale_golden.py 22",
+        oracle="oracle/krylov_oracle.c ko_cg (src/cg.jl:120-291) with ko_set_dot_mode(1): every dot is Dot2 (double-double accumulation)",
+        config="BASELINE cfg 2: cg! on get_div_grad(512,512,512), b = ones; prefix: atol = rtol = 0, 100 iterations; full: atol = 0, rtol = 1e-8, itmax = n",
+        n=A.n, nnz=A.nnz, prefix_residuals=[float(v) for v in pre.residuals], prefix_x_sample=[float(pre.x[i]) for i in idx],
+        niter=full.niter, solved=bool(full.solved), status=full.status, residuals=[float(v) for v in full.residuals],
+        x_index=idx, x_sample=[float(full.x[i]) for i in idx], seconds=time.time() - t0))

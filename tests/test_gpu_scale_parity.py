@@ -323,3 +323,44 @@ def test_cg_1024_over_8_ranks_matches_oracle_prefix(K, ctx, parity_log, halo_mod
     assert dev_exact <= 1e-12, dev_exact
     assert dev <= d_oracle + 1e-12, (dev, d_oracle)
     assert xdev_exact <= 1e-12 and xdev <= d_oracle + 1e-12, (xdev_exact, xdev)
+
+
+# ---- cfg 2 against the oracle with EXACT dots (round 4) -------------------------------------------------------------------
+# tests/golden/oracle_cfg2_cg512_exact_dots.json (make_scale_golden.py leg 22): the same ko_cg with every dot computed by Dot2
+# (ko_set_dot_mode(1)) instead of the documented sequential extended-precision sum.  SpMV and the fma axpys of the HIP path
+# are bit-identical to the oracle's, its dots are Dot2 as well (device_reduce.hpp) -- so against THIS history only the order
+# of the double-double partial sums differs, which changes a correctly rounded result next to never.  Asserted: the
+# 100-iteration prefix AND the full solve to rtol 1e-8 (1225 iterations) within EXACT_TOL of it, same iteration count and
+# status -- the gap to the documented oracle (4e-13 / 7.7e-11) is that oracle's own summation error.
+EXACT_TOL = 1e-13
+
+
+@pytest.mark.parametrize("fused", [2, 0])
+def test_cg_512_against_the_exact_dot_oracle(K, ctx, parity_log, fused):
+    g = _golden("oracle_cfg2_cg512_exact_dots.json")
+    n = 512 ** 3
+    A = K.CsrMatrix.stencil(ctx, "poisson", 512)
+    b = ctx.empty(n)
+    K.kfill_(b, 1.0)
+    ws = K.CgWorkspace(ctx, n, n)
+    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=100, history=True, fused=fused)
+    hp = np.array(g["prefix_residuals"])
+    assert len(ws.stats.residuals) == len(hp)
+    dev_prefix = _rel(ws.stats.residuals, hp)
+    xs = ws.x.to_host()
+    xp = np.array(g["prefix_x_sample"])
+    xdev_prefix = float(np.max(np.abs(xs[g["x_index"]] - xp)) / np.max(np.abs(xp)))
+    K.cg_(ws, A, b, atol=0.0, rtol=1e-8, itmax=n, history=True, fused=fused)
+    st = ws.stats
+    hf = np.array(g["residuals"])
+    m = min(len(hf), len(st.residuals))
+    dev_full = _rel(np.asarray(st.residuals)[:m], hf[:m])
+    xs = ws.x.to_host()
+    xf = np.array(g["x_sample"])
+    xdev_full = float(np.max(np.abs(xs[g["x_index"]] - xf)) / np.max(np.abs(xf)))
+    parity_log(test="cg_512_vs_exact_dot_oracle", fused=fused, prefix_hist_max_rel=dev_prefix, prefix_x_sample_rel=xdev_prefix,
+               full_iterations=st.niter, ref_iterations=g["niter"], full_hist_max_rel=dev_full, full_x_sample_rel=xdev_full,
+               bit_identical_history=bool(len(hf) == len(st.residuals) and np.array_equal(np.asarray(st.residuals), hf)))
+    assert st.niter == g["niter"] and st.status == g["status"]
+    assert dev_prefix <= EXACT_TOL and xdev_prefix <= EXACT_TOL, (dev_prefix, xdev_prefix)
+    assert dev_full <= EXACT_TOL and xdev_full <= EXACT_TOL, (dev_full, xdev_full)
