@@ -96,6 +96,21 @@ def parity_vs_oracle(n1, residuals, full=None):
                "ok": bool(same and fdev is not None and fdev <= 1e-8 and out["ok"]),
                "prefix_100_iterations": {"iterations_compared": k, "max_rel_dev": dev, "tolerance": 1e-12, "ok": bool(dev <= 1e-12)},
                "setting": "full solve: atol = 0, rtol = 1e-8, itmax = n (benchmark/benchmarks.jl:14-21); prefix: atol = rtol = 0"}
+    # the same recurrence with EXACT dots on the oracle's side (ko_set_dot_mode(1): Dot2; tests/golden/oracle_cfg2_cg512_exact_dots.json,
+    # make_scale_golden.py leg 22): what is left when the documented oracle's own sequential extended-precision summation error is
+    # taken out of the comparison -- DESIGN.md 3.2d
+    epath = os.path.join(ROOT, "tests", "golden", "oracle_cfg2_cg512_exact_dots.json")
+    if os.path.exists(epath):
+        e = json.load(open(epath))
+        pdev, pk = _hist_dev(residuals, e["prefix_residuals"])
+        ex = {"against": "oracle/krylov_oracle.c ko_cg with Dot2 dots (tests/golden/oracle_cfg2_cg512_exact_dots.json)",
+              "prefix_iterations_compared": pk, "prefix_max_rel_dev": pdev}
+        if full is not None:
+            fdev, fk = _hist_dev(full["residuals"], e["residuals"])
+            ex.update(full_iterations_compared=fk, full_max_rel_dev=fdev,
+                      full_history_bit_identical=bool(len(full["residuals"]) == len(e["residuals"]) and
+                                                      all(float(a) == b for a, b in zip(full["residuals"], e["residuals"]))))
+        out["vs_exact_dot_oracle"] = ex
     return out
 
 

@@ -249,3 +249,37 @@ if 22 in which:
         n=A.n, nnz=A.nnz, prefix_residuals=[float(v) for v in pre.residuals], prefix_x_sample=[float(pre.x[i]) for i in idx],
         niter=full.niter, solved=bool(full.solved), status=full.status, residuals=[float(v) for v in full.residuals],
         x_index=idx, x_sample=[float(full.x[i]) for i in idx], seconds=time.time() - t0))
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Legs 23 / 24: cfg 3 (gmres!(30, restart) on kron_unsymmetric(256): 45-iteration prefix and the full solve to rtol 1e-8) and
+# bicgstab! on the same operator (25 iterations) with EXACT DOTS on the oracle's side (ko_set_dot_mode(1)); everything else of
+# ko_gmres / ko_bicgstab unchanged.  ~15 minutes on 8 cores.
+# ---------------------------------------------------------------------------------------------------------------------
+if 23 in which or 24 in which:
+    t0 = time.time()
+    A = ok.kron_unsymmetric(256)
+    b = A.matvec(np.ones(A.n))
+    idx = sample_idx(A.n)
+    ok.lib().ko_set_dot_mode(1)
+    try:
+        if 24 in which:
+            r = ok.bicgstab(A, b, atol=0.0, rtol=0.0, itmax=25, history=True)
+            dump("oracle_bicgstab256_exact_dots.json", dict(
+                generator="tests/golden/make_scale_golden.py 24",
+                oracle="oracle/krylov_oracle.c ko_bicgstab (src/bicgstab.jl:125-277) with ko_set_dot_mode(1): Dot2 dots",
+                config="bicgstab! on kron_unsymmetric(256), b = A*ones, atol = rtol = 0, 25 iterations",
+                n=A.n, nnz=A.nnz, niter=r.niter, status=r.status, residuals=[float(v) for v in r.residuals], x_index=idx,
+                x_sample=[float(r.x[i]) for i in idx], seconds=time.time() - t0))
+        if 23 in which:
+            pre = ok.gmres(A, b, memory=30, restart=True, atol=0.0, rtol=0.0, itmax=45, history=True)
+            full = ok.gmres(A, b, memory=30, restart=True, atol=0.0, rtol=FULL_RTOL, itmax=A.n, history=True)
+            dump("oracle_cfg3_gmres256_exact_dots.json", dict(
+                generator="tests/golden/make_scale_golden.py 23",
+                oracle="oracle/krylov_oracle.c ko_gmres (src/gmres.jl:121-384) with ko_set_dot_mode(1): Dot2 dots",
+                config="BASELINE cfg 3: gmres!(memory = 30, restart = true) on kron_unsymmetric(256), b = A*ones; prefix: atol = rtol = 0, "
+                       "45 iterations; full: atol = 0, rtol = 1e-8, itmax = n",
+                n=A.n, nnz=A.nnz, memory=30, prefix_residuals=[float(v) for v in pre.residuals], prefix_x_sample=[float(pre.x[i]) for i in idx],
+                niter=full.niter, solved=bool(full.solved), status=full.status, residuals=[float(v) for v in full.residuals],
+                x_index=idx, x_sample=[float(full.x[i]) for i in idx], seconds=time.time() - t0))
+    finally:
+        ok.lib().ko_set_dot_mode(0)

@@ -333,6 +333,12 @@ def test_cg_1024_over_8_ranks_matches_oracle_prefix(K, ctx, parity_log, halo_mod
 # 100-iteration prefix AND the full solve to rtol 1e-8 (1225 iterations) within EXACT_TOL of it, same iteration count and
 # status -- the gap to the documented oracle (4e-13 / 7.7e-11) is that oracle's own summation error.
 EXACT_TOL = 1e-13
+# gmres! (45-iteration prefix, full solve of 940 iterations = 31 restarts) and bicgstab! (25 iterations) against the same kind of
+# history: measured 0.0 -- bit-identical -- in round 4 for all of them (profiles/r04_parity_log.jsonl), so the north star's 1e-12
+# is asserted even for the restarted full solve, whose distance to the DOCUMENTED oracle (4.0e-4, bound 1.2e-3 above) turns out to
+# be that oracle's extended-precision summation error amplified by the restarts, not a property of the HIP path.
+GMRES_EXACT_TOL = (1e-12, 1e-12)
+BICGSTAB_EXACT_TOL = 1e-12
 
 
 @pytest.mark.parametrize("fused", [2, 0])
@@ -364,3 +370,58 @@ def test_cg_512_against_the_exact_dot_oracle(K, ctx, parity_log, fused):
     assert st.niter == g["niter"] and st.status == g["status"]
     assert dev_prefix <= EXACT_TOL and xdev_prefix <= EXACT_TOL, (dev_prefix, xdev_prefix)
     assert dev_full <= EXACT_TOL and xdev_full <= EXACT_TOL, (dev_full, xdev_full)
+    # measured in round 4: 0.0 everywhere -- all 1226 residual norms of the full solve and all 101 of the prefix bit for bit,
+    # fused = 2 and the reference's primitive sequence alike (profiles/r04_parity_log.jsonl); the bound above leaves room for
+    # the one-ulp difference two faithful dot algorithms may show on some input
+
+
+def test_gmres_cfg3_against_the_exact_dot_oracle(K, ctx, parity_log):
+    """cfg 3 against ko_gmres with Dot2 dots (tests/golden/oracle_cfg3_gmres256_exact_dots.json, leg 23): the 45-iteration prefix
+    and the full solve to rtol 1e-8.  The Gram-Schmidt coefficients and the norms are the only reductions of gmres!; with exact
+    dots on both sides what separates the two implementations is the order of the double-double partial sums alone."""
+    g = _golden("oracle_cfg3_gmres256_exact_dots.json")
+    n = 256 ** 3
+    A = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", 256)
+    ones = ctx.empty(n)
+    K.kfill_(ones, 1.0)
+    b = ctx.empty(n)
+    A.matvec(ones, b)
+    ws = K.GmresWorkspace(ctx, n, n, memory=g["memory"])
+    K.gmres_(ws, A, b, restart=True, atol=0.0, rtol=0.0, itmax=45, history=True)
+    hp = np.array(g["prefix_residuals"])
+    assert len(ws.stats.residuals) == len(hp)
+    dev_prefix = _rel(ws.stats.residuals, hp)
+    K.gmres_(ws, A, b, restart=True, atol=0.0, rtol=1e-8, itmax=n, history=True)
+    st = ws.stats
+    hf = np.array(g["residuals"])
+    m = min(len(hf), len(st.residuals))
+    dev_full = _rel(np.asarray(st.residuals)[:m], hf[:m])
+    xs = ws.x.to_host()
+    xf = np.array(g["x_sample"])
+    xdev_full = float(np.max(np.abs(xs[g["x_index"]] - xf)) / np.max(np.abs(xf)))
+    parity_log(test="gmres_cfg3_vs_exact_dot_oracle", prefix_hist_max_rel=dev_prefix, full_iterations=st.niter, ref_iterations=g["niter"],
+               full_hist_max_rel=dev_full, full_x_sample_rel=xdev_full,
+               bit_identical_history=bool(len(hf) == len(st.residuals) and np.array_equal(np.asarray(st.residuals), hf)))
+    assert st.niter == g["niter"] and st.status == g["status"]
+    assert dev_prefix <= GMRES_EXACT_TOL[0] and dev_full <= GMRES_EXACT_TOL[1], (dev_prefix, dev_full)
+
+
+@pytest.mark.parametrize("fused", [2, 0])
+def test_bicgstab_256_against_the_exact_dot_oracle(K, ctx, parity_log, fused):
+    """bicgstab! on cfg 3's operator, 25 iterations, against ko_bicgstab with Dot2 dots (leg 24)."""
+    g = _golden("oracle_bicgstab256_exact_dots.json")
+    n = 256 ** 3
+    A = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", 256)
+    ones = ctx.empty(n)
+    K.kfill_(ones, 1.0)
+    b = ctx.empty(n)
+    A.matvec(ones, b)
+    ws = K.BicgstabWorkspace(ctx, n, n)
+    K.bicgstab_(ws, A, b, atol=0.0, rtol=0.0, itmax=g["niter"], history=True, fused=fused)
+    st = ws.stats
+    href = np.array(g["residuals"])
+    assert st.niter == g["niter"] and st.status == g["status"] and len(st.residuals) == len(href)
+    dev = _rel(st.residuals, href)
+    parity_log(test="bicgstab_256_vs_exact_dot_oracle", fused=fused, iterations=st.niter, hist_max_rel=dev,
+               bit_identical_history=bool(np.array_equal(np.asarray(st.residuals), href)))
+    assert dev <= BICGSTAB_EXACT_TOL, dev
