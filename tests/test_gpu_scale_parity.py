@@ -425,3 +425,85 @@ def test_bicgstab_256_against_the_exact_dot_oracle(K, ctx, parity_log, fused):
     parity_log(test="bicgstab_256_vs_exact_dot_oracle", fused=fused, iterations=st.niter, hist_max_rel=dev,
                bit_identical_history=bool(np.array_equal(np.asarray(st.residuals), href)))
     assert dev <= BICGSTAB_EXACT_TOL, dev
+
+
+# ---- the row-partitioned path at the BASELINE sizes, all solvers (round 4) ------------------------------------------------
+# gmres!(30) and bicgstab! on cfg 3's operator over 4 / 8 in-process ranks, cg! at 512^3 over 8 (the strong-scaling layout of
+# bench.py --gpus 8), each against the exact-dot oracle history of the GLOBAL system: the per-rank double-double partials are
+# all-gathered as (hi, lo) pairs and merged in rank order, so the partition must not cost a bit either.
+def _ranks(K, world, hub, body):
+    import threading
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            c = K.Context(0)
+            c.comm_init_local(rank, world, hub)
+            out[rank] = body(c, rank)
+            c.barrier()
+            c.close()
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errs.append((rank, repr(e), traceback.format_exc()))
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    return out
+
+
+def test_partitioned_solvers_at_full_size_against_the_exact_dot_oracle(K, ctx, parity_log):
+    import gc
+    gc.collect()
+    gg, gb, gc2 = _golden("oracle_cfg3_gmres256_exact_dots.json"), _golden("oracle_bicgstab256_exact_dots.json"), _golden("oracle_cfg2_cg512_exact_dots.json")
+    n3 = 256 ** 3
+
+    def unsym(world):
+        starts = K.row_partition(n3, world)
+
+        def body(c, rank):
+            r0, r1 = starts[rank], starts[rank + 1]
+            A = K.CsrMatrix.stencil(c, "kron_unsymmetric", 256, rows=(r0, r1), distributed=True)
+            m = r1 - r0
+            ones = c.empty(m)
+            K.kfill_(ones, 1.0)
+            b = c.empty(m)
+            A.matvec(ones, b)
+            ws = K.GmresWorkspace(c, m, m, memory=30)
+            K.gmres_(ws, A, b, restart=True, atol=0.0, rtol=0.0, itmax=45, history=True)
+            hg = ws.stats.residuals.copy()
+            del ws
+            wb = K.BicgstabWorkspace(c, m, m)
+            K.bicgstab_(wb, A, b, atol=0.0, rtol=0.0, itmax=25, history=True, fused=2)
+            return hg, wb.stats.residuals.copy()
+        return body
+
+    for world in (4, 8):
+        res = _ranks(K, world, 5150 + world, unsym(world))
+        hg, hb = res[0]
+        assert all(np.array_equal(r[0], hg) and np.array_equal(r[1], hb) for r in res), "ranks disagree"
+        dg, db = _rel(hg, np.array(gg["prefix_residuals"])), _rel(hb, np.array(gb["residuals"]))
+        parity_log(test="partitioned_cfg3_vs_exact_dot_oracle", ranks=world, gmres_hist_max_rel=dg, bicgstab_hist_max_rel=db)
+        assert dg <= 1e-12 and db <= 1e-12, (world, dg, db)
+
+    n2 = 512 ** 3
+    starts = K.row_partition(n2, 8)
+
+    def cg_body(c, rank):
+        r0, r1 = starts[rank], starts[rank + 1]
+        A = K.CsrMatrix.stencil(c, "poisson", 512, rows=(r0, r1), distributed=True)
+        m = r1 - r0
+        b = c.empty(m)
+        K.kfill_(b, 1.0)
+        ws = K.CgWorkspace(c, m, m)
+        K.cg_(ws, A, b, atol=0.0, rtol=1e-8, itmax=n2, history=True, fused=2)
+        return ws.stats.niter, ws.stats.status, ws.stats.residuals.copy()
+    res = _ranks(K, 8, 5199, cg_body)
+    niter, status, h = res[0]
+    assert all(r[0] == niter and np.array_equal(r[2], h) for r in res)
+    hf = np.array(gc2["residuals"])
+    assert niter == gc2["niter"] and status == gc2["status"] and len(h) == len(hf)
+    dc = _rel(h, hf)
+    parity_log(test="partitioned_cfg2_full_solve_vs_exact_dot_oracle", ranks=8, iterations=niter, hist_max_rel=dc,
+               bit_identical_history=bool(np.array_equal(h, hf)))
+    assert dc <= 1e-12, dc

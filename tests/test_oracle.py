@@ -713,6 +713,12 @@ def test_scale_goldens_are_well_formed():
     assert g4["residuals"][0] == 32768.0 and all(np.isfinite(g4["residuals"])) and len(g4["x_sample"]) == len(g4["x_index"]) == 16
     h, hx = np.array(g4["residuals"]), np.array(g4["residuals_exact_dots"])          # the second history: the same recurrence, Dot2 dots
     assert len(hx) == 101 and hx[0] == 32768.0 and g4["oracle_vs_exact_dots_max_rel_dev"] == float(np.max(np.abs(h - hx) / hx)) < 1e-10
+    for name, n, niter in (("oracle_cfg2_cg512_exact_dots.json", 512 ** 3, 1225), ("oracle_cfg3_gmres256_exact_dots.json", 256 ** 3, 940)):
+        ge = json.load(open(os.path.join(ROOT, "tests", "golden", name)))          # the exact-dot histories (legs 22 / 23)
+        assert ge["n"] == n and ge["niter"] == niter and len(ge["residuals"]) == niter + 1 and len(ge["prefix_residuals"]) in (101, 46)
+        assert all(np.isfinite(ge["residuals"])) and ge["solved"]
+    gbe = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_bicgstab256_exact_dots.json")))
+    assert gbe["niter"] == 25 and len(gbe["residuals"]) == 26
     g2 = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_cfg2_cg512.json")))
     assert g2["residuals"][0] == math.sqrt(512 ** 3) and g2["nnz"] == 7 * 512 ** 3 - 6 * 512 ** 2      # ||ones||, SURVEY 8
 
