@@ -36,7 +36,7 @@ extern "C" {
 #define KHIP_ERR_NUMERIC     -5   /* e.g. operator not SPD (src/cg.jl:163,243) */
 
 #define KHIP_VERSION_MAJOR 0
-#define KHIP_VERSION_MINOR 1
+#define KHIP_VERSION_MINOR 2   /* 2: khip_options gained log_fd (round 4); clients check khip_version() against the header they were built with */
 
 typedef struct khip_ctx khip_ctx;   /* device + stream + scratch + (optional) communicator */
 typedef struct khip_csr khip_csr;   /* CSR operator resident in HBM */
