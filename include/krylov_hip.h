@@ -200,6 +200,10 @@ int khip_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const do
                    double *x, double *r, double *result_host);
 /* y <- y + a x ; *result_host = y . y                      (src/cg.jl:240,242 with M = I: r <- r - alpha Ap ; r.r) */
 int khip_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, double *result_host);
+/* The set-up of cg! with M = I and no warm start (src/cg.jl:153,158,161,162: kfill!(x, 0); kcopy!(r, b); kcopy!(p, r); gamma =
+ * kdotr(r, r)) in ONE pass: 8n bytes read, 24n written instead of 48n; x, r, p and gamma hold what the four primitives leave (the
+ * all-reduce of gamma included on row-partitioned vectors).  The four vectors must be distinct. */
+int khip_cg_setup(khip_ctx *ctx, int64_t n, const double *b, double *x, double *r, double *p, double *result_host);
 /* x <- x + a p ; p <- r + b p in one pass over p          (src/cg.jl:239 and :259 = kaxpy!(n, a, p, x) ; kaxpby!(n, 1, r, b, p)).
  * Legal because x is not read between the two reference lines; 40n bytes instead of 48n. */
 int khip_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x);

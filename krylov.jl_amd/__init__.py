@@ -122,6 +122,7 @@ SIGNATURES = {
     "khip_axpy2_dot": (_int, [_vp, _i64, _dbl, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_waxpy": (_int, [_vp, _i64, _vp, _vp, _dbl, _vp]),
     "khip_axpy_sqnorm": (_int, [_vp, _i64, _dbl, _vp, _vp, c_double_p]),
+    "khip_cg_setup": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_cg_update": (_int, [_vp, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "khip_spmv_dotw": (_int, [_vp, _vp, _vp, _vp, _vp, c_double_p]),
     "khip_spmv_dot2": (_int, [_vp, _vp, _vp, _vp, c_double_p]),
@@ -560,6 +561,13 @@ def axpy_sqnorm(n, a, x, y) -> float:
     """y += a x ; returns y . y (src/cg.jl:240,242)."""
     out = C.c_double()
     _ck(lib().khip_axpy_sqnorm(y.ctx._h, n, a, _p(x), _p(y), C.byref(out)))
+    return out.value
+
+
+def cg_setup_(n, b, x, r, p) -> float:
+    """x = 0 ; r = b ; p = b ; returns b . b in one pass (the set-up of cg!, src/cg.jl:153-162 with M = I, no warm start)."""
+    out = C.c_double()
+    _ck(lib().khip_cg_setup(x.ctx._h, n, _p(b), _p(x), _p(r), _p(p), C.byref(out)))
     return out.value
 
 

@@ -587,6 +587,7 @@ enum RedOp {
   RED_AXPY2 = 3,      // X += a p ; R -= a q ; out0 = R . R
   RED_AXPYDEV = 4,    // Y -= (*coef) x ; out0 = z . Y   (z == Y -> ||Y||^2)
   RED_AXPYSQ = 5,     // Y += a x ; out0 = Y . Y
+  RED_CGSETUP = 6,    // U = x ; V = x ; W = 0 ; out0 = x . x      (cg! setup in one pass: r = b, p = b, x = 0, gamma = b . b)
 };
 
 template <int ROP> struct RedOut { static constexpr int n = (ROP == RED_DOT2) ? 2 : 1; };
@@ -598,6 +599,7 @@ struct RedPtrs {
   double *v;            //                           AXPY2: R
   const double *coef;   // AXPYDEV: device scalar
   double a;             // AXPY2
+  double *w;            // CGSETUP: W
 };
 
 // KEEP: the y / u streams use ordinary (cacheable) accesses even when NT is set for x -- the MGS cascade
@@ -623,6 +625,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
   constexpr bool rd_y = (ROP == RED_DOT || ROP == RED_DOT2 || ROP == RED_AXPY2 || ROP == RED_AXPYDEV);
   constexpr bool rd_u = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV || ROP == RED_AXPYSQ);
   constexpr bool rd_v = (ROP == RED_AXPY2);
+  T *Wv = reinterpret_cast<T *>(p.w);
 
   T xv[U] = {}, yv[U] = {}, uv[U] = {}, vv[U] = {};
 #pragma unroll
@@ -659,6 +662,17 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
           acc_prod<COMP>(acc[0], z_is_y ? yn : vget(yv[u], e), yn);
         }
         stg<NTK>(un, Uv + j);
+      } else if (ROP == RED_CGSETUP) {
+        T zero;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const double xe = vget(xv[u], e);
+          vset(zero, e, 0.0);
+          acc_prod<COMP>(acc[0], xe, xe);
+        }
+        stg<NT>(xv[u], Uv + j);
+        stg<NT>(xv[u], Vv + j);
+        stg<NT>(zero, Wv + j);
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -685,6 +699,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(int64_t n, RedPtrs p, Re
       p.v[t] = rn;
       acc_prod<COMP>(acc[0], rn, rn);
     }
+    if (ROP == RED_CGSETUP) { p.u[t] = xe; p.v[t] = xe; p.w[t] = 0.0; acc_prod<COMP>(acc[0], xe, xe); }
     if (ROP == RED_AXPYDEV || ROP == RED_AXPYSQ) {
       double yn = fma(a, xe, p.u[t]);
       double ze = z_is_y ? yn : p.y[t];
@@ -699,7 +714,7 @@ template <int ROP>
 static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   if (n < 0) { set_error("negative length"); return KHIP_ERR_INVALID; }
   const bool v2 = n >= 2 && aligned16(p.x) && (p.y == nullptr || aligned16(p.y)) && (p.u == nullptr || aligned16(p.u)) &&
-                  (p.v == nullptr || aligned16(p.v));
+                  (p.v == nullptr || aligned16(p.v)) && (p.w == nullptr || aligned16(p.w));
   const bool comp = ctx->tune.compensated != 0;
   // MGS cascade (AXPYDEV): q and the basis vector just dotted are read again by the very next kernel; when both
   // fit in the 256 MiB Infinity Cache, leaving them cacheable beats streaming them (GMRES(30) at 256^3:
@@ -710,7 +725,7 @@ static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   const int64_t nvec = v2 ? n / 2 : n;
   // 16-byte accesses per lane: 4 for the read-only reductions of long vectors (dot 6.1 vs 5.8 TB/s, nrm2 6.1 vs 4.3),
   // 1 for the ones that also write (r -= a Ap ; r.r: 5.96 vs 5.72 TB/s) -- measured at n = 512^3, tools/sweep8.py
-  constexpr bool writes = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV || ROP == RED_AXPYSQ);
+  constexpr bool writes = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV || ROP == RED_AXPYSQ || ROP == RED_CGSETUP);
   const bool u4 = ctx->tune.red_u == 0 ? (!writes && nvec >= (int64_t)kBlock * 4 * 1024) : ctx->tune.red_u == 4;
   const int64_t g = tiles_for(nvec, u4 ? 4 : 1);
   if (g > 0x7fffffffLL) { set_error("vector too long for one launch"); return KHIP_ERR_INVALID; }
@@ -753,6 +768,12 @@ int launch_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *pv, const
 int launch_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, int slot) {
   RedPtrs p{x, nullptr, y, nullptr, nullptr, a};
   return launch_reduce<RED_AXPYSQ>(ctx, n, p, slot);
+}
+// cg! setup (src/cg.jl:153-162 with M = I and no warm start) in ONE pass: x = 0, r = b, p = b, gamma = b . b -- reads 8n and
+// writes 24n bytes instead of the 48n of kfill! + 2 kcopy! + kdotr; every value is what the four primitives leave.
+int launch_cg_setup(khip_ctx *ctx, int64_t n, const double *b, double *x, double *r, double *pvec, int slot) {
+  RedPtrs p{b, nullptr, r, pvec, nullptr, 0.0, x};
+  return launch_reduce<RED_CGSETUP>(ctx, n, p, slot);
 }
 int launch_axpy_dev_dot(khip_ctx *ctx, int64_t n, const double *coef_dev, const double *x, double *y, const double *z,
                         int slot) {

@@ -84,6 +84,7 @@ struct Tuning {
   int spmv_lds_pad = 0;     // experiment: extra dynamic LDS bytes per workgroup (lowers occupancy)
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
   int spmv_pipe = 0;        // staged kernel: software-pipelined form with this many consecutive row blocks per workgroup (0 = one block per workgroup, no pipeline; measured no faster: profiles/r02b_sweep_pipe.log)
+  int cg_setup_fused = 1;   // cg! (fused paths, M = I, no warm start): x = 0, r = p = b, gamma = b.b in one pass (khip_cg_setup) instead of four primitives
   int spmv_stream_nt = 0;   // 16-byte-load stream kernel: matrix stream loaded with the non-temporal policy
   int spmv_blk_pub = 0;     // fused dots of the staged / coded / delta SpMV kernels: 1 = workgroup-level fold in LDS, one wave runs the double-double tree (block_publish); measured equal to the per-wave trees (profiles/r04b_sweep_headline.log): off
   int spmv_delta = 0;       // stream kernel: block-delta column stream (coldelta.hip: 1 or 2 B per entry + 6 B per escape) -- 0: never (default: 18 % fewer bytes but no faster on the banded + random operator, slower on stencils; profiles/r04a_sweep_delta.log); 1: operators of >= 4 M entries where it saves at least a sixth of the column bytes; 2: whatever the size; 8 / 16: that width, always
@@ -260,6 +261,7 @@ int launch_dot2(khip_ctx *ctx, int64_t n, const double *x, const double *y, int 
 int launch_axpy2_dot(khip_ctx *ctx, int64_t n, double a, const double *p, const double *q, double *x,
                      double *r, int slot);
 int launch_axpy_sqnorm(khip_ctx *ctx, int64_t n, double a, const double *x, double *y, int slot);   // y += a x ; y.y
+int launch_cg_setup(khip_ctx *ctx, int64_t n, const double *b, double *x, double *r, double *p, int slot);   // x = 0 ; r = p = b ; b.b
 int launch_cg_update(khip_ctx *ctx, int64_t n, double a, double b, const double *r, double *p, double *x);
 // same with alpha / beta / solved read from a CgDevState in device memory (solver_device.hpp)
 int launch_cg_update_dev(khip_ctx *ctx, int64_t n, const void *cg_state_dev, long long seq, const double *r, double *p,

@@ -109,6 +109,45 @@ def test_empty_vectors(K, ctx):
     K.kaxpy_(0, 1.0, v, v)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 1001, 300007, 5_000_003])
+@pytest.mark.parametrize("mis", [False, True])
+def test_one_pass_cg_setup_equals_the_four_primitives(K, ctx, oracle, n, mis):
+    """khip_cg_setup (round 4): kfill!(x, 0); kcopy!(r, b); kcopy!(p, r); kdotr(r, r) of src/cg.jl:153-162 in one pass -- the same
+    vectors bit for bit, gamma equal to the device's own kdot (and to the oracle's within the dot's bound), and cg! histories
+    identical with the pass on and off."""
+    rng = np.random.default_rng(7 * n + mis)
+    b = _vec(rng, n)
+    db = _dev(K, ctx, b, mis)
+    dx, dr, dp_ = (_dev(K, ctx, rng.standard_normal(n), mis) for _ in range(3))     # garbage to overwrite
+    g = K.cg_setup_(n, db, dx, dr, dp_)
+    assert np.array_equal(dr.to_host(), b) and np.array_equal(dp_.to_host(), b)
+    xh = dx.to_host()
+    assert np.array_equal(xh, np.zeros(n)) and not np.signbit(xh).any()
+    assert g == K.kdot(n, db, db)                          # the same bits as the separate reduction
+    gc = oracle.dot(b, b)
+    assert abs(g - gc) <= 2 * EPS * gc
+    assert np.array_equal(db.to_host(), b)                 # b untouched
+    if n == 300007 and not mis:
+        A_cpu = oracle.poisson3d(20)
+        A = K.CsrMatrix.stencil(ctx, "poisson", 20)
+        bb = ctx.array(np.linspace(0.5, 2.0, A_cpu.n))
+        prev = ctx.get_option("cg_setup_fused")
+        try:
+            hist = {}
+            for on in (1, 0):
+                ctx.set_option("cg_setup_fused", on)
+                for fused in (2, 1):
+                    xs, st, _ = K.cg(A, bb, history=True, fused=fused)
+                    hist[(on, fused)] = (st.niter, st.residuals.copy(), xs.to_host())
+        finally:
+            ctx.set_option("cg_setup_fused", prev)
+        ref = hist[(0, 1)]
+        for k, v in hist.items():
+            assert v[0] == ref[0] and np.array_equal(v[1], ref[1]) and np.array_equal(v[2], ref[2]), k
+        with pytest.raises(K.KhipError):
+            K.cg_setup_(8, bb, bb, dr, dp_)                # the four vectors must be distinct
+
+
 @pytest.mark.parametrize("n", [1, 2, 1001, 300007])
 def test_fused_axpy_sqnorm_and_cg_update(K, ctx, oracle, n):
     """The two kernels of the fused CG iteration (src/cg.jl:239-242,259) against the unfused device
