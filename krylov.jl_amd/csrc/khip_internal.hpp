@@ -74,7 +74,7 @@ struct Tuning {
   int spmv_xcd = 0;         // XCD-aware tile remap: R > 0 runs of R tiles per XCD, -1 contiguous eighths, 0 off
   int spmv_sweep_s = 0;     // plane sweep (spmv_xcd = -2): tiles per grid plane (0 = from the handle's band width)
   int spmv_sweep_w = 16;    // plane sweep: consecutive tiles per XCD column
-  int spmv_nty = 0;         // non-temporal store of y
+  int spmv_nty = -1;        // y store of the SpMV kernels: -1 = non-temporal when y is >= 512 MiB (beyond the Infinity Cache), else plain; 0 plain, 1 non-temporal, 2 write-through (sc1)
   int spmv_dot_early = 0;   // staged kernels with a fused dot: load dotw[row] before the row block's windows
   int spmv_fake_gather = 0; // tuning experiment (wrong results): coalesced x reads
   int spmv_tiles = 1;       // staged kernel: consecutive row blocks per workgroup

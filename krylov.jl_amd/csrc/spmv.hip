@@ -36,6 +36,16 @@
 
 namespace khip {
 
+// y[row] = v under the context's store policy: plain, non-temporal (spmv_nty = 1) or write-through (spmv_nty = 2: an sc1 store
+// leaves no line in the XCD's L2, MI355X_MICROARCH.md, so y does not compete with the x lines the gathers live on)
+__device__ __forceinline__ void store_y(const SpmvArgs &a, int64_t row, double v) {
+  if (a.nt_y == 2) {
+    const double *p = a.y + row;
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+  } else if (a.nt_y) __builtin_nontemporal_store(v, a.y + row);
+  else a.y[row] = v;
+}
+
 // Logical tile id of workgroup b (of G).  The dispatcher places workgroup b on XCD b % 8 (observed,
 // MI355X_MICROARCH.md), each XCD has its own 4 MiB L2.  xcd_run = R > 0 hands every XCD runs of R
 // CONSECUTIVE tiles inside each window of 8R workgroups, so the x entries shared by neighbouring rows
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(SpmvArgs a, RedArgs
       __syncthreads();
     }
     if (tid < nr) {
-      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+      store_y(a, r0 + tid, acc);
       if (DOT) {
         const double wv = a.dotw[r0 + tid];
         acc_prod<COMP>(dacc[0], wv, acc);
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
       __syncthreads();
     }
     if (tid < nr) {
-      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+      store_y(a, r0 + tid, acc);
       if (DOT) {
         if (!a.dot_early) wv = a.dotw[r0 + tid];
         acc_prod<COMP>(dacc[0], wv, acc);
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
       __syncthreads();
     }
     if (tid < nr) {
-      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+      store_y(a, r0 + tid, acc);
       if (DOT) {
         if (!a.dot_early) wv = a.dotw[r0 + tid];
         acc_prod<COMP>(dacc[0], wv, acc);
@@ -597,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pipe_kernel(SpmvArgs a, RedArgs r
         acc = (k0 + u < cnt) ? next : acc;
       }
       if (live) {
-        if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+        store_y(a, r0 + tid, acc);
         if (DOT) {
           acc_prod<COMP>(dacc[0], wv, acc);
           if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void spmv_delta_kernel(SpmvArgs a, RedArgs 
     }
     if (rb + 1 < rb_end) __syncthreads();
     if (tid < nr) {
-      if (a.nt_y) __builtin_nontemporal_store(acc, a.y + r0 + tid); else a.y[r0 + tid] = acc;
+      store_y(a, r0 + tid, acc);
       if (DOT) {
         if (!a.dot_early) wv = a.dotw[r0 + tid];
         acc_prod<COMP>(dacc[0], wv, acc);
@@ -1202,7 +1212,10 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.xcd_remap = ctx->tune.spmv_xcd;
   a.sweep_s = ctx->tune.spmv_sweep_s;
   a.sweep_w = ctx->tune.spmv_sweep_w;
-  a.nt_y = ctx->tune.spmv_nty;
+  // y store: non-temporal once y is far beyond the 256 MiB Infinity Cache (512^3: 1 GiB) -- the coded product 2.04 -> 1.96 ms,
+  // fused 2.18 -> 2.14, CG +1.3 % (profiles/r04l_sweep_nty.log, r04m); below that the next kernel finds y in the cache and the
+  // cacheable store wins (-3 % at 256^3, r01).  Write-through (2) measures like the plain store.
+  a.nt_y = ctx->tune.spmv_nty >= 0 ? ctx->tune.spmv_nty : ((size_t)A->m * sizeof(double) >= ((size_t)512 << 20) ? 1 : 0);
   a.dot_early = ctx->tune.spmv_dot_early;
   a.tiles_per_block = 1;
   a.stage_cap = 2048;
