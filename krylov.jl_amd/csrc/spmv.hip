@@ -375,13 +375,23 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
           __builtin_amdgcn_make_buffer_rsrc(const_cast<CODE *>(code + c0), 0, lim4 * (int)sizeof(CODE), kBufRsrcWord3);
       u32x4 v[4];
       cvec c[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int o = q * (4 * kBlock) + 4 * tid;
-        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, 0);
-        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, 0);
-        c[q] = code_load<CODE>::ld(rc, o * (int)sizeof(CODE));
+      // cache policy of the matrix stream (a.stream_nt; experiment of round 4): 0 default, 1 nt, 2 sc0, 3 sc0 nt, 4 sc1, 5 sc1 nt
+#define KHIP_WIN_LOADS(AUX)                                                                   \
+      _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                        \
+        const int o = q * (4 * kBlock) + 4 * tid;                                            \
+        v[2 * q] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8, 0, AUX);                 \
+        v[2 * q + 1] = __builtin_amdgcn_raw_buffer_load_b128(rv, o * 8 + 16, 0, AUX);        \
+        c[q] = code_load<CODE>::template ld<AUX>(rc, o * (int)sizeof(CODE));                 \
       }
+      switch (a.stream_nt) {
+        case 1: KHIP_WIN_LOADS(2) break;
+        case 2: KHIP_WIN_LOADS(1) break;
+        case 3: KHIP_WIN_LOADS(3) break;
+        case 4: KHIP_WIN_LOADS(16) break;
+        case 5: KHIP_WIN_LOADS(18) break;
+        default: KHIP_WIN_LOADS(0) break;
+      }
+#undef KHIP_WIN_LOADS
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int o = q * (4 * kBlock) + 4 * tid;
