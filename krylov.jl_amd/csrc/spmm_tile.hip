@@ -42,6 +42,7 @@ struct TileArgs {
   int64_t groups, per_xcd;
   int64_t runs, runs_per_xcd;   // sliding windows (run_len > 0): the groups form runs of run_len consecutive records, a wave walks whole runs
   int run_len;
+  int dbuf;               // 1: two windows per wave, the copies of the next group land while this group's products run (LDS: 2 x cap x 32 L bytes)
   int cap;                // list entries per group (multiple of 8)
   int stride;             // bytes per record
   int exp;                // tuning experiments, WRONG results: 1 no panel-row copies, 2 no products, 4 no (val, slot) loads, 8 groups dealt round-robin to the XCDs
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
   };
   if (g >= gend) return;
   const int hq = (sub & 2) ? 16 * L : 0;             // lane groups with bit 1 set read the second half of a panel row first
-  const char *xa = reinterpret_cast<const char *>(tile_win) + 16 * c + hq;
-  const char *xb_ = reinterpret_cast<const char *>(tile_win) + 16 * c + (16 * L - hq);
+  const char *xa0 = reinterpret_cast<const char *>(tile_win) + 16 * c + hq;
+  const char *xb0 = reinterpret_cast<const char *>(tile_win) + 16 * c + (16 * L - hq);
   const int64_t vlast = a.nnz_bound - 2;
   const int slot_off = kTileDescBytes + 4 * w.cap;
 
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
   // compiler counts in this iteration, so its counted waits stay sufficient, and the wait for the copies themselves is the
   // explicit vmcnt below.  M0 (the LDS destination base) is compiler-reserved: saved and restored per statement.
   const unsigned win_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_char *)tile_win);
-  auto issue_dma = [&](const TileRec<L, NL> &r, unsigned mask) {     // mask: bit o set = the slots 8 o .. 8 o + 7 hold rows that are not in the window yet
+  auto issue_dma = [&](const TileRec<L, NL> &r, unsigned mask, unsigned wbase) {     // mask: bit o set = the slots 8 o .. 8 o + 7 hold rows that are not in the window yet; wbase: byte offset of the window (double buffering)
     constexpr int PER = 64 / S::EPI;                 // instructions per list word
     int col[NL * PER];
 #pragma unroll
@@ -261,14 +262,15 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
           rr = own ? rr : rr - (uint64_t)a.n_owned;
         }
         const char *gsrc = src + (rr << w.gshift) + w.coff + 16 * (lane % (2 * L));
-        const unsigned dst = win_lds + 1024u * (unsigned)wq;
+        const unsigned dst = win_lds + wbase + 1024u * (unsigned)wq;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
       }
     }
   };
-  auto products = [&](const TileRec<L, NL> &r, const TileEnt<L> &e) {
+  auto products = [&](const TileRec<L, NL> &r, const TileEnt<L> &e, unsigned wbase) {
+    const char *xa = xa0 + wbase, *xb_ = xb0 + wbase;
 #pragma unroll
     for (int q = 0; q < S::NPASS; ++q) {
       const int4v &d = r.d[q];
@@ -316,11 +318,48 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
   load_rec(g1, r1);
   load_ent(g, r0, e0);
   __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0): the loop starts with nothing in flight
+  if (w.dbuf) {
+    // DOUBLE-BUFFERED WINDOWS (round 4).  With one window a wave cannot start the copies of group g + 1 before the products of
+    // g have read the window empty: copy latency and ~2 us of products alternate inside every wave, and 7 waves per CU do not
+    // cover for each other (TCP misses in flight ~80 lines per CU, profiles/r03c_spmm_tile_pmc_persistent.log).  With two
+    // windows the iteration is: everything outstanding has landed (it is all needed now) -> issue the copies of g + 1 into the
+    // other window, its (val, slot) loads and the record of g + 2 -> products of g while those fly.
+    const unsigned wbytes = (unsigned)w.cap * 32u * (unsigned)L;
+    unsigned cur = 0;
+    {
+      const bool d0 = __builtin_amdgcn_readfirstlane(__shfl(r0.d[0].w, L)) != 0;
+      if (!d0) issue_dma(r0, 0xffffffffu, 0u);
+    }
+    for (;;) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): copies of g, entries of g, record of g + 1
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const bool direct = __builtin_amdgcn_readfirstlane(__shfl(r0.d[0].w, L)) != 0;
+      const bool more = g1 < gend;
+      if (more) {
+        const bool d1 = __builtin_amdgcn_readfirstlane(__shfl(r1.d[0].w, L)) != 0;
+        if (!d1) issue_dma(r1, 0xffffffffu, (cur ^ 1u) * wbytes);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        load_ent(g1, r1, e1);
+        load_rec(g2, r2);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!direct) products(r0, e0, cur * wbytes);
+      g = g1; g1 = g2; g2 = g2 + G;
+      if (!more) break;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every window read of this group has returned before the window is filled again
+      r0 = r1; e0 = e1; r1 = r2;
+      cur ^= 1u;
+    }
+    return;
+  }
   for (;;) {
     // aux of row slot 1 = the group's flag (row slot 1 is lane L of pass 0), of row slot 2 = the octets to copy
     const bool direct = __builtin_amdgcn_readfirstlane(__shfl(r0.d[0].w, L)) != 0;
     const unsigned mask = slide ? (unsigned)__builtin_amdgcn_readfirstlane(__shfl(r0.d[0].w, 2 * L)) : 0xffffffffu;
-    if (!direct) issue_dma(r0, mask);
+    if (!direct) issue_dma(r0, mask, 0u);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     load_ent(g1, r1, e1);
@@ -336,7 +375,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
       __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      products(r0, e0);
+      products(r0, e0, 0u);
     }                                                        // (flagged groups: spmm_tile_direct_kernel, launched next)
     if (slide) { g = g1; g1 = g2; g2 = next_of(run2, t2); } else { g += G; g1 = g + G; g2 = g + 2 * G; }
     if (g >= gend) break;
@@ -836,7 +875,12 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   TileArgs w;
   w.run_len = A->tile_run_len; w.runs = A->tile_runs; w.runs_per_xcd = (A->tile_runs + 7) / 8;
   w.meta = A->tile_meta; w.groups = A->tile_groups; w.per_xcd = (A->tile_groups + 7) / 8; w.cap = A->tile_cap; w.stride = A->tile_stride; w.exp = ctx->tune.spmm_tile_exp; w.gshift = gshift; w.coff = coff;
-  const size_t lds = (size_t)w.cap * 32 * L;
+  // two windows per wave where six waves per CU still fit with them (windows of <= 104 panel rows at p = 16: 7-point grids 1.12 ->
+  // 0.99 ms); at cfg 5 (144 rows: four waves per CU, one per SIMD) the products' own latency shows: 1.84 against 1.36 ms
+  // (profiles/r04r_spmm_dbuf.log).  spmm_tile_dbuf: -1 by that rule, 0 never, 1 always.  (Sliding windows carry ONE window.)
+  const int dbuf_opt = ctx->tune.spmm_tile_dbuf;
+  w.dbuf = (w.run_len == 0 && (dbuf_opt > 0 || (dbuf_opt < 0 && (size_t)w.cap * 32 * L * 2 <= (size_t)26 * 1024))) ? 1 : 0;
+  const size_t lds = (size_t)w.cap * 32 * L * (w.dbuf ? 2 : 1);
   int per_cu = (int)((size_t)(160 * 1024) / lds);                    // LDS-limited residency of the one-wave workgroups
   if (per_cu >= 5) --per_cu;                                         // one wave short of the LDS limit measures 3 % faster (7 instead of 8 at 144 panel rows)
   if (per_cu > 16) per_cu = 16;
