@@ -426,6 +426,40 @@ def test_spmm_tile_grid_operators_bit_identical(K, ctx, oracle, kind, dims):
         assert info["window"] <= 6 * 4 * 4 + 8, info          # 7-point tile: far fewer than the 6 x 6 x 4 box
 
 
+@pytest.mark.parametrize("p", [8, 16, 32])
+def test_spmm_tile_sliding_and_double_buffered_windows_bit_identical(K, ctx, oracle, p):
+    """Round 4's two window schemes of the tile kernel, forced on and off: sliding windows (spmm_tile_slide: a wave walks a run of
+    groups and copies only the panel rows its window lacks; run lengths 1 = whole grid lines, 3, 7; grids with partial tiles, a
+    single plane, and an operator without a grid) and double-buffered windows (spmm_tile_dbuf: the copies of the next group
+    land under this group's products).  Y equals the direct-gather kernel's bit for bit in every combination."""
+    saved = {k: ctx.get_option(k) for k in ("spmm_tile", "spmm_tile_slide", "spmm_tile_dbuf", "spmm_window", "spmm_tile_shape")}
+    rng = np.random.default_rng(31 + p)
+    makers = [lambda: K.CsrMatrix.stencil(ctx, "stencil27", 13, 10, 9), lambda: K.CsrMatrix.stencil(ctx, "poisson", 21, 12, 11),
+              lambda: K.CsrMatrix.stencil(ctx, "poisson", 37, 29, 1), lambda: K.CsrMatrix.banded_random(ctx, 6000, seed=3)]
+    try:
+        for make in makers:
+            ctx.set_option("spmm_tile", 0); ctx.set_option("spmm_window", 0)
+            dA = make()
+            X = rng.standard_normal((dA.n, p))
+            dX = K.Panel.from_host(ctx, X)
+            dY = K.Panel(ctx, dA.m, p)
+            K.spmm_(dA, dX, dY)
+            ref = dY.to_host()
+            ctx.set_option("spmm_tile", 2)
+            for slide, dbuf, shape in ((0, 0, 0), (0, 1, 0), (1, 0, 0), (3, 0, 0), (7, 0, 4), (1, 1, 0), (0, 1, 4)):
+                ctx.set_option("spmm_tile_slide", slide); ctx.set_option("spmm_tile_dbuf", dbuf); ctx.set_option("spmm_tile_shape", shape)
+                dB = make()                               # the group records are built per handle, at its first product
+                dY2 = K.Panel(ctx, dB.m, p)
+                K.spmm_(dB, dX, dY2)
+                assert dB.tile_info["state"] == 1, (slide, dbuf, shape, dB.tile_info)
+                assert np.array_equal(dY2.to_host(), ref), (slide, dbuf, shape)
+                K.spmm_(dB, dX, dY2)                      # a second product on the same records
+                assert np.array_equal(dY2.to_host(), ref), (slide, dbuf, shape, "second product")
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+
+
 def test_spmm_tile_general_operators_and_fallbacks(K, ctx, oracle):
     """No grid: (a) band + seeded long-range columns (identity order, window from the histogram of distinct columns);
     (b) band with dense rows (their groups are flagged: direct path inside the tile kernel); (c) scattered (no reuse: the
