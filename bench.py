@@ -233,6 +233,9 @@ def launch_ranks(args, argv):
 def dry_launch(rank, world, json_fd):
     """--dry-launch: the launch path without the GPU -- every rank joins the gloo group (the control plane of the real run)
     and the ranks are counted by an all-reduce; rank 0 prints the one JSON line."""
+    if os.environ.get("KHIP_BENCH_TEST_FAIL_RANK") == str(rank):      # tests/test_bench_launch.py: a rank that dies before the rendezvous
+        log(f"bench.py: rank {rank} fails on request (KHIP_BENCH_TEST_FAIL_RANK)")
+        os._exit(7)
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -84,3 +84,15 @@ def test_refuses_more_ranks_than_devices():
         p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--n1", "32", "--no-cpu-baseline"],
                            env=env, capture_output=True, timeout=300)
         assert p.returncode == 2 and b"refusing to share a GPU" in p.stderr, (p.returncode, p.stderr[-400:])
+
+
+def test_a_dying_rank_ends_the_launch_with_its_return_code():
+    """One rank dies before the rendezvous: the launcher must not hang on the others (they wait in the gloo rendezvous) -- it
+    stops exactly the processes it started and returns the worst return code; nothing is printed on stdout."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--dry-launch"], env=_clean_env(KHIP_BENCH_TEST_FAIL_RANK="1"),
+                       capture_output=True, timeout=300)
+    assert p.returncode == 9 or p.returncode == 7, (p.returncode, p.stderr.decode()[-500:])      # 7 from the rank, 9 = a survivor that had to be killed
+    assert p.stdout.strip() == b"" and b"rank return codes" in p.stderr
+    assert time.time() - t0 < 120
