@@ -111,8 +111,9 @@ struct Tuning {
   int spmm_tile_exp = 0;    // experiments on the tile kernel (WRONG results): 1 no panel-row copies, 2 no products, 4 no (val, slot) loads, 8 round-robin XCD order
   int spmm_tile_waves = 0;  // persistent waves of the tile kernel = this multiple of the LDS-limited residency (0 = 1)
   int spmm_tile_grid = 0;   // ... or this many waves outright
+  int spmm_tile_pair = 1;   // two waves per window (spmm_tile2_kernel, p >= 16): twice the waves per CU on the same LDS, each wave half of a group's row passes; 0: one wave per window
   int spmm_tile_dbuf = -1;  // two windows per wave, the copies of the next group overlap this group's products: -1 = where six waves per CU still fit (small windows), 0 never, 1 always
-  int spmm_tile_slide = 0;  // sliding windows (opt-in: bit-identical, L2 -> LDS copies halved, but no faster at cfg 5 -- 1.35-1.71 vs 1.39 ms, profiles/r04e_spmm_slide2.log; 10 % faster on 7-point grids): a wave walks a run of groups along the slowest grid direction and copies only the panel rows its window does not hold yet (0: every group fills its window anew; > 1: run length on operators without a grid)
+  int spmm_tile_slide = -1; // sliding windows: a wave (pair) walks a run of groups along the slowest grid direction and copies only the panel rows its window does not hold yet; -1 = runs of <= 27 groups on grid operators, none otherwise; 0 never; 1 whole grid lines; N > 1 runs of N groups (also without a grid)
   int spmm_tile_pencil = 0; // tile rows per pencil in the group order of grid operators (0 = 4)
   int spmm_tile_slices = 0; // panels of 32 columns and more as 16-column slices through the p = 16 tile kernel: 0 = where it measures faster, 1 = always, -1 = never
   int spmm_tile_nt = 0;     // non-temporal hints on the record / entry / Y streams of the tile kernel

@@ -384,6 +384,175 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
   }
 }
 
+// TWO WAVES PER WINDOW (round 4, `spmm_tile_pair`).  The window of a group is what limits the residency (18 KB at 144 panel rows:
+// 7 one-wave workgroups per CU, 1.75 waves per SIMD), and a wave alternates between waiting for its copies and ~2 us of products
+// (304 M VALU wave-instructions per launch).  Here a workgroup is two waves sharing ONE window: each issues half of the copies,
+// they meet at a barrier when the copies have landed, and each runs the products of half of the group's row passes (L = 4: one
+// pass of 16 rows each) -- twice the waves per CU on the same LDS, half the serial work per wave and group.  The record / entry
+// prefetch pipeline is per wave as before.  Same arithmetic, same order per row: Y bit-identical.
+template <int L, bool DIST, int NL>
+__global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w) {
+  using S = TileShape<L>;
+  static_assert(S::NPASS >= 2, "two waves per window need two row passes per group");
+  constexpr int NP = S::NPASS / 2;                   // row passes per wave
+  extern __shared__ dbl2 tile_win[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane / L, c = lane % L;
+  const int64_t last = w.groups - 1;
+  int64_t G = gridDim.x, g = blockIdx.x, gend = w.groups;
+  if (!(w.exp & 8) && (gridDim.x & 7) == 0) {
+    const int64_t x = blockIdx.x & 7;
+    G = gridDim.x >> 3;
+    g = x * w.per_xcd + (blockIdx.x >> 3);
+    gend = (x + 1) * w.per_xcd < w.groups ? (x + 1) * w.per_xcd : w.groups;
+  }
+  // sliding windows (w.run_len > 0): as in spmm_tile_kernel -- the workgroup walks whole runs of groups and copies only the
+  // octets of panel rows its window does not hold yet (mask = aux word of row slot 2)
+  const bool slide = w.run_len > 0;
+  int64_t run = 0;
+  int tpos = 0;
+  if (slide) {
+    const int64_t x = blockIdx.x & 7;
+    const bool by_xcd = (gridDim.x & 7) == 0;
+    G = by_xcd ? (gridDim.x >> 3) : gridDim.x;
+    run = by_xcd ? x * w.runs_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t run_end = by_xcd ? ((x + 1) * w.runs_per_xcd < w.runs ? (x + 1) * w.runs_per_xcd : w.runs) : w.runs;
+    g = run * w.run_len;
+    gend = run_end * w.run_len;
+  }
+  auto next_of = [&](int64_t &rr, int &tt) -> int64_t {
+    if (++tt == w.run_len) { tt = 0; rr += G; }
+    return rr * w.run_len + tt;
+  };
+  if (g >= gend) return;
+  const int hq = (sub & 2) ? 16 * L : 0;
+  const char *xa = reinterpret_cast<const char *>(tile_win) + 16 * c + hq;
+  const char *xb_ = reinterpret_cast<const char *>(tile_win) + 16 * c + (16 * L - hq);
+  const int64_t vlast = a.nnz_bound - 2;
+  const int slot_off = kTileDescBytes + 4 * w.cap;
+  struct Rec { int4v d[NP]; int lw[NL]; int flag; int mask; };
+  struct Ent { dbl2 v[NP][S::F]; int sw[NP][S::SW]; };
+
+  auto load_rec = [&](int64_t gg, Rec &r) {
+    const char *rec = w.meta + (gg < last ? gg : last) * (int64_t)w.stride;
+    const int4v *desc = reinterpret_cast<const int4v *>(rec);
+    const int32_t *lst = reinterpret_cast<const int32_t *>(rec + kTileDescBytes);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) r.d[q] = desc[(wv * NP + q) * S::RP + sub];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int q = lane + 64 * j;
+      r.lw[j] = lst[q < w.cap ? q : w.cap - 1];
+    }
+    r.flag = reinterpret_cast<const int *>(rec)[7];                      // aux word of row slot 1: the group's direct-path flag
+    r.mask = reinterpret_cast<const int *>(rec)[11];                     // ... of row slot 2: the octets of slots to copy (sliding windows)
+  };
+  auto load_ent = [&](int64_t gg, const Rec &r, Ent &e) {
+    const char *slots = w.meta + (gg < last ? gg : last) * (int64_t)w.stride + slot_off;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+      for (int f = 0; f < S::F; ++f) {
+        int64_t i0 = (int64_t)r.d[q].y + 2 * c + 2 * L * f;
+        i0 = i0 < vlast ? i0 : vlast;
+        e.v[q][f] = *reinterpret_cast<const dbl2u *>(a.val + i0);
+      }
+      const char *sp = slots + ((wv * NP + q) * S::RP + sub) * kTileLen + 4 * S::SW * c;
+      if (S::SW == 1) {
+        e.sw[q][0] = *reinterpret_cast<const int *>(sp);
+      } else {
+        const int2v t = *reinterpret_cast<const int2v *>(sp);
+        e.sw[q][0] = t.x; e.sw[q][S::SW - 1] = t.y;
+      }
+    }
+  };
+  const unsigned win_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_char *)tile_win);
+  auto issue_dma = [&](const Rec &r, unsigned mask) {                     // this wave's half: the instructions wq with wq % 2 == wv
+    constexpr int PER = 64 / S::EPI;
+    int col[NL * PER];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) col[j * PER + u] = __builtin_amdgcn_ds_bpermute(4 * (u * S::EPI + lane / (2 * L)), r.lw[j]);
+    }
+#pragma unroll
+    for (int wq = 0; wq < NL * PER; ++wq) {
+      constexpr unsigned OCT = S::EPI >= 8 ? (1u << (S::EPI / 8)) - 1u : 1u;
+      if ((wq & 1) == wv && S::EPI * wq < w.cap && ((mask >> ((S::EPI * wq) >> 3)) & OCT) != 0) {
+        const char *src = reinterpret_cast<const char *>(a.x);
+        uint64_t rr = (unsigned)col[wq];
+        if (DIST) {
+          const bool own = (int64_t)col[wq] < a.n_owned;
+          src = own ? src : reinterpret_cast<const char *>(a.ghost);
+          rr = own ? rr : rr - (uint64_t)a.n_owned;
+        }
+        const char *gsrc = src + (rr << w.gshift) + w.coff + 16 * (lane % (2 * L));
+        const unsigned dst = win_lds + 1024u * (unsigned)wq;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+      }
+    }
+  };
+  auto products = [&](const Rec &r, const Ent &e) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int4v &d = r.d[q];
+      const int len = d.z;
+      const int len0 = __builtin_amdgcn_readfirstlane(len);
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (__ballot(len != len0) == 0) {
+        tile_rows<L, false>(e.v[q], e.sw[q], xa, xb_, len, len0, acc);
+      } else {
+        int nmax = len;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) { const int o = __shfl_xor(nmax, sft); nmax = o > nmax ? o : nmax; }
+        nmax = __builtin_amdgcn_readfirstlane(nmax);
+        tile_rows<L, true>(e.v[q], e.sw[q], xa, xb_, len, nmax, acc);
+      }
+      if (d.x >= 0) {
+        double *yr = a.y + ((int64_t)d.x << (w.gshift - 3)) + (w.coff >> 3) + 2 * c;
+        *reinterpret_cast<dbl2 *>(yr + (hq >> 3)) = dbl2{acc[0], acc[1]};
+        *reinterpret_cast<dbl2 *>(yr + 2 * L - (hq >> 3)) = dbl2{acc[2], acc[3]};
+      }
+    }
+  };
+
+  Rec r0, r1, r2;
+  Ent e0, e1;
+  int64_t run1 = run, run2;
+  int t1 = tpos, t2;
+  int64_t g1 = slide ? next_of(run1, t1) : g + G;
+  run2 = run1; t2 = t1;
+  int64_t g2 = slide ? next_of(run2, t2) : g + 2 * G;
+  load_rec(g, r0);
+  load_rec(g1, r1);
+  load_ent(g, r0, e0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (;;) {
+    const bool direct = __builtin_amdgcn_readfirstlane(r0.flag) != 0;      // the same for both waves: barriers stay matched
+    const unsigned mask = slide ? (unsigned)__builtin_amdgcn_readfirstlane(r0.mask) : 0xffffffffu;
+    if (!direct) issue_dma(r0, mask);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    load_ent(g1, r1, e1);
+    load_rec(g2, r2);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!direct) {
+      constexpr int N = NP * (S::F + 1) + NP + NL + 2;                      // loads issued after this wave's copies
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+      asm volatile("s_barrier" ::: "memory");                               // both halves of the window have landed
+      __builtin_amdgcn_sched_barrier(0);
+      products(r0, e0);
+    }
+    if (slide) { g = g1; g1 = g2; g2 = next_of(run2, t2); } else { g += G; g1 = g + G; g2 = g + 2 * G; }
+    if (g >= gend) break;
+    if (!direct) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both waves are done with the window before the next copies
+    r0 = r1; e0 = e1; r1 = r2;
+  }
+}
+
 // The flagged groups (a row longer than 32 entries, or more distinct columns than the window holds): direct gathers, same
 // order of operations.  One workgroup per flagged group, launched after the main kernel over the handle's list of such groups
 // (kept out of the main kernel: a second arm with loads of its own made hipcc's wait-count merging drain the prefetches there).
@@ -756,8 +925,9 @@ static TileOrder tile_order_for(const khip_csr *A, bool tiles) {
 }
 // sliding windows (ctx option spmm_tile_slide): runs along k (along j on a single plane); identity order: 64 consecutive groups
 static void tile_order_set_runs(const khip_csr *A, TileOrder &o) {
-  const int slide = A->ctx ? A->ctx->tune.spmm_tile_slide : 0;
+  int slide = A->ctx ? A->ctx->tune.spmm_tile_slide : 0;
   o.run_len = 0;
+  if (slide < 0) slide = o.s1 != 0 ? 27 : 0;      // default: runs of <= 27 groups on grids (with two waves per window: -3 ... -5 % at cfg 5, -16 % on 7-point grids), none without a grid (+3 % there); profiles/r04t_spmm_pair_slide.log, r04u_spmm_pair3.log
   if (!slide) return;
   if (o.s1 == 0) o.run_len = slide > 1 ? slide : 64;
   else {
@@ -879,7 +1049,9 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   // 0.99 ms); at cfg 5 (144 rows: four waves per CU, one per SIMD) the products' own latency shows: 1.84 against 1.36 ms
   // (profiles/r04r_spmm_dbuf.log).  spmm_tile_dbuf: -1 by that rule, 0 never, 1 always.  (Sliding windows carry ONE window.)
   const int dbuf_opt = ctx->tune.spmm_tile_dbuf;
-  w.dbuf = (w.run_len == 0 && (dbuf_opt > 0 || (dbuf_opt < 0 && (size_t)w.cap * 32 * L * 2 <= (size_t)26 * 1024))) ? 1 : 0;
+  const bool use_pair = ctx->tune.spmm_tile_pair && L >= 4 && !ctx->tune.spmm_tile_nt;
+  w.dbuf = (!use_pair && (dbuf_opt > 0 || (dbuf_opt < 0 && (size_t)w.cap * 32 * L * 2 <= (size_t)26 * 1024))) ? 1 : 0;
+  if (w.dbuf) w.run_len = 0;      // records built for sliding windows serve every other scheme too: their list names the column of EVERY slot, so a kernel that copies all octets of every group (in any order of the groups) fills a consistent window
   const size_t lds = (size_t)w.cap * 32 * L * (w.dbuf ? 2 : 1);
   int per_cu = (int)((size_t)(160 * 1024) / lds);                    // LDS-limited residency of the one-wave workgroups
   if (per_cu >= 5) --per_cu;                                         // one wave short of the LDS limit measures 3 % faster (7 instead of 8 at 144 panel rows)
@@ -899,6 +1071,35 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   if (grid >= 64) grid &= ~(int64_t)7;                               // whole waves per XCD
   const bool dist = a.ghost != a.x;
   const int NL = (w.cap + 63) / 64;
+  if (use_pair) {
+    // two waves per window (spmm_tile2_kernel): the residency is counted in windows as before, every window now carries two waves
+    const size_t lds1 = (size_t)w.cap * 32 * L;
+    int wg_per_cu = (int)((size_t)(160 * 1024) / lds1);
+    if (wg_per_cu >= 5) --wg_per_cu;
+    if (wg_per_cu > 8) wg_per_cu = 8;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int64_t grid2 = ctx->tune.spmm_tile_grid > 0 ? ctx->tune.spmm_tile_grid : (int64_t)ctx->num_cu * wg_per_cu;
+    if (w.run_len > 0 && ctx->tune.spmm_tile_grid <= 0) {               // sliding windows: equally many runs per workgroup
+      const int64_t per_x = w.runs_per_xcd, max_wx = grid2 / 8 > 0 ? grid2 / 8 : 1;
+      const int64_t kk = (per_x + max_wx - 1) / max_wx;
+      grid2 = 8 * ((per_x + kk - 1) / kk);
+    }
+    if (w.run_len > 0 && grid2 > w.runs) grid2 = w.runs;
+    if (grid2 > w.groups) grid2 = w.groups;
+    if (grid2 >= 64) grid2 &= ~(int64_t)7;
+    const dim3 gd2((unsigned)grid2), bd2(128);
+#define KHIP_TILE2(D, N) hipLaunchKernelGGL((spmm_tile2_kernel<(L >= 4 ? L : 4), D, N>), gd2, bd2, lds1, ctx->stream, a, w)
+    if (dist) { switch (NL) { case 1: KHIP_TILE2(true, 1); break; case 2: KHIP_TILE2(true, 2); break; case 3: KHIP_TILE2(true, 3); break; default: KHIP_TILE2(true, 4); break; } }
+    else      { switch (NL) { case 1: KHIP_TILE2(false, 1); break; case 2: KHIP_TILE2(false, 2); break; case 3: KHIP_TILE2(false, 3); break; default: KHIP_TILE2(false, 4); break; } }
+#undef KHIP_TILE2
+    if (A->tile_direct > 0) {
+      const dim3 gdd((unsigned)A->tile_direct), bdd(kBlock);
+      if (dist) hipLaunchKernelGGL((spmm_tile_direct_kernel<L, true>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+      else hipLaunchKernelGGL((spmm_tile_direct_kernel<L, false>), gdd, bdd, 0, ctx->stream, a, w, A->tile_direct_list, A->tile_direct);
+    }
+    KHIP_CHECK_HIP(hipGetLastError());
+    return KHIP_OK;
+  }
   const dim3 gd((unsigned)grid), bd(64);
 #define KHIP_TILE_LAUNCH1(D, N, T)                                                                                      \
   do {                                                                                                                  \
