@@ -36,7 +36,8 @@ extern "C" {
 #define KHIP_ERR_NUMERIC     -5   /* e.g. operator not SPD (src/cg.jl:163,243) */
 
 #define KHIP_VERSION_MAJOR 0
-#define KHIP_VERSION_MINOR 2   /* 2: khip_options gained log_fd (round 4); clients check khip_version() against the header they were built with */
+#define KHIP_VERSION_MINOR 3   /* 2: khip_options gained log_fd (round 4); 3: khip_*_workspace_adopt & co. (round 5).  Clients check
+                                * khip_version() against the header they were built with */
 
 typedef struct khip_ctx khip_ctx;   /* device + stream + scratch + (optional) communicator */
 typedef struct khip_csr khip_csr;   /* CSR operator resident in HBM */
@@ -398,7 +399,28 @@ typedef struct khip_gmres_workspace       khip_gmres_workspace;        /* GmresW
 typedef struct khip_bicgstab_workspace    khip_bicgstab_workspace;     /* BicgstabWorkspace :1568-1629 */
 typedef struct khip_block_gmres_workspace khip_block_gmres_workspace;  /* BlockGmresWorkspace src/block_krylov_workspaces.jl:115-171 */
 
+/* ---- workspaces on CALLER-OWNED vectors ("adopt") -------------------------------------------------------------------
+ * The reference's workspaces own their vectors on the Julia side (`x, r, p, Ap :: S`, src/krylov_workspaces.jl:236-291) and
+ * `solution(ws) === ws.x` (test/test_interface.jl:260).  A binding that specialises `cg!(ws::CgWorkspace{..,HIPVector}, A, b)`
+ * therefore hands the device pointers of THOSE vectors to khip_*_workspace_adopt once, and then runs khip_*_solve -- the fused,
+ * device-resident loops -- directly on them: the solution lands in the caller's x, nothing is copied, nothing the caller
+ * owns is ever freed or replaced by the library.  Vectors the reference allocates lazily (z, Δx, npc_dir, p, q, yz, t;
+ * allocate_if, src/krylov_utils.jl:281-299) are handed over with khip_*_workspace_adopt_vector once the caller has
+ * allocated them (ptr == NULL empties the slot again); a solve that needs one the caller never handed over allocates and
+ * owns it.  Histories and stats are the same bits as on a khip_*_workspace_create workspace.  After a solve only x and the
+ * stats are defined: the other work vectors hold scratch (the reference promises nothing about them either), and the
+ * restart-time zero fill of the basis (src/gmres.jl:211-213, src/block_gmres.jl:195-197) is not performed.
+ * khip_grow_fn: restart = false lets the basis outgrow `memory`; the library then asks the caller for one more vector
+ * (`push!(V, similar(x))`, src/gmres.jl:319-324; a ZEROED panel for block-GMRES, src/block_gmres.jl:300-305) -- return its
+ * device pointer, or NULL to fail the solve.  Without a grow callback the library allocates (and owns) the extra vectors. */
+typedef double *(*khip_grow_fn)(void *userdata);
+
 int khip_cg_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_cg_workspace **out);
+/* CgWorkspace on the caller's x, r, p, Ap (distinct device vectors of n doubles); adopt_vector names: "x", "r", "p", "Ap",
+ * "z", "dx" (the reference's Δx: hand it over, then khip_cg_warm_start(ws, dx) only sets the flag), "npc_dir" */
+int khip_cg_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, double *x, double *r, double *p, double *Ap,
+                            khip_cg_workspace **out);
+int khip_cg_workspace_adopt_vector(khip_cg_workspace *ws, const char *name, double *ptr);
 int khip_cg_workspace_destroy(khip_cg_workspace *ws);
 int khip_cg_warm_start(khip_cg_workspace *ws, const double *x0);                   /* warm_start! src/workspace_accessors.jl:193-200 */
 /* cg!(ws, A, b; M, ...)  src/cg.jl:120-291.  M == NULL means M = I; otherwise z <- M r. */
@@ -411,6 +433,18 @@ double           *khip_cg_vector(khip_cg_workspace *ws, const char *name);
 size_t            khip_cg_workspace_bytes(khip_cg_workspace *ws);                  /* storage test, test/test_allocations.jl:41-57 */
 
 int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory, khip_gmres_workspace **out);
+/* GmresWorkspace on the caller's x, w and basis V_host[0 .. memory) (device pointers in a HOST array; `V::Vector{S}`,
+ * src/krylov_workspaces.jl:2857-2873).  adopt_vector names: "x", "w", "p", "q", "dx".  adopt_basis replaces the whole list
+ * (k >= memory: the caller's V after restart = false grew it).  khip_gmres_host_state copies c, s, z (cap entries each at
+ * most) and the packed R (cap (cap + 1) / 2) of the last solve out, *len = their current length, *inner_iter as the
+ * reference's field; any output may be NULL. */
+int khip_gmres_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, int memory, double *x, double *w,
+                               double *const *V_host, khip_gmres_workspace **out);
+int khip_gmres_workspace_adopt_vector(khip_gmres_workspace *ws, const char *name, double *ptr);
+int khip_gmres_workspace_adopt_basis(khip_gmres_workspace *ws, int k, double *const *V_host);
+int khip_gmres_workspace_set_grow(khip_gmres_workspace *ws, khip_grow_fn grow, void *userdata);
+int khip_gmres_host_state(khip_gmres_workspace *ws, int cap, double *c_host, double *s_host, double *z_host, double *R_host,
+                          int *len, int *inner_iter);
 int khip_gmres_workspace_destroy(khip_gmres_workspace *ws);
 int khip_gmres_warm_start(khip_gmres_workspace *ws, const double *x0);
 /* gmres!(ws, A, b; M, N, restart, reorthogonalization, ...)  src/gmres.jl:121-384 */
@@ -421,6 +455,11 @@ const khip_stats *khip_gmres_stats(khip_gmres_workspace *ws);
 size_t            khip_gmres_workspace_bytes(khip_gmres_workspace *ws);
 
 int khip_bicgstab_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_bicgstab_workspace **out);
+/* BicgstabWorkspace on the caller's x, r, p, v, s, qd (src/krylov_workspaces.jl:1568-1582); adopt_vector names: those six and
+ * "yz", "t", "dx" */
+int khip_bicgstab_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, double *x, double *r, double *p, double *v, double *s,
+                                  double *qd, khip_bicgstab_workspace **out);
+int khip_bicgstab_workspace_adopt_vector(khip_bicgstab_workspace *ws, const char *name, double *ptr);
 int khip_bicgstab_workspace_destroy(khip_bicgstab_workspace *ws);
 int khip_bicgstab_warm_start(khip_bicgstab_workspace *ws, const double *x0);
 /* bicgstab!(ws, A, b; c, M, N, ...)  src/bicgstab.jl:125-277 ; c == NULL -> c = b */
@@ -433,8 +472,17 @@ size_t            khip_bicgstab_workspace_bytes(khip_bicgstab_workspace *ws);
 
 int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p, int memory,
                                       khip_block_gmres_workspace **out);
+/* BlockGmresWorkspace on the caller's panels X, W, V_host[0 .. memory): row-major panels of khip_panel_rows(n) x p doubles
+ * with zero padding rows (the tall blocks of a BlockGmresWorkspace{..,HIPMatrix}, src/block_krylov_workspaces.jl:115-163;
+ * the small blocks stay inside the library).  adopt_panel names: "X", "W", "P", "Q", "dX". */
+int khip_block_gmres_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, int p, int memory, double *X, double *W,
+                                     double *const *V_host, khip_block_gmres_workspace **out);
+int khip_block_gmres_workspace_adopt_panel(khip_block_gmres_workspace *ws, const char *name, double *ptr);
+int khip_block_gmres_workspace_adopt_basis(khip_block_gmres_workspace *ws, int k, double *const *V_host);
+int khip_block_gmres_workspace_set_grow(khip_block_gmres_workspace *ws, khip_grow_fn grow, void *userdata);
 int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws);
 int khip_block_gmres_warm_start(khip_block_gmres_workspace *ws, const double *X0_colmajor);
+int khip_block_gmres_warm_start_panel(khip_block_gmres_workspace *ws, const double *X0_panel);   /* X0 already a row-major panel */
 /* block_gmres!(ws, A, B; restart, reorthogonalization, ...) src/block_gmres.jl:110-358.
  * B and the solution are n-by-p COLUMN-MAJOR device arrays (the reference layout); the
  * workspace converts to row-major panels internally.  A: CSR handle (SpMM kernel) or an apply
@@ -442,6 +490,9 @@ int khip_block_gmres_warm_start(khip_block_gmres_workspace *ws, const double *X0
  * device panels of khip_panel_rows(n) x p doubles (padding rows zero, and they must stay zero). */
 int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
                            const khip_operator *N, const double *B_colmajor, const khip_options *opts);
+/* the same with B a row-major panel (khip_panel_rows(n) x p, zero padding rows) read in place; the solution is the X panel */
+int khip_block_gmres_solve_panel(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                                 const khip_operator *N, const double *B_panel, const khip_options *opts);
 int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor);
 const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws);
 /* storage test (test/test_allocations.jl:734-761): bytes of the workspace with n x p blocks at their logical size;

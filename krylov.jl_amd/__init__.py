@@ -22,6 +22,7 @@ import math
 import os
 import subprocess
 import sys
+import time
 
 import numpy as np
 
@@ -33,6 +34,7 @@ c_void_pp = C.POINTER(C.c_void_p)
 
 APPLY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 CALLBACK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+GROW_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p)      # khip_grow_fn: push!(V, similar(x)) of an adopted workspace
 
 
 class KhipError(RuntimeError):
@@ -161,6 +163,8 @@ SIGNATURES = {
     "khip_comm_info": (_int, [_vp] + [C.POINTER(_int)] * 5),
     "khip_default_options": (COptions, []),
     "khip_cg_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
+    "khip_cg_workspace_adopt": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, c_void_pp]),
+    "khip_cg_workspace_adopt_vector": (_int, [_vp, C.c_char_p, _vp]),
     "khip_cg_workspace_destroy": (_int, [_vp]),
     "khip_cg_warm_start": (_int, [_vp, _vp]),
     "khip_cg_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _vp, C.POINTER(COptions)]),
@@ -169,6 +173,11 @@ SIGNATURES = {
     "khip_cg_vector": (_vp, [_vp, C.c_char_p]),
     "khip_cg_workspace_bytes": (_sz, [_vp]),
     "khip_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, c_void_pp]),
+    "khip_gmres_workspace_adopt": (_int, [_vp, _i64, _i64, _int, _vp, _vp, c_void_pp, c_void_pp]),
+    "khip_gmres_workspace_adopt_vector": (_int, [_vp, C.c_char_p, _vp]),
+    "khip_gmres_workspace_adopt_basis": (_int, [_vp, _int, c_void_pp]),
+    "khip_gmres_workspace_set_grow": (_int, [_vp, GROW_FN, _vp]),
+    "khip_gmres_host_state": (_int, [_vp, _int, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(_int), C.POINTER(_int)]),
     "khip_gmres_workspace_destroy": (_int, [_vp]),
     "khip_gmres_warm_start": (_int, [_vp, _vp]),
     "khip_gmres_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), C.POINTER(COperator), _vp,
@@ -177,6 +186,8 @@ SIGNATURES = {
     "khip_gmres_stats": (C.POINTER(CStats), [_vp]),
     "khip_gmres_workspace_bytes": (_sz, [_vp]),
     "khip_bicgstab_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
+    "khip_bicgstab_workspace_adopt": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, c_void_pp]),
+    "khip_bicgstab_workspace_adopt_vector": (_int, [_vp, C.c_char_p, _vp]),
     "khip_bicgstab_workspace_destroy": (_int, [_vp]),
     "khip_bicgstab_warm_start": (_int, [_vp, _vp]),
     "khip_bicgstab_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), C.POINTER(COperator), _vp, _vp,
@@ -194,6 +205,13 @@ SIGNATURES = {
     "khip_test_roots_quadratic": (_int, [C.c_double, C.c_double, C.c_double, _int, c_double_p, c_double_p]),
     "khip_test_to_boundary": (_int, [_vp, _i64, _vp, _vp, C.c_double, _int, c_double_p, c_double_p]),
     "khip_block_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, _int, c_void_pp]),
+    "khip_block_gmres_workspace_adopt": (_int, [_vp, _i64, _i64, _int, _int, _vp, _vp, c_void_pp, c_void_pp]),
+    "khip_block_gmres_workspace_adopt_panel": (_int, [_vp, C.c_char_p, _vp]),
+    "khip_block_gmres_workspace_adopt_basis": (_int, [_vp, _int, c_void_pp]),
+    "khip_block_gmres_workspace_set_grow": (_int, [_vp, GROW_FN, _vp]),
+    "khip_block_gmres_warm_start_panel": (_int, [_vp, _vp]),
+    "khip_block_gmres_solve_panel": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), C.POINTER(COperator), _vp,
+                                     C.POINTER(COptions)]),
     "khip_block_gmres_workspace_destroy": (_int, [_vp]),
     "khip_block_gmres_warm_start": (_int, [_vp, _vp]),
     "khip_block_gmres_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), C.POINTER(COperator), _vp,
@@ -947,8 +965,17 @@ def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, ra
     return o
 
 
+# Workspaces own their vectors on THIS side, as the reference's do on the Julia side (`x, r, p, Ap :: S`,
+# src/krylov_workspaces.jl:236-291), and hand the device pointers to the library (khip_*_workspace_adopt): the solvers run on the
+# caller's vectors, `solution(ws) is ws.x`.  This is the executed twin of julia/KrylovHIP/src/KrylovHIP.jl.  `adopt=False` (or
+# KHIP_PY_WORKSPACES=create in the environment) takes the library-owned workspaces of khip_*_workspace_create instead.
+def _adopt_default() -> bool:
+    return os.environ.get("KHIP_PY_WORKSPACES", "adopt") != "create"
+
+
 class _Workspace:
     _prefix = ""
+    _fields = ()
 
     def _fn(self, name):
         return getattr(lib(), f"khip_{self._prefix}_{name}")
@@ -960,18 +987,42 @@ class _Workspace:
         except Exception:
             pass
 
+    def _adopt_vector(self, name: str, v: "DeviceVector"):
+        """allocate_if(..., workspace, :name, S, workspace.x) followed by the hand-over of the pointer."""
+        self._vec[name] = v
+        _ck(self._fn("workspace_adopt_vector")(self._h, name.encode(), v.ptr))
+        return v
+
+    def _allocate_if(self, cond: bool, name: str):
+        """src/krylov_utils.jl:281-288: allocate the lazily-held vector `name` on first need."""
+        if cond and self.adopted and name not in self._vec:
+            t0 = time.perf_counter()
+            v = self.ctx.empty(self.n)
+            self._alloc_s += time.perf_counter() - t0            # stats.allocation_timer counts the lazy allocations too
+            self._adopt_vector(name, v)
+
     @property
     def x(self) -> DeviceVector:
         """solution(workspace) === workspace.x (src/workspace_accessors.jl:151, test/test_interface.jl:260)."""
+        if self.adopted:
+            return self._vec["x"]
         return DeviceVector(self.ctx, self.n, ptr=self._fn("solution")(self._h), owner=self)
 
     @property
     def stats(self) -> SimpleStats:
-        return SimpleStats(self._fn("stats")(self._h).contents)
+        st = SimpleStats(self._fn("stats")(self._h).contents)
+        if self.adopted:                                  # the vectors were allocated (and timed) on this side
+            st.allocation_timer += self._alloc_s
+        return st
 
     def warm_start_(self, x0: DeviceVector):
-        """warm_start!(workspace, x0) (src/workspace_accessors.jl:193-200)."""
-        _ck(self._fn("warm_start")(self._h, _p(x0)))
+        """warm_start!(workspace, x0) (src/workspace_accessors.jl:193-200): allocate_if(true, ws, :Δx, ...); kcopy!(n, ws.Δx, x0)."""
+        if self.adopted:
+            self._allocate_if(True, "dx")
+            kcopy_(self.n, self._vec["dx"], x0)
+            _ck(self._fn("warm_start")(self._h, self._vec["dx"].ptr))     # same pointer: only sets the flag
+        else:
+            _ck(self._fn("warm_start")(self._h, _p(x0)))
         return self
 
     @property
@@ -983,12 +1034,22 @@ class CgWorkspace(_Workspace):
     """CgWorkspace(m, n, S) (src/krylov_workspaces.jl:236-291)."""
     _prefix = "cg"
 
-    def __init__(self, ctx: Context, m: int, n: int):
+    def __init__(self, ctx: Context, m: int, n: int, adopt: bool | None = None):
         self.ctx, self.m, self.n = ctx, m, n
+        self.adopted = _adopt_default() if adopt is None else bool(adopt)
         self._h = C.c_void_p()
-        _ck(lib().khip_cg_workspace_create(ctx._h, m, n, C.byref(self._h)))
+        if self.adopted:
+            t0 = time.perf_counter()
+            self._vec = {k: ctx.empty(n) for k in ("x", "r", "p", "Ap")}     # S(undef, n) x 4; dx, npc_dir, z stay empty
+            self._alloc_s = time.perf_counter() - t0
+            v = self._vec
+            _ck(lib().khip_cg_workspace_adopt(ctx._h, m, n, v["x"].ptr, v["r"].ptr, v["p"].ptr, v["Ap"].ptr, C.byref(self._h)))
+        else:
+            _ck(lib().khip_cg_workspace_create(ctx._h, m, n, C.byref(self._h)))
 
     def vector(self, name: str):
+        if self.adopted and name in self._vec:
+            return self._vec[name]
         p = lib().khip_cg_vector(self._h, name.encode())
         return DeviceVector(self.ctx, self.n, ptr=p, owner=self) if p else None
 
@@ -997,20 +1058,60 @@ class GmresWorkspace(_Workspace):
     """GmresWorkspace(m, n, S; memory = 20) (src/krylov_workspaces.jl:2857-2924)."""
     _prefix = "gmres"
 
-    def __init__(self, ctx: Context, m: int, n: int, memory: int = 20):
+    def __init__(self, ctx: Context, m: int, n: int, memory: int = 20, adopt: bool | None = None):
         self.ctx, self.m, self.n, self.memory = ctx, m, n, memory
+        self.adopted = _adopt_default() if adopt is None else bool(adopt)
         self._h = C.c_void_p()
-        _ck(lib().khip_gmres_workspace_create(ctx._h, m, n, memory, C.byref(self._h)))
+        if self.adopted:
+            mem = 20 if memory <= 0 else memory
+            mem = min(m, mem)                                                  # memory = min(m, memory), :2900
+            t0 = time.perf_counter()
+            self._vec = {k: ctx.empty(n) for k in ("x", "w")}
+            self.V = [ctx.empty(n) for _ in range(mem)]                        # V = S[S(undef, n) for i = 1 : memory]
+            self._alloc_s = time.perf_counter() - t0
+            ptrs = (C.c_void_p * max(mem, 1))(*[v.ptr for v in self.V])
+            _ck(lib().khip_gmres_workspace_adopt(ctx._h, m, n, mem, self._vec["x"].ptr, self._vec["w"].ptr, ptrs, C.byref(self._h)))
+
+            def grow(_ud):                                                     # push!(V, similar(x)), src/gmres.jl:319-324
+                try:
+                    self.V.append(self.ctx.empty(self.n))
+                    return self.V[-1].ptr
+                except Exception as e:
+                    sys.stderr.write(f"grow callback failed: {e}\n")
+                    return None
+            self._grow = GROW_FN(grow)
+            _ck(lib().khip_gmres_workspace_set_grow(self._h, self._grow, None))
+        else:
+            _ck(lib().khip_gmres_workspace_create(ctx._h, m, n, memory, C.byref(self._h)))
+
+    def host_state(self):
+        """(c, s, z, R, inner_iter) of the last solve: the host fields of the reference's workspace (:2866-2871)."""
+        ln, it = C.c_int(), C.c_int()
+        _ck(lib().khip_gmres_host_state(self._h, 0, None, None, None, None, C.byref(ln), C.byref(it)))
+        k = ln.value
+        c, s_, z, R = np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k * (k + 1) // 2)
+        _ck(lib().khip_gmres_host_state(self._h, k, c.ctypes.data_as(c_double_p), s_.ctypes.data_as(c_double_p),
+                                        z.ctypes.data_as(c_double_p), R.ctypes.data_as(c_double_p), C.byref(ln), C.byref(it)))
+        return c, s_, z, R, it.value
 
 
 class BicgstabWorkspace(_Workspace):
     """BicgstabWorkspace(m, n, S) (src/krylov_workspaces.jl:1568-1629)."""
     _prefix = "bicgstab"
 
-    def __init__(self, ctx: Context, m: int, n: int):
+    def __init__(self, ctx: Context, m: int, n: int, adopt: bool | None = None):
         self.ctx, self.m, self.n = ctx, m, n
+        self.adopted = _adopt_default() if adopt is None else bool(adopt)
         self._h = C.c_void_p()
-        _ck(lib().khip_bicgstab_workspace_create(ctx._h, m, n, C.byref(self._h)))
+        if self.adopted:
+            t0 = time.perf_counter()
+            self._vec = {k: ctx.empty(n) for k in ("x", "r", "p", "v", "s", "qd")}
+            self._alloc_s = time.perf_counter() - t0
+            v = self._vec
+            _ck(lib().khip_bicgstab_workspace_adopt(ctx._h, m, n, v["x"].ptr, v["r"].ptr, v["p"].ptr, v["v"].ptr, v["s"].ptr,
+                                                    v["qd"].ptr, C.byref(self._h)))
+        else:
+            _ck(lib().khip_bicgstab_workspace_create(ctx._h, m, n, C.byref(self._h)))
 
 
 def _finish(ws, rc):
@@ -1024,6 +1125,8 @@ def cg_(ws: CgWorkspace, A, b: DeviceVector, M=None, **kw):
     """cg!(workspace, A, b; M, radius, linesearch, atol, rtol, itmax, timemax, history, callback)
     (src/cg.jl:120-291).  Returns the workspace."""
     keep = []
+    ws._allocate_if(M is not None, "z")                                                   # src/cg.jl:142
+    ws._allocate_if(bool(kw.get("linesearch")) or kw.get("radius", 0.0) > 0, "npc_dir")    # :143
     opts = _make_options(keep=keep, ws=ws, **kw)
     rc = lib().khip_cg_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep), _make_operator(ws.ctx, M, ws.n, keep),
                              _p(b), C.byref(opts))
@@ -1033,6 +1136,9 @@ def cg_(ws: CgWorkspace, A, b: DeviceVector, M=None, **kw):
 def gmres_(ws: GmresWorkspace, A, b: DeviceVector, M=None, N=None, **kw):
     """gmres!(workspace, A, b; M, N, restart, reorthogonalization, ...) (src/gmres.jl:121-384)."""
     keep = []
+    ws._allocate_if(M is not None, "q")                                                   # src/gmres.jl:142-144
+    ws._allocate_if(N is not None, "p")
+    ws._allocate_if(bool(kw.get("restart")), "dx")
     opts = _make_options(keep=keep, ws=ws, **kw)
     rc = lib().khip_gmres_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep), _make_operator(ws.ctx, M, ws.n, keep),
                                 _make_operator(ws.ctx, N, ws.n, keep), _p(b), C.byref(opts))
@@ -1042,6 +1148,8 @@ def gmres_(ws: GmresWorkspace, A, b: DeviceVector, M=None, N=None, **kw):
 def bicgstab_(ws: BicgstabWorkspace, A, b: DeviceVector, c: DeviceVector | None = None, M=None, N=None, **kw):
     """bicgstab!(workspace, A, b; c, M, N, ...) (src/bicgstab.jl:125-277)."""
     keep = []
+    ws._allocate_if(M is not None, "t")                                                   # src/bicgstab.jl:148-149
+    ws._allocate_if(N is not None, "yz")
     opts = _make_options(keep=keep, ws=ws, **kw)
     rc = lib().khip_bicgstab_solve(ws._h, _make_operator(ws.ctx, A, ws.n, keep),
                                    _make_operator(ws.ctx, M, ws.n, keep), _make_operator(ws.ctx, N, ws.n, keep),
@@ -1381,16 +1489,49 @@ def spmm_(A: CsrMatrix, X: Panel, Y: Panel) -> Panel:
 
 
 class BlockGmresWorkspace(_Workspace):
-    """BlockGmresWorkspace(m, n, p, SV, SM; memory = 5) (src/block_krylov_workspaces.jl:115-171)."""
+    """BlockGmresWorkspace(m, n, p, SV, SM; memory = 5) (src/block_krylov_workspaces.jl:115-171).  Adopted form: the tall
+    blocks X, W, V[i] are Panels of this side (the HIPMatrix of julia/KrylovHIP), the small blocks live in the library."""
     _prefix = "block_gmres"
 
-    def __init__(self, ctx: Context, m: int, n: int, p: int, memory: int = 5):
+    def __init__(self, ctx: Context, m: int, n: int, p: int, memory: int = 5, adopt: bool | None = None):
         self.ctx, self.m, self.n, self.p, self.memory = ctx, m, n, p, memory
+        self.adopted = _adopt_default() if adopt is None else bool(adopt)
         self._h = C.c_void_p()
-        _ck(lib().khip_block_gmres_workspace_create(ctx._h, m, n, p, memory, C.byref(self._h)))
+        if self.adopted:
+            mem = 5 if memory <= 0 else memory
+            mem = max(1, min(n // p, mem))                                     # memory = min(div(n, p), memory), :138
+            t0 = time.perf_counter()
+            self._pan = {k: Panel(ctx, n, p) for k in ("X", "W")}
+            self.V = [Panel(ctx, n, p) for _ in range(mem)]
+            self._alloc_s = time.perf_counter() - t0
+            ptrs = (C.c_void_p * mem)(*[v.buf.ptr for v in self.V])
+            _ck(lib().khip_block_gmres_workspace_adopt(ctx._h, m, n, p, mem, self._pan["X"].buf.ptr, self._pan["W"].buf.ptr, ptrs,
+                                                       C.byref(self._h)))
+
+            def grow(_ud):                                                     # push!(V, SM(undef, n, p)), src/block_gmres.jl:300-305
+                try:
+                    self.V.append(Panel(self.ctx, self.n, self.p))
+                    return self.V[-1].buf.ptr
+                except Exception as e:
+                    sys.stderr.write(f"grow callback failed: {e}\n")
+                    return None
+            self._grow = GROW_FN(grow)
+            _ck(lib().khip_block_gmres_workspace_set_grow(self._h, self._grow, None))
+        else:
+            _ck(lib().khip_block_gmres_workspace_create(ctx._h, m, n, p, memory, C.byref(self._h)))
+
+    def _allocate_panel_if(self, cond: bool, name: str):
+        if cond and self.adopted and name not in self._pan:
+            t0 = time.perf_counter()
+            P = Panel(self.ctx, self.n, self.p)
+            self._alloc_s += time.perf_counter() - t0
+            self._pan[name] = P
+            _ck(lib().khip_block_gmres_workspace_adopt_panel(self._h, name.encode(), P.buf.ptr))
 
     @property
     def X(self) -> np.ndarray:
+        if self.adopted:
+            return self._pan["X"].to_host()
         col = self.ctx.empty(self.n * self.p)
         _ck(lib().khip_block_gmres_get_X(self._h, col.ptr))
         return col.to_host().reshape(self.p, self.n).T.copy()
@@ -1398,6 +1539,12 @@ class BlockGmresWorkspace(_Workspace):
     x = X
 
     def warm_start_(self, X0):
+        if self.adopted:                                                       # allocate_if(true, ws, :ΔX, ...); copyto!(ws.ΔX, X0)
+            self._allocate_panel_if(True, "dX")
+            P0 = Panel.from_host(self.ctx, np.asarray(X0, dtype=np.float64))
+            kcopy_(P0.n_pad * P0.p, self._pan["dX"].buf, P0.buf)
+            _ck(lib().khip_block_gmres_warm_start_panel(self._h, self._pan["dX"].buf.ptr))
+            return self
         col = self.ctx.array(np.asfortranarray(np.asarray(X0, dtype=np.float64)).ravel(order="F"))
         _ck(lib().khip_block_gmres_warm_start(self._h, col.ptr))
         return self
@@ -1442,9 +1589,22 @@ def block_gmres_(ws: BlockGmresWorkspace, A, B_colmajor: DeviceVector, M=None, N
     (src/block_gmres.jl:110-358); B is an n x p column-major device array."""
     keep = []
     opts = _make_options(keep=keep, ws=ws, **kw)
-    rc = lib().khip_block_gmres_solve(ws._h, _make_block_operator(ws.ctx, A, ws.n, ws.p, keep),
-                                      _make_block_operator(ws.ctx, M, ws.n, ws.p, keep),
-                                      _make_block_operator(ws.ctx, N, ws.n, ws.p, keep), _p(B_colmajor), C.byref(opts))
+    ops = (_make_block_operator(ws.ctx, A, ws.n, ws.p, keep), _make_block_operator(ws.ctx, M, ws.n, ws.p, keep),
+           _make_block_operator(ws.ctx, N, ws.n, ws.p, keep))
+    if ws.adopted:
+        # the binding's matrix type IS a panel (HIPMatrix(B::Matrix) converts once, at construction): B is read in place
+        ws._allocate_panel_if(M is not None, "Q")                                          # src/block_gmres.jl:146-147
+        ws._allocate_panel_if(N is not None, "P")
+        ws._allocate_panel_if(bool(kw.get("restart")), "dX")
+        if isinstance(B_colmajor, Panel):
+            Bp = B_colmajor
+        else:
+            Bp = Panel(ws.ctx, ws.n, ws.p)
+            _ck(lib().khip_panel_from_colmajor(ws.ctx._h, ws.n, ws.p, _p(B_colmajor), Bp.buf.ptr))
+        keep.append(Bp)
+        rc = lib().khip_block_gmres_solve_panel(ws._h, *ops, Bp.buf.ptr, C.byref(opts))
+    else:
+        rc = lib().khip_block_gmres_solve(ws._h, *ops, _p(B_colmajor), C.byref(opts))
     return _finish(ws, rc)
 
 

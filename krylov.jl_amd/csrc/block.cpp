@@ -449,7 +449,13 @@ struct khip_block_gmres_workspace {
   std::vector<double> sweep, Yall, tmp;                        // staging of the fused sweeps: mem p x p each (grown with the basis), p x p
   std::vector<const double *> Vp;
   bool warm_start = false;
+  std::vector<const double *> borrowed;                        // panels of a caller's BlockGmresWorkspace (khip_block_gmres_workspace_adopt)
+  khip_grow_fn grow = nullptr;                                 // the caller's push!(V, SM(undef, n, p)) (src/block_gmres.jl:300-305)
+  void *grow_data = nullptr;
   StatsBoxB box;
+  bool is_borrowed(const double *q) const { for (const double *b : borrowed) if (b == q) return true; return false; }
+  void borrow(const double *q) { if (q && !is_borrowed(q)) borrowed.push_back(q); }
+  void unborrow(const double *q) { for (size_t i = 0; i < borrowed.size(); ++i) if (borrowed[i] == q) { borrowed.erase(borrowed.begin() + (long)i); return; } }
 };
 
 #define KB(expr)                                        \
@@ -465,6 +471,21 @@ static int alloc_panel(khip_ctx *ctx, int64_t np, int p, double **out) {
   g_alloc_seconds += now_s() - t_alloc;
   KHIP_TRY(rc_alloc);
   return khip_fill(ctx, np * p, *out, 0.0);
+}
+
+static void block_host_arrays(khip_block_gmres_workspace *ws, int memory) {
+  const int p = ws->p;
+  const size_t pp = (size_t)p * p;
+  ws->Z.assign(memory, std::vector<double>(pp, 0.0));
+  ws->R.assign((size_t)memory * (memory + 1) / 2, std::vector<double>(pp, 0.0));
+  ws->H.assign(memory, std::vector<double>(2 * pp, 0.0));
+  ws->tau.assign(memory, std::vector<double>(p, 0.0));
+  ws->C.assign(pp, 0.0);
+  ws->D.assign(2 * pp, 0.0);
+  ws->sweep.assign((size_t)memory * pp, 0.0);
+  ws->Yall.assign((size_t)memory * pp, 0.0);
+  ws->tmp.assign(pp, 0.0);
+  ws->Vp.assign((size_t)memory, nullptr);
 }
 
 extern "C" {
@@ -488,27 +509,74 @@ int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p
     if (!rc) ws->V.push_back(v);
   }
   if (rc) { khip_block_gmres_workspace_destroy(ws); return rc; }
-  const size_t pp = (size_t)p * p;
-  ws->Z.assign(memory, std::vector<double>(pp, 0.0));
-  ws->R.assign((size_t)memory * (memory + 1) / 2, std::vector<double>(pp, 0.0));
-  ws->H.assign(memory, std::vector<double>(2 * pp, 0.0));
-  ws->tau.assign(memory, std::vector<double>(p, 0.0));
-  ws->C.assign(pp, 0.0);
-  ws->D.assign(2 * pp, 0.0);
-  ws->sweep.assign((size_t)memory * pp, 0.0);
-  ws->Yall.assign((size_t)memory * pp, 0.0);
-  ws->tmp.assign(pp, 0.0);
-  ws->Vp.assign((size_t)memory, nullptr);
+  block_host_arrays(ws, memory);
   g_alloc_seconds = 0.0;
   ws->box.st.allocation_timer = now_s() - t_create;                // workspace.stats.allocation_timer, :161
   *out = ws;
   return KHIP_OK;
 }
 
+// BlockGmresWorkspace on the CALLER's panels: X, W and the `memory` basis panels V_host[0 .. memory) (device pointers in a host
+// array), each a row-major panel of khip_panel_rows(n) x p doubles whose padding rows are zero -- the tall blocks of a Julia
+// BlockGmresWorkspace{Float64,Float64,Vector{Float64},HIPMatrix} (src/block_krylov_workspaces.jl:115-163; the small blocks
+// Z, C, D, R, H, tau of the reference stay inside the library).  Solve with khip_block_gmres_solve_panel.
+int khip_block_gmres_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, int p, int memory, double *X, double *W,
+                                     double *const *V_host, khip_block_gmres_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0 && p >= 1 && p <= 32, "block_gmres_workspace_adopt: bad argument (1 <= p <= 32)");
+  KHIP_REQUIRE(memory >= 1 && V_host && X && W && X != W, "block_gmres_workspace_adopt: X, W and `memory` >= 1 basis panels are needed");
+  for (int i = 0; i < memory; ++i) KHIP_REQUIRE(V_host[i] != nullptr, "block_gmres_workspace_adopt: null basis panel");
+  khip_block_gmres_workspace *ws = new khip_block_gmres_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n; ws->p = p; ws->mem = memory;
+  khip_panel_rows(n, &ws->np);
+  ws->X = X; ws->W = W;
+  ws->borrow(X); ws->borrow(W);
+  for (int i = 0; i < memory; ++i) { ws->V.push_back(V_host[i]); ws->borrow(V_host[i]); }
+  block_host_arrays(ws, memory);
+  g_alloc_seconds = 0.0;
+  ws->box.st.allocation_timer = 0.0;
+  *out = ws;
+  return KHIP_OK;
+}
+
+int khip_block_gmres_workspace_adopt_panel(khip_block_gmres_workspace *ws, const char *name, double *ptr) {
+  KHIP_REQUIRE(ws && name, "block_gmres_workspace_adopt_panel: null argument");
+  struct { const char *k; double **slot; bool required; } tab[] = {
+      {"X", &ws->X, true}, {"W", &ws->W, true}, {"P", &ws->Pn, false}, {"Q", &ws->Qm, false}, {"dX", &ws->dX, false}};
+  for (auto &e : tab)
+    if (strcmp(e.k, name) == 0) {
+      KHIP_REQUIRE(ptr || !e.required, "block_gmres_workspace_adopt_panel: X and W cannot be emptied");
+      if (*e.slot != ptr) {
+        if (*e.slot) { if (ws->is_borrowed(*e.slot)) ws->unborrow(*e.slot); else khip_free(ws->ctx, *e.slot); }
+        *e.slot = ptr;
+      }
+      ws->borrow(ptr);
+      return KHIP_OK;
+    }
+  set_error("block_gmres_workspace_adopt_panel: unknown panel '%s' (X, W, P, Q, dX)", name);
+  return KHIP_ERR_INVALID;
+}
+
+int khip_block_gmres_workspace_adopt_basis(khip_block_gmres_workspace *ws, int k, double *const *V_host) {
+  KHIP_REQUIRE(ws && k >= 1 && V_host, "block_gmres_workspace_adopt_basis: bad argument");
+  for (double *v : ws->V) KHIP_REQUIRE(ws->is_borrowed(v), "block_gmres_workspace_adopt_basis: this workspace owns its basis");
+  KHIP_REQUIRE(k >= ws->mem, "block_gmres_workspace_adopt_basis: fewer panels than the workspace's memory");
+  for (int i = 0; i < k; ++i) KHIP_REQUIRE(V_host[i] != nullptr, "block_gmres_workspace_adopt_basis: null basis panel");
+  for (double *v : ws->V) ws->unborrow(v);
+  ws->V.assign(V_host, V_host + k);
+  for (double *v : ws->V) ws->borrow(v);
+  return KHIP_OK;
+}
+
+int khip_block_gmres_workspace_set_grow(khip_block_gmres_workspace *ws, khip_grow_fn grow, void *userdata) {
+  KHIP_REQUIRE(ws, "block_gmres_workspace_set_grow: null workspace");
+  ws->grow = grow; ws->grow_data = userdata;
+  return KHIP_OK;
+}
+
 int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws) {
   if (!ws) return KHIP_OK;
-  for (double *v : {ws->dX, ws->X, ws->W, ws->Bp, ws->Pn, ws->Qm}) khip_free(ws->ctx, v);
-  for (double *v : ws->V) khip_free(ws->ctx, v);
+  for (double *v : {ws->dX, ws->X, ws->W, ws->Bp, ws->Pn, ws->Qm}) if (v && !ws->is_borrowed(v)) khip_free(ws->ctx, v);
+  for (double *v : ws->V) if (v && !ws->is_borrowed(v)) khip_free(ws->ctx, v);
   delete ws;
   return KHIP_OK;
 }
@@ -545,6 +613,16 @@ int khip_block_gmres_warm_start(khip_block_gmres_workspace *ws, const double *X0
   return KHIP_OK;
 }
 
+// warm_start!(workspace, X0) with X0 already a row-major panel (the caller's ΔX, src/workspace_accessors.jl:193-200);
+// X0_panel == the adopted "dX" panel only sets the flag
+int khip_block_gmres_warm_start_panel(khip_block_gmres_workspace *ws, const double *X0_panel) {
+  KHIP_REQUIRE(ws && X0_panel, "block_gmres_warm_start_panel: null argument");
+  if (!ws->dX) KHIP_TRY(alloc_panel(ws->ctx, ws->np, ws->p, &ws->dX));
+  if (X0_panel != ws->dX) KHIP_TRY(khip_copy(ws->ctx, ws->np * ws->p, ws->dX, X0_panel));
+  ws->warm_start = true;
+  return KHIP_OK;
+}
+
 // Y <- Op X for row-major panels: CSR handle -> SpMM kernel; callback -> user code on the device panels
 static int apply_block_op(khip_ctx *ctx, const khip_operator *op, const double *X, double *Y, int p) {
   if (op->apply) {
@@ -556,9 +634,13 @@ static int apply_block_op(khip_ctx *ctx, const khip_operator *op, const double *
   return khip_spmm(ctx, op->csr, X, Y, p);
 }
 
-int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
-                           const khip_operator *N, const double *B_colmajor, const khip_options *opts_in) {
-  KHIP_REQUIRE(ws && A && B_colmajor, "block_gmres_solve: null argument");
+}  // extern "C"
+
+// B_is_panel: B is a row-major panel of the caller (khip_block_gmres_solve_panel), read in place; otherwise the reference's
+// column-major n x p array, converted into the workspace's own panel copy first.
+static int block_gmres_solve_impl(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                                  const khip_operator *N, const double *B_in, bool B_is_panel, const khip_options *opts_in) {
+  KHIP_REQUIRE(ws && A && B_in, "block_gmres_solve: null argument");
   khip_ctx *ctx = ws->ctx;
   khip_options o = opts_in ? *opts_in : khip_default_options();
   g_alloc_seconds = 0.0;
@@ -576,7 +658,9 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   if (o.variant != 0) return ws->box.fail(KHIP_ERR_INVALID, "block_gmres: options.variant must be 0 (there is no other recurrence)");
 
   if (restart && !ws->dX) KB(alloc_panel(ctx, np, p, &ws->dX));
-  double *dX = ws->dX, *X = ws->X, *W = ws->W, *Bp = ws->Bp;
+  if (!B_is_panel && !ws->Bp) KB(alloc_panel(ctx, np, p, &ws->Bp));                // adopted workspaces have no panel copy of B until a column-major B arrives
+  double *dX = ws->dX, *X = ws->X, *W = ws->W;
+  const double *Bp = B_is_panel ? B_in : ws->Bp;
   std::vector<double *> &V = ws->V;
   auto &Z = ws->Z; auto &R = ws->R; auto &H = ws->H; auto &tau = ws->tau;
   std::vector<double> &C = ws->C, &D = ws->D, &sweep = ws->sweep, &gram = ws->gram;      // in-place solve: no allocation per call (test/test_allocations.jl:752)
@@ -589,7 +673,7 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   double *Q = MisI ? W : ws->Qm, *R0 = MisI ? W : ws->Qm;
   double *Xr = restart ? dX : X;
 
-  KB(khip_panel_from_colmajor(ctx, n, p, B_colmajor, Bp));
+  if (!B_is_panel) KB(khip_panel_from_colmajor(ctx, n, p, B_in, ws->Bp));
   KB(khip_fill(ctx, len, X, 0.0));                                                 // src/block_gmres.jl:155
   if (warm_start) {
     KB(apply_block_op(ctx, A, dX, W, p));
@@ -744,7 +828,15 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
         if (!restart && (inner_iter >= mem)) {                                     // :300-305
           while ((int)V.size() <= inner_iter) {
             double *v = nullptr;
-            KB(alloc_panel(ctx, np, p, &v));
+            if (ws->grow) {                                                        // the caller's push!(V, SM(undef, n, p)): a zeroed panel
+              const double t_grow = now_s();
+              v = ws->grow(ws->grow_data);
+              g_alloc_seconds += now_s() - t_grow;
+              if (!v) return ws->box.fail(KHIP_ERR_INVALID, "block_gmres: the workspace's grow callback returned no panel");
+              ws->borrow(v);
+            } else {
+              KB(alloc_panel(ctx, np, p, &v));
+            }
             V.push_back(v);
           }
           while ((int)Z.size() <= inner_iter) Z.emplace_back(pp, 0.0);
@@ -824,6 +916,21 @@ int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *
   snprintf(st->status, sizeof(st->status), "%s", status);
   ws->box.publish();
   return KHIP_OK;
+}
+
+extern "C" {
+
+int khip_block_gmres_solve(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                           const khip_operator *N, const double *B_colmajor, const khip_options *opts_in) {
+  return block_gmres_solve_impl(ws, A, M, N, B_colmajor, false, opts_in);
+}
+
+// block_gmres!(ws, A, B) with B a row-major panel of khip_panel_rows(n) x p doubles (padding rows zero), read in place: what a
+// binding whose matrix type already is a panel passes (no column-major round trip, no panel copy of B).  The solution is the
+// workspace's X panel (the caller's, for an adopted workspace).
+int khip_block_gmres_solve_panel(khip_block_gmres_workspace *ws, const khip_operator *A, const khip_operator *M,
+                                 const khip_operator *N, const double *B_panel, const khip_options *opts_in) {
+  return block_gmres_solve_impl(ws, A, M, N, B_panel, true, opts_in);
 }
 
 }  // extern "C"

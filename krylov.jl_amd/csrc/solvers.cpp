@@ -90,6 +90,31 @@ int alloc_vec(khip_ctx *ctx, int64_t n, double **out) {
 }
 double take_alloc_seconds() { const double v = g_alloc_seconds; g_alloc_seconds = 0.0; return v; }
 
+// Caller-owned work vectors (khip_*_workspace_adopt, khip_*_workspace_adopt_vector): the workspace of the reference owns
+// its vectors on the Julia side (src/krylov_workspaces.jl:236-291), so a binding hands their device pointers over and the
+// library must neither free nor replace them.  One list per workspace; everything not in it was allocated here.
+struct Borrowed {
+  std::vector<const double *> v;
+  bool has(const double *p) const {
+    for (const double *q : v) if (q == p) return true;
+    return false;
+  }
+  void add(const double *p) { if (p && !has(p)) v.push_back(p); }
+  void drop(const double *p) {
+    for (size_t i = 0; i < v.size(); ++i) if (v[i] == p) { v.erase(v.begin() + (long)i); return; }
+  }
+};
+void free_unless_borrowed(khip_ctx *ctx, const Borrowed &b, double *p) {
+  if (p && !b.has(p)) khip_free(ctx, p);
+}
+// slot <- ptr as a caller-owned vector (ptr == nullptr empties the slot); what the library had allocated there is freed
+void adopt_into(khip_ctx *ctx, Borrowed &b, double **slot, double *ptr) {
+  if (*slot == ptr) { b.add(ptr); return; }
+  if (*slot) { if (b.has(*slot)) b.drop(*slot); else khip_free(ctx, *slot); }
+  *slot = ptr;
+  b.add(ptr);
+}
+
 // ---- options.verbose: the reference's per-iteration log (kdisplay, src/krylov_utils.jl:301) on stdout.  Column headers are
 // padded by hand: the labels are UTF-8 and printf pads bytes, Julia pads characters.
 inline bool kdisplay(int64_t iter, int verbose) { return verbose > 0 && iter % verbose == 0; }
@@ -108,6 +133,7 @@ struct khip_cg_workspace {
   int64_t m, n;
   double *dx = nullptr, *x = nullptr, *r = nullptr, *npc_dir = nullptr, *p = nullptr, *Ap = nullptr, *z = nullptr;
   bool warm_start = false;
+  Borrowed borrowed;                   // vectors of a caller's CgWorkspace (khip_cg_workspace_adopt)
   StatsBox box;
   // device-resident loop state (fused = 2), allocated on first use
   CgDevState *dev_state = nullptr;
@@ -409,9 +435,43 @@ int khip_cg_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_cg_worksp
   return KHIP_OK;
 }
 
+// CgWorkspace whose x, r, p, Ap are the CALLER's device vectors of n entries (a Julia CgWorkspace{Float64,Float64,HIPVector}:
+// src/krylov_workspaces.jl:236-248).  Nothing is allocated; solution(ws) === x.  The lazily allocated fields (z, dx = Δx,
+// npc_dir, src/cg.jl:142-143) are handed over with khip_cg_workspace_adopt_vector when the caller has them; a solve that
+// needs one the caller did not hand over allocates it here (and owns it).
+int khip_cg_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, double *x, double *r, double *p, double *Ap,
+                            khip_cg_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "cg_workspace_adopt: bad argument");
+  KHIP_REQUIRE(n == 0 || (x && r && p && Ap), "cg_workspace_adopt: x, r, p, Ap must be device vectors of n entries");
+  KHIP_REQUIRE(n == 0 || (x != r && x != p && x != Ap && r != p && r != Ap && p != Ap), "cg_workspace_adopt: x, r, p, Ap must be distinct");
+  khip_cg_workspace *ws = new khip_cg_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n;
+  ws->x = x; ws->r = r; ws->p = p; ws->Ap = Ap;
+  for (double *v : {x, r, p, Ap}) ws->borrowed.add(v);
+  (void)take_alloc_seconds();
+  ws->box.st.allocation_timer = 0.0;                            // the caller allocated (and timed) the vectors
+  *out = ws;
+  return KHIP_OK;
+}
+
+int khip_cg_workspace_adopt_vector(khip_cg_workspace *ws, const char *name, double *ptr) {
+  KHIP_REQUIRE(ws && name, "cg_workspace_adopt_vector: null argument");
+  struct { const char *k; double **slot; bool required; } tab[] = {
+      {"x", &ws->x, true}, {"r", &ws->r, true}, {"p", &ws->p, true}, {"Ap", &ws->Ap, true},
+      {"z", &ws->z, false}, {"dx", &ws->dx, false}, {"npc_dir", &ws->npc_dir, false}};
+  for (auto &e : tab)
+    if (strcmp(e.k, name) == 0) {
+      KHIP_REQUIRE(ptr || !e.required, "cg_workspace_adopt_vector: x, r, p, Ap cannot be emptied");
+      adopt_into(ws->ctx, ws->borrowed, e.slot, ptr);
+      return KHIP_OK;
+    }
+  set_error("cg_workspace_adopt_vector: unknown vector '%s' (x, r, p, Ap, z, dx, npc_dir)", name);
+  return KHIP_ERR_INVALID;
+}
+
 int khip_cg_workspace_destroy(khip_cg_workspace *ws) {
   if (!ws) return KHIP_OK;
-  for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z, ws->pz, ws->pq}) khip_free(ws->ctx, v);
+  for (double *v : {ws->dx, ws->x, ws->r, ws->npc_dir, ws->p, ws->Ap, ws->z, ws->pz, ws->pq}) free_unless_borrowed(ws->ctx, ws->borrowed, v);
   if (ws->dev_state) (void)hipFree(ws->dev_state);
   if (ws->snap) (void)hipHostFree(ws->snap);
   if (ws->cgcg_state) (void)hipFree(ws->cgcg_state);
@@ -425,7 +485,7 @@ int khip_cg_workspace_destroy(khip_cg_workspace *ws) {
 int khip_cg_warm_start(khip_cg_workspace *ws, const double *x0) {
   KHIP_REQUIRE(ws && x0, "cg_warm_start: null argument");
   if (!ws->dx) KHIP_TRY(alloc_vec(ws->ctx, ws->n, &ws->dx));
-  KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
+  if (x0 != ws->dx) KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));   // x0 == dx: an adopted Δx that warm_start! already filled
   ws->warm_start = true;
   return KHIP_OK;
 }
@@ -805,10 +865,24 @@ struct khip_gmres_workspace {
   std::vector<double> look;      // mem + 1 doubles: landing buffer of the look-ahead fetch (k coefficients + ||q||^2); no per-iteration allocation
   int inner_iter = 0;
   bool warm_start = false;
+  Borrowed borrowed;             // vectors of a caller's GmresWorkspace (khip_gmres_workspace_adopt)
+  khip_grow_fn grow = nullptr;   // adopted workspaces: the caller's push!(V, similar(x)) (src/gmres.jl:319-324)
+  void *grow_data = nullptr;
   StatsBox box;
 };
 
 static int gmres_grow_basis(khip_gmres_workspace *ws, int count) {   // push!(V, similar(x)) in slabs
+  if (ws->grow) {                // the basis belongs to the caller: one push!(V, similar(x)) per missing vector
+    for (int i = 0; i < count; ++i) {
+      const double t_alloc = now_s();
+      double *v = ws->grow(ws->grow_data);
+      g_alloc_seconds += now_s() - t_alloc;
+      if (!v) { set_error("gmres: the workspace's grow callback returned no vector"); return KHIP_ERR_INVALID; }
+      ws->borrowed.add(v);
+      ws->V.push_back(v);
+    }
+    return KHIP_OK;
+  }
   double *slab = nullptr;
   const double t_alloc = now_s();
   KHIP_TRY(khip_malloc(ws->ctx, sizeof(double) * (size_t)ws->stride * (size_t)count, reinterpret_cast<void **>(&slab)));
@@ -872,9 +946,90 @@ int khip_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int memory,
   return KHIP_OK;
 }
 
+// GmresWorkspace on the CALLER's vectors: x, w and the `memory` basis vectors V_host[0 .. memory) (device pointers in a host
+// array; a Julia GmresWorkspace{Float64,Float64,HIPVector} keeps them as `V::Vector{S}`, src/krylov_workspaces.jl:2857-2873).
+// The host arrays c, s, z, R of the reference stay inside the library (khip_gmres_host_state copies them out).
+int khip_gmres_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, int memory, double *x, double *w,
+                               double *const *V_host, khip_gmres_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0 && memory >= 0, "gmres_workspace_adopt: bad argument");
+  KHIP_REQUIRE(n == 0 || (x && w && x != w), "gmres_workspace_adopt: x and w must be distinct device vectors of n entries");
+  KHIP_REQUIRE(memory == 0 || V_host, "gmres_workspace_adopt: V_host must hold `memory` device pointers");
+  khip_gmres_workspace *ws = new khip_gmres_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n; ws->mem = memory;
+  ws->stride = padded(n > 0 ? n : 1);
+  ws->x = x; ws->w = w;
+  ws->borrowed.add(x); ws->borrowed.add(w);
+  for (int i = 0; i < memory; ++i) {
+    if (!V_host[i]) { delete ws; set_error("gmres_workspace_adopt: V_host[%d] is null", i); return KHIP_ERR_INVALID; }
+    ws->V.push_back(V_host[i]);
+    ws->borrowed.add(V_host[i]);
+  }
+  ws->c.assign(memory, 0.0); ws->s.assign(memory, 0.0); ws->z.assign(memory, 0.0);
+  ws->R.assign((size_t)memory * (memory + 1) / 2, 0.0);
+  ws->look.assign((size_t)memory + 1, 0.0);
+  (void)take_alloc_seconds();
+  ws->box.st.allocation_timer = 0.0;
+  *out = ws;
+  return KHIP_OK;
+}
+
+int khip_gmres_workspace_adopt_vector(khip_gmres_workspace *ws, const char *name, double *ptr) {
+  KHIP_REQUIRE(ws && name, "gmres_workspace_adopt_vector: null argument");
+  struct { const char *k; double **slot; bool required; } tab[] = {
+      {"x", &ws->x, true}, {"w", &ws->w, true}, {"p", &ws->p, false}, {"q", &ws->q, false}, {"dx", &ws->dx, false}};
+  for (auto &e : tab)
+    if (strcmp(e.k, name) == 0) {
+      KHIP_REQUIRE(ptr || !e.required, "gmres_workspace_adopt_vector: x and w cannot be emptied");
+      adopt_into(ws->ctx, ws->borrowed, e.slot, ptr);
+      return KHIP_OK;
+    }
+  set_error("gmres_workspace_adopt_vector: unknown vector '%s' (x, w, p, q, dx)", name);
+  return KHIP_ERR_INVALID;
+}
+
+// The basis of an adopted workspace as the caller holds it NOW (k >= the workspace's memory: after a solve with
+// restart = false the caller's V has grown through the grow callback, and the next solve starts from all of it).
+int khip_gmres_workspace_adopt_basis(khip_gmres_workspace *ws, int k, double *const *V_host) {
+  KHIP_REQUIRE(ws && k >= 0 && (k == 0 || V_host), "gmres_workspace_adopt_basis: bad argument");
+  KHIP_REQUIRE(ws->slabs.empty(), "gmres_workspace_adopt_basis: this workspace owns its basis (khip_gmres_workspace_create)");
+  KHIP_REQUIRE(k >= ws->mem, "gmres_workspace_adopt_basis: fewer vectors than the workspace's memory");
+  for (int i = 0; i < k; ++i) KHIP_REQUIRE(V_host[i] != nullptr, "gmres_workspace_adopt_basis: null basis vector");
+  for (double *v : ws->V) ws->borrowed.drop(v);
+  ws->V.assign(V_host, V_host + k);
+  for (double *v : ws->V) ws->borrowed.add(v);
+  return KHIP_OK;
+}
+
+int khip_gmres_workspace_set_grow(khip_gmres_workspace *ws, khip_grow_fn grow, void *userdata) {
+  KHIP_REQUIRE(ws, "gmres_workspace_set_grow: null workspace");
+  KHIP_REQUIRE(ws->slabs.empty() || !grow, "gmres_workspace_set_grow: this workspace owns its basis");
+  ws->grow = grow; ws->grow_data = userdata;
+  return KHIP_OK;
+}
+
+// Host state of the last solve in the reference's own storage (src/krylov_workspaces.jl:2866-2871): c, s, z of *len entries
+// each, R packed upper triangular (len (len + 1) / 2), inner_iter.  Any output may be null; cap = entries c / s / z can take
+// (R: cap (cap + 1) / 2).  *len = current length (it exceeds the workspace's memory after restart = false grew the basis).
+int khip_gmres_host_state(khip_gmres_workspace *ws, int cap, double *c_host, double *s_host, double *z_host, double *R_host,
+                          int *len, int *inner_iter) {
+  KHIP_REQUIRE(ws && cap >= 0, "gmres_host_state: bad argument");
+  const int L = (int)ws->c.size();
+  if (len) *len = L;
+  if (inner_iter) *inner_iter = ws->inner_iter;
+  const int k = L < cap ? L : cap;
+  if (c_host) memcpy(c_host, ws->c.data(), sizeof(double) * (size_t)k);
+  if (s_host) memcpy(s_host, ws->s.data(), sizeof(double) * (size_t)k);
+  if (z_host) memcpy(z_host, ws->z.data(), sizeof(double) * (size_t)(ws->z.size() < (size_t)k ? ws->z.size() : (size_t)k));
+  if (R_host) {
+    const size_t nr = (size_t)k * (k + 1) / 2;
+    memcpy(R_host, ws->R.data(), sizeof(double) * (ws->R.size() < nr ? ws->R.size() : nr));
+  }
+  return KHIP_OK;
+}
+
 int khip_gmres_workspace_destroy(khip_gmres_workspace *ws) {
   if (!ws) return KHIP_OK;
-  for (double *v : {ws->dx, ws->x, ws->w, ws->p, ws->q}) khip_free(ws->ctx, v);
+  for (double *v : {ws->dx, ws->x, ws->w, ws->p, ws->q}) free_unless_borrowed(ws->ctx, ws->borrowed, v);
   for (double *s : ws->slabs) khip_free(ws->ctx, s);
   delete ws;
   return KHIP_OK;
@@ -883,7 +1038,7 @@ int khip_gmres_workspace_destroy(khip_gmres_workspace *ws) {
 int khip_gmres_warm_start(khip_gmres_workspace *ws, const double *x0) {
   KHIP_REQUIRE(ws && x0, "gmres_warm_start: null argument");
   if (!ws->dx) KHIP_TRY(alloc_vec(ws->ctx, ws->n, &ws->dx));
-  KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
+  if (x0 != ws->dx) KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
   ws->warm_start = true;
   return KHIP_OK;
 }
@@ -1321,7 +1476,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
 
       if (!(solved || inner_tired || breakdown || user_requested_exit || overtimed)) {
         if (!restart && (inner_iter >= mem)) {                                     // :319-324
-          if ((int)V.size() <= inner_iter) K(gmres_grow_basis(ws, mem > 4 ? mem : 4));
+          if ((int)V.size() <= inner_iter) K(gmres_grow_basis(ws, ws->grow ? inner_iter + 1 - (int)V.size() : (mem > 4 ? mem : 4)));
           if ((int)z.size() <= inner_iter) z.resize(inner_iter + 1, 0.0);
         }
         if (!spec_done) K(khip_divcopy(ctx, n, V[inner_iter], q, Hbis));           // :325 (already enqueued by the look-ahead)
@@ -1394,6 +1549,7 @@ struct khip_bicgstab_workspace {
   double *dx = nullptr, *x = nullptr, *r = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *qd = nullptr,
          *yz = nullptr, *t = nullptr;
   bool warm_start = false;
+  Borrowed borrowed;                   // vectors of a caller's BicgstabWorkspace (khip_bicgstab_workspace_adopt)
   StatsBox box;
   // device-resident loop state (fused = 2), allocated on first use
   BicgDevState *dev_state = nullptr;
@@ -1515,9 +1671,44 @@ int khip_bicgstab_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_bic
   return KHIP_OK;
 }
 
+// BicgstabWorkspace on the CALLER's six vectors x, r, p, v, s, qd (src/krylov_workspaces.jl:1568-1582); yz, t, dx are handed
+// over with khip_bicgstab_workspace_adopt_vector when the caller has allocated them (src/bicgstab.jl:148-150).
+int khip_bicgstab_workspace_adopt(khip_ctx *ctx, int64_t m, int64_t n, double *x, double *r, double *p, double *v, double *s,
+                                  double *qd, khip_bicgstab_workspace **out) {
+  KHIP_REQUIRE(ctx && out && m >= 0 && n >= 0, "bicgstab_workspace_adopt: bad argument");
+  double *six[6] = {x, r, p, v, s, qd};
+  for (int i = 0; i < 6 && n > 0; ++i) {
+    KHIP_REQUIRE(six[i] != nullptr, "bicgstab_workspace_adopt: x, r, p, v, s, qd must be device vectors of n entries");
+    for (int j = 0; j < i; ++j) KHIP_REQUIRE(six[i] != six[j], "bicgstab_workspace_adopt: x, r, p, v, s, qd must be distinct");
+  }
+  khip_bicgstab_workspace *ws = new khip_bicgstab_workspace();
+  ws->ctx = ctx; ws->m = m; ws->n = n;
+  ws->x = x; ws->r = r; ws->p = p; ws->v = v; ws->s = s; ws->qd = qd;
+  for (double *u : six) ws->borrowed.add(u);
+  (void)take_alloc_seconds();
+  ws->box.st.allocation_timer = 0.0;
+  *out = ws;
+  return KHIP_OK;
+}
+
+int khip_bicgstab_workspace_adopt_vector(khip_bicgstab_workspace *ws, const char *name, double *ptr) {
+  KHIP_REQUIRE(ws && name, "bicgstab_workspace_adopt_vector: null argument");
+  struct { const char *k; double **slot; bool required; } tab[] = {
+      {"x", &ws->x, true}, {"r", &ws->r, true}, {"p", &ws->p, true}, {"v", &ws->v, true}, {"s", &ws->s, true},
+      {"qd", &ws->qd, true}, {"yz", &ws->yz, false}, {"t", &ws->t, false}, {"dx", &ws->dx, false}};
+  for (auto &e : tab)
+    if (strcmp(e.k, name) == 0) {
+      KHIP_REQUIRE(ptr || !e.required, "bicgstab_workspace_adopt_vector: x, r, p, v, s, qd cannot be emptied");
+      adopt_into(ws->ctx, ws->borrowed, e.slot, ptr);
+      return KHIP_OK;
+    }
+  set_error("bicgstab_workspace_adopt_vector: unknown vector '%s' (x, r, p, v, s, qd, yz, t, dx)", name);
+  return KHIP_ERR_INVALID;
+}
+
 int khip_bicgstab_workspace_destroy(khip_bicgstab_workspace *ws) {
   if (!ws) return KHIP_OK;
-  for (double *v : {ws->dx, ws->x, ws->r, ws->p, ws->v, ws->s, ws->qd, ws->yz, ws->t}) khip_free(ws->ctx, v);
+  for (double *v : {ws->dx, ws->x, ws->r, ws->p, ws->v, ws->s, ws->qd, ws->yz, ws->t}) free_unless_borrowed(ws->ctx, ws->borrowed, v);
   if (ws->dev_state) (void)hipFree(ws->dev_state);
   if (ws->snap) (void)hipHostFree(ws->snap);
   if (ws->hist_dev) (void)hipFree(ws->hist_dev);
@@ -1529,7 +1720,7 @@ int khip_bicgstab_workspace_destroy(khip_bicgstab_workspace *ws) {
 int khip_bicgstab_warm_start(khip_bicgstab_workspace *ws, const double *x0) {
   KHIP_REQUIRE(ws && x0, "bicgstab_warm_start: null argument");
   if (!ws->dx) KHIP_TRY(alloc_vec(ws->ctx, ws->n, &ws->dx));
-  KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
+  if (x0 != ws->dx) KHIP_TRY(khip_copy(ws->ctx, ws->n, ws->dx, x0));
   ws->warm_start = true;
   return KHIP_OK;
 }

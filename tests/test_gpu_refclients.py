@@ -112,3 +112,19 @@ def test_block_gmres_primitive_sequence_equals_the_solver():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "0 failure(s)" in out.stdout, out.stdout + out.stderr[-800:]
     assert out.stdout.count("PASS") == 2 and "FAIL" not in out.stdout
+
+
+@pytest.mark.parametrize("sizes", [("64",), ("512",)])
+def test_adopted_workspaces_equal_the_owned_ones(sizes):
+    """tests/c/adopt_sequence.c: cg! / gmres! / bicgstab! / block_gmres! on CALLER-OWNED vectors (khip_*_workspace_adopt -- what
+    the cg!(ws::CgWorkspace{..,HIPVector}, ...) methods of julia/KrylovHIP forward to) against the library-owned workspaces:
+    iteration counts, statuses, residual histories and solutions bit for bit, the solution in the caller's x, lazily
+    allocated vectors handed over late, the basis grown through the caller's push!.  64^3: every solver; 512^3 (cfg 2, the
+    bench workload): the full cg! solve to rtol 1e-8."""
+    exe = os.path.join(ROOT, "tests", "c", "adopt_sequence")
+    if not os.path.exists(exe):
+        pytest.skip("tests/c/adopt_sequence not built")
+    out = subprocess.run([exe, *sizes], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "0 failure(s)" in out.stdout and "PASS" in out.stdout, out.stdout[-3000:] + out.stderr[-800:]
+    assert "FAIL" not in out.stdout
+    assert "bit-identical" in out.stdout
