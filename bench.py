@@ -308,14 +308,27 @@ def main():
     # the explicit test switches for running the distributed path on a 1-GPU box.
     ndev = K.device_count() if K.gpu_available() else 0
     restricted = any(os.environ.get(v) for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+    allow_shared = os.environ.get("KHIP_ALLOW_SHARED_GPU") == "1"
     if local_rank < ndev:
-        ctx = K.Context(local_rank)
-    elif ndev == 1 and (restricted or os.environ.get("KHIP_ALLOW_SHARED_GPU") == "1"):
-        ctx = K.Context(0)
+        dev = local_rank
+    elif ndev == 1 and (restricted or allow_shared):
+        dev = 0
     else:
         log(f"bench.py: rank {rank} (local rank {local_rank}) has no device of its own: {ndev} HIP device(s) visible, "
             f"{world} ranks; refusing to share a GPU between ranks")
         sys.exit(2)
+    # A *_VISIBLE_DEVICES exported to EVERY rank (not per rank) would put them all on one GPU while n_gpus = WORLD_SIZE is
+    # reported: compare the PHYSICAL devices (host, PCI bus id) over the control plane and refuse duplicates.
+    if dist is not None and world > 1 and not allow_shared:
+        import socket
+        ids = [None] * world
+        dist.all_gather_object(ids, (socket.gethostname(), K.device_pci_id(dev)))
+        if len(set(ids)) != world:
+            if rank == 0:
+                log(f"bench.py: {world} ranks on {len(set(ids))} physical GPU(s) {sorted(set(ids))}: refusing to share a GPU "
+                    f"between ranks (KHIP_ALLOW_SHARED_GPU=1 is the explicit test switch)")
+            sys.exit(2)
+    ctx = K.Context(dev)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
@@ -397,6 +410,34 @@ def main():
                                   "different rounding (own parity budget, DESIGN.md 3.1c)",
               "value": sr_iters / sr_elapsed, "unit": "iter/s", "steps": int(sr_iters), "ms_per_step": 1e3 * sr_elapsed / max(sr_iters, 1)}
     code_bits, code_diags = A.code_info
+    # General-CSR leg (untimed for `value`, clearly labelled): the SAME operator and fused iteration with the dictionary codes
+    # switched off, i.e. the kernel that moves every algorithmic byte of SURVEY 8(d) (12 B per entry: Float64 value + int32
+    # column).  HIP-event average over the same number of steps.
+    int32_leg = None
+    if world == 1 and code_bits != 32 and not templates and args.variant == 0:
+        ctx.set_option("spmv_codes", 0)
+        try:
+            K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=max(args.warmup, 1), fused=args.fused)
+            ctx.set_option("profile_spmv", 1)
+            ctx.profile_spmv()
+            barrier()
+            t2 = time.perf_counter()
+            K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.steps, fused=args.fused)
+            barrier()
+            el32 = time.perf_counter() - t2
+            l32, ms32 = ctx.profile_spmv()
+            ctx.set_option("profile_spmv", 0)
+            it32 = ws.stats.niter
+            avg32 = ms32 / max(it32, 1)
+            int32_leg = {"NOT_THE_HEADLINE": "same operator, same fused cg! iteration, ctx option spmv_codes = 0: the staged SpMV reads the "
+                                             "int32 column stream (12 B per entry) -- the general-CSR kernel, for the '>= 70 % on CSR SpMV' target",
+                         "bound": "hbm", "kernel": f"SpMV kernel {A.spmv_kernel_choice} (4 = spmv_stage_kernel) fused with p.Ap, int32 columns",
+                         "achieved": A.spmv_bytes / (avg32 * 1e-3) / 1e9 if avg32 > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (A.spmv_bytes / (avg32 * 1e-3) / 1e9 / HBM_PEAK_GBPS) if avg32 > 0 else 0.0,
+                         "bytes_per_launch": A.spmv_bytes, "avg_ms": avg32, "launches_per_iteration": l32 / max(it32, 1),
+                         "steps": int(it32), "cg_iters_per_sec": it32 / el32, "ms_per_step": 1e3 * el32 / max(it32, 1)}
+        finally:
+            ctx.set_option("spmv_codes", 1)
     rccl_ranks = ctx.comm_info()["rccl_ranks"] if use_comm else 0
     if dist is not None:
         import torch
@@ -430,7 +471,10 @@ def main():
                        "n": n, "nnz_global": 7 * n - 6 * n1 * n1, "fused": args.fused,
                        "partition": f"1-D rows over {world} GPU(s)", "atol": 0.0, "rtol": 0.0,
                        "operator_format": f"row templates ({templates})" if templates else f"CSR; column stream read as {col_note}",
-                       "recurrence": "single-reduction CG (Chronopoulos-Gear)" if args.variant == 1 else "cg! (src/cg.jl)"},
+                       "recurrence": "single-reduction CG (Chronopoulos-Gear)" if args.variant == 1 else "cg! (src/cg.jl)",
+                       "entry": ("khip_cg_solve via khip_cg_workspace_adopt (x, r, p, Ap owned by the caller, as a Krylov.jl "
+                                 "CgWorkspace{Float64,Float64,HIPVector} holds them: julia/KrylovHIP/src/KrylovHIP.jl cg!)")
+                                if ws.adopted else "khip_cg_solve on a khip_cg_workspace_create workspace"},
             "hbm_gbps_iteration": its * iter_bytes_local * world / 1e9,
             "bytes_per_iteration_algorithmic_fused": iter_bytes_local * world,
             "bytes_per_iteration_reference_sequence": iter_bytes_unfused_local * world,
@@ -439,6 +483,7 @@ def main():
             "self_consistency": self_consistency(n1, parity_hist),
             "rccl_ranks_seen": rccl_ranks,
             "single_reduction_cg": sr,
+            "roofline_int32_csr": int32_leg,
             "roofline": {"bound": "hbm", "kernel": kern + " (SpMV fused with p.Ap)",
                          "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,

@@ -48,6 +48,7 @@ void        khip_version(int *major, int *minor);
 /* ---------------------------------------------------------------- context ---- */
 /* stream: a hipStream_t to borrow (e.g. the caller's current stream) or NULL to create one. */
 int   khip_device_count(int *count);            /* HIP devices visible to this process (0 without a GPU; never fails) */
+int   khip_device_pci_id(int device, char *buf, size_t cap);   /* "0000:05:00.0": the physical GPU behind a device index (cap >= 16) */
 int   khip_ctx_create(int device, void *stream, khip_ctx **out);
 int   khip_ctx_destroy(khip_ctx *ctx);
 int   khip_ctx_sync(khip_ctx *ctx);

@@ -160,6 +160,7 @@ SIGNATURES = {
     "khip_comm_rank": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "khip_comm_barrier": (_int, [_vp]),
     "khip_device_count": (_int, [C.POINTER(_int)]),
+    "khip_device_pci_id": (_int, [_int, C.c_char_p, _sz]),
     "khip_comm_info": (_int, [_vp] + [C.POINTER(_int)] * 5),
     "khip_default_options": (COptions, []),
     "khip_cg_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
@@ -267,6 +268,13 @@ def device_count() -> int:
     n = C.c_int()
     lib().khip_device_count(C.byref(n))
     return n.value
+
+
+def device_pci_id(device: int = 0) -> str:
+    """PCI bus id of the physical GPU behind a visible device index."""
+    buf = C.create_string_buffer(64)
+    _ck(lib().khip_device_pci_id(device, buf, 64))
+    return buf.value.decode()
 
 
 # --------------------------------------------------------------------------- context / vectors

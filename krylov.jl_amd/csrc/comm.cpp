@@ -288,6 +288,40 @@ int comm_build_plan(khip_ctx *ctx, khip_csr *A, int local_rc) {
   }
   row_starts[G] = all[4 * (G - 1)] + all[4 * (G - 1) + 1];
   A->part_starts = row_starts;
+  if (G == 1 && ctx->tune.halo_self && status == PLAN_OK && (A->row0 != 0 || A->m != A->n_global)) {
+    // ---- self halo (measurement hook, Tuning::halo_self): the slab's off-slab columns wrap onto its own rows and travel
+    //      through the real neighbour exchange, from this rank to itself
+    if (c->hub) { set_error("halo_self needs the RCCL backend"); return KHIP_ERR_UNSUPPORTED; }
+    std::vector<int32_t> send_idx(ghost.size());
+    for (size_t i = 0; i < ghost.size(); ++i) {
+      int64_t loc = ((int64_t)ghost[i] - A->row0) % A->m;
+      if (loc < 0) loc += A->m;
+      send_idx[i] = (int32_t)loc;
+    }
+    A->recv_off = {0, (int64_t)ghost.size()};
+    A->send_off = {0, (int64_t)ghost.size()};
+    A->n_ghost = (int64_t)ghost.size();
+    A->n_send = (int64_t)send_idx.size();
+    A->ghost_gid = ghost;
+    A->self_halo = true;
+    int32_t *d_ghost_sorted = nullptr;
+    KHIP_TRY(scratch.alloc(&d_ghost_sorted, (size_t)std::max<int64_t>(A->n_ghost, 1)));
+    if (A->n_ghost)
+      KHIP_CHECK_HIP(hipMemcpyAsync(d_ghost_sorted, ghost.data(), sizeof(int32_t) * (size_t)A->n_ghost, hipMemcpyHostToDevice, ctx->stream));
+    KHIP_TRY(launch_col_remap(ctx, A, d_ghost_sorted, A->n_ghost));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    KHIP_CHECK_HIP(hipMalloc(&A->ghost, sizeof(double) * (size_t)std::max<int64_t>(A->n_ghost, 1)));
+    KHIP_CHECK_HIP(hipMalloc(&A->sendbuf, sizeof(double) * (size_t)std::max<int64_t>(A->n_send, 1)));
+    KHIP_CHECK_HIP(hipMalloc(&A->send_idx, sizeof(int32_t) * (size_t)std::max<int64_t>(A->n_send, 1)));
+    if (A->n_send)
+      KHIP_CHECK_HIP(hipMemcpy(A->send_idx, send_idx.data(), sizeof(int32_t) * (size_t)A->n_send, hipMemcpyHostToDevice));
+    KHIP_CHECK_HIP(hipMemsetAsync(A->ghost, 0, sizeof(double) * (size_t)std::max<int64_t>(A->n_ghost, 1), ctx->stream));
+    int64_t lo_hi_self[2];
+    KHIP_TRY(launch_row_ghost_range(ctx, A, lo_hi_self));
+    A->interior_lo = lo_hi_self[0];
+    A->interior_hi = lo_hi_self[1];
+    return KHIP_OK;
+  }
   if (bad_partition || row_starts[0] != 0 || row_starts[G] != A->n_global) {     // same data on every rank: all fail together
     set_error("row partition [%lld, %lld) is not contiguous or does not cover n_global = %lld", (long long)row_starts[0],
               (long long)row_starts[G], (long long)A->n_global);
@@ -511,7 +545,7 @@ static int ensure_panel_halo(khip_csr *A, int width) {
 int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *x, int width) {
   Comm *c = ctx->comm;
   khip_csr *A = const_cast<khip_csr *>(A_in);
-  if (!c || c->nranks == 1 || (A->n_send == 0 && A->n_ghost == 0)) return KHIP_OK;
+  if (!c || (c->nranks == 1 && !A->self_halo) || (A->n_send == 0 && A->n_ghost == 0)) return KHIP_OK;
   double *sendbuf = A->sendbuf, *ghost = A->ghost;
   if (width > 1) {
     KHIP_TRY(ensure_panel_halo(A, width));
@@ -574,7 +608,7 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
   }
   KHIP_CHECK_NCCL(g_rccl.GroupStart());
   for (int r = 0; r < c->nranks; ++r) {
-    if (r == c->rank) continue;
+    if (r == c->rank && !A->self_halo) continue;
     const int64_t ns = A->send_off[r + 1] - A->send_off[r];
     const int64_t nr = A->recv_off[r + 1] - A->recv_off[r];
     if (ns > 0) KHIP_CHECK_NCCL(g_rccl.Send(sendbuf + A->send_off[r] * w, (size_t)ns * w, ncclFloat64, r, c->halo_comm, cs));
@@ -587,7 +621,7 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
 
 int comm_halo_exchange_end(khip_ctx *ctx, const khip_csr *A) {
   Comm *c = ctx->comm;
-  if (!c || c->nranks == 1 || (A->n_send == 0 && A->n_ghost == 0)) return KHIP_OK;
+  if (!c || (c->nranks == 1 && !A->self_halo) || (A->n_send == 0 && A->n_ghost == 0)) return KHIP_OK;
   if (c->hub) {
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));          // my copies out of the peers' buffers are done
     c->hub->barrier();                                          // ... and so are theirs out of mine
@@ -727,7 +761,7 @@ int khip_comm_init(khip_ctx *ctx, int rank, int nranks, const void *id128_host) 
     return KHIP_ERR_COMM;
   }
   c->halo_comm = c->comm;
-  if (g_rccl.CommSplit && nranks > 1) {
+  if (g_rccl.CommSplit && (nranks > 1 || ctx->tune.halo_self)) {
     ncclComm_t h2 = nullptr;
     if (g_rccl.CommSplit(c->comm, 0, rank, &h2, nullptr) == ncclSuccess && h2) c->halo_comm = h2;
   }

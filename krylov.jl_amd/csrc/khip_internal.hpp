@@ -126,6 +126,7 @@ struct Tuning {
   int overlap_halo = 1;     // overlap halo exchange with interior rows
   int halo_mode = 0;        // distributed operators: 1 = exchange only the needed remote x entries (neighbour Send/Recv), 2 = all-gather x before every product, 0 = choose per operator (gather when a rank needs more than halo_gather_pct % of its own row count from its peers)
   int halo_gather_pct = 50; // see halo_mode
+  int halo_self = 0;        // TEST / MEASUREMENT hook: with a ONE-rank communicator, a row slab [row0, row0 + m) of a larger operator gets a real halo plan whose off-slab columns wrap onto the slab's own rows (the slab becomes periodic) and are exchanged with grouped ncclSend / ncclRecv to the rank ITSELF: pack kernel, grouped call on the halo stream, interior / boundary split, 16-byte all-gather + combine all run as on N ranks (tools/slab_iteration.py).  Set BEFORE khip_comm_init
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
 
@@ -199,6 +200,7 @@ struct khip_csr {
   std::vector<int64_t> part_starts;          // row partition of the global operator (size nranks+1), kept for khip_csr_transpose
   std::vector<int32_t> ghost_gid;            // neighbour mode: global column of every ghost slot (ascending), kept for khip_csr_transpose
   // gather mode (comm.cpp): x is all-gathered before the product instead of exchanging the needed entries only
+  bool self_halo = false;                    // ctx option "halo_self": the one rank exchanges its halo with itself
   bool gather = false;
   int64_t gather_maxm = 0;                   // slice stride of the receive buffer (largest local row count)
   std::vector<int64_t> gather_rows;          // local row count of every rank

@@ -1,0 +1,45 @@
+#!/bin/bash
+# tools/evidence.sh <round-tag> <stage ...> -- the GPU passes behind profiles/<round-tag>_* (one script instead of the per-letter
+# gpu_r0x_*.sh of earlier rounds).  Run on the GPU box: gpurun --timeout 900 -- 'bash tools/evidence.sh r05 tests bench'
+# Stages (any order, each under its own timeout; outputs under gpurun_out/, copy what is to be judged into profiles/):
+#   tests     pytest -m gpu (parity log -> gpurun_out/parity_log.jsonl) + smoke()
+#   bench     bench.py at the driver's setting (20 steps, 5 warm-up) and at 100 steps
+#   floors    tools/streamfloor: 2R / 3R (+1W) panel streams, tile-SpMM twin
+#   slab      tools/slab_iteration.py: one rank's CG iteration at the N = 1 / 2 / 4 / 8 slab shapes, self halo over RCCL
+#   slabprof  rocprofv3 --kernel-trace --stats of the N = 8 slab iteration
+#   prof      rocprofv3 --kernel-trace --stats of bench.py; PMC passes of the SpMV (tools/gpu_prof.sh)
+#   cfg5      cfg-5 block-GMRES: kernel stats + bench_configs.py
+#   adopt     tests/c/adopt_sequence 64 512
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+R=$PWD; TAG=${1:-r05}; shift; mkdir -p gpurun_out; export TMPDIR=/tmp
+for stage in "$@"; do
+  echo "=== $stage"
+  case $stage in
+    tests)
+      rm -f gpurun_out/parity_log.jsonl
+      timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | tail -15
+      timeout 100 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)
+      timeout 400 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_setting.json 2> gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench_driver_setting.json
+      timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2>> gpurun_out/${TAG}_bench.err; tail -c 300 gpurun_out/${TAG}_bench.json ;;
+    floors)
+      timeout 200 tools/streamfloor panel > gpurun_out/${TAG}_panel_stream_floor.log 2>&1; cat gpurun_out/${TAG}_panel_stream_floor.log
+      timeout 200 tools/streamfloor spmm > gpurun_out/${TAG}_spmm_floor.log 2>&1; cat gpurun_out/${TAG}_spmm_floor.log ;;
+    slab)
+      rm -f gpurun_out/${TAG}_slab_iteration.jsonl
+      timeout 200 python tools/slab_iteration.py --only 1 --out gpurun_out/${TAG}_slab_iteration.jsonl 2>&1 | tail -2
+      for N in 2 4 8; do timeout 200 python tools/slab_iteration.py --only $N --variants --out gpurun_out/${TAG}_slab_iteration.jsonl 2>&1 | tail -3; done ;;
+    slabprof)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_slab8_stats -o s -- python $R/tools/slab_iteration.py --only 8 --out $R/gpurun_out/${TAG}_slab8_prof.jsonl > $R/gpurun_out/${TAG}_slab8_prof.log 2>&1; echo "slabprof exit $?")
+      head -12 gpurun_out/${TAG}_slab8_stats/s_kernel_stats.csv | cut -c1-220 ;;
+    prof)
+      bash tools/gpu_prof.sh ${TAG} 2>&1 | tail -20 ;;
+    cfg5)
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfg5_stats -o s -- python $R/tools/cfg5_only.py > $R/gpurun_out/${TAG}_cfg5_prof.log 2>&1; echo "cfg5 prof exit $?")
+      head -14 gpurun_out/${TAG}_cfg5_stats/s_kernel_stats.csv | cut -c1-220
+      timeout 600 python tools/bench_configs.py > gpurun_out/${TAG}_bench_configs.jsonl 2> gpurun_out/${TAG}_bench_configs.err; cut -c1-400 gpurun_out/${TAG}_bench_configs.jsonl ;;
+    adopt)
+      timeout 300 tests/c/adopt_sequence 64 512 2>&1 | tail -12 ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done

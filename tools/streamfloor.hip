@@ -1,0 +1,206 @@
+// streamfloor.hip -- what the memory system of this chip gives the ACCESS MIXES of the block-GMRES kernels, free of their
+// arithmetic and of their structure.  Two synthetic twins:
+//
+//   panel   the Gram-Schmidt step of csrc/panel.hip (panel_nn_tn_kernel: read V_i, read Q, write Q, read V_{i+1} = 3R + 1W over
+//           n_pad x 16 doubles each) and the two-read form (panel_gemm_tn / axpby: 2R [+ 1W]) as plain streams: NR read streams and
+//           one in-place written stream, 8 or 16 bytes per lane and load, U loads in flight per stream and lane, flat tiles.
+//           The panel kernels load 8 B per lane (one MFMA operand element); BLAS-1 loads 16 B per lane.
+//   spmm    the tile SpMM of csrc/spmm_tile.hip at cfg 5 (27-point 216^3, p = 16): per group of 32 rows (a 4 x 4 x 2 grid tile)
+//           9 B per entry (8 B value + 1 B slot) + the group record, the 6 x 6 x 4 = 144 distinct panel rows of 128 B the tile
+//           references (same reuse between neighbouring tiles, same pencil order of the groups, same XCD split), 32 rows of Y
+//           written.  No LDS, no dependence between loads: every load of a group is issued before anything waits.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/streamfloor tools/streamfloor.hip ;  tools/streamfloor panel | spmm
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <typename F> static float timeit(F f, int reps) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); f(); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a)); for (int r = 0; r < reps; ++r) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
+}
+
+// ------------------------------------------------------------------------------------------------ panel streams
+template <typename T> struct Acc;
+template <> struct Acc<double> { static __device__ double mad(double a, double b, double c) { return fma(a, b, c); } };
+template <> struct Acc<dbl2> { static __device__ dbl2 mad(dbl2 a, dbl2 b, dbl2 c) { dbl2 o; o.x = fma(a.x, b.x, c.x); o.y = fma(a.y, b.y, c.y); return o; } };
+
+// q <- q + 0.5 v [+ 0.25 u]; NR = 2: reads v, q; NR = 3: reads v, q, u.  WRITE = false: reads only (the TN product's mix).
+template <typename T, int NR, int U, bool WRITE, bool NTS>
+__global__ __launch_bounds__(256) void k_panel(const T *v, T *q, const T *u, long nv, double *sink) {
+  const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
+  T a[U], b[U], c[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < nv) { a[j] = v[i]; b[j] = q[i]; if (NR == 3) c[j] = u[i]; } }
+  T half, quarter, acc;
+  memset(&acc, 0, sizeof(T));
+  if constexpr (sizeof(T) == 8) { half = 0.5; quarter = 0.25; } else { half = dbl2{0.5, 0.5}; quarter = dbl2{0.25, 0.25}; }
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < nv) {
+      T o = Acc<T>::mad(half, a[j], b[j]);
+      if (NR == 3) o = Acc<T>::mad(quarter, c[j], o);
+      if (WRITE) { if (NTS) __builtin_nontemporal_store(o, q + i); else q[i] = o; } else acc = Acc<T>::mad(o, o, acc);
+  } }
+  if (!WRITE) {
+    double s; if constexpr (sizeof(T) == 8) s = acc; else s = acc.x + acc.y;
+    if (s == 12345.678) *sink = s;
+  }
+}
+
+template <typename T, int NR, int U, bool WRITE, bool NTS>
+static void run_panel(const char *name, double *v, double *q, double *u, long n, double *sink) {
+  const long nv = n * 8 / (long)sizeof(T);
+  const long G = (nv + 256L * U - 1) / (256L * U);
+  const float ms = timeit([&] { hipLaunchKernelGGL((k_panel<T, NR, U, WRITE, NTS>), dim3((unsigned)G), dim3(256), 0, 0, (const T *)v, (T *)q, (const T *)u, nv, sink); }, 20);
+  const double bytes = (double)(NR + (WRITE ? 1 : 0)) * 8.0 * (double)n;
+  printf("%-10s %2d B/lane  U=%d  nts=%d  %.3f ms  %7.0f GB/s  %.3f of 8 TB/s\n", name, (int)sizeof(T), U, (int)NTS, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+  fflush(stdout);
+}
+
+static void panel_main(long rows, int p) {
+  const long n = ((rows + 15) / 16 * 16) * p;          // doubles of one panel (cfg 5: 10,077,696 x 16 = 1.29 GB)
+  double *v, *q, *u, *sink;
+  CK(hipMalloc(&v, n * 8)); CK(hipMalloc(&q, n * 8)); CK(hipMalloc(&u, n * 8)); CK(hipMalloc(&sink, 8));
+  CK(hipMemset(v, 0, n * 8)); CK(hipMemset(q, 0, n * 8)); CK(hipMemset(u, 0, n * 8));
+  printf("panel streams: %ld x %d doubles per panel (%.2f GB)\n", rows, p, n * 8 / 1e9);
+#define BOTH(NAME, NR, WRITE, NTS) \
+  run_panel<double, NR, 4, WRITE, NTS>(NAME, v, q, u, n, sink); run_panel<double, NR, 8, WRITE, NTS>(NAME, v, q, u, n, sink); \
+  run_panel<double, NR, 16, WRITE, NTS>(NAME, v, q, u, n, sink); \
+  run_panel<dbl2, NR, 2, WRITE, NTS>(NAME, v, q, u, n, sink); run_panel<dbl2, NR, 4, WRITE, NTS>(NAME, v, q, u, n, sink); \
+  run_panel<dbl2, NR, 8, WRITE, NTS>(NAME, v, q, u, n, sink)
+  BOTH("2R", 2, false, false);
+  BOTH("2R+1W", 2, true, false);
+  BOTH("2R+1W", 2, true, true);
+  BOTH("3R", 3, false, false);
+  BOTH("3R+1W", 3, true, false);
+  BOTH("3R+1W", 3, true, true);
+}
+
+// ------------------------------------------------------------------------------------------------ tile SpMM twin
+struct TwinArgs {
+  const dbl2 *val;       // 8 B per entry, contiguous per group: epg entries
+  const dbl2 *slot;      // 1 B per entry
+  const dbl2 *rec;       // record: 32 x 12 B + 144 x 4 B = 960 B per group
+  const dbl2 *X;         // n x 16 doubles, row-major
+  dbl2 *Y;
+  int n1, tiles_x, tiles_y, tiles_z;
+  long groups;
+  int epg;               // entries per group (27 x 32 = 864 in the interior)
+  int waves_total;       // persistent waves
+  int pencil;            // tile rows per pencil (4)
+  int xrows;             // 1: read the 144 panel rows; 0: skip them (the matrix-stream floor)
+  int entries;           // 1: read the entry / record streams
+};
+
+__device__ __forceinline__ void tile_of_group(const TwinArgs &a, long g, int &tx, int &ty, int &tz) {
+  // pencils of `pencil` tile rows walked through all planes: for P: for tz: for ty in pencil: for tx
+  const long per_pencil = (long)a.pencil * a.tiles_x * a.tiles_z;
+  const long P = g / per_pencil;
+  long r = g - P * per_pencil;
+  const int rows_here = (int)((P + 1) * a.pencil <= a.tiles_y ? a.pencil : a.tiles_y - P * a.pencil);
+  const long per_plane = (long)rows_here * a.tiles_x;
+  tz = (int)(r / per_plane); r -= (long)tz * per_plane;
+  ty = (int)(P * a.pencil + r / a.tiles_x);
+  tx = (int)(r % a.tiles_x);
+}
+
+__global__ __launch_bounds__(256) void k_spmm_twin(TwinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= a.waves_total) return;
+  // XCD x (= workgroup number mod 8) takes the x-th of eight contiguous runs of groups
+  const int xcd = blockIdx.x & 7;
+  const long waves_per_xcd = a.waves_total / 8;
+  const long w_in_xcd = (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+  const long g0 = a.groups * xcd / 8, g1 = a.groups * (xcd + 1) / 8;
+  const int n1 = a.n1;
+  for (long g = g0 + w_in_xcd; g < g1; g += waves_per_xcd) {
+    int tx, ty, tz;
+    tile_of_group(a, g, tx, ty, tz);
+    dbl2 acc = {0.0, 0.0};
+    dbl2 e[8], xr[18];
+    // entries: epg x 8 B = epg / 2 vectors of 16 B; slots epg / 16 vectors; record 60 vectors
+    if (a.entries) {
+      const dbl2 *vp = a.val + g * (a.epg / 2);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) { const int i = j * 64 + lane; e[j] = i < a.epg / 2 ? vp[i] : dbl2{0.0, 0.0}; }
+      const dbl2 *sp = a.slot + g * (a.epg / 16);
+      const dbl2 *rp = a.rec + g * 60;
+      e[7] = lane < a.epg / 16 ? sp[lane] : (lane < 60 ? rp[lane] : dbl2{0.0, 0.0});
+      if (lane < a.epg / 16 && lane < 60) { const dbl2 t = rp[lane]; e[7].x += t.x; e[7].y += t.y; }
+    }
+    // the 6 x 6 x 4 panel rows around the tile (clipped at the faces): 8 lanes per 128-byte row, 8 rows per instruction
+    if (a.xrows) {
+#pragma unroll
+      for (int j = 0; j < 18; ++j) {
+        const int r = j * 8 + (lane >> 3);            // 0 .. 143 : (dz, dy, dx) in 4 x 6 x 6
+        const int dx = r % 6, dy = (r / 6) % 6, dz = r / 36;
+        int x = tx * 4 - 1 + dx, y = ty * 4 - 1 + dy, z = tz * 2 - 1 + dz;
+        x = x < 0 ? 0 : (x >= n1 ? n1 - 1 : x); y = y < 0 ? 0 : (y >= n1 ? n1 - 1 : y); z = z < 0 ? 0 : (z >= n1 ? n1 - 1 : z);
+        const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
+        xr[j] = a.X[row * 8 + (lane & 7)];
+      }
+    }
+    if (a.entries) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc.x += e[j].x; acc.y += e[j].y; }
+    }
+    if (a.xrows) {
+#pragma unroll
+      for (int j = 0; j < 18; ++j) { acc.x += xr[j].x; acc.y += xr[j].y; }
+    }
+    // Y: the tile's 32 rows, 8 rows per instruction
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 8 + (lane >> 3);              // (dz, dy, dx) in 2 x 4 x 4
+      const int x = tx * 4 + (r & 3), y = ty * 4 + ((r >> 2) & 3), z = tz * 2 + (r >> 4);
+      const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
+      a.Y[row * 8 + (lane & 7)] = acc;
+    }
+  }
+}
+
+static void spmm_main(int n1) {
+  TwinArgs a;
+  a.n1 = n1; a.tiles_x = n1 / 4; a.tiles_y = n1 / 4; a.tiles_z = n1 / 2;
+  a.groups = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+  a.epg = 864; a.pencil = 4;
+  const long n = (long)n1 * n1 * n1;
+  double *val, *slot, *rec, *X, *Y;
+  CK(hipMalloc(&val, a.groups * a.epg * 8)); CK(hipMalloc(&slot, a.groups * a.epg)); CK(hipMalloc(&rec, a.groups * 960));
+  CK(hipMalloc(&X, n * 128)); CK(hipMalloc(&Y, n * 128));
+  CK(hipMemset(val, 0, a.groups * a.epg * 8)); CK(hipMemset(slot, 0, a.groups * a.epg)); CK(hipMemset(rec, 0, a.groups * 960));
+  CK(hipMemset(X, 0, n * 128)); CK(hipMemset(Y, 0, n * 128));
+  a.val = (const dbl2 *)val; a.slot = (const dbl2 *)slot; a.rec = (const dbl2 *)rec; a.X = (const dbl2 *)X; a.Y = (dbl2 *)Y;
+  const double nnz = 27.0 * n - 0.0;                  // the real operator has 7n - ... fewer at the faces; the twin streams 27 per row
+  const double stream = (double)a.groups * (a.epg * 9.0 + 960.0);
+  const double alg = 12.0 * nnz + 4.0 * (n + 1) + 2.0 * 128.0 * n;
+  printf("tile SpMM twin: %d^3 rows, %ld groups, matrix-side stream %.2f GB (9 B per entry + 960 B records), X + Y %.2f GB, algorithmic (SURVEY 8d) %.3f GB\n",
+         n1, a.groups, stream / 1e9, 2.0 * 128.0 * n / 1e9, alg / 1e9);
+  for (int mode = 0; mode < 3; ++mode) {
+    a.entries = mode != 1; a.xrows = mode != 0;
+    for (int wpc : {8, 12, 16, 24, 32}) {
+      a.waves_total = 256 * wpc;
+      const int blocks = a.waves_total / 4;
+      const float ms = timeit([&] { hipLaunchKernelGGL(k_spmm_twin, dim3(blocks), dim3(256), 0, 0, a); }, 10);
+      printf("%-34s waves/CU=%2d  %.3f ms  (algorithmic bytes / time = %.0f GB/s = %.3f of 8 TB/s)\n",
+             mode == 0 ? "entries + records + Y" : (mode == 1 ? "panel rows + Y" : "entries + records + panel rows + Y"), wpc, ms,
+             alg / ms / 1e6, alg / ms / 1e6 / 8000.0);
+      fflush(stdout);
+    }
+  }
+}
+
+int main(int argc, char **argv) {
+  const char *mode = argc > 1 ? argv[1] : "panel";
+  if (strcmp(mode, "panel") == 0) panel_main(argc > 2 ? atol(argv[2]) : 10077696L, 16);
+  else if (strcmp(mode, "spmm") == 0) spmm_main(argc > 2 ? atoi(argv[2]) : 216);
+  else { printf("usage: streamfloor panel [rows] | spmm [n1]\n"); return 2; }
+  return 0;
+}
