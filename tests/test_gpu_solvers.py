@@ -637,8 +637,11 @@ def test_block_gmres_storage_formula(K, ctx, oracle):
     B = S @ np.stack([t ** j for j in range(p)], axis=1)
     ws = K.BlockGmresWorkspace(ctx, n, n, p, memory=mem)
     formula = 8 * (2 * n * p + p * p + 2 * p * p + mem * p + mem * n * p + mem * p * p + (mem * (mem + 1) // 2) * p * p + mem * 2 * p * p)
-    extra = 8 * n * p + 8 * (2 * mem + 1) * p * p
+    # a workspace on the caller's panels (the default of the Python mirror, as julia/KrylovHIP) reads B in place: no panel copy
+    extra = (0 if ws.adopted else 8 * n * p) + 8 * (2 * mem + 1) * p * p
     assert ws.nbytes_extra == extra and ws.nbytes == formula + extra
+    wo = K.BlockGmresWorkspace(ctx, n, n, p, memory=mem, adopt=False)
+    assert wo.nbytes_extra == 8 * n * p + 8 * (2 * mem + 1) * p * p and wo.nbytes == formula + wo.nbytes_extra
     Bd = ctx.array(np.asfortranarray(B).ravel(order="F"))
     K.block_gmres_(ws, dA, Bd, itmax=mem)                                          # as the reference's test: itmax = mem, no basis growth
     assert ws.stats.niter == mem and ws.nbytes == formula + extra                  # the in-place solve allocated nothing

@@ -17,18 +17,19 @@ for stage in "$@"; do
   case $stage in
     tests)
       rm -f gpurun_out/parity_log.jsonl
-      timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | tail -15
+      timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -25
       timeout 100 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)
       timeout 400 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_setting.json 2> gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench_driver_setting.json
       timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2>> gpurun_out/${TAG}_bench.err; tail -c 300 gpurun_out/${TAG}_bench.json ;;
     floors)
       timeout 200 tools/streamfloor panel > gpurun_out/${TAG}_panel_stream_floor.log 2>&1; cat gpurun_out/${TAG}_panel_stream_floor.log
-      timeout 200 tools/streamfloor spmm > gpurun_out/${TAG}_spmm_floor.log 2>&1; cat gpurun_out/${TAG}_spmm_floor.log ;;
+      timeout 300 tools/streamfloor spmm > gpurun_out/${TAG}_spmm_floor.log 2>&1; cat gpurun_out/${TAG}_spmm_floor.log
+      timeout 200 tools/streamfloor cgfold > gpurun_out/${TAG}_cgfold_twin.log 2>&1; cat gpurun_out/${TAG}_cgfold_twin.log ;;
     slab)
       rm -f gpurun_out/${TAG}_slab_iteration.jsonl
       timeout 200 python tools/slab_iteration.py --only 1 --out gpurun_out/${TAG}_slab_iteration.jsonl 2>&1 | tail -2
-      for N in 2 4 8; do timeout 200 python tools/slab_iteration.py --only $N --variants --out gpurun_out/${TAG}_slab_iteration.jsonl 2>&1 | tail -3; done ;;
+      for N in 2 4 8; do timeout 200 python tools/slab_iteration.py --only $N --variants --out gpurun_out/${TAG}_slab_iteration.jsonl 2>&1 | grep '^{' | cut -c1-200; done ;;
     slabprof)
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_slab8_stats -o s -- python $R/tools/slab_iteration.py --only 8 --out $R/gpurun_out/${TAG}_slab8_prof.jsonl > $R/gpurun_out/${TAG}_slab8_prof.log 2>&1; echo "slabprof exit $?")
       head -12 gpurun_out/${TAG}_slab8_stats/s_kernel_stats.csv | cut -c1-220 ;;

@@ -96,6 +96,7 @@ struct TwinArgs {
   int pencil;            // tile rows per pencil (4)
   int xrows;             // 1: read the 144 panel rows; 0: skip them (the matrix-stream floor)
   int entries;           // 1: read the entry / record streams
+  int sx, sy, sz;        // tile shape in grid points (4 x 4 x 2 = the 32-row groups of csrc/spmm_tile.hip; 4 x 4 x 4: 64 rows per group)
 };
 
 __device__ __forceinline__ void tile_of_group(const TwinArgs &a, long g, int &tx, int &ty, int &tz) {
@@ -124,68 +125,85 @@ __global__ __launch_bounds__(256) void k_spmm_twin(TwinArgs a) {
     int tx, ty, tz;
     tile_of_group(a, g, tx, ty, tz);
     dbl2 acc = {0.0, 0.0};
-    dbl2 e[8], xr[18];
-    // entries: epg x 8 B = epg / 2 vectors of 16 B; slots epg / 16 vectors; record 60 vectors
+    dbl2 e[16], xr[32];
+    const int rows = a.sx * a.sy * a.sz;               // 32 or 64
+    const int nvec = a.epg / 2;                        // 16-byte vectors of values
+    // entries: epg x 8 B = epg / 2 vectors of 16 B; slots epg / 16 vectors; record 60 (120) vectors
     if (a.entries) {
-      const dbl2 *vp = a.val + g * (a.epg / 2);
+      const dbl2 *vp = a.val + g * (long)nvec;
 #pragma unroll
-      for (int j = 0; j < 7; ++j) { const int i = j * 64 + lane; e[j] = i < a.epg / 2 ? vp[i] : dbl2{0.0, 0.0}; }
-      const dbl2 *sp = a.slot + g * (a.epg / 16);
-      const dbl2 *rp = a.rec + g * 60;
-      e[7] = lane < a.epg / 16 ? sp[lane] : (lane < 60 ? rp[lane] : dbl2{0.0, 0.0});
-      if (lane < a.epg / 16 && lane < 60) { const dbl2 t = rp[lane]; e[7].x += t.x; e[7].y += t.y; }
+      for (int j = 0; j < 14; ++j) { const int i = j * 64 + lane; e[j] = i < nvec ? vp[i] : dbl2{0.0, 0.0}; }
+      const dbl2 *sp = a.slot + g * (long)(a.epg / 16);
+      const dbl2 *rp = a.rec + g * (long)(rows * 60 / 32);
+      e[14] = lane < a.epg / 16 ? sp[lane] : dbl2{0.0, 0.0};
+      if (lane + 64 < a.epg / 16) { const dbl2 t = sp[lane + 64]; e[14].x += t.x; e[14].y += t.y; }
+      e[15] = lane < rows * 60 / 32 ? rp[lane] : dbl2{0.0, 0.0};
+      if (lane + 64 < rows * 60 / 32) { const dbl2 t = rp[lane + 64]; e[15].x += t.x; e[15].y += t.y; }
     }
-    // the 6 x 6 x 4 panel rows around the tile (clipped at the faces): 8 lanes per 128-byte row, 8 rows per instruction
+    // the (sx + 2) x (sy + 2) x (sz + 2) panel rows around the tile (clipped at the faces): 8 lanes per 128-byte row
+    const int wx = a.sx + 2, wy = a.sy + 2, wz = a.sz + 2, nwin = wx * wy * wz;
     if (a.xrows) {
 #pragma unroll
-      for (int j = 0; j < 18; ++j) {
-        const int r = j * 8 + (lane >> 3);            // 0 .. 143 : (dz, dy, dx) in 4 x 6 x 6
-        const int dx = r % 6, dy = (r / 6) % 6, dz = r / 36;
-        int x = tx * 4 - 1 + dx, y = ty * 4 - 1 + dy, z = tz * 2 - 1 + dz;
-        x = x < 0 ? 0 : (x >= n1 ? n1 - 1 : x); y = y < 0 ? 0 : (y >= n1 ? n1 - 1 : y); z = z < 0 ? 0 : (z >= n1 ? n1 - 1 : z);
-        const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
-        xr[j] = a.X[row * 8 + (lane & 7)];
+      for (int j = 0; j < 32; ++j) {
+        const int r = j * 8 + (lane >> 3);
+        xr[j] = dbl2{0.0, 0.0};
+        if (r < nwin) {
+          const int dx = r % wx, dy = (r / wx) % wy, dz = r / (wx * wy);
+          int x = tx * a.sx - 1 + dx, y = ty * a.sy - 1 + dy, z = tz * a.sz - 1 + dz;
+          x = x < 0 ? 0 : (x >= n1 ? n1 - 1 : x); y = y < 0 ? 0 : (y >= n1 ? n1 - 1 : y); z = z < 0 ? 0 : (z >= n1 ? n1 - 1 : z);
+          const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
+          xr[j] = a.X[row * 8 + (lane & 7)];
+        }
       }
     }
     if (a.entries) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { acc.x += e[j].x; acc.y += e[j].y; }
+      for (int j = 0; j < 16; ++j) { acc.x += e[j].x; acc.y += e[j].y; }
     }
     if (a.xrows) {
 #pragma unroll
-      for (int j = 0; j < 18; ++j) { acc.x += xr[j].x; acc.y += xr[j].y; }
+      for (int j = 0; j < 32; ++j) { acc.x += xr[j].x; acc.y += xr[j].y; }
     }
-    // Y: the tile's 32 rows, 8 rows per instruction
+    // Y: the tile's rows, 8 rows per instruction
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j * 8 + (lane >> 3);              // (dz, dy, dx) in 2 x 4 x 4
-      const int x = tx * 4 + (r & 3), y = ty * 4 + ((r >> 2) & 3), z = tz * 2 + (r >> 4);
-      const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
-      a.Y[row * 8 + (lane & 7)] = acc;
+    for (int j = 0; j < 8; ++j) {
+      const int r = j * 8 + (lane >> 3);
+      if (r < rows) {
+        const int x = tx * a.sx + r % a.sx, y = ty * a.sy + (r / a.sx) % a.sy, z = tz * a.sz + r / (a.sx * a.sy);
+        const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
+        a.Y[row * 8 + (lane & 7)] = acc;
+      }
     }
   }
 }
 
+static void spmm_shape(int n1, int sx, int sy, int sz);
 static void spmm_main(int n1) {
+  spmm_shape(n1, 4, 4, 2);          // the groups of csrc/spmm_tile.hip
+  spmm_shape(n1, 4, 4, 4);          // 64 rows per group: 216 instead of 2 x 144 panel rows per 64 rows
+  spmm_shape(n1, 8, 4, 2);          // 64 rows per group, 10 x 6 x 4 = 240 panel rows
+}
+static void spmm_shape(int n1, int sx, int sy, int sz) {
   TwinArgs a;
-  a.n1 = n1; a.tiles_x = n1 / 4; a.tiles_y = n1 / 4; a.tiles_z = n1 / 2;
+  a.sx = sx; a.sy = sy; a.sz = sz;
+  a.n1 = n1; a.tiles_x = n1 / sx; a.tiles_y = n1 / sy; a.tiles_z = n1 / sz;
   a.groups = (long)a.tiles_x * a.tiles_y * a.tiles_z;
-  a.epg = 864; a.pencil = 4;
+  a.epg = 27 * sx * sy * sz; a.pencil = 4;
   const long n = (long)n1 * n1 * n1;
   double *val, *slot, *rec, *X, *Y;
-  CK(hipMalloc(&val, a.groups * a.epg * 8)); CK(hipMalloc(&slot, a.groups * a.epg)); CK(hipMalloc(&rec, a.groups * 960));
+  CK(hipMalloc(&val, a.groups * a.epg * 8)); CK(hipMalloc(&slot, a.groups * a.epg)); CK(hipMalloc(&rec, a.groups * 1920));
   CK(hipMalloc(&X, n * 128)); CK(hipMalloc(&Y, n * 128));
-  CK(hipMemset(val, 0, a.groups * a.epg * 8)); CK(hipMemset(slot, 0, a.groups * a.epg)); CK(hipMemset(rec, 0, a.groups * 960));
+  CK(hipMemset(val, 0, a.groups * a.epg * 8)); CK(hipMemset(slot, 0, a.groups * a.epg)); CK(hipMemset(rec, 0, a.groups * 1920));
   CK(hipMemset(X, 0, n * 128)); CK(hipMemset(Y, 0, n * 128));
   a.val = (const dbl2 *)val; a.slot = (const dbl2 *)slot; a.rec = (const dbl2 *)rec; a.X = (const dbl2 *)X; a.Y = (dbl2 *)Y;
   const double nnz = 27.0 * n - 0.0;                  // the real operator has 7n - ... fewer at the faces; the twin streams 27 per row
-  const double stream = (double)a.groups * (a.epg * 9.0 + 960.0);
+  const double stream = (double)a.groups * (a.epg * 9.0 + 30.0 * sx * sy * sz);
   const double alg = 12.0 * nnz + 4.0 * (n + 1) + 2.0 * 128.0 * n;
-  printf("tile SpMM twin: %d^3 rows, %ld groups, matrix-side stream %.2f GB (9 B per entry + 960 B records), X + Y %.2f GB, algorithmic (SURVEY 8d) %.3f GB\n",
-         n1, a.groups, stream / 1e9, 2.0 * 128.0 * n / 1e9, alg / 1e9);
+  printf("tile SpMM twin: %d^3 rows, tiles %d x %d x %d (%d panel rows per %d rows), %ld groups, matrix-side stream %.2f GB (9 B per entry + 30 B per row of records), X + Y %.2f GB, algorithmic (SURVEY 8d) %.3f GB\n",
+         n1, sx, sy, sz, (sx + 2) * (sy + 2) * (sz + 2), sx * sy * sz, a.groups, stream / 1e9, 2.0 * 128.0 * n / 1e9, alg / 1e9);
   for (int mode = 0; mode < 3; ++mode) {
     a.entries = mode != 1; a.xrows = mode != 0;
-    for (int wpc : {8, 12, 16, 24, 32}) {
+    for (int wpc : {4, 6, 8, 10, 12, 16}) {
       a.waves_total = 256 * wpc;
       const int blocks = a.waves_total / 4;
       const float ms = timeit([&] { hipLaunchKernelGGL(k_spmm_twin, dim3(blocks), dim3(256), 0, 0, a); }, 10);
@@ -195,12 +213,67 @@ static void spmm_main(int n1) {
       fflush(stdout);
     }
   }
+  CK(hipFree(val)); CK(hipFree(slot)); CK(hipFree(rec)); CK(hipFree(X)); CK(hipFree(Y));
+}
+
+// ------------------------------------------------------------------------------------------------ cg! update folded into the SpMV?
+// fold `x += alpha p_old` and `p = r + beta p_old` into the SpMV of the NEXT iteration (the
+// product gathers r and p_old instead of p, writes p_new, Ap and x): matrix + 72n instead of matrix + 80n bytes per iteration.
+// Twin of both forms on the 7-point 512^3 row walk with the coded operator's 63 B of matrix data per row (streamed as 64):
+//   now     : gather 1 vector at the 7 offsets, write y                                    (+ kernel C: 3 reads, 2 writes = 40n)
+//   folded  : gather 2 vectors at the 7 offsets, read x, write p_new, Ap, x                 (kernel C gone)
+template <int NG, int NEXTRA_R, int NW>
+__global__ __launch_bounds__(256) void k_cgfold(const double *__restrict__ g0, const double *__restrict__ g1, const dbl2 *__restrict__ st,
+                                                const double *__restrict__ xr, double *__restrict__ w0, double *__restrict__ w1,
+                                                double *__restrict__ w2, long n, int n1) {
+  const long tile = blockIdx.x;
+  const long i = tile * 256 + threadIdx.x;
+  const long d[7] = {-(long)n1 * n1, -(long)n1, -1, 0, 1, (long)n1, (long)n1 * n1};
+  dbl2 sv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sv[q] = st[(tile * 4 + q) * 256 + threadIdx.x];
+  double a[7], b[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { const long j = i + d[k]; const bool ok = j >= 0 && j < n; a[k] = ok ? g0[j] : 0.0; b[k] = (NG == 2 && ok) ? g1[j] : 0.0; }
+  double acc = NEXTRA_R ? xr[i] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) acc += fma(0.5, b[k], a[k]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc += sv[q].x + sv[q].y;
+  w0[i] = acc;
+  if (NW >= 2) w1[i] = acc + 1.0;
+  if (NW >= 3) w2[i] = acc + 2.0;
+}
+
+static void cgfold_main(int n1) {
+  const long n = (long)n1 * n1 * n1;
+  double *v[7]; dbl2 *st;
+  for (auto &p : v) { CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 0, n * 8)); }
+  CK(hipMalloc(&st, n * 64)); CK(hipMemset(st, 0, n * 64));
+  const unsigned G = (unsigned)(n / 256);
+  printf("cg! update folded into the SpMV? twin on the 7-point %d^3 row walk, 64 B of matrix data per row\n", n1);
+  for (int rep = 0; rep < 2; ++rep) {
+    const float t_now = timeit([&] { hipLaunchKernelGGL((k_cgfold<1, 0, 1>), dim3(G), dim3(256), 0, 0, v[0], v[1], st, v[2], v[3], v[4], v[5], n, n1); }, 10);
+    const float t_fold = timeit([&] { hipLaunchKernelGGL((k_cgfold<2, 1, 3>), dim3(G), dim3(256), 0, 0, v[0], v[1], st, v[2], v[3], v[4], v[5], n, n1); }, 10);
+    const float t_g2 = timeit([&] { hipLaunchKernelGGL((k_cgfold<2, 0, 1>), dim3(G), dim3(256), 0, 0, v[0], v[1], st, v[2], v[3], v[4], v[5], n, n1); }, 10);
+    // kernel C of today: x += a p ; p = r + b p  (3 reads, 2 writes)
+    const long nv = n / 2;
+    const long GC = (nv + 256L * 4 - 1) / (256L * 4);
+    const float t_c = timeit([&] { hipLaunchKernelGGL((k_panel<dbl2, 3, 4, true, false>), dim3((unsigned)GC), dim3(256), 0, 0, (const dbl2 *)v[0], (dbl2 *)v[1], (const dbl2 *)v[2], nv, v[6]);
+                                   hipLaunchKernelGGL((k_panel<dbl2, 2, 4, true, false>), dim3((unsigned)GC), dim3(256), 0, 0, (const dbl2 *)v[3], (dbl2 *)v[4], (const dbl2 *)v[2], nv, v[6]); }, 10);
+    printf("SpMV twin now (1 gathered vector, 1 store)             %.3f ms\n", t_now);
+    printf("SpMV twin, 2 gathered vectors, 1 store                 %.3f ms\n", t_g2);
+    printf("SpMV twin folded (2 gathered, + read x, 3 stores)      %.3f ms   (+%.3f ms over now)\n", t_fold, t_fold - t_now);
+    printf("streams of today's update kernel as 3R+1W then 2R+1W (56n; the real kernel moves 40n in one pass: 0.875 ms, profiles/r04_rocprofv3_kernel_stats.csv)  %.3f ms\n", t_c);
+    fflush(stdout);
+  }
 }
 
 int main(int argc, char **argv) {
   const char *mode = argc > 1 ? argv[1] : "panel";
   if (strcmp(mode, "panel") == 0) panel_main(argc > 2 ? atol(argv[2]) : 10077696L, 16);
   else if (strcmp(mode, "spmm") == 0) spmm_main(argc > 2 ? atoi(argv[2]) : 216);
-  else { printf("usage: streamfloor panel [rows] | spmm [n1]\n"); return 2; }
+  else if (strcmp(mode, "cgfold") == 0) cgfold_main(argc > 2 ? atoi(argv[2]) : 512);
+  else { printf("usage: streamfloor panel [rows] | spmm [n1] | cgfold [n1]\n"); return 2; }
   return 0;
 }
