@@ -283,3 +283,30 @@ if 23 in which or 24 in which:
                 x_index=idx, x_sample=[float(full.x[i]) for i in idx], seconds=time.time() - t0))
     finally:
         ok.lib().ko_set_dot_mode(0)
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Leg 25: cfg 5 BEYOND THE STENCIL -- block_gmres!(memory = 5, restart = true), p = 16, on the
+# "banded + random, fixed seed" operator of tools/bench_irregular.py (10 x 2^20 rows, ~26 entries per row, symmetric, seed 1;
+# ko_csr_banded_random == csrc/gen_irregular.cpp entry for entry, tests/test_abi.py), B = A X_true, atol = rtol = 0,
+# 20 iterations = four cycles: the non-stencil parity pin at full size, and the evidence that the slow decay of the residual on
+# this operator (the HIP path's 400-iteration stall, profiles/r04_bench_irregular.jsonl) is the ALGORITHM's.
+# ---------------------------------------------------------------------------------------------------------------------
+if 25 in which:
+    t0 = time.time()
+    n, p, mem, iters = 10 * (1 << 20), 16, 5, 20
+    A = ok.banded_random(n, seed=1)
+    Xt = cfg5_xtrue(A.n, p)
+    B = np.stack([A.matvec(np.ascontiguousarray(Xt[:, j])) for j in range(p)], axis=1)
+    res = ok.block_gmres(A, B, memory=mem, restart=True, atol=0.0, rtol=0.0, itmax=iters, history=True)
+    assert res.niter == iters, (res.niter, res.status)
+    idx = sample_idx(A.n)
+    dump("oracle_cfg5_banded_block.json", dict(
+        generator="tests/golden/make_scale_golden.py 25",
+        oracle="oracle/krylov_oracle.c ko_block_gmres (src/block_gmres.jl:110-358)",
+        config="cfg 5 on the non-stencil operator: block_gmres!(memory = 5, restart = true), p = 16, banded + random (n = 10 * 2^20, "
+               "half_band 13, links 3, seed 1, symmetric; ko_csr_banded_random), B = A*X_true with X_true[i, j] = cos(j pi (i+1)/n) + 0.1 j, "
+               "atol = rtol = 0, 20 iterations",
+        n=A.n, nnz=A.nnz, p=p, memory=mem, niter=res.niter, status=res.status,
+        residuals=[float(v) for v in res.residuals], x_index=idx,
+        x_sample=[[float(v) for v in res.x[i]] for i in idx],
+        max_err_after_20=float(np.abs(res.x - Xt).max()), seconds=time.time() - t0))

@@ -9,6 +9,7 @@
 #   slabprof  rocprofv3 --kernel-trace --stats of the N = 8 slab iteration
 #   prof      rocprofv3 --kernel-trace --stats of bench.py; PMC passes of the SpMV (tools/gpu_prof.sh)
 #   cfg5      cfg-5 block-GMRES: kernel stats + bench_configs.py
+#   ilu       tools/bench_ilu.py 64 128 256
 #   adopt     tests/c/adopt_sequence 64 512
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; TAG=${1:-r05}; shift; mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -39,6 +40,8 @@ for stage in "$@"; do
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfg5_stats -o s -- python $R/tools/cfg5_only.py > $R/gpurun_out/${TAG}_cfg5_prof.log 2>&1; echo "cfg5 prof exit $?")
       head -14 gpurun_out/${TAG}_cfg5_stats/s_kernel_stats.csv | cut -c1-220
       timeout 600 python tools/bench_configs.py > gpurun_out/${TAG}_bench_configs.jsonl 2> gpurun_out/${TAG}_bench_configs.err; cut -c1-400 gpurun_out/${TAG}_bench_configs.jsonl ;;
+    ilu)
+      timeout 400 python tools/bench_ilu.py 64 128 256 > gpurun_out/${TAG}_bench_ilu.jsonl 2> gpurun_out/${TAG}_bench_ilu.err; cut -c1-500 gpurun_out/${TAG}_bench_ilu.jsonl ;;
     adopt)
       timeout 300 tests/c/adopt_sequence 64 512 2>&1 | tail -12 ;;
     *) echo "unknown stage $stage" ;;
