@@ -48,6 +48,11 @@ int khip_test_householder_signs(int p, int64_t n, double *Q1, double *S, double 
  * 3 the inverse of an upper triangular n x n matrix into C. */
 int khip_test_small_dense(int which, int m, int n, int nc, double *A, double *tau, double *Cmat);
 
+/* test-only: how many lazily built accelerators (coded / delta column streams, SpMM tile records) failed to build for a reason
+ * OTHER than an out-of-memory device since the library was loaded -- such a failure degrades to the plain kernels (results stay
+ * right) and is a defect of the builder; the GPU test session asserts 0 (tests/conftest.py). */
+int khip_test_optional_build_failures(int *count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,7 @@ SIGNATURES = {
     "khip_test_deflating_chol": (_int, [_int, c_double_p, C.c_double, _int, C.c_uint, c_double_p, C.POINTER(_int), C.POINTER(C.c_uint)]),
     "khip_test_householder_r": (_int, [_int, _int, c_double_p, c_double_p]),
     "khip_test_householder_signs": (_int, [_int, _i64, c_double_p, c_double_p, c_double_p]),
+    "khip_test_optional_build_failures": (_int, [C.POINTER(_int)]),
     "khip_test_sym_givens": (_int, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     "khip_test_roots_quadratic": (_int, [C.c_double, C.c_double, C.c_double, _int, c_double_p, c_double_p]),
     "khip_test_to_boundary": (_int, [_vp, _i64, _vp, _vp, C.c_double, _int, c_double_p, c_double_p]),

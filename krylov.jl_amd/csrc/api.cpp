@@ -13,7 +13,25 @@ enum MapOpHost { H_COPY = 0, H_FILL, H_SCAL, H_SCALCOPY, H_DIVCOPY, H_AXPY, H_AX
 constexpr int kPadHost = 8;
 }  // namespace khip
 
+namespace khip {
+static int g_optional_build_failures = 0;
+void optional_build(int rc) {
+  if (rc == KHIP_OK) return;
+  const hipError_t e = hipGetLastError();                       // clears the sticky error of the failed call
+  if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) return;   // a full device: the other kernels serve the product
+  ++g_optional_build_failures;
+  fprintf(stderr, "libkrylov_hip: an optional accelerator build failed (%d: %s; HIP: %s) -- falling back to the plain kernels\n", rc,
+          khip_last_error(), hipGetErrorString(e));
+}
+}  // namespace khip
+
 extern "C" {
+
+int khip_test_optional_build_failures(int *count) {
+  KHIP_REQUIRE(count, "test_optional_build_failures: null output");
+  *count = khip::g_optional_build_failures;
+  return KHIP_OK;
+}
 
 void khip_version(int *major, int *minor) {
   if (major) *major = KHIP_VERSION_MAJOR;

@@ -896,6 +896,8 @@ void csr_free_tiles(khip_csr *A) {
   A->tile_meta = nullptr;
   A->tile_direct_list = nullptr;
   A->tile_state = 0;
+  A->tile_run_len = 0;
+  A->tile_runs = 0;
 }
 
 static TileOrder tile_order_for(const khip_csr *A, bool tiles) {

@@ -743,8 +743,9 @@ __global__ __launch_bounds__(kBlock) void spmv_delta_kernel(SpmvArgs a, RedArgs 
       int eidx = -1;
       if (has_esc) {
         eidx = (int)(s - c0) + epos;
-        if (eidx < lim) { ev = a.val[s + epos]; ex = gather_x<DIST>(a, ecol); } else eidx = -1;
-        if (eidx >= CAP || eidx < 0) eidx = -1;
+        // an escape of an earlier / later window of a multi-window row block is skipped BEFORE its loads (a negative
+        // index used to fetch val and gather x only to be discarded)
+        if (eidx >= 0 && eidx < lim && eidx < CAP) { ev = a.val[s + epos]; ex = gather_x<DIST>(a, ecol); } else eidx = -1;
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {

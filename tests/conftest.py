@@ -40,6 +40,11 @@ def ctx(K):
         pytest.fail("GPU test selected but /dev/kfd is absent: the HIP path has no CPU fallback")
     c = K.Context(0)
     yield c
+    # no lazily built accelerator may have failed for a reason other than a full device (such a failure falls back
+    # to the plain kernels, so result-only tests would still pass)
+    import ctypes
+    cnt = ctypes.c_int(-1)
+    assert K.lib().khip_test_optional_build_failures(ctypes.byref(cnt)) == 0 and cnt.value == 0, cnt.value
     c.close()
 
 
