@@ -9,4 +9,4 @@ timeout 600 bash tools/gpu_r04_irregular_pmc.sh > gpurun_out/r04a_irregular_pmc.
 timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r04a_bench.json 2> gpurun_out/r04a_bench.err; echo "bench exit $?"; cut -c1-600 gpurun_out/r04a_bench.json
 timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-full-parity --opt compensated=0 > gpurun_out/r04a_bench_nocomp.json 2>/dev/null; cut -c1-200 gpurun_out/r04a_bench_nocomp.json
 timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-full-parity > gpurun_out/r04a_bench_100.json 2>/dev/null; cut -c1-200 gpurun_out/r04a_bench_100.json
-timeout 200 python tools/sweep7.py 512 > gpurun_out/r04a_sweep7_coded_plane.log 2>&1; cat gpurun_out/r04a_sweep7_coded_plane.log
+timeout 200 python tools/sweep_plane_order.py 512 > gpurun_out/r04a_sweep7_coded_plane.log 2>&1; cat gpurun_out/r04a_sweep7_coded_plane.log
