@@ -165,3 +165,26 @@ def test_block_gmres_adopted_equals_owned(K, ctx, restart):
         res[adopt] = (ws.stats, ws.X)
     _same(res[True][0], res[False][0])
     assert np.array_equal(res[True][1], res[False][1])
+
+
+def test_bench_line_names_the_adopt_entry_and_carries_the_int32_leg():
+    """bench.py's one JSON line (here at 96^3, 6 steps): config.entry says the timed solve ran through khip_cg_workspace_adopt, and
+    the nested, labelled general-CSR leg (int32 columns, spmv_codes = 0) is present beside the headline's roofline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KHIP_SPMV_CODES="2")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--n1", "96", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["steps"] == 6 and d["n_gpus"] == 1 and d["value"] > 0
+    assert "khip_cg_workspace_adopt" in d["config"]["entry"]
+    r, r32 = d["roofline"], d["roofline_int32_csr"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] and r["bytes_moved_per_launch"] < r["bytes_per_launch"]        # 8-bit codes: fewer bytes moved
+    assert r32 is not None and "NOT_THE_HEADLINE" in r32 and r32["bytes_per_launch"] == r["bytes_per_launch"]
+    assert r32["steps"] == 6 and r32["avg_ms"] > 0 and 0 < r32["frac"]
