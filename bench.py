@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PARITY_ITERS = 100          # iterations of the oracle history (tests/golden/oracle_cfg2_cg512.json)
-PMC_PROFILE = "r04_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
+PMC_PROFILE = "r05_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
 
 

@@ -74,7 +74,22 @@ int khip_ctx_create(int device, void *stream, khip_ctx **out) {
     KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
   }
-  KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+  // The communication stream carries the halo exchange that is meant to run UNDER the interior rows of a product.  At default
+  // priority its (small) RCCL kernel is dispatched behind the product's remaining workgroups and finishes only when the product
+  // drains (rocprofv3 trace of the N = 8 slab iteration, profiles/r05b_slab8_one_iteration_trace.txt: 260 us under a 263 us
+  // product) -- i.e. the transfer would start late on real links.  Highest priority lets its workgroups in first.
+  // KHIP_COMM_PRIORITY=0 keeps the default priority (A/B).
+  {
+    int least = 0, greatest = 0;
+    const char *pe = getenv("KHIP_COMM_PRIORITY");
+    const bool high = !pe || atoi(pe) != 0;
+    if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+      KHIP_CHECK_HIP(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest));
+    } else {
+      (void)hipGetLastError();
+      KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    }
+  }
   for (int i = 0; i < khip_ctx::kEvRing; ++i) {
     KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_a[i], hipEventDisableTiming));
     KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_b[i], hipEventDisableTiming));

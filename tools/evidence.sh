@@ -9,6 +9,8 @@
 #   slabprof  rocprofv3 --kernel-trace --stats of the N = 8 slab iteration
 #   prof      rocprofv3 --kernel-trace --stats of bench.py; PMC passes of the SpMV (tools/gpu_prof.sh)
 #   cfg5      cfg-5 block-GMRES: kernel stats + bench_configs.py
+#   prio      halo-stream priority A/B at the N = 8 slab + kernel trace
+#   newtests  the GPU tests added last
 #   ilu       tools/bench_ilu.py 64 128 256
 #   adopt     tests/c/adopt_sequence 64 512
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
@@ -40,6 +42,13 @@ for stage in "$@"; do
       (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_cfg5_stats -o s -- python $R/tools/cfg5_only.py > $R/gpurun_out/${TAG}_cfg5_prof.log 2>&1; echo "cfg5 prof exit $?")
       head -14 gpurun_out/${TAG}_cfg5_stats/s_kernel_stats.csv | cut -c1-220
       timeout 600 python tools/bench_configs.py > gpurun_out/${TAG}_bench_configs.jsonl 2> gpurun_out/${TAG}_bench_configs.err; cut -c1-400 gpurun_out/${TAG}_bench_configs.jsonl ;;
+    prio)
+      # halo stream priority A/B on the N = 8 slab (same box): KHIP_COMM_PRIORITY = 1 (default: highest) vs 0
+      for P in 1 0 1 0; do KHIP_COMM_PRIORITY=$P timeout 200 python tools/slab_iteration.py --only 8 --out gpurun_out/${TAG}_slab_prio$P.jsonl 2>&1 | grep '^{' | cut -c1-170; done
+      (cd /tmp && KHIP_COMM_PRIORITY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_slab8p_stats -o s -- python $R/tools/slab_iteration.py --only 8 --out $R/gpurun_out/${TAG}_slab8p_prof.jsonl > $R/gpurun_out/${TAG}_slab8p_prof.log 2>&1; echo "slab8 priority trace exit $?") ;;
+    newtests)
+      timeout 900 python -m pytest tests/test_gpu_scale_parity.py::test_block_gmres_cfg5_banded_random_matches_oracle tests/test_gpu_adopt.py tests/test_gpu_self_halo.py -q 2>&1 | tail -8
+      grep banded gpurun_out/parity_log.jsonl | tail -1 ;;
     ilu)
       timeout 400 python tools/bench_ilu.py 64 128 256 > gpurun_out/${TAG}_bench_ilu.jsonl 2> gpurun_out/${TAG}_bench_ilu.err; cut -c1-500 gpurun_out/${TAG}_bench_ilu.jsonl ;;
     adopt)
