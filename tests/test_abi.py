@@ -236,7 +236,8 @@ def _julia_ccalls(paths=None):
     """(symbol, return type, [argument types], number of actual arguments) of every ccall((:sym, lib), ...) in the shipped Julia
     package (julia/KrylovHIP/src/KrylovHIP.jl) and in the remaining snippets of INTEGRATION.md (the multi-GPU set-up)."""
     import re
-    txt = "\n".join(open(f).read() for f in (paths or (JULIA_SRC, os.path.join(ROOT, "INTEGRATION.md"))))
+    txt = "\n".join(open(f).read() for f in (paths or (JULIA_SRC, os.path.join(ROOT, "julia", "KrylovHIP", "examples", "mpi_krylov_hip.jl"),
+                                                      os.path.join(ROOT, "INTEGRATION.md"))))
     out = []
     for m in re.finditer(r"ccall\(\(:(khip_[a-z0-9_]+),\s*lib\),\s*([A-Za-z0-9_{}]+),\s*\(", txt):
         sym, ret = m.group(1), m.group(2)
