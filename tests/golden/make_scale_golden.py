@@ -310,3 +310,30 @@ if 25 in which:
         residuals=[float(v) for v in res.residuals], x_index=idx,
         x_sample=[[float(v) for v in res.x[i]] for i in idx],
         max_err_after_20=float(np.abs(res.x - Xt).max()), seconds=time.time() - t0))
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Leg 26: how sensitive IS the recurrence of leg 25?  The same oracle solve with every entry of B moved by ONE ULP (factor
+# 1 +- 2^-52, seeded signs), 8 iterations; the relative change of each residual norm is stored in the golden of leg 25 as
+# `one_ulp_sensitivity`.  (Measured: 1.6e-16 at iteration 1, 1.8e-8 at iteration 2, 1e-7 .. 1e-6 up to iteration 7, 2.6e-5 at
+# iteration 8 -- block-GMRES with 16 trigonometric right-hand sides on this operator amplifies rounding by 1e8 .. 1e11 within
+# one cycle, in the ORACLE.  binary128 is out of reach at 10.5 M rows x 16, so this is the yardstick the GPU test's tolerance
+# is derived from.)  3 minutes on 8 cores.
+# ---------------------------------------------------------------------------------------------------------------------
+if 26 in which:
+    t0 = time.time()
+    n, p, mem, iters = 10 * (1 << 20), 16, 5, 8
+    A = ok.banded_random(n, seed=1)
+    Xt = cfg5_xtrue(A.n, p)
+    B = np.stack([A.matvec(np.ascontiguousarray(Xt[:, j])) for j in range(p)], axis=1)
+    rng = np.random.default_rng(11)
+    Bp = B * (1.0 + (rng.integers(0, 2, size=B.shape) * 2 - 1) * 2.0 ** -52)
+    res = ok.block_gmres(A, Bp, memory=mem, restart=True, atol=0.0, rtol=0.0, itmax=iters, history=True)
+    path = os.path.join(HERE, "oracle_cfg5_banded_block.json")
+    g = json.load(open(path))
+    h, href = np.array(res.residuals), np.array(g["residuals"][:iters + 1])
+    sv = np.linalg.svd(np.linalg.qr(B, mode="r"), compute_uv=False)
+    g["one_ulp_sensitivity"] = [float(abs(a - b) / b) for a, b in zip(h, href)]
+    g["one_ulp_sensitivity_note"] = ("relative change of the ORACLE's residual norms (iterations 0..8) when every entry of B is moved by one ulp "
+                                     "(make_scale_golden.py leg 26); cond_2(B) = %.1f" % float(sv[0] / sv[-1]))
+    g["one_ulp_sensitivity_seconds"] = time.time() - t0
+    dump("oracle_cfg5_banded_block.json", g)
