@@ -252,6 +252,12 @@ def lib():
         fn = getattr(L, name)      # AttributeError here == header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    # khip_options / khip_stats are passed by pointer without a size field: a binding must have been written against the ABI
+    # version the library reports; this mirror follows include/krylov_hip.h of version 0.3 (adopt entries, log_fd)
+    major, minor = C.c_int(), C.c_int()
+    L.khip_version(C.byref(major), C.byref(minor))
+    if (major.value, minor.value) != (0, 3):
+        raise ImportError(f"{LIB_PATH} reports ABI {major.value}.{minor.value}; krylov.jl_amd/__init__.py binds 0.3: rebuild (build.sh)")
     _lib = L
     return L
 
