@@ -18,6 +18,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL between processes needs dmabuf IPC on this driver (hipIpcGetMemHandle fails in legacy mode): set before any HIP runtime loads,
+# whatever launcher started this rank (the self-launcher below sets it too; torch.distributed.run inherits the caller's environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PARITY_ITERS = 100          # iterations of the oracle history (tests/golden/oracle_cfg2_cg512.json)
 PMC_PROFILE = "r05_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
