@@ -31,7 +31,11 @@
 
 namespace khip {
 
-constexpr int kTileR = 32;          // rows per group (two passes of 16 rows x 4 lanes)
+#ifndef KHIP_TILE_ROWS
+#define KHIP_TILE_ROWS 32           // rows per group.  64 (an experiment build, -DKHIP_TILE_ROWS=64): 4 x 4 x 4 grid tiles, 216 instead of 2 x 144 panel rows
+#endif                              // per 64 rows of the 27-point operator -- the synthetic twin's floor is 13 % lower for them (profiles/r05b_spmm_floor.log)
+constexpr int kTileR = KHIP_TILE_ROWS;   // rows per group (p = 16: kTileR / 16 passes of 16 rows x 4 lanes)
+static_assert(kTileR == 32 || kTileR == 64, "spmm_tile: groups of 32 or 64 rows");
 constexpr int kTileLen = 32;        // entries per row the register path takes
 constexpr int kTileCapMax = 256;    // distinct panel rows per group (one-byte slots); the window is cap x 128 B of LDS
 constexpr int kTileDescBytes = kTileR * 16;
@@ -707,11 +711,12 @@ __device__ int tile_group_unique(TileBuildShared &S, const int32_t *rowptr, cons
       __syncthreads();
     }
   }
-  // unique: thread t owns keys 4 t .. 4 t + 3
+  // unique: thread t owns keys KPT t .. KPT t + KPT - 1
+  constexpr int KPT = kTileKeys / kBlock;
   int mine = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int q = 4 * tid + j;
+  for (int j = 0; j < KPT; ++j) {
+    const int q = KPT * tid + j;
     const int k = S.keys[q];
     mine += (k != kTileEmpty && (q == 0 || S.keys[q - 1] != k)) ? 1 : 0;
   }
@@ -726,8 +731,8 @@ __device__ int tile_group_unique(TileBuildShared &S, const int32_t *rowptr, cons
   const int n_uniq = S.scan[kBlock - 1];
   int pos = S.scan[tid] - mine;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int q = 4 * tid + j;
+  for (int j = 0; j < KPT; ++j) {
+    const int q = KPT * tid + j;
     const int k = S.keys[q];
     if (k != kTileEmpty && (q == 0 || S.keys[q - 1] != k)) S.uniq[pos++] = k;
   }
@@ -917,7 +922,8 @@ static TileOrder tile_order_for(const khip_csr *A, bool tiles) {
       case 5: o.bi = 32; o.bj = 1; o.bk = 1; break;
       default: o.bi = 4; o.bj = 4; o.bk = 2; break;
     }
-  } else { o.bi = 8; o.bj = 4; o.bk = 1; }
+    if (kTileR == 64) { if (shape == 6) o.bi *= 2; else if (shape == 7) o.bj *= 2; else o.bk *= 2; }      // 64-row groups: 4 x 4 x 4 by default (6: 8 x 4 x 2, 7: 4 x 8 x 2)
+  } else { o.bi = 8; o.bj = kTileR / 8; o.bk = 1; }
   o.gi = (o.n1 + o.bi - 1) / o.bi;
   o.gj = (o.n2 + o.bj - 1) / o.bj;
   o.gk = (o.n3 + o.bk - 1) / o.bk;
