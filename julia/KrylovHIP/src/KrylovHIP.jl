@@ -150,7 +150,9 @@ end
 kmul!(y::HIPVector, M::HIPOperator, x::HIPVector) = mul!(y, M, x)
 
 # ------------------------------------------------------------------------------------------------ shared pieces of the forwarding methods
-const HANDLES = IdDict{Any,Ptr{Cvoid}}()      # Julia workspace -> its khip_*_workspace handle (adopted once, destroyed with it)
+# Julia workspace -> its khip_*_workspace handle: adopted once, destroyed by the workspace's finalizer.  Weak keys (identity of the mutable
+# workspace): the table must not keep a workspace alive.  The finalizers capture the handle and do not touch the table.
+const HANDLES = WeakKeyDict{Any,Ptr{Cvoid}}()
 dptr(v::HIPVector) = isempty(v) ? Ptr{Cdouble}(C_NULL) : v.ptr
 native_precond(M) = M === I || M isa HIPOperator
 opref(M) = M === I ? Ptr{Operator}(C_NULL) : Base.unsafe_convert(Ptr{Operator}, M.op)
@@ -177,8 +179,9 @@ function cg_handle(ws::CgWs)
     r = Ref{Ptr{Cvoid}}()
     ck(ccall((:khip_cg_workspace_adopt, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
              CTX[].h, ws.m, ws.n, ws.x.ptr, ws.r.ptr, ws.p.ptr, ws.Ap.ptr, r))
-    finalizer(w -> (h = pop!(HANDLES, w, C_NULL); h == C_NULL || ccall((:khip_cg_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h)), ws)
-    r[]
+    h = r[]
+    finalizer(_ -> ccall((:khip_cg_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h), ws)
+    h
   end
 end
 cg_adopt(h, name, v::HIPVector) = ck(ccall((:khip_cg_workspace_adopt_vector, lib), Cint, (Ptr{Cvoid}, Cstring, Ptr{Cdouble}), h, name, dptr(v)))
@@ -222,8 +225,9 @@ function gmres_handle(ws::GmresWs)
     ck(ccall((:khip_gmres_workspace_adopt, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Ptr{Cdouble}}, Ref{Ptr{Cvoid}}),
              CTX[].h, ws.m, ws.n, length(ws.c), ws.x.ptr, ws.w.ptr, Vp, r))
     ck(ccall((:khip_gmres_workspace_set_grow, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), r[], GROW_VECTOR[], pointer_from_objref(ws)))
-    finalizer(w -> (h = pop!(HANDLES, w, C_NULL); h == C_NULL || ccall((:khip_gmres_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h)), ws)
-    r[]
+    h = r[]
+    finalizer(_ -> ccall((:khip_gmres_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h), ws)
+    h
   end
 end
 # khip_grow_fn: restart = false lets the basis outgrow `memory` -- push!(V, similar(x)), src/gmres.jl:319-324
@@ -286,8 +290,9 @@ function bicgstab_handle(ws::BicgstabWs)
     ck(ccall((:khip_bicgstab_workspace_adopt, lib), Cint,
              (Ptr{Cvoid}, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Ptr{Cvoid}}),
              CTX[].h, ws.m, ws.n, ws.x.ptr, ws.r.ptr, ws.p.ptr, ws.v.ptr, ws.s.ptr, ws.qd.ptr, r))
-    finalizer(w -> (h = pop!(HANDLES, w, C_NULL); h == C_NULL || ccall((:khip_bicgstab_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h)), ws)
-    r[]
+    h = r[]
+    finalizer(_ -> ccall((:khip_bicgstab_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h), ws)
+    h
   end
 end
 bicgstab_adopt(h, name, v::HIPVector) = ck(ccall((:khip_bicgstab_workspace_adopt_vector, lib), Cint, (Ptr{Cvoid}, Cstring, Ptr{Cdouble}), h, name, dptr(v)))
@@ -402,8 +407,9 @@ function block_gmres_handle(ws::BlockGmresWs)
     ck(ccall((:khip_block_gmres_workspace_adopt, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Ptr{Cdouble}}, Ref{Ptr{Cvoid}}),
              CTX[].h, ws.m, ws.n, ws.p, length(ws.V), ws.X.ptr, ws.W.ptr, Vp, r))
     ck(ccall((:khip_block_gmres_workspace_set_grow, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), r[], GROW_PANEL[], pointer_from_objref(ws)))
-    finalizer(w -> (h = pop!(HANDLES, w, C_NULL); h == C_NULL || ccall((:khip_block_gmres_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h)), ws)
-    r[]
+    h = r[]
+    finalizer(_ -> ccall((:khip_block_gmres_workspace_destroy, lib), Cint, (Ptr{Cvoid},), h), ws)
+    h
   end
 end
 function grow_panel(ud::Ptr{Cvoid})::Ptr{Cdouble}            # push!(V, SM(undef, n, p)), src/block_gmres.jl:300-305 (a zeroed panel)
