@@ -3,6 +3,7 @@
 # gpu_r0x_*.sh of earlier rounds).  Run on the GPU box: gpurun --timeout 900 -- 'bash tools/evidence.sh r05 tests bench'
 # Stages (any order, each under its own timeout; outputs under gpurun_out/, copy what is to be judged into profiles/):
 #   tests     pytest -m gpu (parity log -> gpurun_out/parity_log.jsonl) + smoke()
+#   tests_create  the GPU suite with KHIP_PY_WORKSPACES=create (library-owned workspaces)
 #   bench     bench.py at the driver's setting (20 steps, 5 warm-up) and at 100 steps
 #   floors    tools/streamfloor: 2R / 3R (+1W) panel streams, tile-SpMM twin
 #   slab      tools/slab_iteration.py: one rank's CG iteration at the N = 1 / 2 / 4 / 8 slab shapes, self halo over RCCL
@@ -22,6 +23,8 @@ for stage in "$@"; do
       rm -f gpurun_out/parity_log.jsonl
       timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -25
       timeout 100 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    tests_create)      # the same suite on library-owned workspaces (khip_*_workspace_create), the other kind the ABI offers
+      KHIP_PY_WORKSPACES=create timeout 1200 python -m pytest tests -q -m gpu --deselect tests/test_gpu_adopt.py 2>&1 | tail -6 ;;
     bench)
       timeout 400 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_setting.json 2> gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench_driver_setting.json
       timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2>> gpurun_out/${TAG}_bench.err; tail -c 300 gpurun_out/${TAG}_bench.json ;;
