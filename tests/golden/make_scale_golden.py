@@ -337,3 +337,62 @@ if 26 in which:
                                      "(make_scale_golden.py leg 26); cond_2(B) = %.1f" % float(sv[0] / sv[-1]))
     g["one_ulp_sensitivity_seconds"] = time.time() - t0
     dump("oracle_cfg5_banded_block.json", g)
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Legs 27 / 28: the VECTOR solvers on the non-stencil operators at full size (10 x 2^20 rows), documented dots and exact (Dot2) dots:
+#   27: cg! on banded + random (symmetric, seed 1), b = A x_true with x_true = cos(1e-3 i) + 0.5 (tools/bench_irregular.py), atol = rtol = 0, 100 iterations;
+#       and the full solve to rtol 1e-8 (the oracle needs ~210 iterations)
+#   28: gmres!(30, restart) and bicgstab! on the nonsymmetric variant with four rows of 3000 further entries, b = A x_true, 45 / 25 iterations
+# These products run through the LDS stream kernel / the strided vector kernel for the dense rows, not the staged stencil kernels.
+# ~10 minutes on 8 cores.
+# ---------------------------------------------------------------------------------------------------------------------
+def _irregular_case(unsym):
+    n = 10 * (1 << 20)
+    A = ok.banded_random(n, seed=1, unsym=unsym, dense_rows=4 if unsym else 0)
+    xt = np.cos(np.arange(n) * 1e-3) + 0.5
+    return A, A.matvec(xt)
+
+
+if 27 in which:
+    t0 = time.time()
+    A, b = _irregular_case(False)
+    idx = sample_idx(A.n)
+    out = dict(generator="tests/golden/make_scale_golden.py 27", oracle="oracle/krylov_oracle.c ko_cg (src/cg.jl:120-291); *_exact = with ko_set_dot_mode(1) (Dot2 dots)",
+               config="cg! on banded + random (n = 10 * 2^20, half_band 13, links 3, seed 1, symmetric), b = A (cos(1e-3 i) + 0.5); prefix: atol = rtol = 0, "
+                      "100 iterations; full: atol = 0, rtol = 1e-8", n=A.n, nnz=A.nnz, x_index=idx)
+    for tag, mode in (("", 0), ("_exact", 1)):
+        ok.lib().ko_set_dot_mode(mode)
+        try:
+            pre = ok.cg(A, b, atol=0.0, rtol=0.0, itmax=100, history=True)
+            full = ok.cg(A, b, atol=0.0, rtol=FULL_RTOL, itmax=A.n, history=True)
+        finally:
+            ok.lib().ko_set_dot_mode(0)
+        out["prefix_residuals" + tag] = [float(v) for v in pre.residuals]
+        out["prefix_x_sample" + tag] = [float(pre.x[i]) for i in idx]
+        out["niter" + tag], out["status" + tag] = full.niter, full.status
+        out["residuals" + tag] = [float(v) for v in full.residuals]
+    out["seconds"] = time.time() - t0
+    dump("oracle_irregular_cg.json", out)
+
+if 28 in which:
+    t0 = time.time()
+    A, b = _irregular_case(True)
+    idx = sample_idx(A.n)
+    out = dict(generator="tests/golden/make_scale_golden.py 28",
+               oracle="oracle/krylov_oracle.c ko_gmres (src/gmres.jl:121-384), ko_bicgstab (src/bicgstab.jl:125-277); *_exact = with ko_set_dot_mode(1) (Dot2 dots)",
+               config="banded + random, nonsymmetric, four rows of 3000 further entries (n = 10 * 2^20, seed 1), b = A (cos(1e-3 i) + 0.5), atol = rtol = 0: "
+                      "gmres!(memory = 30, restart = true) 45 iterations; bicgstab! 25 iterations", n=A.n, nnz=A.nnz, x_index=idx)
+    for tag, mode in (("", 0), ("_exact", 1)):
+        ok.lib().ko_set_dot_mode(mode)
+        try:
+            g = ok.gmres(A, b, memory=30, restart=True, atol=0.0, rtol=0.0, itmax=45, history=True)
+            bi = ok.bicgstab(A, b, atol=0.0, rtol=0.0, itmax=25, history=True)
+        finally:
+            ok.lib().ko_set_dot_mode(0)
+        out["gmres_residuals" + tag] = [float(v) for v in g.residuals]
+        out["gmres_x_sample" + tag] = [float(g.x[i]) for i in idx]
+        out["bicgstab_residuals" + tag] = [float(v) for v in bi.residuals]
+        out["bicgstab_x_sample" + tag] = [float(bi.x[i]) for i in idx]
+        out["bicgstab_niter" + tag], out["bicgstab_status" + tag] = bi.niter, bi.status
+    out["seconds"] = time.time() - t0
+    dump("oracle_irregular_gmres_bicgstab.json", out)

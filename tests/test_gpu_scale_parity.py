@@ -554,3 +554,88 @@ def test_partitioned_solvers_at_full_size_against_the_exact_dot_oracle(K, ctx, p
     parity_log(test="partitioned_cfg2_full_solve_vs_exact_dot_oracle", ranks=8, iterations=niter, hist_max_rel=dc,
                bit_identical_history=bool(np.array_equal(h, hf)))
     assert dc <= 1e-12, dc
+
+
+# ---- the vector solvers on the NON-STENCIL operators at full size (round 5) ------------------------------------------------
+# tests/golden/oracle_irregular_cg.json / oracle_irregular_gmres_bicgstab.json (make_scale_golden.py legs 27 / 28): cg! on the 10.5 M-row
+# banded + random operator, gmres!(30, restart) and bicgstab! on its nonsymmetric variant with four rows of 3000 further entries --
+# products through the LDS stream kernel and the strided vector kernel, not the staged stencil kernels -- against the oracle with the
+# documented dots and with exact (Dot2) dots.  Asserted as for cfg 4: <= 1e-12 against the exact-dot history (the HIP dots are Dot2 too;
+# two faithful dots may differ by an ulp), and <= d + 1e-12 against the documented history, d = the documented oracle's own distance to
+# its exact-dot variant, computed from the two histories of the golden.
+
+def _irregular_rhs(K, ctx, A, n):
+    xt = ctx.array(np.cos(np.arange(n) * 1e-3) + 0.5)
+    b = ctx.zeros(n)
+    A.matvec(xt, b)                                # bit-identical to the oracle's serial product
+    return b
+
+
+def _own_distance(a, b):
+    a, b = np.array(a), np.array(b)
+    k = min(len(a), len(b))
+    return float(np.max(np.abs(a[:k] - b[:k]) / b[:k]))
+
+
+@pytest.mark.parametrize("fused", [2, 0])
+def test_irregular_cg_full_size_against_the_oracles(K, ctx, parity_log, fused):
+    path = os.path.join(ROOT, "tests", "golden", "oracle_irregular_cg.json")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated (make_scale_golden.py 27)")
+    g = json.load(open(path))
+    n = g["n"]
+    A = K.CsrMatrix.banded_random(ctx, n, seed=1)
+    assert A.nnz == g["nnz"]
+    b = _irregular_rhs(K, ctx, A, n)
+    ws = K.CgWorkspace(ctx, n, n)
+    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=100, history=True, fused=fused)
+    h = ws.stats.residuals
+    d = _own_distance(g["prefix_residuals"], g["prefix_residuals_exact"])
+    dev, dev_exact = _rel(h, np.array(g["prefix_residuals"])), _rel(h, np.array(g["prefix_residuals_exact"]))
+    xs = ws.x.to_host()[g["x_index"]]
+    xdev_exact = float(np.max(np.abs(xs - np.array(g["prefix_x_sample_exact"]))) / np.max(np.abs(g["prefix_x_sample_exact"])))
+    K.cg_(ws, A, b, atol=0.0, rtol=1e-8, itmax=n, history=True, fused=fused)
+    st = ws.stats
+    hf, he = st.residuals, np.array(g["residuals_exact"])
+    full_exact = _rel(hf, he) if len(hf) == len(he) else None
+    parity_log(test="irregular_cg_full_size", fused=fused, kernel=A.spmv_kernel_choice, prefix_vs_documented=dev, prefix_vs_exact=dev_exact,
+               documented_vs_exact=d, x_sample_vs_exact=xdev_exact, niter=st.niter, oracle_niter=g["niter"], oracle_niter_exact=g["niter_exact"],
+               full_vs_exact=full_exact)
+    assert dev_exact <= 1e-12, dev_exact
+    assert dev <= d + 1e-12, (dev, d)
+    assert xdev_exact <= 1e-12, xdev_exact
+    assert st.niter == g["niter_exact"] and st.status == g["status_exact"] and st.solved
+    assert full_exact is not None and full_exact <= 1e-12, full_exact
+    assert abs(st.niter - g["niter"]) <= 2           # the documented oracle's last iterates sit within a fraction of a percent of the threshold
+
+
+def test_irregular_gmres_bicgstab_full_size_against_the_oracles(K, ctx, parity_log):
+    path = os.path.join(ROOT, "tests", "golden", "oracle_irregular_gmres_bicgstab.json")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated (make_scale_golden.py 28)")
+    g = json.load(open(path))
+    n = g["n"]
+    A = K.CsrMatrix.banded_random(ctx, n, seed=1, unsym=True, dense_rows=4)
+    assert A.nnz == g["nnz"]
+    b = _irregular_rhs(K, ctx, A, n)
+    ws = K.GmresWorkspace(ctx, n, n, memory=30)
+    K.gmres_(ws, A, b, restart=True, atol=0.0, rtol=0.0, itmax=45, history=True)
+    hg = ws.stats.residuals
+    dg = _own_distance(g["gmres_residuals"], g["gmres_residuals_exact"])
+    g_dev, g_exact = _rel(hg, np.array(g["gmres_residuals"])), _rel(hg, np.array(g["gmres_residuals_exact"]))
+    xg = ws.x.to_host()[g["x_index"]]
+    gx_exact = float(np.max(np.abs(xg - np.array(g["gmres_x_sample_exact"]))) / np.max(np.abs(g["gmres_x_sample_exact"])))
+    del ws
+    wb = K.BicgstabWorkspace(ctx, n, n)
+    K.bicgstab_(wb, A, b, atol=0.0, rtol=0.0, itmax=25, history=True)
+    hb = wb.stats.residuals
+    db = _own_distance(g["bicgstab_residuals"], g["bicgstab_residuals_exact"])
+    b_dev, b_exact = _rel(hb, np.array(g["bicgstab_residuals"])), _rel(hb, np.array(g["bicgstab_residuals_exact"]))
+    parity_log(test="irregular_gmres_bicgstab_full_size", kernel=A.spmv_kernel_choice, gmres_vs_documented=g_dev, gmres_vs_exact=g_exact,
+               gmres_documented_vs_exact=dg, gmres_x_vs_exact=gx_exact, bicgstab_vs_documented=b_dev, bicgstab_vs_exact=b_exact,
+               bicgstab_documented_vs_exact=db)
+    assert g_exact <= 1e-12 and gx_exact <= 1e-12, (g_exact, gx_exact)
+    assert g_dev <= dg + 1e-12, (g_dev, dg)
+    assert wb.stats.niter == g["bicgstab_niter_exact"]
+    assert b_exact <= 1e-12, b_exact
+    assert b_dev <= db + 1e-12, (b_dev, db)
