@@ -427,9 +427,25 @@ __global__ __launch_bounds__(kBlock) void panel_multi_nn_lds_kernel(int64_t n_pa
   const int i = lane & 15, kq = lane >> 4;
   constexpr int KK = NT * 4;
   const int64_t tile0 = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * T;
+  // The A fragments of the NEXT factor (or of the next tile's first factor) are requested before the MFMA chain of the current
+  // one (round 5): with k a run-time count the loop is not unrolled, and a wave used to have the 2 KB of ONE factor tile in flight
+  // at a time -- k = 5 ran at 0.61 of peak where the one-factor form reaches the 1R + 1W floor (0.72).  Same operand values into
+  // the same MFMA chain in the same order: X stays bit-identical.
+  auto load_a = [&](int64_t r0, int j, double (&a)[KK]) {
+    const double *Vj = V.v[j];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const int vcol = 4 * kk + kq;
+      a[kk] = (vcol < p) ? Vj[(r0 + i) * p + vcol] : 0.0;
+    }
+  };
+  if (tile0 * 16 >= n_pad) return;
+  double af[KK], afn[KK];
+  load_a(tile0 * 16, 0, af);
   for (int t = 0; t < T; ++t) {
     const int64_t r0 = (tile0 + t) * 16;
     if (r0 >= n_pad) return;
+    const bool next_tile = t + 1 < T && r0 + 16 < n_pad;
     dbl4 x[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b)
@@ -440,13 +456,12 @@ __global__ __launch_bounds__(kBlock) void panel_multi_nn_lds_kernel(int64_t n_pa
       }
     double bcur = beta;
     for (int j = 0; j < k; ++j) {
-      const double *Vj = V.v[j];
+      if (j + 1 < k) load_a(r0, j + 1, afn);
+      else if (next_tile) load_a(r0 + 16, 0, afn);
       const double *Yj = s_Y + (size_t)j * pp;
-      double af[KK], bf[KK][NT];
+      double bf[KK][NT];
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        const int vcol = 4 * kk + kq;
-        af[kk] = (vcol < p) ? Vj[(r0 + i) * p + vcol] : 0.0;
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
           const int prow = 4 * kk + kq, pcol = 16 * b + i;
@@ -465,6 +480,8 @@ __global__ __launch_bounds__(kBlock) void panel_multi_nn_lds_kernel(int64_t n_pa
 #pragma unroll
         for (int g = 0; g < 4; ++g) x[b][g] = fma(alpha, acc[b][g], bcur * x[b][g]);
       bcur = 1.0;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) af[kk] = afn[kk];
     }
 #pragma unroll
     for (int b = 0; b < NT; ++b)
