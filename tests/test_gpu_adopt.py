@@ -188,3 +188,33 @@ def test_bench_line_names_the_adopt_entry_and_carries_the_int32_leg():
     assert r["bound"] == "hbm" and 0 < r["frac"] and r["bytes_moved_per_launch"] < r["bytes_per_launch"]        # 8-bit codes: fewer bytes moved
     assert r32 is not None and "NOT_THE_HEADLINE" in r32 and r32["bytes_per_launch"] == r["bytes_per_launch"]
     assert r32["steps"] == 6 and r32["avg_ms"] > 0 and 0 < r32["frac"]
+
+
+def test_adopt_argument_errors(K, ctx):
+    """The adopt entries validate what a binding hands over (error codes, never a crash; khip_last_error says why)."""
+    import ctypes as C
+    L = K.lib()
+    n = 1000
+    v = [ctx.empty(n) for _ in range(6)]
+    h = C.c_void_p()
+    assert L.khip_cg_workspace_adopt(ctx._h, n, n, v[0].ptr, v[0].ptr, v[2].ptr, v[3].ptr, C.byref(h)) == -1      # x and r alias
+    assert b"distinct" in L.khip_last_error()
+    assert L.khip_cg_workspace_adopt(ctx._h, n, n, v[0].ptr, None, v[2].ptr, v[3].ptr, C.byref(h)) == -1           # a null vector
+    assert L.khip_bicgstab_workspace_adopt(ctx._h, n, n, v[0].ptr, v[1].ptr, v[2].ptr, v[3].ptr, v[4].ptr, v[4].ptr, C.byref(h)) == -1
+    ptrs = (C.c_void_p * 3)(v[2].ptr, None, v[4].ptr)
+    assert L.khip_gmres_workspace_adopt(ctx._h, n, n, 3, v[0].ptr, v[1].ptr, ptrs, C.byref(h)) == -1                 # a null basis vector
+    ptrs = (C.c_void_p * 3)(v[2].ptr, v[3].ptr, v[4].ptr)
+    assert L.khip_gmres_workspace_adopt(ctx._h, n, n, 3, v[0].ptr, v[1].ptr, ptrs, C.byref(h)) == 0
+    assert L.khip_gmres_workspace_adopt_vector(h, b"x", None) == -1                                                 # x cannot be emptied
+    assert L.khip_gmres_workspace_adopt_vector(h, b"nope", v[5].ptr) == -1
+    two = (C.c_void_p * 2)(v[2].ptr, v[3].ptr)
+    assert L.khip_gmres_workspace_adopt_basis(h, 2, two) == -1                                                      # fewer vectors than the memory
+    assert L.khip_gmres_workspace_destroy(h) == 0
+    # a library-owned workspace keeps its basis to itself
+    ho = C.c_void_p()
+    assert L.khip_gmres_workspace_create(ctx._h, n, n, 3, C.byref(ho)) == 0
+    assert L.khip_gmres_workspace_adopt_basis(ho, 3, ptrs) == -1 and b"owns its basis" in L.khip_last_error()
+    assert L.khip_gmres_workspace_destroy(ho) == 0
+    for x in v:                                           # nothing of the caller's was freed along the way
+        K.kfill_(x, 1.0)
+    assert K.knorm(n, v[0]) == pytest.approx(np.sqrt(n))
