@@ -29,6 +29,7 @@ for stage in "$@"; do
       timeout 400 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_setting.json 2> gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench_driver_setting.json
       timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2>> gpurun_out/${TAG}_bench.err; tail -c 300 gpurun_out/${TAG}_bench.json ;;
     floors)
+      [ -x tools/streamfloor ] && [ tools/streamfloor -nt tools/streamfloor.hip ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/streamfloor tools/streamfloor.hip
       timeout 200 tools/streamfloor panel > gpurun_out/${TAG}_panel_stream_floor.log 2>&1; cat gpurun_out/${TAG}_panel_stream_floor.log
       timeout 300 tools/streamfloor spmm > gpurun_out/${TAG}_spmm_floor.log 2>&1; cat gpurun_out/${TAG}_spmm_floor.log
       timeout 200 tools/streamfloor cgfold > gpurun_out/${TAG}_cgfold_twin.log 2>&1; cat gpurun_out/${TAG}_cgfold_twin.log ;;
