@@ -627,6 +627,7 @@ static void launch_window(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, i
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {
   if (p < 1 || p > 64) { set_error("spmm: 1 <= p <= 64 required (got %d)", p); return KHIP_ERR_INVALID; }
   SpmvArgs a;
+  a.hole_lo = INT64_MAX; a.hole_len = 0;
   a.rowptr = A->rowptr; a.blockptr = nullptr; a.col = A->col; a.val = A->val; a.x = X; a.ghost = X; a.y = Y;
   a.n_owned = (int64_t)1 << 40;                      // single GPU: every column is owned
   if (A->dist && ctx->comm) {                        // row-partitioned: fetch the remote panel rows first (no overlap yet)

@@ -309,7 +309,8 @@ int fetch_results(khip_ctx *ctx, int slot, int count, double *out_host, bool alr
 // dot_slot >= 0: results[dot_slot] = dotw . y (dotw = x when null); dot_sq: also results[dot_slot + 1] = y . y
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot /* -1 = none */,
                 int64_t row_lo, int64_t row_hi, int64_t *wave_cursor = nullptr, bool finish = true,
-                const double *dotw = nullptr, int dot_sq = 0);     // dot_sq: 0 none, 1 second output y.y, 2 second output dotw.dotw
+                const double *dotw = nullptr, int dot_sq = 0,      // dot_sq: 0 none, 1 second output y.y, 2 second output dotw.dotw
+                int64_t hole_lo = 0, int64_t hole_hi = 0);         // hole_hi > hole_lo: rows [hole_lo, hole_hi) are left out (two ranges, one launch where the kernel can)
 int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A);
 int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p);
 int csr_finalize(khip_ctx *ctx, khip_csr *A);   // row statistics after arrays are resident

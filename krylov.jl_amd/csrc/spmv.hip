@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
   double *s_val = reinterpret_cast<double *>(s_stage);
   int32_t *s_col = reinterpret_cast<int32_t *>(s_stage + (size_t)CAP * sizeof(double));
   const int tid = threadIdx.x;
-  const int64_t nrows = a.row_hi - a.row_lo;
+  const int64_t nrows = a.row_hi - a.row_lo - a.hole_len;
   const int64_t nrb = (nrows + ROWS - 1) / ROWS;
   const int tpb = a.tiles_per_block > 0 ? a.tiles_per_block : 1;
   const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap, a.sweep_s, a.sweep_w);
@@ -215,7 +215,8 @@ __global__ __launch_bounds__(kBlock) void spmv_stage_kernel(SpmvArgs a, RedArgs 
   dacc[1] = dd{0.0, 0.0};
 
   for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
-    const int64_t r0 = a.row_lo + rb * ROWS;
+    int64_t r0 = a.row_lo + rb * ROWS;
+    if (r0 >= a.hole_lo) r0 += a.hole_len;   // the second range of a two-range launch
     const int nr = (int)((a.row_hi - r0) < ROWS ? (a.row_hi - r0) : ROWS);
     const int64_t s = a.rowptr[r0], e = a.rowptr[r0 + nr];
     const int my_a = (tid < nr) ? a.rowptr[r0 + tid] : 0;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
   int32_t *s_tab = reinterpret_cast<int32_t *>(s_stage + (size_t)CAP * (sizeof(double) + sizeof(CODE)));
   const int tid = threadIdx.x;
   const CODE *code = reinterpret_cast<const CODE *>(a.code);
-  const int64_t nrows = a.row_hi - a.row_lo;
+  const int64_t nrows = a.row_hi - a.row_lo - a.hole_len;
   const int64_t nrb = (nrows + ROWS - 1) / ROWS;
   const int tpb = a.tiles_per_block > 0 ? a.tiles_per_block : 1;
   const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap, a.sweep_s, a.sweep_w);
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
   for (int i = tid; i < a.code_T; i += kBlock) s_tab[i] = a.code_tab[i];
 
   for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
-    const int64_t r0 = a.row_lo + rb * ROWS;
+    int64_t r0 = a.row_lo + rb * ROWS;
+    if (r0 >= a.hole_lo) r0 += a.hole_len;   // the second range of a two-range launch
     const int nr = (int)((a.row_hi - r0) < ROWS ? (a.row_hi - r0) : ROWS);
     const int64_t s = a.rowptr[r0], e = a.rowptr[r0 + nr];
     const int my_a = (tid < nr) ? a.rowptr[r0 + tid] : 0;
@@ -1200,9 +1202,24 @@ int spmv_kernel_choice(const khip_ctx *ctx, const khip_csr *A) {
 }
 
 int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, int dot_slot, int64_t row_lo,
-                int64_t row_hi, int64_t *wave_cursor, bool finish, const double *dotw, int dot_sq) {
+                int64_t row_hi, int64_t *wave_cursor, bool finish, const double *dotw, int dot_sq, int64_t hole_lo, int64_t hole_hi) {
   int64_t local_cursor = 0;
   if (!wave_cursor) wave_cursor = &local_cursor;
+  // Two ranges [row_lo, hole_lo) and [hole_hi, row_hi) in one launch (the boundary rows of a row-partitioned product, api.cpp
+  // spmv_any): taken by the staged / coded kernels when the first range is whole row blocks; anything else runs them as two launches.
+  bool hole = hole_hi > hole_lo && hole_lo >= row_lo && hole_hi <= row_hi;
+  if (hole && (hole_lo == row_lo || hole_hi == row_hi)) {        // one of the ranges is empty: an ordinary launch
+    if (hole_lo == row_lo) row_lo = hole_hi; else row_hi = hole_lo;
+    hole = false;
+  }
+  if (hole) {
+    const bool one_launch = spmv_kernel_choice(ctx, A) == 4 && ((hole_lo - row_lo) & 255) == 0 && ctx->tune.spmv_pipe <= 0 &&
+                            ctx->tune.spmv_persist == 0 && ctx->tune.spmv_nt == 0 && ctx->tune.spmv_delta == 0 && ctx->tune.spmv_wide == 0;
+    if (!one_launch) {
+      KHIP_TRY(launch_spmv(ctx, A, x, y, dot_slot, row_lo, hole_lo, wave_cursor, false, dotw, dot_sq));
+      return launch_spmv(ctx, A, x, y, dot_slot, hole_hi, row_hi, wave_cursor, finish, dotw, dot_sq);
+    }
+  }
   const int nout = dot_sq ? 2 : 1;
   if (dot_sq && spmv_kernel_choice(ctx, A) != 4 && spmv_kernel_choice(ctx, A) != 5 && spmv_kernel_choice(ctx, A) != 1 && spmv_kernel_choice(ctx, A) != 6) { set_error("spmv: the second reduction output needs the staged, stream, wave or template kernel"); return KHIP_ERR_UNSUPPORTED; }
   if (row_hi <= row_lo) {
@@ -1220,6 +1237,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.x = x; a.ghost = A->ghost; a.y = y;
   a.n_owned = A->dist ? A->m : A->n;
   a.row_lo = row_lo; a.row_hi = row_hi;
+  a.hole_lo = hole ? hole_lo : INT64_MAX; a.hole_len = hole ? hole_hi - hole_lo : 0;
   a.xcd_remap = ctx->tune.spmv_xcd;
   a.sweep_s = ctx->tune.spmv_sweep_s;
   a.sweep_w = ctx->tune.spmv_sweep_w;
@@ -1246,7 +1264,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   const bool dot = dot_slot >= 0, comp = ctx->tune.compensated != 0, dist = A->dist;
   const bool persist = ctx->tune.spmv_persist != 0;
   const bool nt = ctx->tune.spmv_nt != 0;
-  const int64_t nrows = row_hi - row_lo;
+  const int64_t nrows = row_hi - row_lo - a.hole_len;
 
   hipEvent_t ev_stop = nullptr;
   if (ctx->tune.profile_spmv) {

@@ -24,6 +24,7 @@ struct SpmvArgs {
   double *y;
   int64_t n_owned;       // columns < n_owned read x, others read ghost
   int64_t row_lo, row_hi;
+  int64_t hole_lo, hole_len;   // staged / coded kernels: the launch covers [row_lo, hole_lo) and [hole_lo + hole_len, row_hi) -- the two boundary ranges of a row-partitioned product in ONE launch (hole_lo - row_lo is a multiple of the row block; hole_len = 0: none)
   int xcd_remap;         // see chunk_id() in spmv.hip
   int sweep_s, sweep_w;  // plane sweep (xcd_remap == -2): tiles per plane, tiles per XCD column
   int nt_y;              // non-temporal store of y
