@@ -4,7 +4,7 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/csrc"
-OUT="${KHIP_OUT:-$HERE/libkrylov_hip.so}"          # KHIP_OUT / KHIP_BUILD_DIR / KHIP_EXTRA_FLAGS: instrumented variants (tools/spmm_trace.py)
+OUT="${KHIP_OUT:-$HERE/libkrylov_hip.so}"          # KHIP_OUT / KHIP_BUILD_DIR / KHIP_EXTRA_FLAGS: instrumented variants (tools/archive/spmm_trace.py)
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I/opt/rocm/include $KHIP_EXTRA_FLAGS"
 BUILD="${KHIP_BUILD_DIR:-$HERE/build}"

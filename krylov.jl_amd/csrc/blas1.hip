@@ -724,7 +724,7 @@ static int launch_reduce(khip_ctx *ctx, int64_t n, const RedPtrs &p, int slot) {
   const bool nt = use_nt(ctx, n) && !(ROP == RED_AXPYDEV && keep == 2);
   const int64_t nvec = v2 ? n / 2 : n;
   // 16-byte accesses per lane: 4 for the read-only reductions of long vectors (dot 6.1 vs 5.8 TB/s, nrm2 6.1 vs 4.3),
-  // 1 for the ones that also write (r -= a Ap ; r.r: 5.96 vs 5.72 TB/s) -- measured at n = 512^3, tools/sweep_reduce_width.py
+  // 1 for the ones that also write (r -= a Ap ; r.r: 5.96 vs 5.72 TB/s) -- measured at n = 512^3, tools/archive/sweep_reduce_width.py
   constexpr bool writes = (ROP == RED_AXPY2 || ROP == RED_AXPYDEV || ROP == RED_AXPYSQ || ROP == RED_CGSETUP);
   const bool u4 = ctx->tune.red_u == 0 ? (!writes && nvec >= (int64_t)kBlock * 4 * 1024) : ctx->tune.red_u == 4;
   const int64_t g = tiles_for(nvec, u4 ? 4 : 1);

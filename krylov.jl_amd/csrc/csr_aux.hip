@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void spmm2_kernel(SpmvArgs a, int p) {
 // goes down the direct-gather path.  Same operations in the same order => Y is bit-identical to spmm2_kernel /
 // spmm_kernel / p SpMVs.
 //
-// What shaped the kernel (216^3, 27 points, p = 16; tools/spmm_window_check.py, rocprofv3 SQ counters):
+// What shaped the kernel (216^3, 27 points, p = 16; tools/archive/spmm_window_check.py, rocprofv3 SQ counters):
 //  * one-shot workgroups: 2.5 ms (direct gathers 3.05 ms) -- ~16 waves per CU, the LDS limit, cannot hide the three
 //    dependent latencies row pointer / list -> panel row -> product;
 //  * persistent workgroups with the next groups prefetched into registers: no gain until the prefetch stages were
@@ -233,7 +233,7 @@ struct BatchSpread<L, 8> {
   __device__ static __forceinline__ void run(const double (&)[8 / L], const int (&)[8 / L], double (&)[8], int (&)[8]) {}
 };
 
-// Phase stamps of one wave (tools/spmm_trace.py builds a variant of the library with -DKHIP_WIN_TRACE; compiled out otherwise):
+// Phase stamps of one wave (tools/archive/spmm_trace.py builds a variant of the library with -DKHIP_WIN_TRACE; compiled out otherwise):
 // wave 0 of workgroup 5 writes the shader clock at the phase boundaries of its iterations 8..23.  What it showed
 // (profiles/r02_spmm_trace.log, 216^3 x 16): of ~8500 cycles per row group, ~1200 go into writing the window to LDS,
 // ~2400 into ISSUING the 34 prefetch loads (the CU's texture path takes ~17 cycles per wave instruction and 8 waves issue

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kIluBlock) void ilu_small_levels_kernel(IluView v, 
 #ifndef KHIP_ILU_SPIN
 #define KHIP_ILU_SPIN (1 << 22)
 #endif
-// -DKHIP_ILU_TRACE: shader-clock stamps of the phases of 64 consecutive blocks of the lower solve (tools/ilu_trace.py)
+// -DKHIP_ILU_TRACE: shader-clock stamps of the phases of 64 consecutive blocks of the lower solve (tools/archive/ilu_trace.py)
 #ifdef KHIP_ILU_TRACE
 __device__ unsigned long long g_ilu_trace[64 * 8];
 #define ILU_STAMP(slot) do { if (KIND == 1 && lane == 0 && t >= a.nb / 2 && t < a.nb / 2 + 64) g_ilu_trace[(t - a.nb / 2) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)

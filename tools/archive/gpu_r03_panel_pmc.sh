@@ -6,7 +6,7 @@ R=$PWD; mkdir -p gpurun_out; export TMPDIR=/tmp
 for set in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"; do
   t=$(echo $set | cut -d' ' -f1)
   cd /tmp
-  timeout 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/prof_panel_$t -o c -- python $R/tools/panel_mgs_only.py > $R/gpurun_out/prof_panel_$t.log 2>&1
+  timeout 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/prof_panel_$t -o c -- python $R/tools/archive/panel_mgs_only.py > $R/gpurun_out/prof_panel_$t.log 2>&1
   cd $R
   python3 - "$t" <<'PY'
 import csv, collections, sys, glob

@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r04b_pytest.log 2>&1; echo "pytest exit $?"; tail -5 gpurun_out/r04b_pytest.log
-timeout 300 python tools/sweep_headline.py "" "spmv_blk_pub=0" "spmv_tiles=2" "spmv_tiles=4" "spmv_blk_pub=0,spmv_tiles=2" "compensated=0" > gpurun_out/r04b_sweep_headline.log 2>&1; cat gpurun_out/r04b_sweep_headline.log
-timeout 300 python tools/sweep_links.py > gpurun_out/r04b_sweep_links.log 2>&1; cat gpurun_out/r04b_sweep_links.log
+timeout 300 python tools/archive/sweep_headline.py "" "spmv_blk_pub=0" "spmv_tiles=2" "spmv_tiles=4" "spmv_blk_pub=0,spmv_tiles=2" "compensated=0" > gpurun_out/r04b_sweep_headline.log 2>&1; cat gpurun_out/r04b_sweep_headline.log
+timeout 300 python tools/archive/sweep_links.py > gpurun_out/r04b_sweep_links.log 2>&1; cat gpurun_out/r04b_sweep_links.log
 timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-full-parity > gpurun_out/r04b_bench_100.json 2>/dev/null; cut -c1-200 gpurun_out/r04b_bench_100.json
 timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-full-parity --opt spmv_blk_pub=0 > gpurun_out/r04b_bench_100_wavepub.json 2>/dev/null; cut -c1-200 gpurun_out/r04b_bench_100_wavepub.json

@@ -21,4 +21,4 @@ timeout 400 python tools/bench_irregular.py > gpurun_out/r04_bench_irregular.log
 timeout 100 python tools/bench_mtx.py --oracle tests/golden > gpurun_out/r04_bench_mtx.log 2>&1; cut -c1-300 gpurun_out/r04_bench_mtx.log
 timeout 300 python tools/bench_sizes.py > gpurun_out/r04_bench_sizes.jsonl 2>&1; tail -3 gpurun_out/r04_bench_sizes.jsonl | cut -c1-260
 timeout 300 python tools/bench_ilu.py 256 > gpurun_out/r04_bench_ilu.jsonl 2>&1; tail -2 gpurun_out/r04_bench_ilu.jsonl | cut -c1-400
-timeout 200 python tools/cg_solve_overhead.py > gpurun_out/r04_cg_solve_overhead.log 2>&1; cat gpurun_out/r04_cg_solve_overhead.log | cut -c1-200
+timeout 200 python tools/archive/cg_solve_overhead.py > gpurun_out/r04_cg_solve_overhead.log 2>&1; cat gpurun_out/r04_cg_solve_overhead.log | cut -c1-200
