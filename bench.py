@@ -418,6 +418,7 @@ def main():
     # column).  HIP-event average over the same number of steps.
     int32_leg = None
     if world == 1 and code_bits != 32 and not templates and args.variant == 0:
+        saved = {k: ctx.get_option(k) for k in ("spmv_codes", "profile_spmv")}     # a user's --opt spmv_codes=... survives the leg
         ctx.set_option("spmv_codes", 0)
         try:
             K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=max(args.warmup, 1), fused=args.fused)
@@ -440,7 +441,8 @@ def main():
                          "bytes_per_launch": A.spmv_bytes, "avg_ms": avg32, "launches_per_iteration": l32 / max(it32, 1),
                          "steps": int(it32), "cg_iters_per_sec": it32 / el32, "ms_per_step": 1e3 * el32 / max(it32, 1)}
         finally:
-            ctx.set_option("spmv_codes", 1)
+            for k, v in saved.items():
+                ctx.set_option(k, v)
     rccl_ranks = ctx.comm_info()["rccl_ranks"] if use_comm else 0
     if dist is not None:
         import torch

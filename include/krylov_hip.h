@@ -36,7 +36,8 @@ extern "C" {
 #define KHIP_ERR_NUMERIC     -5   /* e.g. operator not SPD (src/cg.jl:163,243) */
 
 #define KHIP_VERSION_MAJOR 0
-#define KHIP_VERSION_MINOR 3   /* 2: khip_options gained log_fd (round 4); 3: khip_*_workspace_adopt & co. (round 5).  Clients check
+#define KHIP_VERSION_MINOR 4   /* 2: khip_options gained log_fd (round 4); 3: khip_*_workspace_adopt & co. (round 5); 4: khip_*_last_path,
+                                * history published before every callback (round 6).  Clients check
                                 * khip_version() against the header they were built with */
 
 typedef struct khip_ctx khip_ctx;   /* device + stream + scratch + (optional) communicator */
@@ -429,6 +430,13 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
                   const double *b, const khip_options *opts);
 double           *khip_cg_solution(khip_cg_workspace *ws);                         /* solution(ws) === ws.x */
 const khip_stats *khip_cg_stats(khip_cg_workspace *ws);
+/* Which loop the workspace's last solve ran: 2 = the device-resident loop (cg!, bicgstab!) / the look-ahead loop (gmres!) --
+ * what the default keywords of the reference's entry points get (src/interface.jl:146-154 forwards M = I, ldiv = false,
+ * callback = workspace -> false, verbose = 0: the binding maps that default callback to NULL); 1 = the host-driven loop on the
+ * fused kernels (a callback, verbose > 0, a preconditioner, a user operator; same bits); 0 = one launch per primitive
+ * (options.fused = 0); -1 = no solve yet.  block_gmres!: 1 (it has one loop).  A binding's test asserts on this that an entry
+ * point reached the loop it was meant to reach. */
+int khip_cg_last_path(khip_cg_workspace *ws);
 /* named work vectors for callbacks: "x","r","p","Ap","z","dx","npc_dir" */
 double           *khip_cg_vector(khip_cg_workspace *ws, const char *name);
 size_t            khip_cg_workspace_bytes(khip_cg_workspace *ws);                  /* storage test, test/test_allocations.jl:41-57 */
@@ -453,6 +461,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
                      const khip_operator *N, const double *b, const khip_options *opts);
 double           *khip_gmres_solution(khip_gmres_workspace *ws);
 const khip_stats *khip_gmres_stats(khip_gmres_workspace *ws);
+int khip_gmres_last_path(khip_gmres_workspace *ws);
 size_t            khip_gmres_workspace_bytes(khip_gmres_workspace *ws);
 
 int khip_bicgstab_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, khip_bicgstab_workspace **out);
@@ -469,6 +478,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
                         const khip_options *opts);
 double           *khip_bicgstab_solution(khip_bicgstab_workspace *ws);
 const khip_stats *khip_bicgstab_stats(khip_bicgstab_workspace *ws);
+int khip_bicgstab_last_path(khip_bicgstab_workspace *ws);
 size_t            khip_bicgstab_workspace_bytes(khip_bicgstab_workspace *ws);
 
 int khip_block_gmres_workspace_create(khip_ctx *ctx, int64_t m, int64_t n, int p, int memory,
@@ -496,6 +506,7 @@ int khip_block_gmres_solve_panel(khip_block_gmres_workspace *ws, const khip_oper
                                  const khip_operator *N, const double *B_panel, const khip_options *opts);
 int khip_block_gmres_get_X(khip_block_gmres_workspace *ws, double *X_colmajor);
 const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws);
+int khip_block_gmres_last_path(khip_block_gmres_workspace *ws);
 /* storage test (test/test_allocations.jl:734-761): bytes of the workspace with n x p blocks at their logical size;
  * *extra_bytes (may be null) = what this implementation holds beyond the reference's formula (the row-major panel copy
  * of B and the p x p staging blocks of the fused sweeps) */

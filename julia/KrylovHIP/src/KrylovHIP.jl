@@ -10,10 +10,19 @@
 #   2. Method specialisations of `cg!`, `gmres!`, `bicgstab!` and `block_gmres!` for workspaces whose storage type is
 #      `HIPVector` / `HIPMatrix` and an operator that is a `HIPCsr`.  They hand the device pointers of the WORKSPACE'S OWN
 #      vectors to the library (`khip_*_workspace_adopt`, include/krylov_hip.h) and run its fused, device-resident loop on them
-#      (`khip_*_solve`; 274-290 it/s for cg! at 512^3): `solution(ws) === ws.x`, `ws.stats` is filled as the generic method fills
-#      it, nothing is copied.  Options the native loop does not take (a Julia `callback`, `ldiv = true`, a preconditioner that
-#      is not a `HIPOperator`, a verbose log into a non-file `IO`) fall back to the generic method of layer 1 with `invoke`:
-#      same results, primitive by primitive.
+#      (`khip_*_solve`; 272-277 it/s for cg! at 512^3): `solution(ws) === ws.x`, `ws.stats` is filled as the generic method fills
+#      it, nothing is copied.
+#
+#      EVERY entry point of the reference reaches them.  `cg(A, b)`, `krylov_solve(Val(:cg), A, b)`, `krylov_solve!(ws, A, b)`
+#      and the `x0` forms are generated methods that forward ALL keywords to `cg!(ws, A, b; ...)` explicitly -- including their
+#      own default `callback = workspace -> false` (src/cg.jl:110; src/interface.jl:146-154, 160-170, 306-320).  `user_callback`
+#      below recognises those defaults (anonymous functions of module Krylov that capture nothing) as "no callback", so the
+#      device-resident loop is what `x, stats = cg(A_gpu, b_gpu)` runs; `NATIVE_SOLVES[]` / `LAST_PATH[]` record it and
+#      test/runtests.jl asserts on them.  A REAL callback runs inside the library's host-driven loop on the fused kernels through a
+#      `@cfunction` trampoline (`khip_options.callback`): it sees the workspace's own vectors and the residual history so far.
+#      What the library cannot take (`ldiv = true`, a preconditioner that is not a `HIPOperator`, a verbose log into a non-file
+#      `IO`) falls back to the generic method of layer 1 with `invoke` on the fully parametrised generic signature: same
+#      results, primitive by primitive.
 #
 # Julia is not installed in the image this library is built in: this file is checked mechanically (tests/test_abi.py parses every
 # `ccall` against include/krylov_hip.h -- symbol, arity, return and argument types -- and checks that every `k*` primitive the
@@ -37,7 +46,7 @@ mutable struct Ctx; h::Ptr{Cvoid}; end
 function Ctx(device::Integer = 0)
   major = Ref{Cint}(); minor = Ref{Cint}()
   ccall((:khip_version, lib), Cvoid, (Ref{Cint}, Ref{Cint}), major, minor)
-  (major[] == 0 && minor[] >= 3) || error("libkrylov_hip $(major[]).$(minor[]) lacks the khip_*_workspace_adopt entry points (need >= 0.3)")
+  (major[] == 0 && minor[] >= 4) || error("libkrylov_hip $(major[]).$(minor[]) lacks khip_*_last_path / the adopt entry points (need >= 0.4)")
   r = Ref{Ptr{Cvoid}}(); ck(ccall((:khip_ctx_create, lib), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, r))
   Ctx(r[])
 end
@@ -89,23 +98,33 @@ kref!(n::Integer, x::HIPVector, y::HIPVector, c::Float64, s::Float64) = (ck(ccal
 
 # ------------------------------------------------------------------------------------------------ operator: size, eltype, kmul!
 # (docs/src/matrix_free.md:32-34)
-mutable struct HIPCsr; h::Ptr{Cvoid}; m::Int; n::Int; end
+mutable struct HIPCsr; h::Ptr{Cvoid}; m::Int; n::Int; adj::Union{Nothing,HIPCsr}; end      # adj: A' once it has been built
+HIPCsr(h::Ptr{Cvoid}, m::Integer, n::Integer) = HIPCsr(h, m, n, nothing)
+destroy_csr(A::HIPCsr) = ccall((:khip_csr_destroy, lib), Cint, (Ptr{Cvoid},), A.h)
 function HIPCsr(A::SparseArrays.SparseMatrixCSC{Float64,<:Integer})    # CSC of a symmetric matrix == its CSR;
   At = SparseArrays.sparse(A')                                         # general case: CSR of A = CSC of A'
   r = Ref{Ptr{Cvoid}}()
   ck(ccall((:khip_csr_create, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Cdouble}, Cint, Cint, Ref{Ptr{Cvoid}}),
            CTX[].h, size(A, 1), size(A, 2), SparseArrays.nnz(At), Int64.(At.colptr), 64, Int32.(At.rowval), At.nzval, 1, 0, r))   # index_base = 1
-  A_d = HIPCsr(r[], size(A)...)
-  finalizer(x -> ccall((:khip_csr_destroy, lib), Cint, (Ptr{Cvoid},), x.h), A_d)
+  finalizer(destroy_csr, HIPCsr(r[], size(A)...))
 end
 Base.size(A::HIPCsr) = (A.m, A.n);  Base.size(A::HIPCsr, i::Integer) = i == 1 ? A.m : (i == 2 ? A.n : 1);  Base.eltype(::HIPCsr) = Float64
 kmul!(y::HIPVector, A::HIPCsr, x::HIPVector) = (ck(ccall((:khip_spmv, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), CTX[].h, A.h, x.ptr, y.ptr)); y)   # src/krylov_utils.jl:305
 kmul!(y::HIPVector, ::UniformScaling, x::HIPVector) = kcopy!(length(x), y, x)   # the unguarded mul!(v, I, q) of src/bicgstab.jl:222
 LinearAlgebra.mul!(y::HIPVector, A::HIPCsr, x::HIPVector) = kmul!(y, A, x)
 Base.:*(A::HIPCsr, x::HIPVector) = kmul!(HIPVector(undef, A.m), A, x)
-# adjoint products for the solvers that need A' (MINRES-QLP, LSQR, LSMR, BiLQ, QMR, ...): build A' once, then the same kmul!
-function Base.adjoint(A::HIPCsr); r = Ref{Ptr{Cvoid}}()
-  ck(ccall((:khip_csr_transpose, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), CTX[].h, A.h, r)); HIPCsr(r[], A.n, A.m); end
+# adjoint products for the solvers that need A' (LSQR, LSMR, BiLQ, QMR, ...; they write `Aᴴ = A'` once per solve): the transposed
+# operator is built ONCE per matrix (khip_csr_transpose makes an independent handle), cached in `A.adj`, owned by a finalizer of its
+# own, and points back so that (A')' === A.  Repeated solves neither rebuild nor leak it.
+function Base.adjoint(A::HIPCsr)
+  A.adj === nothing || return A.adj
+  r = Ref{Ptr{Cvoid}}()
+  ck(ccall((:khip_csr_transpose, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), CTX[].h, A.h, r))
+  At = finalizer(destroy_csr, HIPCsr(r[], A.n, A.m, A))
+  A.adj = At
+  return At
+end
+Base.transpose(A::HIPCsr) = adjoint(A)            # real element type
 
 # ------------------------------------------------------------------------------------------------ C structs of the solver entries
 struct Operator                     # khip_operator, include/krylov_hip.h
@@ -119,10 +138,13 @@ struct Options                      # khip_options: same members, same order (is
   variant::Cint; verbose::Cint; log_fd::Cint
 end
 function Options(; atol, rtol, itmax, timemax, history, radius = 0.0, linesearch = false, restart = false, reorthogonalization = false,
-                 fused = 2, variant = 0, verbose = 0, log_fd = 0)
-  # timemax: NaN or <= 0 means "no limit" on the C side (include/krylov_hip.h); itmax above the Cint range is "no limit" too
-  Options(atol, rtol, Cint(clamp(itmax, 0, typemax(Cint))), isfinite(timemax) ? timemax : NaN, history, radius, linesearch, restart,
-          reorthogonalization, fused, C_NULL, C_NULL, variant, verbose, log_fd)
+                 fused = 2, variant = 0, verbose = 0, log_fd = 0, callback = C_NULL, callback_data = C_NULL)
+  # timemax: NaN or <= 0 means "no limit" on the C side (include/krylov_hip.h); itmax above the Cint range is "no limit" too.
+  # A time limit the entry point has already used up (`timemax -= elapsed_time`, src/interface.jl:151) must stay a limit: the
+  # smallest positive one.
+  tm = isfinite(timemax) ? max(timemax, floatmin(Float64)) : NaN
+  Options(atol, rtol, Cint(clamp(itmax, 0, typemax(Cint))), tm, history, radius, linesearch, restart,
+          reorthogonalization, fused, callback, callback_data, variant, verbose, log_fd)
 end
 
 struct Stats                        # khip_stats
@@ -160,6 +182,46 @@ opref(M) = M === I ? Ptr{Operator}(C_NULL) : Base.unsafe_convert(Ptr{Operator}, 
 logfd(io::IO) = io === Krylov.kstdout || io === stdout ? Cint(0) : (io isa IOStream ? Cint(fd(io)) : Cint(-1))
 native_log(verbose, io) = verbose <= 0 || logfd(io) >= 0
 
+# ---- callbacks ------------------------------------------------------------------------------------------------------------
+# The reference's generated entry points pass `callback = workspace -> false` EXPLICITLY (see the header of this file): one
+# anonymous function per generated method, all defined in module Krylov, none capturing anything.  Those are "no callback".
+default_callback(cb) = parentmodule(typeof(cb)) === Krylov && Base.issingletontype(typeof(cb))
+user_callback(cb) = (cb === nothing || default_callback(cb)) ? nothing : cb
+# A user's callback runs inside the library's host-driven loop (khip_options.callback, include/krylov_hip.h): the trampoline
+# brings the residual history of the C side into `ws.stats.residuals` (what the reference's callbacks read, docs/src/callbacks.md),
+# calls `callback(ws)::Bool` and keeps an exception for after the solve (nothing may unwind through the C frames).
+mutable struct CallbackBox
+  f::Any; ws::Any; stats::Ptr{Cvoid}; history::Bool; err::Any
+end
+function callback_trampoline(_::Ptr{Cvoid}, ud::Ptr{Cvoid})::Cint
+  box = unsafe_pointer_to_objref(ud)::CallbackBox
+  try
+    if box.history
+      st = unsafe_load(Ptr{Stats}(box.stats)); res = box.ws.stats.residuals
+      for i in (length(res) + 1):Int(st.nres); push!(res, unsafe_load(st.residuals, i)); end
+    end
+    return box.f(box.ws) ? Cint(1) : Cint(0)
+  catch e
+    box.err = e
+    return Cint(1)                                 # stop the solve; `finish_callback` rethrows
+  end
+end
+const CALLBACK = Ref{Ptr{Cvoid}}(C_NULL)
+# (callback, callback_data) of khip_options and the box to GC.@preserve; `stats_ptr` = khip_*_stats(h) (stable per handle)
+function callback_args(cb, ws, stats_ptr::Ptr{Stats}, history::Bool)
+  cb === nothing && return C_NULL, C_NULL, nothing
+  history && empty!(ws.stats.residuals)
+  box = CallbackBox(cb, ws, Ptr{Cvoid}(stats_ptr), history, nothing)
+  return CALLBACK[], pointer_from_objref(box), box
+end
+finish_callback(box) = (box !== nothing && box.err !== nothing) ? throw(box.err) : nothing
+
+# how many solves took the library's loop, and which loop the last one ran (khip_*_last_path: 2 = device-resident / look-ahead,
+# 1 = host-driven on the fused kernels, 0 = one launch per primitive) -- test/runtests.jl asserts on both after every entry point
+const NATIVE_SOLVES = Ref(0)
+const LAST_PATH = Ref(-1)
+const GENERIC_SOLVES = Ref(0)                      # solves handed to the generic method by `invoke`
+
 function fill_stats!(stats::Krylov.SimpleStats{Float64}, sp::Ptr{Stats}, history::Bool)
   st = unsafe_load(sp)
   Krylov.reset!(stats)
@@ -189,8 +251,9 @@ cg_adopt(h, name, v::HIPVector) = ck(ccall((:khip_cg_workspace_adopt_vector, lib
 function Krylov.cg!(ws::CgWs, A::HIPCsr, b::HIPVector; M = I, ldiv::Bool = false, radius::Float64 = 0.0, linesearch::Bool = false,
                     atol::Float64 = √eps(Float64), rtol::Float64 = √eps(Float64), itmax::Int = 0, timemax::Float64 = Inf,
                     verbose::Int = 0, history::Bool = false, callback = nothing, iostream::IO = Krylov.kstdout, fused::Int = 2)
-  if callback !== nothing || ldiv || !native_precond(M) || !native_log(verbose, iostream)
-    return invoke(Krylov.cg!, Tuple{CgWorkspace,Any,AbstractVector}, ws, A, b; M, ldiv, radius, linesearch, atol, rtol, itmax, timemax, verbose,
+  if ldiv || !native_precond(M) || !native_log(verbose, iostream)
+    GENERIC_SOLVES[] += 1
+    return invoke(Krylov.cg!, Tuple{CgWs,Any,AbstractVector{Float64}}, ws, A, b; M, ldiv, radius, linesearch, atol, rtol, itmax, timemax, verbose,
                   history, callback = callback === nothing ? (w -> false) : callback, iostream)
   end
   m, n = size(A)                                                                            # the reference's own argument checks, :128-139
@@ -206,12 +269,16 @@ function Krylov.cg!(ws::CgWs, A::HIPCsr, b::HIPVector; M = I, ldiv::Bool = false
     cg_adopt(h, name, v)                                                                    # the fields as they are NOW (pointer hand-over only)
   end
   ws.warm_start && ck(ccall((:khip_cg_warm_start, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h, ws.Δx.ptr))   # Δx already holds x0: sets the flag
-  opts = Ref(Options(; atol, rtol, itmax, timemax, history, radius, linesearch, fused, verbose, log_fd = logfd(iostream)))
+  sp = ccall((:khip_cg_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h)
+  cbf, cbd, box = callback_args(user_callback(callback), ws, sp, history)
+  opts = Ref(Options(; atol, rtol, itmax, timemax, history, radius, linesearch, fused, verbose, log_fd = logfd(iostream), callback = cbf, callback_data = cbd))
   opA = Ref(Operator(A))
-  rc = GC.@preserve ws A b M opts opA ccall((:khip_cg_solve, lib), Cint, (Ptr{Cvoid}, Ref{Operator}, Ptr{Operator}, Ptr{Cdouble}, Ref{Options}),
-                                             h, opA, opref(M), b.ptr, opts)
-  st = fill_stats!(ws.stats, ccall((:khip_cg_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h), history)
+  rc = GC.@preserve ws A b M opts opA box ccall((:khip_cg_solve, lib), Cint, (Ptr{Cvoid}, Ref{Operator}, Ptr{Operator}, Ptr{Cdouble}, Ref{Options}),
+                                                 h, opA, opref(M), b.ptr, opts)
+  st = fill_stats!(ws.stats, sp, history)
+  NATIVE_SOLVES[] += 1;  LAST_PATH[] = ccall((:khip_cg_last_path, lib), Cint, (Ptr{Cvoid},), h)
   ws.warm_start = false
+  finish_callback(box)
   rc == 0 || failed(st)
   return ws
 end
@@ -246,8 +313,9 @@ function Krylov.gmres!(ws::GmresWs, A::HIPCsr, b::HIPVector; M = I, N = I, ldiv:
                        reorthogonalization::Bool = false, atol::Float64 = √eps(Float64), rtol::Float64 = √eps(Float64), itmax::Int = 0,
                        timemax::Float64 = Inf, verbose::Int = 0, history::Bool = false, callback = nothing, iostream::IO = Krylov.kstdout,
                        fused::Int = 2)
-  if callback !== nothing || ldiv || !native_precond(M) || !native_precond(N) || !native_log(verbose, iostream)
-    return invoke(Krylov.gmres!, Tuple{GmresWorkspace,Any,AbstractVector}, ws, A, b; M, N, ldiv, restart, reorthogonalization, atol, rtol, itmax,
+  if ldiv || !native_precond(M) || !native_precond(N) || !native_log(verbose, iostream)
+    GENERIC_SOLVES[] += 1
+    return invoke(Krylov.gmres!, Tuple{GmresWs,Any,AbstractVector{Float64}}, ws, A, b; M, N, ldiv, restart, reorthogonalization, atol, rtol, itmax,
                   timemax, verbose, history, callback = callback === nothing ? (w -> false) : callback, iostream)
   end
   m, n = size(A)                                                                            # :128-140
@@ -264,11 +332,14 @@ function Krylov.gmres!(ws::GmresWs, A::HIPCsr, b::HIPVector; M = I, N = I, ldiv:
   Vp = basis_ptrs(ws.V)                                                                     # the basis as it is now (it may have grown)
   ck(ccall((:khip_gmres_workspace_adopt_basis, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cdouble}}), h, length(Vp), Vp))
   ws.warm_start && ck(ccall((:khip_gmres_warm_start, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h, ws.Δx.ptr))
-  opts = Ref(Options(; atol, rtol, itmax, timemax, history, restart, reorthogonalization, fused, verbose, log_fd = logfd(iostream)))
+  sp = ccall((:khip_gmres_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h)
+  cbf, cbd, box = callback_args(user_callback(callback), ws, sp, history)
+  opts = Ref(Options(; atol, rtol, itmax, timemax, history, restart, reorthogonalization, fused, verbose, log_fd = logfd(iostream), callback = cbf, callback_data = cbd))
   opA = Ref(Operator(A))
-  rc = GC.@preserve ws A b M N opts opA ccall((:khip_gmres_solve, lib), Cint, (Ptr{Cvoid}, Ref{Operator}, Ptr{Operator}, Ptr{Operator}, Ptr{Cdouble}, Ref{Options}),
-                                               h, opA, opref(M), opref(N), b.ptr, opts)
-  st = fill_stats!(ws.stats, ccall((:khip_gmres_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h), history)
+  rc = GC.@preserve ws A b M N opts opA box ccall((:khip_gmres_solve, lib), Cint, (Ptr{Cvoid}, Ref{Operator}, Ptr{Operator}, Ptr{Operator}, Ptr{Cdouble}, Ref{Options}),
+                                                   h, opA, opref(M), opref(N), b.ptr, opts)
+  st = fill_stats!(ws.stats, sp, history)
+  NATIVE_SOLVES[] += 1;  LAST_PATH[] = ccall((:khip_gmres_last_path, lib), Cint, (Ptr{Cvoid},), h)
   # the host fields of the workspace in the reference's own storage (c, s, z, packed R, inner_iter; src/krylov_workspaces.jl:2866-2871)
   len = Ref{Cint}(); inner = Ref{Cint}()
   ck(ccall((:khip_gmres_host_state, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Cint}, Ref{Cint}),
@@ -278,6 +349,7 @@ function Krylov.gmres!(ws::GmresWs, A::HIPCsr, b::HIPVector; M = I, N = I, ldiv:
            h, k, ws.c, ws.s, ws.z, ws.R, len, inner))
   ws.inner_iter = inner[]
   ws.warm_start = false
+  finish_callback(box)
   rc == 0 || failed(st)
   return ws
 end
@@ -300,8 +372,9 @@ bicgstab_adopt(h, name, v::HIPVector) = ck(ccall((:khip_bicgstab_workspace_adopt
 function Krylov.bicgstab!(ws::BicgstabWs, A::HIPCsr, b::HIPVector; c::HIPVector = b, M = I, N = I, ldiv::Bool = false,
                           atol::Float64 = √eps(Float64), rtol::Float64 = √eps(Float64), itmax::Int = 0, timemax::Float64 = Inf,
                           verbose::Int = 0, history::Bool = false, callback = nothing, iostream::IO = Krylov.kstdout, fused::Int = 2)
-  if callback !== nothing || ldiv || !native_precond(M) || !native_precond(N) || !native_log(verbose, iostream)
-    return invoke(Krylov.bicgstab!, Tuple{BicgstabWorkspace,Any,AbstractVector}, ws, A, b; c, M, N, ldiv, atol, rtol, itmax, timemax, verbose, history,
+  if ldiv || !native_precond(M) || !native_precond(N) || !native_log(verbose, iostream)
+    GENERIC_SOLVES[] += 1
+    return invoke(Krylov.bicgstab!, Tuple{BicgstabWs,Any,AbstractVector{Float64}}, ws, A, b; c, M, N, ldiv, atol, rtol, itmax, timemax, verbose, history,
                   callback = callback === nothing ? (w -> false) : callback, iostream)
   end
   m, n = size(A)                                                                            # :132-143
@@ -315,13 +388,17 @@ function Krylov.bicgstab!(ws::BicgstabWs, A::HIPCsr, b::HIPVector; c::HIPVector 
     bicgstab_adopt(h, name, v)
   end
   ws.warm_start && ck(ccall((:khip_bicgstab_warm_start, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h, ws.Δx.ptr))
-  opts = Ref(Options(; atol, rtol, itmax, timemax, history, fused, verbose, log_fd = logfd(iostream)))
+  sp = ccall((:khip_bicgstab_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h)
+  cbf, cbd, box = callback_args(user_callback(callback), ws, sp, history)
+  opts = Ref(Options(; atol, rtol, itmax, timemax, history, fused, verbose, log_fd = logfd(iostream), callback = cbf, callback_data = cbd))
   opA = Ref(Operator(A))
-  rc = GC.@preserve ws A b c M N opts opA ccall((:khip_bicgstab_solve, lib), Cint,
+  rc = GC.@preserve ws A b c M N opts opA box ccall((:khip_bicgstab_solve, lib), Cint,
                                                  (Ptr{Cvoid}, Ref{Operator}, Ptr{Operator}, Ptr{Operator}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Options}),
                                                  h, opA, opref(M), opref(N), b.ptr, c.ptr, opts)
-  st = fill_stats!(ws.stats, ccall((:khip_bicgstab_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h), history)
+  st = fill_stats!(ws.stats, sp, history)
+  NATIVE_SOLVES[] += 1;  LAST_PATH[] = ccall((:khip_bicgstab_last_path, lib), Cint, (Ptr{Cvoid},), h)
   ws.warm_start = false
+  finish_callback(box)
   rc == 0 || failed(st)
   return ws
 end
@@ -427,9 +504,10 @@ function Krylov.block_gmres!(ws::BlockGmresWs, A::HIPCsr, B::HIPMatrix; M = I, N
                              reorthogonalization::Bool = false, atol::Float64 = √eps(Float64), rtol::Float64 = √eps(Float64), itmax::Int = 0,
                              timemax::Float64 = Inf, verbose::Int = 0, history::Bool = false, callback = nothing, iostream::IO = Krylov.kstdout)
   n, p = ws.n, ws.p
-  # native loop: M = N = I (the block solver's preconditioners would be applied to panels), tall panels, no Julia callback
-  if callback !== nothing || ldiv || M !== I || N !== I || !native_log(verbose, iostream) || !tall(B) || !tall(ws.X)
-    return invoke(Krylov.block_gmres!, Tuple{BlockGmresWorkspace,Any,AbstractMatrix}, ws, A, B; M, N, ldiv, restart, reorthogonalization, atol, rtol,
+  # native loop: M = N = I (the block solver's preconditioners would be applied to panels), tall panels
+  if ldiv || M !== I || N !== I || !native_log(verbose, iostream) || !tall(B) || !tall(ws.X)
+    GENERIC_SOLVES[] += 1
+    return invoke(Krylov.block_gmres!, Tuple{BlockGmresWs,Any,AbstractMatrix{Float64}}, ws, A, B; M, N, ldiv, restart, reorthogonalization, atol, rtol,
                   itmax, timemax, verbose, history, callback = callback === nothing ? (w -> false) : callback, iostream)
   end
   m, nA = size(A);  s, pB = size(B)                                                          # :117-128
@@ -445,13 +523,17 @@ function Krylov.block_gmres!(ws::BlockGmresWs, A::HIPCsr, B::HIPMatrix; M = I, N
   Vp = panel_ptrs(ws.V)
   ck(ccall((:khip_block_gmres_workspace_adopt_basis, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cdouble}}), h, length(Vp), Vp))
   ws.warm_start && ck(ccall((:khip_block_gmres_warm_start_panel, lib), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h, ws.ΔX.ptr))
-  opts = Ref(Options(; atol, rtol, itmax, timemax, history, restart, reorthogonalization, verbose, log_fd = logfd(iostream)))
+  sp = ccall((:khip_block_gmres_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h)
+  cbf, cbd, box = callback_args(user_callback(callback), ws, sp, history)
+  opts = Ref(Options(; atol, rtol, itmax, timemax, history, restart, reorthogonalization, verbose, log_fd = logfd(iostream), callback = cbf, callback_data = cbd))
   opA = Ref(Operator(A))
-  rc = GC.@preserve ws A B opts opA ccall((:khip_block_gmres_solve_panel, lib), Cint,
+  rc = GC.@preserve ws A B opts opA box ccall((:khip_block_gmres_solve_panel, lib), Cint,
                                            (Ptr{Cvoid}, Ref{Operator}, Ptr{Operator}, Ptr{Operator}, Ptr{Cdouble}, Ref{Options}),
                                            h, opA, C_NULL, C_NULL, B.ptr, opts)
-  st = fill_stats!(ws.stats, ccall((:khip_block_gmres_stats, lib), Ptr{Stats}, (Ptr{Cvoid},), h), history)
+  st = fill_stats!(ws.stats, sp, history)
+  NATIVE_SOLVES[] += 1;  LAST_PATH[] = ccall((:khip_block_gmres_last_path, lib), Cint, (Ptr{Cvoid},), h)
   ws.warm_start = false
+  finish_callback(box)
   rc == 0 || failed(st)
   return ws
 end
@@ -459,6 +541,7 @@ end
 function __init__()
   GROW_VECTOR[] = @cfunction(grow_vector, Ptr{Cdouble}, (Ptr{Cvoid},))
   GROW_PANEL[] = @cfunction(grow_panel, Ptr{Cdouble}, (Ptr{Cvoid},))
+  CALLBACK[] = @cfunction(callback_trampoline, Cint, (Ptr{Cvoid}, Ptr{Cvoid}))
   return nothing
 end
 

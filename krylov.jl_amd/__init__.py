@@ -171,6 +171,7 @@ SIGNATURES = {
     "khip_cg_solve": (_int, [_vp, C.POINTER(COperator), C.POINTER(COperator), _vp, C.POINTER(COptions)]),
     "khip_cg_solution": (_vp, [_vp]),
     "khip_cg_stats": (C.POINTER(CStats), [_vp]),
+    "khip_cg_last_path": (_int, [_vp]),
     "khip_cg_vector": (_vp, [_vp, C.c_char_p]),
     "khip_cg_workspace_bytes": (_sz, [_vp]),
     "khip_gmres_workspace_create": (_int, [_vp, _i64, _i64, _int, c_void_pp]),
@@ -185,6 +186,7 @@ SIGNATURES = {
                                 C.POINTER(COptions)]),
     "khip_gmres_solution": (_vp, [_vp]),
     "khip_gmres_stats": (C.POINTER(CStats), [_vp]),
+    "khip_gmres_last_path": (_int, [_vp]),
     "khip_gmres_workspace_bytes": (_sz, [_vp]),
     "khip_bicgstab_workspace_create": (_int, [_vp, _i64, _i64, c_void_pp]),
     "khip_bicgstab_workspace_adopt": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, c_void_pp]),
@@ -195,6 +197,7 @@ SIGNATURES = {
                                    C.POINTER(COptions)]),
     "khip_bicgstab_solution": (_vp, [_vp]),
     "khip_bicgstab_stats": (C.POINTER(CStats), [_vp]),
+    "khip_bicgstab_last_path": (_int, [_vp]),
     "khip_bicgstab_workspace_bytes": (_sz, [_vp]),
     "khip_block_gmres_workspace_bytes": (_sz, [_vp, C.POINTER(C.c_size_t)]),
     "khip_test_gen_banded_random_host": (_int, [_i64, _int, _int, C.c_uint64, _int, _int, _i64, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_double_p, C.POINTER(_i64)]),
@@ -220,6 +223,7 @@ SIGNATURES = {
                                C.POINTER(COptions)]),
     "khip_block_gmres_get_X": (_int, [_vp, _vp]),
     "khip_block_gmres_stats": (C.POINTER(CStats), [_vp]),
+    "khip_block_gmres_last_path": (_int, [_vp]),
     # host-only helpers (partition / halo plan logic, testable without a GPU)
     "khip_ghost_columns_host": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, C.POINTER(_i64)]),
     "khip_halo_plan_host": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _i64]),
@@ -253,11 +257,11 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     # khip_options / khip_stats are passed by pointer without a size field: a binding must have been written against the ABI
-    # version the library reports; this mirror follows include/krylov_hip.h of version 0.3 (adopt entries, log_fd)
+    # version the library reports; this mirror follows include/krylov_hip.h of version 0.4 (adopt entries, log_fd, last_path)
     major, minor = C.c_int(), C.c_int()
     L.khip_version(C.byref(major), C.byref(minor))
-    if (major.value, minor.value) != (0, 3):
-        raise ImportError(f"{LIB_PATH} reports ABI {major.value}.{minor.value}; krylov.jl_amd/__init__.py binds 0.3: rebuild (build.sh)")
+    if (major.value, minor.value) != (0, 4):
+        raise ImportError(f"{LIB_PATH} reports ABI {major.value}.{minor.value}; krylov.jl_amd/__init__.py binds 0.4: rebuild (build.sh)")
     _lib = L
     return L
 
@@ -948,8 +952,43 @@ def _make_operator(ctx, op, n, keep):
     return C.byref(co)
 
 
+# The reference's entry points forward EVERY keyword to the in-place method explicitly, their own defaults included:
+# `cg(A, b)`, `krylov_solve(Val(:cg), A, b)`, `krylov_solve!(ws, A, b)` and the x0 forms all call
+# `cg!(ws, A, b; M, ldiv, ..., callback, iostream)` with `callback = workspace -> false` (src/cg.jl:110, src/interface.jl:146-154,
+# 266-275, 331, 336-345).  A binding that takes its device-resident loop only when NO callback was passed would therefore never take
+# it from those entry points: the default callback has to be recognised for what it is.  `default_callback` below is
+# this mirror's `workspace -> false`; `_user_callback` maps it (and None) to "no callback", exactly as `user_callback` in
+# julia/KrylovHIP/src/KrylovHIP.jl maps the anonymous functions the reference's generated methods forward.
+def default_callback(workspace) -> bool:          # `callback = workspace -> false`
+    return False
+
+
+def _user_callback(callback):
+    return None if (callback is None or callback is default_callback) else callback
+
+
+def _log_fd(iostream) -> int:
+    """The reference's `iostream` keyword (default kstdout) as khip_options.log_fd: 0 = stdout, else the caller's descriptor."""
+    if iostream is None or iostream is sys.stdout:
+        return 0
+    if isinstance(iostream, int):
+        return iostream
+    iostream.flush()
+    return iostream.fileno()
+
+
 def _make_options(atol=None, rtol=None, itmax=0, timemax=None, history=False, radius=0.0, linesearch=False,
-                  restart=False, reorthogonalization=False, fused=True, callback=None, keep=None, ws=None, variant=0, verbose=0, log_fd=0):
+                  restart=False, reorthogonalization=False, fused=True, callback=None, keep=None, ws=None, variant=0, verbose=0, log_fd=0,
+                  ldiv=False, iostream=None):
+    if ldiv:        # `ldiv = true` applies M / N with ldiv! (src/krylov_utils.jl:307): a factorisation object of the HOST language
+        raise KhipError(-4, "ldiv = true has no meaning across the C ABI: pass M / N as operators z <- M r (Jacobi, Ilu0, a callable)")
+    if iostream is not None:
+        log_fd = _log_fd(iostream)
+    if timemax is not None:
+        # Inf (the reference's default) = no limit = the C default; a limit the entry point has already used up
+        # (`timemax -= elapsed_time`, src/interface.jl:151) stays a limit: the C side reads <= 0 as "none"
+        timemax = None if math.isinf(timemax) else max(timemax, sys.float_info.min)
+    callback = _user_callback(callback)
     o = lib().khip_default_options()
     if atol is not None:
         o.atol = atol
@@ -1028,7 +1067,14 @@ class _Workspace:
         st = SimpleStats(self._fn("stats")(self._h).contents)
         if self.adopted:                                  # the vectors were allocated (and timed) on this side
             st.allocation_timer += self._alloc_s
+        st.timer += getattr(self, "_timer_extra", 0.0)    # `workspace.stats.timer += elapsed_time`, src/interface.jl:153
         return st
+
+    @property
+    def last_path(self) -> int:
+        """Which loop the last solve ran (khip_*_last_path): 2 device-resident / look-ahead, 1 host-driven fused, 0 one launch per
+        primitive, -1 none yet.  What KrylovHIP.NATIVE_SOLVES / LAST_PATH report on the Julia side."""
+        return self._fn("last_path")(self._h)
 
     def warm_start_(self, x0: DeviceVector):
         """warm_start!(workspace, x0) (src/workspace_accessors.jl:193-200): allocate_if(true, ws, :Δx, ...); kcopy!(n, ws.Δx, x0)."""
@@ -1130,6 +1176,7 @@ class BicgstabWorkspace(_Workspace):
 
 
 def _finish(ws, rc):
+    ws._timer_extra = 0.0          # an entry point that did work of its own before the solve adds it afterwards
     if rc != 0:
         st = ws.stats
         raise KhipError(rc, st.error or lib().khip_last_error().decode("utf-8", "replace"))
@@ -1176,29 +1223,102 @@ def _local_rows(A):
     return A.m if isinstance(A, CsrMatrix) else None
 
 
+# ---- the generated entry points of src/interface.jl, with what they FORWARD -----------------------------------------------------
+# def_kwargs_cg / _gmres / _bicgstab / _block_gmres (src/cg.jl:101-112, src/gmres.jl:96-110, src/bicgstab.jl:105-116,
+# src/block_gmres.jl:85-99) as this mirror spells them (M / N: None = I; iostream: None = kstdout; timemax: inf).  Every
+# out-of-place and generic entry below builds the complete keyword set from these tables and passes ALL of it on, as the reference's
+# generated methods do -- tests/test_abi.py compares the tables with the reference's, and test_gpu_adopt.py asserts that the solve
+# they lead to ran the device-resident loop (`last_path == 2`).
+_SQRT_EPS = math.sqrt(np.finfo(np.float64).eps)
+FORWARDED_DEFAULTS = {
+    "cg": dict(M=None, ldiv=False, radius=0.0, linesearch=False, atol=_SQRT_EPS, rtol=_SQRT_EPS, itmax=0, timemax=math.inf,
+               verbose=0, history=False, callback=default_callback, iostream=None),
+    "gmres": dict(M=None, N=None, ldiv=False, restart=False, reorthogonalization=False, atol=_SQRT_EPS, rtol=_SQRT_EPS, itmax=0,
+                  timemax=math.inf, verbose=0, history=False, callback=default_callback, iostream=None),
+    "bicgstab": dict(c=None, M=None, N=None, ldiv=False, atol=_SQRT_EPS, rtol=_SQRT_EPS, itmax=0, timemax=math.inf, verbose=0,
+                     history=False, callback=default_callback, iostream=None),
+    "block_gmres": dict(M=None, N=None, ldiv=False, restart=False, reorthogonalization=False, atol=_SQRT_EPS, rtol=_SQRT_EPS, itmax=0,
+                        timemax=math.inf, verbose=0, history=False, callback=default_callback, iostream=None),
+}
+WORKSPACE_KWARGS = {"gmres": dict(memory=20), "block_gmres": dict(memory=5)}      # kwargs_workspace_gmres, _block_gmres
+
+
+def _forward(method: str, kw: dict) -> dict:
+    """The keyword set a generated entry point passes to the in-place method: its defaults, overridden by what the caller gave.
+    Keywords of this library that the reference does not have (fused, variant) pass through."""
+    full = dict(FORWARDED_DEFAULTS[method])
+    full.update(kw)
+    return full
+
+
+def krylov_workspace(method: str, *args, ctx: Context | None = None, **kw):
+    """krylov_workspace(Val(method), m, n, S; memory) / (Val(method), A, b; memory) (src/interface.jl:117-141, 237-244)."""
+    cls = {"cg": CgWorkspace, "gmres": GmresWorkspace, "bicgstab": BicgstabWorkspace, "block_gmres": BlockGmresWorkspace}[method]
+    if len(args) == 2 and isinstance(args[1], DeviceVector):                  # (A, b)
+        A, b = args
+        return cls(b.ctx, len(b), len(b), **kw)
+    if method == "block_gmres":
+        if len(args) == 2:                                                       # (A, B) with a host n x p array B
+            B = np.asarray(args[1])
+            return cls(ctx or args[0].ctx, B.shape[0], B.shape[0], B.shape[1], **kw)
+        m, n, p = args
+        return cls(ctx, m, n, p, **kw)
+    m, n = args
+    return cls(ctx, m, n, **kw)
+
+
+_INPLACE = {}      # filled below: CgWorkspace -> ("cg", cg_), ...
+
+
+def krylov_solve_(ws, A, b, x0=None, **kw):
+    """krylov_solve!(workspace, A, b[, x0]; kwargs...) (src/interface.jl:331-345, 306-320): dispatch on the workspace type; the x0
+    form warm-starts first and charges that time to the solve, as the reference does."""
+    method, inplace = _INPLACE[type(ws)]
+    full = _forward(method, kw)
+    elapsed = 0.0
+    if x0 is not None:
+        t0 = time.perf_counter()
+        ws.warm_start_(x0)
+        elapsed = time.perf_counter() - t0
+        full["timemax"] = full["timemax"] - elapsed
+    inplace(ws, A, b, **full)
+    ws._timer_extra = elapsed
+    return ws
+
+
+def krylov_solve(method: str, A, b, x0=None, ctx: Context | None = None, **kw):
+    """krylov_solve(Val(method), A, b[, x0]; kwargs...) = method(A, b[, x0]; kwargs...) (src/interface.jl:146-199): a fresh
+    workspace (its creation charged to `timemax` and `stats.timer`), every keyword forwarded.  Returns (x, stats, workspace)."""
+    wkw = {k: kw.pop(k) for k in list(kw) if k in WORKSPACE_KWARGS.get(method, {})}
+    t0 = time.perf_counter()
+    if method == "block_gmres":
+        B = np.asarray(b, dtype=np.float64)
+        ctx = ctx or A.ctx
+        ws = krylov_workspace(method, A, B, ctx=ctx, **wkw)
+        b = ctx.array(np.asfortranarray(B).ravel(order="F"))
+    else:
+        ws = krylov_workspace(method, A, b, **wkw)
+    if x0 is not None:
+        ws.warm_start_(x0)
+    elapsed = time.perf_counter() - t0
+    full = _forward(method, kw)
+    full["timemax"] = full["timemax"] - elapsed
+    _INPLACE[type(ws)][1](ws, A, b, **full)
+    ws._timer_extra = elapsed
+    return (ws.X if method == "block_gmres" else ws.x), ws.stats, ws
+
+
 def cg(A, b: DeviceVector, x0=None, **kw):
-    """Out-of-place cg(A, b; kwargs...) -> (x, stats) (src/interface.jl:146-154)."""
-    ws = CgWorkspace(b.ctx, len(b), len(b))
-    if x0 is not None:
-        ws.warm_start_(x0)
-    cg_(ws, A, b, **kw)
-    return ws.x, ws.stats, ws
+    """Out-of-place cg(A, b[, x0]; kwargs...) -> (x, stats, workspace) (src/interface.jl:146-154, 160-170)."""
+    return krylov_solve("cg", A, b, x0, **kw)
 
 
-def gmres(A, b: DeviceVector, x0=None, memory=20, **kw):
-    ws = GmresWorkspace(b.ctx, len(b), len(b), memory=memory)
-    if x0 is not None:
-        ws.warm_start_(x0)
-    gmres_(ws, A, b, **kw)
-    return ws.x, ws.stats, ws
+def gmres(A, b: DeviceVector, x0=None, **kw):
+    return krylov_solve("gmres", A, b, x0, **kw)
 
 
 def bicgstab(A, b: DeviceVector, x0=None, **kw):
-    ws = BicgstabWorkspace(b.ctx, len(b), len(b))
-    if x0 is not None:
-        ws.warm_start_(x0)
-    bicgstab_(ws, A, b, **kw)
-    return ws.x, ws.stats, ws
+    return krylov_solve("bicgstab", A, b, x0, **kw)
 
 
 # --------------------------------------------------------------------------- Krylov processes
@@ -1623,14 +1743,11 @@ def block_gmres_(ws: BlockGmresWorkspace, A, B_colmajor: DeviceVector, M=None, N
     return _finish(ws, rc)
 
 
-def block_gmres(A, B, X0=None, memory=5, ctx=None, **kw):
-    """Out-of-place block_gmres(A, B) for a host n x p array B -> (X, stats, workspace)."""
-    B = np.asarray(B, dtype=np.float64)
-    n, p = B.shape
-    ctx = ctx or A.ctx
-    ws = BlockGmresWorkspace(ctx, n, n, p, memory=memory)
-    if X0 is not None:
-        ws.warm_start_(X0)
-    Bd = ctx.array(np.asfortranarray(B).ravel(order="F"))
-    block_gmres_(ws, A, Bd, **kw)
-    return ws.X, ws.stats, ws
+def block_gmres(A, B, X0=None, ctx=None, **kw):
+    """Out-of-place block_gmres(A, B[, X0]; memory, kwargs...) for a host n x p array B -> (X, stats, workspace)
+    (src/interface.jl:247-290)."""
+    return krylov_solve("block_gmres", A, B, X0, ctx=ctx, **kw)
+
+
+_INPLACE.update({CgWorkspace: ("cg", cg_), GmresWorkspace: ("gmres", gmres_), BicgstabWorkspace: ("bicgstab", bicgstab_),
+                 BlockGmresWorkspace: ("block_gmres", block_gmres_)})

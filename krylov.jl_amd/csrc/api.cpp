@@ -17,7 +17,8 @@ namespace khip {
 static int g_optional_build_failures = 0;
 void optional_build(int rc) {
   if (rc == KHIP_OK) return;
-  const hipError_t e = hipGetLastError();                       // clears the sticky error of the failed call
+  const hipError_t e = (hipError_t)take_hip_error();            // the cause, recorded at the failing call (not inferred afterwards)
+  (void)hipGetLastError();                                      // clears the runtime's sticky error of the failed call
   if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) return;   // a full device: the other kernels serve the product
   ++g_optional_build_failures;
   fprintf(stderr, "libkrylov_hip: an optional accelerator build failed (%d: %s; HIP: %s) -- falling back to the plain kernels\n", rc,

@@ -207,6 +207,7 @@ void householder_signs(int p, int64_t n, double *Q1, double *S, double *tau) {
 struct StatsBoxB {
   khip_stats st;
   std::vector<double> residuals;
+  int path = -1;       // khip_block_gmres_last_path: 1 once the library's loop (tile SpMM + fused panel sweeps) has run a solve
   StatsBoxB() { memset(&st, 0, sizeof(st)); snprintf(st.status, sizeof(st.status), "unknown"); }
   void reset() { residuals.clear(); st.residuals = nullptr; st.nres = 0; st.indefinite = 0; st.npcCount = 0; st.error[0] = 0; }
   void publish() { st.residuals = residuals.empty() ? nullptr : residuals.data(); st.nres = (int)residuals.size(); }
@@ -545,10 +546,13 @@ int khip_block_gmres_workspace_adopt_panel(khip_block_gmres_workspace *ws, const
   for (auto &e : tab)
     if (strcmp(e.k, name) == 0) {
       KHIP_REQUIRE(ptr || !e.required, "block_gmres_workspace_adopt_panel: X and W cannot be emptied");
-      if (*e.slot != ptr) {
-        if (*e.slot) { if (ws->is_borrowed(*e.slot)) ws->unborrow(*e.slot); else khip_free(ws->ctx, *e.slot); }
-        *e.slot = ptr;
+      if (*e.slot == ptr) return KHIP_OK;                       // nothing changes, in particular not who owns the panel
+      if (ptr) {                                                // one panel, one slot (`borrowed` is a set of pointers)
+        for (auto &o : tab) KHIP_REQUIRE(o.slot == e.slot || *o.slot != ptr, "block_gmres_workspace_adopt_panel: the pointer already is another panel of the workspace");
+        for (const double *v : ws->V) KHIP_REQUIRE(v != ptr, "block_gmres_workspace_adopt_panel: the pointer already is a basis panel of the workspace");
       }
+      if (*e.slot) { if (ws->is_borrowed(*e.slot)) ws->unborrow(*e.slot); else khip_free(ws->ctx, *e.slot); }
+      *e.slot = ptr;
       ws->borrow(ptr);
       return KHIP_OK;
     }
@@ -560,7 +564,12 @@ int khip_block_gmres_workspace_adopt_basis(khip_block_gmres_workspace *ws, int k
   KHIP_REQUIRE(ws && k >= 1 && V_host, "block_gmres_workspace_adopt_basis: bad argument");
   for (double *v : ws->V) KHIP_REQUIRE(ws->is_borrowed(v), "block_gmres_workspace_adopt_basis: this workspace owns its basis");
   KHIP_REQUIRE(k >= ws->mem, "block_gmres_workspace_adopt_basis: fewer panels than the workspace's memory");
-  for (int i = 0; i < k; ++i) KHIP_REQUIRE(V_host[i] != nullptr, "block_gmres_workspace_adopt_basis: null basis panel");
+  for (int i = 0; i < k; ++i) {
+    KHIP_REQUIRE(V_host[i] != nullptr, "block_gmres_workspace_adopt_basis: null basis panel");
+    for (const double *named : {ws->dX, ws->X, ws->W, ws->Pn, ws->Qm})
+      KHIP_REQUIRE(V_host[i] != named, "block_gmres_workspace_adopt_basis: a basis panel is also one of X, W, P, Q, dX");
+    for (int j = 0; j < i; ++j) KHIP_REQUIRE(V_host[i] != V_host[j], "block_gmres_workspace_adopt_basis: the same panel twice");
+  }
   for (double *v : ws->V) ws->unborrow(v);
   ws->V.assign(V_host, V_host + k);
   for (double *v : ws->V) ws->borrow(v);
@@ -582,6 +591,7 @@ int khip_block_gmres_workspace_destroy(khip_block_gmres_workspace *ws) {
 }
 
 const khip_stats *khip_block_gmres_stats(khip_block_gmres_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+int khip_block_gmres_last_path(khip_block_gmres_workspace *ws) { return ws ? ws->box.path : -1; }
 
 // Storage as test/test_allocations.jl:734-761 counts it (n x p blocks at their logical size, without the <= 15 padding
 // rows of a panel): X, W, V[1..mem] (+ dX / P / Q when allocated) on the device, C, D, tau, Z, R, H on the host -- plus what
@@ -667,6 +677,7 @@ static int block_gmres_solve_impl(khip_block_gmres_workspace *ws, const khip_ope
   bool have_gram = false;
   const bool warm_start = ws->warm_start;
   ws->box.reset();
+  ws->box.path = 1;
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
   if (!MisI && !ws->Qm) KB(alloc_panel(ctx, np, p, &ws->Qm));                      // :146
   if (!NisI && !ws->Pn) KB(alloc_panel(ctx, np, p, &ws->Pn));                      // :147
@@ -812,7 +823,7 @@ static int block_gmres_solve_impl(khip_block_gmres_workspace *ws, const khip_ope
       if (o.history) ws->box.residuals.push_back(RNorm);
       nr = nr + inner_iter;
 
-      if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+      if (o.callback) { ws->box.publish(); user_requested_exit = o.callback(ws, o.callback_data) != 0; }
       solved = RNorm <= eps_tol;
       if (restart) {
         const int64_t lim = (int64_t)mem < inner_itmax ? (int64_t)mem : inner_itmax;

@@ -33,6 +33,9 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 const char *get_error() { return g_err; }
+static thread_local int g_hip_err = 0;
+void note_hip_error(int e) { g_hip_err = e; }
+int take_hip_error() { const int e = g_hip_err; g_hip_err = 0; return e; }
 
 struct Rccl {
   void *handle = nullptr;

@@ -17,6 +17,11 @@
 namespace khip {
 
 void set_error(const char *fmt, ...);
+// the hipError_t of the last failed HIP call on this thread, recorded AT the failing call by KHIP_CHECK_HIP (the runtime's own
+// "last error" is overwritten by every later successful call on ROCm < 7: a builder's clean-up hipFree would hide an
+// out-of-memory failure from optional_build -- ADVICE r05); take_hip_error() returns it and resets it to hipSuccess
+void note_hip_error(int e);
+int take_hip_error();
 
 // options.verbose rows: stdout (log_fd = 0) or the caller's file descriptor (the reference's `iostream`, src/cg.jl:24)
 inline void klogf(int fd, const char *fmt, ...) {
@@ -27,7 +32,8 @@ inline void klogf(int fd, const char *fmt, ...) {
 }
 // Lazily built optional accelerators (coded column stream, SpMM tiles) set their state to -1 ("not usable") before they
 // start: a build that fails -- typically hipMalloc on a full device -- must not fail the user's product, the other kernels
-// are still there.  The sticky HIP error of the failed call is cleared.  Only an out-of-memory failure is silent:
+// are still there.  The sticky HIP error of the failed call is cleared.  Only an out-of-memory failure (as recorded at
+// the failing call, note_hip_error) is silent:
 // anything else (a launch error, an inconsistency a builder detects) is a defect of the builder and is reported on stderr and
 // counted (khip_test_optional_build_failures: the GPU test session asserts the count is zero) -- api.cpp.
 void optional_build(int rc);
@@ -37,6 +43,7 @@ inline void klog_flush(int fd) { if (fd <= 0) fflush(stdout); }
   do {                                                                                    \
     hipError_t e__ = (expr);                                                              \
     if (e__ != hipSuccess) {                                                              \
+      ::khip::note_hip_error((int)e__);                                                   \
       ::khip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
                         __LINE__);                                                        \
       return KHIP_ERR_HIP;                                                                \

@@ -36,6 +36,7 @@ double timemax_of(const khip_options &o) {
 struct StatsBox {
   khip_stats st;
   std::vector<double> residuals;
+  int path = -1;       // which loop the last solve ran (khip_*_last_path): 2 device-resident / look-ahead, 1 host-driven fused, 0 primitive sequence
   StatsBox() {
     memset(&st, 0, sizeof(st));
     snprintf(st.status, sizeof(st.status), "unknown");
@@ -108,11 +109,22 @@ void free_unless_borrowed(khip_ctx *ctx, const Borrowed &b, double *p) {
   if (p && !b.has(p)) khip_free(ctx, p);
 }
 // slot <- ptr as a caller-owned vector (ptr == nullptr empties the slot); what the library had allocated there is freed
+// (`Borrowed` is a set of pointers, so a pointer may sit in ONE slot only -- the callers below refuse a pointer that
+// already is another vector of the workspace; handing a slot the pointer it already holds changes nothing, in particular not
+// who owns it.)
 void adopt_into(khip_ctx *ctx, Borrowed &b, double **slot, double *ptr) {
-  if (*slot == ptr) { b.add(ptr); return; }
+  if (*slot == ptr) return;
   if (*slot) { if (b.has(*slot)) b.drop(*slot); else khip_free(ctx, *slot); }
   *slot = ptr;
   b.add(ptr);
+}
+// ptr (non-null) already is a vector of the workspace other than `self`: the name of that slot, else nullptr
+template <class Tab>
+const char *held_elsewhere(const Tab &tab, const double *const *self, const double *ptr, const std::vector<double *> *basis = nullptr) {
+  if (!ptr) return nullptr;
+  for (const auto &e : tab) if (e.slot != self && *e.slot == ptr) return e.k;
+  if (basis) for (const double *v : *basis) if (v == ptr) return "V";
+  return nullptr;
 }
 
 // ---- options.verbose: the reference's per-iteration log (kdisplay, src/krylov_utils.jl:301) on stdout.  Column headers are
@@ -462,6 +474,10 @@ int khip_cg_workspace_adopt_vector(khip_cg_workspace *ws, const char *name, doub
   for (auto &e : tab)
     if (strcmp(e.k, name) == 0) {
       KHIP_REQUIRE(ptr || !e.required, "cg_workspace_adopt_vector: x, r, p, Ap cannot be emptied");
+      if (const char *other = held_elsewhere(tab, e.slot, ptr, nullptr)) {
+        set_error("cg_workspace_adopt_vector: the pointer for '%s' already is the workspace's '%s' (every vector needs its own storage)", name, other);
+        return KHIP_ERR_INVALID;
+      }
       adopt_into(ws->ctx, ws->borrowed, e.slot, ptr);
       return KHIP_OK;
     }
@@ -492,6 +508,7 @@ int khip_cg_warm_start(khip_cg_workspace *ws, const double *x0) {
 
 double *khip_cg_solution(khip_cg_workspace *ws) { return ws ? ws->x : nullptr; }
 const khip_stats *khip_cg_stats(khip_cg_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+int khip_cg_last_path(khip_cg_workspace *ws) { return ws ? ws->box.path : -1; }
 double *khip_cg_vector(khip_cg_workspace *ws, const char *name) {
   if (!ws || !name) return nullptr;
   struct { const char *k; double *p; } tab[] = {{"x", ws->x}, {"r", ws->r}, {"p", ws->p}, {"Ap", ws->Ap},
@@ -728,6 +745,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
     }
   }
   const bool device_loop = o.variant == 0 && o.fused >= 2 && !A->apply && A->csr && MisI && radius == 0 && !linesearch && !o.callback && verbose <= 0;
+  ws->box.path = device_loop ? 2 : (fused ? 1 : 0);
   if (device_loop && !(solved || tired)) {
     CgDevState fin;
     K(cg_device_loop(ws, A->csr, gamma, eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
@@ -822,7 +840,7 @@ int khip_cg_solve(khip_cg_workspace *ws, const khip_operator *A, const khip_oper
 
     iter = iter + 1;
     tired = iter >= itmax;
-    if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;    // :264
+    if (o.callback) { ws->box.publish(); user_requested_exit = o.callback(ws, o.callback_data) != 0; }    // :264
     overtimed = time_limit_reached(ctx, now_s() - t0, timemax);
     if (kdisplay(iter, verbose)) klogf(o.log_fd, "%5lld  %7.1e", (long long)iter, rNorm);                                 // :267
   }
@@ -980,6 +998,10 @@ int khip_gmres_workspace_adopt_vector(khip_gmres_workspace *ws, const char *name
   for (auto &e : tab)
     if (strcmp(e.k, name) == 0) {
       KHIP_REQUIRE(ptr || !e.required, "gmres_workspace_adopt_vector: x and w cannot be emptied");
+      if (const char *other = held_elsewhere(tab, e.slot, ptr, &ws->V)) {
+        set_error("gmres_workspace_adopt_vector: the pointer for '%s' already is the workspace's '%s' (every vector needs its own storage)", name, other);
+        return KHIP_ERR_INVALID;
+      }
       adopt_into(ws->ctx, ws->borrowed, e.slot, ptr);
       return KHIP_OK;
     }
@@ -993,7 +1015,12 @@ int khip_gmres_workspace_adopt_basis(khip_gmres_workspace *ws, int k, double *co
   KHIP_REQUIRE(ws && k >= 0 && (k == 0 || V_host), "gmres_workspace_adopt_basis: bad argument");
   KHIP_REQUIRE(ws->slabs.empty(), "gmres_workspace_adopt_basis: this workspace owns its basis (khip_gmres_workspace_create)");
   KHIP_REQUIRE(k >= ws->mem, "gmres_workspace_adopt_basis: fewer vectors than the workspace's memory");
-  for (int i = 0; i < k; ++i) KHIP_REQUIRE(V_host[i] != nullptr, "gmres_workspace_adopt_basis: null basis vector");
+  for (int i = 0; i < k; ++i) {
+    KHIP_REQUIRE(V_host[i] != nullptr, "gmres_workspace_adopt_basis: null basis vector");
+    for (const double *named : {ws->x, ws->w, ws->p, ws->q, ws->dx})
+      KHIP_REQUIRE(V_host[i] != named, "gmres_workspace_adopt_basis: a basis vector is also one of x, w, p, q, dx");
+    for (int j = 0; j < i; ++j) KHIP_REQUIRE(V_host[i] != V_host[j], "gmres_workspace_adopt_basis: the same vector twice");
+  }
   for (double *v : ws->V) ws->borrowed.drop(v);
   ws->V.assign(V_host, V_host + k);
   for (double *v : ws->V) ws->borrowed.add(v);
@@ -1045,6 +1072,7 @@ int khip_gmres_warm_start(khip_gmres_workspace *ws, const double *x0) {
 
 double *khip_gmres_solution(khip_gmres_workspace *ws) { return ws ? ws->x : nullptr; }
 const khip_stats *khip_gmres_stats(khip_gmres_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+int khip_gmres_last_path(khip_gmres_workspace *ws) { return ws ? ws->box.path : -1; }
 size_t khip_gmres_workspace_bytes(khip_gmres_workspace *ws) {
   if (!ws) return 0;
   size_t cnt = ws->V.size();
@@ -1076,6 +1104,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
   const bool MisI = (M == nullptr), NisI = (N == nullptr);
   // (a verbose solve keeps the host in step with every inner iteration, like the cg! / bicgstab! device loops)
   const bool look = o.variant == 0 && fused && o.fused >= 2 && MisI && NisI && !reorth && !o.callback && !A->apply && A->csr && verbose <= 0;
+  ws->box.path = look ? 2 : (fused ? 1 : 0);
   if (!MisI && !ws->q) K(alloc_vec(ctx, n, &ws->q));                               // src/gmres.jl:142-144
   if (!NisI && !ws->p) K(alloc_vec(ctx, n, &ws->p));
   if (restart && !ws->dx) K(alloc_vec(ctx, n, &ws->dx));
@@ -1460,7 +1489,7 @@ int khip_gmres_solve(khip_gmres_workspace *ws, const khip_operator *A, const khi
       nr = nr + inner_iter;
 
       const bool resid_decrease_mach = (rNorm + 1.0 <= 1.0);
-      if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+      if (o.callback) { ws->box.publish(); user_requested_exit = o.callback(ws, o.callback_data) != 0; }
       const bool resid_decrease_lim = rNorm <= eps_tol;
       breakdown = Hbis <= btol;
       solved = resid_decrease_lim || resid_decrease_mach;
@@ -1699,6 +1728,10 @@ int khip_bicgstab_workspace_adopt_vector(khip_bicgstab_workspace *ws, const char
   for (auto &e : tab)
     if (strcmp(e.k, name) == 0) {
       KHIP_REQUIRE(ptr || !e.required, "bicgstab_workspace_adopt_vector: x, r, p, v, s, qd cannot be emptied");
+      if (const char *other = held_elsewhere(tab, e.slot, ptr, nullptr)) {
+        set_error("bicgstab_workspace_adopt_vector: the pointer for '%s' already is the workspace's '%s' (every vector needs its own storage)", name, other);
+        return KHIP_ERR_INVALID;
+      }
       adopt_into(ws->ctx, ws->borrowed, e.slot, ptr);
       return KHIP_OK;
     }
@@ -1727,6 +1760,7 @@ int khip_bicgstab_warm_start(khip_bicgstab_workspace *ws, const double *x0) {
 
 double *khip_bicgstab_solution(khip_bicgstab_workspace *ws) { return ws ? ws->x : nullptr; }
 const khip_stats *khip_bicgstab_stats(khip_bicgstab_workspace *ws) { return ws ? &ws->box.st : nullptr; }
+int khip_bicgstab_last_path(khip_bicgstab_workspace *ws) { return ws ? ws->box.path : -1; }
 size_t khip_bicgstab_workspace_bytes(khip_bicgstab_workspace *ws) {
   if (!ws) return 0;
   size_t cnt = 0;
@@ -1816,6 +1850,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
 
   const bool fast = fused && MisI && NisI && !A->apply && A->csr;
   const bool device_loop = fast && o.fused >= 2 && !o.callback && verbose <= 0;      // the log rows need alpha and omega on the host
+  ws->box.path = device_loop ? 2 : (fused ? 1 : 0);
   if (device_loop && !(solved || tired)) {
     BicgDevState fin;
     K(bicgstab_device_loop(ws, A->csr, c, next_rho, rNorm, eps_tol, itmax, o.history != 0, t0, timemax, &fin, &overtimed));
@@ -1852,7 +1887,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
       rNorm = std::sqrt(two[1]);                                                   // :240
       if (o.history) ws->box.push(rNorm);
       const bool rdm = (rNorm + 1.0 <= 1.0);
-      if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+      if (o.callback) { ws->box.publish(); user_requested_exit = o.callback(ws, o.callback_data) != 0; }
       solved = (rNorm <= eps_tol) || rdm;
       tired = iter >= itmax;
       breakdown = (alpha == 0 || std::isnan(alpha));
@@ -1902,7 +1937,7 @@ int khip_bicgstab_solve(khip_bicgstab_workspace *ws, const khip_operator *A, con
     if (o.history) ws->box.push(rNorm);
 
     const bool resid_decrease_mach = (rNorm + 1.0 <= 1.0);
-    if (o.callback) user_requested_exit = o.callback(ws, o.callback_data) != 0;
+    if (o.callback) { ws->box.publish(); user_requested_exit = o.callback(ws, o.callback_data) != 0; }
     const bool resid_decrease_lim = rNorm <= eps_tol;
     solved = resid_decrease_lim || resid_decrease_mach;
     tired = iter >= itmax;

@@ -1205,6 +1205,14 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
                 int64_t row_hi, int64_t *wave_cursor, bool finish, const double *dotw, int dot_sq, int64_t hole_lo, int64_t hole_hi) {
   int64_t local_cursor = 0;
   if (!wave_cursor) wave_cursor = &local_cursor;
+  // mid-length rows on few diagonals (the 27-point stencil): try the coded column stream once, it decides between the staged
+  // and the stream kernel (spmv_kernel_choice).  BEFORE the two-range decision below, which asks spmv_kernel_choice: a build
+  // that changed the choice after a hole had been accepted would hand a row range with a hole to a kernel that does not
+  // skip it (tests/test_gpu_dist.py: first product on a handle = the boundary launch).
+  if (ctx->tune.spmv_kernel == 0 && A->code_state == 0 && A->mean_row_nnz > 12.0 && A->mean_row_nnz <= 64.0 && A->max_row_nnz <= 64 &&
+      ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && ctx->tune.spmv_nt == 0 && !ctx->tune.spmv_fake_gather &&
+      !(A->tmpl_id && ctx->tune.spmv_template))
+    optional_build(csr_build_codes(ctx, const_cast<khip_csr *>(A)));
   // Two ranges [row_lo, hole_lo) and [hole_hi, row_hi) in one launch (the boundary rows of a row-partitioned product, api.cpp
   // spmv_any): taken by the staged / coded kernels when the first range is whole row blocks; anything else runs them as two launches.
   bool hole = hole_hi > hole_lo && hole_lo >= row_lo && hole_hi <= row_hi;
@@ -1280,12 +1288,8 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     ctx->prof_used += 2;
   }
 
-  // mid-length rows on few diagonals (the 27-point stencil): try the coded column stream once, it decides between the staged
-  // and the stream kernel (spmv_kernel_choice)
-  if (ctx->tune.spmv_kernel == 0 && A->code_state == 0 && A->mean_row_nnz > 12.0 && A->mean_row_nnz <= 64.0 && A->max_row_nnz <= 64 &&
-      ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && !nt && !a.fake_gather && !(A->tmpl_id && ctx->tune.spmv_template))
-    optional_build(csr_build_codes(ctx, const_cast<khip_csr *>(A)));
-  const int kernel = spmv_kernel_choice(ctx, A);
+  const int kernel = spmv_kernel_choice(ctx, A);               // (the lazy code build that can change it ran at the top of this call)
+  if (hole && kernel != 4) { set_error("spmv: a two-range launch reached kernel %d, which takes one range", kernel); return KHIP_ERR_INVALID; }
   unsigned grid = 1;
   RedArgs ra;
   int wpb = kWavesPerBlock;                   // reduction partials one workgroup of the chosen kernel writes

@@ -48,6 +48,18 @@ static double *dvec(khip_ctx *ctx, int64_t n) {           /* S(undef, n): exactl
   return (double *)p;
 }
 
+/* khip_options.callback as the Julia trampoline uses it (KrylovHIP.jl callback_trampoline): the history so far is readable through
+ * khip_cg_stats() INSIDE the callback (published before every call, ABI 0.4); stop after `stop_at` calls */
+typedef struct { khip_cg_workspace *ws; int calls, stop_at, nres_seen[8]; double last; } cb_state;
+static int count_callback(void *workspace, void *userdata) {
+  cb_state *c = (cb_state *)userdata;
+  const khip_stats *st = khip_cg_stats((khip_cg_workspace *)workspace);
+  if (c->calls < 8) c->nres_seen[c->calls] = st->nres;
+  c->last = st->nres > 0 ? st->residuals[st->nres - 1] : -1.0;
+  c->calls++;
+  return c->calls >= c->stop_at;
+}
+
 /* history of a finished solve, copied (the stats pointer is only valid until the workspace's next solve) */
 typedef struct { int niter, solved, nres; char status[96]; double *res; } snapshot;
 static snapshot snap(const khip_stats *st) {
@@ -109,6 +121,7 @@ static void run_size(khip_ctx *ctx, int n1, int quick) {
   EXPECT(so.solved && so.niter > 0, "cg n1=%d did not converge", n1);
   EXPECT(same_vector(ctx, n, khip_cg_solution(wo), x, scratch), "cg n1=%d: solution bits differ", n1);
   printf("cg   n1=%d  niter=%d  %s  adopted == owned: history %s\n", n1, sa.niter, sa.status, same_history(&so, &sa) ? "bit-identical" : "DIFFERS");
+  EXPECT(khip_cg_last_path(wa) == 2 && khip_cg_last_path(wo) == 2, "cg n1=%d: the default options did not run the device-resident loop", n1);
   /* a second solve on the same adopted workspace (in-place API, test/test_allocations.jl:53-56) */
   CK(khip_cg_solve(wa, &opA, NULL, b, &o));
   snapshot sa2 = snap(khip_cg_stats(wa));
@@ -116,6 +129,16 @@ static void run_size(khip_ctx *ctx, int n1, int quick) {
   free(sa2.res);
 
   if (!quick) {
+    /* a user callback: the host-driven loop on the fused kernels (last_path 1), same bits, history visible inside the callback */
+    cb_state cs; memset(&cs, 0, sizeof(cs)); cs.ws = wa; cs.stop_at = 5;
+    khip_options oc = o; oc.callback = count_callback; oc.callback_data = &cs;
+    CK(khip_cg_solve(wa, &opA, NULL, b, &oc));
+    snapshot sc = snap(khip_cg_stats(wa));
+    EXPECT(khip_cg_last_path(wa) == 1, "cg n1=%d callback: last_path %d", n1, khip_cg_last_path(wa));
+    EXPECT(cs.calls == 5 && sc.niter == 5 && strcmp(sc.status, "user-requested exit") == 0, "cg n1=%d callback: calls %d niter %d status %s", n1, cs.calls, sc.niter, sc.status);
+    for (int i = 0; i < 5; i++) EXPECT(cs.nres_seen[i] == i + 2, "cg n1=%d callback %d saw %d history entries", n1, i, cs.nres_seen[i]);
+    EXPECT(sc.nres == 6 && memcmp(sc.res, so.res, sizeof(double) * 6) == 0 && cs.last == so.res[5], "cg n1=%d callback: history prefix differs from the device loop's", n1);
+    free(sc.res);
     /* fused = 0 (the reference's primitive sequence) on the adopted vectors: same bits as on the owned ones */
     khip_options o0 = o; o0.fused = 0; o0.itmax = 60;
     CK(khip_cg_solve(wo, &opA, NULL, b, &o0)); snapshot s0o = snap(khip_cg_stats(wo));
@@ -265,7 +288,7 @@ int main(int argc, char **argv) {
   CK(khip_ctx_create(0, NULL, &ctx));
   int maj = 0, min = 0;
   khip_version(&maj, &min);
-  if (maj != KHIP_VERSION_MAJOR || min < 3) { fprintf(stderr, "library %d.%d lacks the adopt entry points\n", maj, min); return 1; }
+  if (maj != KHIP_VERSION_MAJOR || min < 4) { fprintf(stderr, "library %d.%d lacks the adopt / last_path entry points\n", maj, min); return 1; }
   if (argc <= 1) run_size(ctx, 64, 0);
   for (int i = 1; i < argc; i++) {
     const int n1 = atoi(argv[i]);

@@ -412,3 +412,141 @@ def test_julia_glue_defines_what_the_reference_solvers_call():
         body = re.search(r"mutable struct " + struct + r"\{T,FC,S\}.*?\nend", wsrc, flags=re.S).group(0)
         for f in fields:
             assert re.search(r"^\s+" + re.escape(f) + r"\s+::", body, flags=re.M), (struct, f)
+
+
+# ---- every entry point of the reference reaches the library's loop ("What's weak" 1) -------------------------------
+_SOLVERS = (("cg", "CgWs", "cg.jl", "CgWorkspace", "AbstractVector{Float64}"), ("gmres", "GmresWs", "gmres.jl", "GmresWorkspace", "AbstractVector{Float64}"),
+            ("bicgstab", "BicgstabWs", "bicgstab.jl", "BicgstabWorkspace", "AbstractVector{Float64}"),
+            ("block_gmres", "BlockGmresWs", "block_gmres.jl", "BlockGmresWorkspace", "AbstractMatrix{Float64}"))
+
+
+def _reference_forwarded_keywords(method, src_file):
+    """What the reference's generated entry points pass to `method!`: (names in order, {name: default expression}) from
+    `kwargs_<method>` and `def_kwargs_<method>` (src/<method>.jl), after checking in src/interface.jl that EVERY generated method calls
+    the in-place one with `$(kwargs...)`, i.e. forwards the whole list, its own defaults included."""
+    ref = open(os.path.join(REFERENCE_SRC, src_file)).read()
+    names = re.findall(r":(\w+)", re.search(r"^kwargs_" + method + r" = \((.*?)\)", ref, flags=re.M).group(1))
+    table = re.search(r"^def_kwargs_" + method + r" = \((.*?)\)\n\n", ref, flags=re.M | re.S).group(1)
+    defaults = {}
+    for m in re.finditer(r":\(;\s*(\w+)(?:::[^=]+?)?\s*=\s*(.*?)\s*\)\s*[,)]?\s*$", table, flags=re.M):
+        defaults[m.group(1)] = m.group(2)
+    assert list(defaults) == names, (list(defaults), names)
+    iface = re.sub(r"#.*", "", open(os.path.join(REFERENCE_SRC, "interface.jl")).read())
+    calls = re.findall(r"\$\(krylov!\)\(workspace, \$\(args\.\.\.\); (.*?)\)\n", iface)
+    assert len(calls) >= 14 and set(calls) == {"$(kwargs...)"}, set(calls)          # out-of-place (4 forms), krylov_solve! and the x0 forms, vector and block
+    return names, defaults
+
+
+def _julia_gate(glue, fn, ws_t):
+    """(keyword part of the signature, condition of the first `if` = the fallback gate, body up to the solve) of a specialised method."""
+    m = re.search(r"function Krylov\." + re.escape(fn) + r"!\(ws::" + ws_t + r", A::HIPCsr, \w+::HIP(?:Vector|Matrix);(.*?)\)\n(?:  [^\n]*\n){0,3}?  if (.*?)\n(.*?)\nend\n", glue, flags=re.S)
+    assert m, fn
+    return m.group(1), m.group(2), m.group(3)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_SRC), reason="the reference tree is only present in the build container")
+def test_forwarded_defaults_reach_the_native_loop():
+    """The reference's `cg(A, b)`, `krylov_solve(Val(:cg), A, b)`, `krylov_solve!(ws, A, b)` and the x0 forms forward EVERY keyword to
+    `cg!` explicitly, `callback = workspace -> false` included (src/interface.jl:146-154, 160-170, 306-347).  For that keyword set the
+    fallback gate of each specialised method in julia/KrylovHIP/src/KrylovHIP.jl must be FALSE (the native branch is taken), the
+    callback must be recognised as the default (-> NULL in khip_options: the device-resident loop), and the same holds for the Python
+    mirror's tables, which are executed on the GPU (tests/test_gpu_adopt.py)."""
+    glue = open(JULIA_SRC).read()
+    # the helper predicates the gates use, as defined in the package (a change there must be re-read here)
+    assert "native_precond(M) = M === I || M isa HIPOperator" in glue
+    assert "native_log(verbose, io) = verbose <= 0 || logfd(io) >= 0" in glue
+    assert "default_callback(cb) = parentmodule(typeof(cb)) === Krylov && Base.issingletontype(typeof(cb))" in glue
+    assert "user_callback(cb) = (cb === nothing || default_callback(cb)) ? nothing : cb" in glue
+    I, kstdout = object(), object()
+
+    class Panel:                                     # a tall HIPMatrix
+        pass
+    env_fns = {"native_precond": lambda M: M is I, "native_log": lambda verbose, io: verbose <= 0 or io is kstdout, "tall": lambda P: isinstance(P, Panel)}
+
+    def julia_value(expr, names):
+        expr = expr.strip()
+        table = {"I": I, "false": False, "true": True, "zero(T)": 0.0, "√eps(T)": float(np.sqrt(np.finfo(np.float64).eps)), "Inf": float("inf"),
+                 "kstdout": kstdout, "b": "b"}
+        if expr == "workspace -> false":
+            return "DEFAULT_CALLBACK"
+        if expr in table:
+            return table[expr]
+        return int(expr)
+
+    import krylov_jl_amd as K
+    for method, ws_t, src_file, ws_struct, rhs_t in _SOLVERS:
+        names, defaults = _reference_forwarded_keywords(method, src_file)
+        assert defaults["callback"] == "workspace -> false"
+        forwarded = {k: julia_value(v, names) for k, v in defaults.items()}
+        sig, gate, body = _julia_gate(glue, method, ws_t)
+        # (i) the gate never looks at the callback, and is false for the forwarded defaults
+        assert "callback" not in gate, f"{method}!: the fallback gate tests the callback -- cg(A, b) forwards one ALWAYS ({gate})"
+        py = gate.replace("||", " or ").replace("&&", " and ").replace("!==", " is not ").replace("===", " is ")
+        py = re.sub(r"!(?=[\w(])", " not ", py)
+        py = py.replace("ws.X", "wsX")
+        scope = dict(env_fns)
+        scope.update({k: v for k, v in forwarded.items() if k != "callback"})
+        scope.update({"B": Panel(), "wsX": Panel(), "I": I})
+        assert eval(py, {"__builtins__": {}}, scope) is False, f"{method}!: forwarded defaults do not reach the native branch: {gate}"
+        # ... and true for what the library cannot take
+        for k, v in (("ldiv", True), ("M", object()), ("verbose", 1)):
+            s2 = dict(scope)
+            s2[k] = v
+            if k == "verbose":
+                s2["iostream"] = object()                   # an IOBuffer: no file descriptor
+            assert eval(py, {"__builtins__": {}}, s2) is True, (method, k, gate)
+        # (ii) the callback reaches khip_options only through user_callback, and the native branch records itself
+        assert "callback_args(user_callback(callback), ws, sp, history)" in body
+        assert "NATIVE_SOLVES[] += 1" in body and f"khip_{method}_last_path" in body
+        assert re.search(r"callback = nothing", sig)
+        # (iii) the fallback names argument types that are a subtype of the generic signature: the fully parametrised alias
+        # (T, FC and the storage type fixed) and the element type FC = Float64 on the right-hand side (src/cg.jl:120: FC is shared)
+        tuples = re.findall(r"invoke\(Krylov\." + method + r"!, Tuple\{((?:[^{}]|\{[^{}]*\})*)\}", glue)
+        assert tuples == [f"{ws_t},Any,{rhs_t}"], tuples
+        alias = re.search(r"const " + ws_t + r" = (\w+)\{(.*)\}\n", glue)
+        assert alias.group(1) == ws_struct
+        nparams = len(re.search(r"mutable struct " + ws_struct + r"\{([^}]*)\}", open(os.path.join(
+            REFERENCE_SRC, "block_krylov_workspaces.jl" if method == "block_gmres" else "krylov_workspaces.jl")).read()).group(1).split(","))
+        depth, parts, cur = 0, [], ""
+        for ch in alias.group(2):
+            if ch == "," and depth == 0:
+                parts.append(cur); cur = ""
+                continue
+            depth += ch == "{"
+            depth -= ch == "}"
+            cur += ch
+        parts.append(cur)
+        assert len(parts) == nparams and parts[:2] == ["Float64", "Float64"], (parts, nparams)
+        gen = re.search(r"function " + method + r"!\(workspace :: " + ws_struct + r"\{[^}]*\}, \$\(def_args_" + method + r"\.\.\.\)", open(os.path.join(REFERENCE_SRC, src_file)).read())
+        assert gen, "the generic signature moved"
+        # (iv) the Python mirror forwards the same names with the same defaults
+        mine = K.FORWARDED_DEFAULTS[method]
+        assert list(mine) == names, (list(mine), names)
+        for k in names:
+            want = forwarded[k]
+            if want is I or want is kstdout or want == "b":
+                assert mine[k] is None, (method, k)
+            elif want == "DEFAULT_CALLBACK":
+                assert mine[k] is K.default_callback and K._user_callback(mine[k]) is None
+            else:
+                assert mine[k] == want and type(mine[k]) is type(want), (method, k, mine[k], want)
+    # workspace keywords of the out-of-place entries (src/gmres.jl:110, src/block_gmres.jl:99)
+    assert K.WORKSPACE_KWARGS == {"gmres": {"memory": 20}, "block_gmres": {"memory": 5}}
+    ref_g = open(os.path.join(REFERENCE_SRC, "gmres.jl")).read()
+    ref_b = open(os.path.join(REFERENCE_SRC, "block_gmres.jl")).read()
+    assert "def_kwargs_workspace_gmres = (:(; memory::Int = 20),)" in ref_g and "def_kwargs_workspace_block_gmres = (:(; memory::Int = 5),)" in ref_b
+    # the package's own test asserts the same on a GPU, and its `invoke` helpers are parametrised too
+    rt = open(JULIA_TEST).read()
+    assert "Tuple{typeof(ws),Any,AbstractVector{Float64}}" in rt and "Tuple{typeof(ws2),Any,AbstractMatrix{Float64}}" in rt
+    assert not re.search(r"Tuple\{\w+Workspace,Any,Abstract(?:Vector|Matrix)\}", rt + glue), "an unparametrised invoke signature is left"
+    for entry in ("cg(A_gpu, b_gpu)", "krylov_solve(Val(:cg), A_gpu, b)", "krylov_solve!(ws, A_gpu, b)", "cg!(ws, A_gpu, b, x0)", "krylov_solve!(ws, A_gpu, b, x0)",
+                  "cg(A_gpu, b, x0)", "gmres(U_gpu, b)", "bicgstab(U_gpu, b)", "block_gmres(U_gpu, B)"):
+        assert re.search(r"native\(\d\) do; " + re.escape(entry), rt), f"runtests.jl does not assert the native path after {entry}"
+
+
+def test_adjoint_of_the_julia_operator_is_cached_and_finalised():
+    """ADVICE / VERDICT r05: `A'` built a new transposed operator per call, without a finalizer."""
+    glue = open(JULIA_SRC).read()
+    body = re.search(r"function Base\.adjoint\(A::HIPCsr\)\n(.*?)\nend\n", glue, flags=re.S).group(1)
+    assert "A.adj === nothing || return A.adj" in body and "finalizer(destroy_csr" in body and "A.adj = At" in body
+    assert body.count("khip_csr_transpose") == 1

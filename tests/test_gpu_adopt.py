@@ -209,12 +209,32 @@ def test_adopt_argument_errors(K, ctx):
     assert L.khip_gmres_workspace_adopt_vector(h, b"nope", v[5].ptr) == -1
     two = (C.c_void_p * 2)(v[2].ptr, v[3].ptr)
     assert L.khip_gmres_workspace_adopt_basis(h, 2, two) == -1                                                      # fewer vectors than the memory
+    # one pointer, one slot -- a pointer that already is another vector of the workspace (or a basis vector) is refused,
+    # so emptying one slot can never hand the other slot's storage to khip_free
+    assert L.khip_gmres_workspace_adopt_vector(h, b"p", v[5].ptr) == 0
+    assert L.khip_gmres_workspace_adopt_vector(h, b"q", v[5].ptr) == -1 and b"already is the workspace's 'p'" in L.khip_last_error()
+    assert L.khip_gmres_workspace_adopt_vector(h, b"dx", v[3].ptr) == -1 and b"'V'" in L.khip_last_error()
+    assert L.khip_gmres_workspace_adopt_vector(h, b"p", v[5].ptr) == 0                                              # the same pointer again: a no-op
+    dup = (C.c_void_p * 3)(v[2].ptr, v[5].ptr, v[4].ptr)
+    assert L.khip_gmres_workspace_adopt_basis(h, 3, dup) == -1                                                      # v[5] is p
+    dup = (C.c_void_p * 3)(v[2].ptr, v[2].ptr, v[4].ptr)
+    assert L.khip_gmres_workspace_adopt_basis(h, 3, dup) == -1
+    assert L.khip_gmres_workspace_adopt_vector(h, b"p", None) == 0
     assert L.khip_gmres_workspace_destroy(h) == 0
     # a library-owned workspace keeps its basis to itself
     ho = C.c_void_p()
     assert L.khip_gmres_workspace_create(ctx._h, n, n, 3, C.byref(ho)) == 0
     assert L.khip_gmres_workspace_adopt_basis(ho, 3, ptrs) == -1 and b"owns its basis" in L.khip_last_error()
     assert L.khip_gmres_workspace_destroy(ho) == 0
+    # re-adopting the pointer a library-owned slot already holds must not turn it into a borrowed one (it would leak):
+    # the lazily allocated z of an owned workspace stays the library's and is freed by destroy (no double free, no error)
+    hc = C.c_void_p()
+    assert L.khip_cg_workspace_create(ctx._h, n, n, C.byref(hc)) == 0
+    A = K.CsrMatrix.stencil(ctx, "poisson", 10)
+    assert L.khip_cg_workspace_adopt_vector(hc, b"z", v[5].ptr) == 0
+    assert L.khip_cg_workspace_adopt_vector(hc, b"dx", v[5].ptr) == -1                                               # z already holds it
+    assert L.khip_cg_workspace_adopt_vector(hc, b"z", None) == 0
+    assert L.khip_cg_workspace_destroy(hc) == 0
     for x in v:                                           # nothing of the caller's was freed along the way
         K.kfill_(x, 1.0)
     assert K.knorm(n, v[0]) == pytest.approx(np.sqrt(n))
