@@ -46,6 +46,7 @@ struct TileArgs {
   int64_t groups, per_xcd;
   int64_t runs, runs_per_xcd;   // sliding windows (run_len > 0): the groups form runs of run_len consecutive records, a wave walks whole runs
   int run_len;
+  int ahead;              // 1 (two-wave kernel, sliding windows): the copies of group g + 1 are issued before the products of g where its record allows it
   int dbuf;               // 1: two windows per wave, the copies of the next group land while this group's products run (LDS: 2 x cap x 32 L bytes)
   int cap;                // list entries per group (multiple of 8)
   int stride;             // bytes per record
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w)
   const char *xb_ = reinterpret_cast<const char *>(tile_win) + 16 * c + (16 * L - hq);
   const int64_t vlast = a.nnz_bound - 2;
   const int slot_off = kTileDescBytes + 4 * w.cap;
-  struct Rec { int4v d[NP]; int lw[NL]; int flag; int mask; };
+  struct Rec { int4v d[NP]; int lw[NL]; int flag; int mask; int look; };
   struct Ent { dbl2 v[NP][S::F]; int sw[NP][S::SW]; };
 
   auto load_rec = [&](int64_t gg, Rec &r) {
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w)
     }
     r.flag = reinterpret_cast<const int *>(rec)[7];                      // aux word of row slot 1: the group's direct-path flag
     r.mask = reinterpret_cast<const int *>(rec)[11];                     // ... of row slot 2: the octets of slots to copy (sliding windows)
+    r.look = reinterpret_cast<const int *>(rec)[15];                     // ... of row slot 3: 1 = the new rows avoid the predecessor's slots (look-ahead)
   };
   auto load_ent = [&](int64_t gg, const Rec &r, Ent &e) {
     const char *slots = w.meta + (gg < last ? gg : last) * (int64_t)w.stride + slot_off;
@@ -533,6 +535,45 @@ __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w)
   load_rec(g1, r1);
   load_ent(g, r0, e0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
+  if (slide && w.ahead) {
+    // LOOK-AHEAD ON SLIDING WINDOWS (round 6).  Per group: everything this wave has in flight has landed (vmcnt(0): the copies of
+    // g, its entries, the record of g + 1) -> ONE barrier (the partner's half of the copies has landed too, and both waves are
+    // past the products of g - 1) -> issue the copies of g + 1 (its new rows avoid every slot g reads: record flag `look`), its
+    // entries and the record of g + 2 -> products of g while those fly.  One memory round trip per group is overlapped with the
+    // products instead of following them, one barrier per group instead of two, and the copies are half a window (the rows the
+    // window does not hold yet).  A group whose record does not allow it (first of a run, or its new rows did not fit) is
+    // copied after a second barrier behind the products, as in the loop below.  vmcnt(0) keeps hipcc's own wait bookkeeping
+    // exact (the asm copies are outside it): nothing is in flight across the top of the loop.
+    if (__builtin_amdgcn_readfirstlane(r0.flag) == 0) issue_dma(r0, (unsigned)__builtin_amdgcn_readfirstlane(r0.mask));
+    for (;;) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const bool direct = __builtin_amdgcn_readfirstlane(r0.flag) != 0;
+      const bool more = g1 < gend;
+      bool direct1 = true, early = false;
+      if (more) {
+        direct1 = __builtin_amdgcn_readfirstlane(r1.flag) != 0;
+        early = !direct1 && __builtin_amdgcn_readfirstlane(r1.look) != 0;
+        if (early) issue_dma(r1, (unsigned)__builtin_amdgcn_readfirstlane(r1.mask));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        load_ent(g1, r1, e1);
+        load_rec(g2, r2);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!direct) products(r0, e0);
+      if (!more) break;
+      if (!early && !direct1) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both waves are done with the window: it may be filled anew
+        issue_dma(r1, (unsigned)__builtin_amdgcn_readfirstlane(r1.mask));
+      }
+      g = g1; g1 = g2; g2 = next_of(run2, t2);
+      r0 = r1; e0 = e1; r1 = r2;
+    }
+    return;
+  }
   for (;;) {
     const bool direct = __builtin_amdgcn_readfirstlane(r0.flag) != 0;      // the same for both waves: barriers stay matched
     const unsigned mask = slide ? (unsigned)__builtin_amdgcn_readfirstlane(r0.mask) : 0xffffffffu;
@@ -802,13 +843,21 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_kernel(const int32_t *
 // octets of slots that received one are the group's copy mask (aux word of row slot 2).  The list keeps naming, for EVERY
 // slot, the column that sits there, so an octet that is copied again for one new row rewrites its other seven rows with
 // themselves.  A group on the direct-gather path (or an empty one) ends the chain: the next group fills the window anew.
+//
+// LOOK-AHEAD (ahead != 0, round 6).  The kernel wants to issue the copies of group t BEFORE the products of group t - 1 have
+// read the window: the new columns of t then must not land in a slot that t - 1 still reads.  So they take only slots that
+// neither t (kept columns) nor t - 1 (used_prev) uses -- the window needs |columns(t - 1)| + |new columns(t)| slots -- and the
+// record says so (aux word of row slot 3 = 1).  Where the free slots do not suffice, or at the start of a chain, the old rule
+// applies and the flag is 0: the kernel copies that group after the products of its predecessor, as before.  (An octet that is
+// copied for one new row rewrites its other rows with THEMSELVES, also those t - 1 is reading: same bytes, no hazard.)
 __global__ __launch_bounds__(kBlock) void spmm_tile_build_run_kernel(const int32_t *rowptr, const int32_t *col, TileOrder o, int cap,
-                                                                      int stride, char *meta, int run_len) {
+                                                                      int stride, char *meta, int run_len, int ahead) {
   __shared__ TileBuildShared S;
-  __shared__ int slot_col[kTileCapMax], uslot[kTileCapMax], freelist[kTileCapMax], flag[kBlock];
+  __shared__ int slot_col[kTileCapMax], uslot[kTileCapMax], freelist[kTileCapMax], flag[kBlock], used_prev[kTileCapMax], used_now[kTileCapMax];
   __shared__ unsigned mask_sh;
   const int tid = threadIdx.x;
-  for (int q = tid; q < kTileCapMax; q += kBlock) slot_col[q] = kTileEmpty;
+  for (int q = tid; q < kTileCapMax; q += kBlock) { slot_col[q] = kTileEmpty; used_prev[q] = 0; }
+  bool chain = false;                  // the previous group of this run left a window behind (uniform)
   for (int t = 0; t < run_len; ++t) {
     const int64_t g = (int64_t)blockIdx.x * run_len + t;
     const int n_uniq0 = tile_group_unique(S, rowptr, col, o, g);
@@ -819,10 +868,12 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_run_kernel(const int32
     int32_t *lst = reinterpret_cast<int32_t *>(rec + kTileDescBytes);
     uint8_t *slots = reinterpret_cast<uint8_t *>(rec + kTileDescBytes + 4 * cap);
     if (tid == 0) mask_sh = 0u;
+    int look = 0;
     if (direct) {
       for (int q = tid; q < cap; q += kBlock) lst[q] = 0;
       for (int q = tid; q < kTileSlotBytes; q += kBlock) slots[q] = 0;
-      for (int q = tid; q < kTileCapMax; q += kBlock) slot_col[q] = kTileEmpty;       // the chain ends here
+      for (int q = tid; q < kTileCapMax; q += kBlock) { slot_col[q] = kTileEmpty; used_prev[q] = 0; }       // the chain ends here
+      chain = false;
       __syncthreads();
     } else {
       // (a) slots whose column the group needs again keep it
@@ -840,18 +891,8 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_run_kernel(const int32
           if (S.uniq[lo] == c) { uslot[lo] = tid; keep = 1; }
         }
       }
-      // (b) the free slots, ascending
-      flag[tid] = (tid < cap && !keep) ? 1 : 0;
       __syncthreads();
-      for (int d = 1; d < kBlock; d <<= 1) {
-        const int add = tid >= d ? flag[tid - d] : 0;
-        __syncthreads();
-        flag[tid] += add;
-        __syncthreads();
-      }
-      if (tid < cap && !keep) freelist[flag[tid] - 1] = tid;
-      __syncthreads();
-      // (c) the new columns, ascending, into them
+      // (b) how many columns are new, and how many slots are free of this group AND of the previous one
       const int isnew = (tid < n_uniq && uslot[tid] < 0) ? 1 : 0;
       flag[tid] = isnew;
       __syncthreads();
@@ -861,14 +902,48 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_run_kernel(const int32
         flag[tid] += add;
         __syncthreads();
       }
+      const int new_rank = flag[tid], n_new = flag[kBlock - 1];
+      __syncthreads();
+      const int free2 = (tid < cap && !keep && !used_prev[tid]) ? 1 : 0;
+      flag[tid] = free2;
+      __syncthreads();
+      for (int d = 1; d < kBlock; d <<= 1) {
+        const int add = tid >= d ? flag[tid - d] : 0;
+        __syncthreads();
+        flag[tid] += add;
+        __syncthreads();
+      }
+      const int n_free2 = flag[kBlock - 1];
+      look = (ahead && chain && n_free2 >= n_new) ? 1 : 0;
+      // (c) the free slots, ascending: free of this group (and, with look-ahead, of the previous one)
+      int isfree = (tid < cap && !keep) ? 1 : 0;
+      if (look) isfree = free2;
+      __syncthreads();
+      if (!look) {
+        flag[tid] = isfree;
+        __syncthreads();
+        for (int d = 1; d < kBlock; d <<= 1) {
+          const int add = tid >= d ? flag[tid - d] : 0;
+          __syncthreads();
+          flag[tid] += add;
+          __syncthreads();
+        }
+      }
+      if (isfree) freelist[flag[tid] - 1] = tid;
+      used_now[tid] = keep;
+      __syncthreads();
+      // (d) the new columns, ascending, into them
       if (isnew) {
-        const int sl = freelist[flag[tid] - 1];
+        const int sl = freelist[new_rank - 1];
         uslot[tid] = sl;
         slot_col[sl] = S.uniq[tid];
+        used_now[sl] = 1;
         atomicOr(&mask_sh, 1u << (sl >> 3));
       }
       __syncthreads();
-      // (d) the record: list in slot order (an empty slot names the group's last column: any valid row will do), slot bytes
+      used_prev[tid] = used_now[tid];
+      chain = true;
+      // (e) the record: list in slot order (an empty slot names the group's last column: any valid row will do), slot bytes
       for (int q = tid; q < cap; q += kBlock) lst[q] = slot_col[q] != kTileEmpty ? slot_col[q] : (n_uniq > 0 ? S.uniq[n_uniq - 1] : 0);
       for (int q = tid; q < kTileKeys; q += kBlock) {
         const int tt = q / kTileLen, k = q % kTileLen;
@@ -889,7 +964,7 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_build_run_kernel(const int32
     if (tid < kTileR) {
       int4v d;
       d.x = S.rrow[tid]; d.y = S.rstart[tid]; d.z = S.rlen[tid];
-      d.w = tid == 0 ? n_uniq : (tid == 1 ? (direct ? 1 : 0) : (tid == 2 ? (int)mask_sh : 0));
+      d.w = tid == 0 ? n_uniq : (tid == 1 ? (direct ? 1 : 0) : (tid == 2 ? (int)mask_sh : (tid == 3 ? look : 0)));
       reinterpret_cast<int4v *>(rec)[tid] = d;
     }
   }
@@ -902,6 +977,7 @@ void csr_free_tiles(khip_csr *A) {
   A->tile_direct_list = nullptr;
   A->tile_state = 0;
   A->tile_run_len = 0;
+  A->tile_ahead = 0;
   A->tile_runs = 0;
 }
 
@@ -1009,6 +1085,12 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
     cap = kTileCapMax;
   }
   if (cap < 8) cap = 8;
+  // look-ahead on sliding windows (tune.spmm_tile_ahead): the window also holds the NEW panel rows of the next group while the
+  // current one is being read -- half a window more covers two shared planes out of four (4 x 4 x 2 tiles: 144 + 72 = 216
+  // slots); a group whose new rows do not fit keeps the old rule (its record says so)
+  const int ahead_opt = ctx->tune.spmm_tile_ahead;
+  const bool ahead = best.run_len > 0 && ahead_opt != 0 && ctx->tune.spmm_tile_pair != 0 && cap + cap / 2 <= kTileCapMax;
+  if (ahead) cap = ((cap + cap / 2) + 7) & ~7;
   const int stride = kTileDescBytes + 4 * cap + kTileSlotBytes;
   size_t free_b = 0, total_b = 0;
   KHIP_CHECK_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1016,7 +1098,7 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
   KHIP_CHECK_HIP(hipMalloc(&A->tile_meta, (size_t)groups * (size_t)stride));
   if (best.run_len > 0)
     hipLaunchKernelGGL(spmm_tile_build_run_kernel, dim3((unsigned)tile_runs_for(best)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, best, cap,
-                       stride, A->tile_meta, best.run_len);
+                       stride, A->tile_meta, best.run_len, ahead ? 1 : 0);
   else
     hipLaunchKernelGGL((spmm_tile_build_kernel<true>), dim3((unsigned)groups), dim3(kBlock), 0, ctx->stream, A->rowptr, A->col, best, cap, stride,
                        A->tile_meta, (int32_t *)nullptr, (unsigned long long *)nullptr);
@@ -1041,6 +1123,7 @@ int spmm_tile_build(khip_ctx *ctx, khip_csr *A) {
   A->tile_stride = stride;
   A->tile_groups = groups;
   A->tile_run_len = best.run_len;
+  A->tile_ahead = ahead ? 1 : 0;
   A->tile_runs = tile_runs_for(best);
   A->tile_grid = best.s1 != 0 ? 1 : 0;
   A->tile_direct = n_direct;
@@ -1058,6 +1141,7 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   // (profiles/r04r_spmm_dbuf.log).  spmm_tile_dbuf: -1 by that rule, 0 never, 1 always.  (Sliding windows carry ONE window.)
   const int dbuf_opt = ctx->tune.spmm_tile_dbuf;
   const bool use_pair = ctx->tune.spmm_tile_pair && L >= 4 && !ctx->tune.spmm_tile_nt;
+  w.ahead = (use_pair && A->tile_ahead && w.run_len > 0 && ctx->tune.spmm_tile_ahead != 0) ? 1 : 0;
   w.dbuf = (!use_pair && (dbuf_opt > 0 || (dbuf_opt < 0 && (size_t)w.cap * 32 * L * 2 <= (size_t)26 * 1024))) ? 1 : 0;
   if (w.dbuf) w.run_len = 0;      // records built for sliding windows serve every other scheme too: their list names the column of EVERY slot, so a kernel that copies all octets of every group (in any order of the groups) fills a consistent window
   const size_t lds = (size_t)w.cap * 32 * L * (w.dbuf ? 2 : 1);
@@ -1083,7 +1167,7 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
     // two waves per window (spmm_tile2_kernel): the residency is counted in windows as before, every window now carries two waves
     const size_t lds1 = (size_t)w.cap * 32 * L;
     int wg_per_cu = (int)((size_t)(160 * 1024) / lds1);
-    if (wg_per_cu >= 5) --wg_per_cu;
+    if (wg_per_cu >= 5 && !w.ahead) --wg_per_cu;
     if (wg_per_cu > 8) wg_per_cu = 8;
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t grid2 = ctx->tune.spmm_tile_grid > 0 ? ctx->tune.spmm_tile_grid : (int64_t)ctx->num_cu * wg_per_cu;

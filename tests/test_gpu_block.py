@@ -432,7 +432,7 @@ def test_spmm_tile_sliding_and_double_buffered_windows_bit_identical(K, ctx, ora
     groups and copies only the panel rows its window lacks; run lengths 1 = whole grid lines, 3, 7; grids with partial tiles, a
     single plane, and an operator without a grid) and double-buffered windows (spmm_tile_dbuf: the copies of the next group
     land under this group's products).  Y equals the direct-gather kernel's bit for bit in every combination."""
-    saved = {k: ctx.get_option(k) for k in ("spmm_tile", "spmm_tile_slide", "spmm_tile_dbuf", "spmm_window", "spmm_tile_shape", "spmm_tile_pair")}
+    saved = {k: ctx.get_option(k) for k in ("spmm_tile", "spmm_tile_slide", "spmm_tile_dbuf", "spmm_window", "spmm_tile_shape", "spmm_tile_pair", "spmm_tile_ahead")}
     rng = np.random.default_rng(31 + p)
     makers = [lambda: K.CsrMatrix.stencil(ctx, "stencil27", 13, 10, 9), lambda: K.CsrMatrix.stencil(ctx, "poisson", 21, 12, 11),
               lambda: K.CsrMatrix.stencil(ctx, "poisson", 37, 29, 1), lambda: K.CsrMatrix.banded_random(ctx, 6000, seed=3)]
@@ -448,17 +448,21 @@ def test_spmm_tile_sliding_and_double_buffered_windows_bit_identical(K, ctx, ora
             ctx.set_option("spmm_tile", 2)
             # (slide, dbuf, shape, pair): pair = two waves per window (spmm_tile2_kernel, p >= 16; with and without sliding windows);
             # the last rows are the defaults (-1: by rule)
-            for slide, dbuf, shape, pair in ((0, 0, 0, 0), (0, 1, 0, 0), (1, 0, 0, 0), (3, 0, 0, 0), (7, 0, 4, 0), (1, 1, 0, 0), (0, 1, 4, 0),
-                                             (0, 0, 0, 1), (1, 0, 0, 1), (3, 0, 4, 1), (27, 0, 0, 1), (-1, -1, 0, 1), (-1, -1, 0, 0)):
+            # ahead (round 6): the sliding windows' look-ahead -- the next group's new panel rows are copied BEFORE this group's
+            # products, into slots neither group reads (two-wave kernel with runs; 0 = the one-window loop of round 4)
+            for slide, dbuf, shape, pair, ahead in ((0, 0, 0, 0, 0), (0, 1, 0, 0, 0), (1, 0, 0, 0, 0), (3, 0, 0, 0, 1), (7, 0, 4, 0, 0), (1, 1, 0, 0, 1), (0, 1, 4, 0, 0),
+                                                    (0, 0, 0, 1, 1), (1, 0, 0, 1, 0), (1, 0, 0, 1, 1), (3, 0, 4, 1, 0), (3, 0, 4, 1, 1), (2, 0, 0, 1, 1), (27, 0, 0, 1, 0),
+                                                    (27, 0, 0, 1, 1), (-1, -1, 0, 1, -1), (-1, -1, 0, 0, -1)):
                 ctx.set_option("spmm_tile_pair", pair)
+                ctx.set_option("spmm_tile_ahead", ahead)
                 ctx.set_option("spmm_tile_slide", slide); ctx.set_option("spmm_tile_dbuf", dbuf); ctx.set_option("spmm_tile_shape", shape)
                 dB = make()                               # the group records are built per handle, at its first product
                 dY2 = K.Panel(ctx, dB.m, p)
                 K.spmm_(dB, dX, dY2)
-                assert dB.tile_info["state"] == 1, (slide, dbuf, shape, pair, dB.tile_info)
-                assert np.array_equal(dY2.to_host(), ref), (slide, dbuf, shape, pair)
+                assert dB.tile_info["state"] == 1, (slide, dbuf, shape, pair, ahead, dB.tile_info)
+                assert np.array_equal(dY2.to_host(), ref), (slide, dbuf, shape, pair, ahead)
                 K.spmm_(dB, dX, dY2)                      # a second product on the same records
-                assert np.array_equal(dY2.to_host(), ref), (slide, dbuf, shape, pair, "second product")
+                assert np.array_equal(dY2.to_host(), ref), (slide, dbuf, shape, pair, ahead, "second product")
     finally:
         for k, v in saved.items():
             ctx.set_option(k, v)

@@ -216,6 +216,130 @@ static void spmm_shape(int n1, int sx, int sy, int sz) {
   CK(hipFree(val)); CK(hipFree(slot)); CK(hipFree(rec)); CK(hipFree(X)); CK(hipFree(Y));
 }
 
+// ------------------------------------------------------------------------------------------------ tile SpMM twin, SLIDING windows
+// The traffic of the shipped kernel (spmm_tile2_kernel with runs of <= 27 groups along k) and of its look-ahead form (round 6): a
+// wave walks a run of `run_len` 4 x 4 x 2 tiles along k for one (tx, ty); the first group of a run reads the whole 6 x 6 x 4 box of
+// panel rows, every later one only the two NEW planes (72 rows); entries + records + Y as in k_spmm_twin.  `ahead` = 0: the loads
+// of a group are issued, waited for and folded before the next group's are issued (what a single window enforces); 1: the next
+// group's loads are issued BEFORE this group's are folded (what the look-ahead slot assignment allows).  Runs are numbered with
+// tx fastest, then ty, the pieces of a line slowest; XCD x takes the x-th eighth of the runs.
+struct SlideArgs {
+  TwinArgs t;
+  int run_len, pieces;   // groups per run, runs per line of tiles along z
+  long runs;
+  int ahead;
+};
+struct SlideLoads { dbl2 e[16]; dbl2 xr[18]; };
+__device__ __forceinline__ void slide_issue(const SlideArgs &s, long g, int tx, int ty, int tz, bool first, int lane, SlideLoads &L) {
+  const TwinArgs &a = s.t;
+  const int nvec = a.epg / 2, n1 = a.n1;
+  const dbl2 *vp = a.val + g * (long)nvec;
+#pragma unroll
+  for (int j = 0; j < 14; ++j) { const int i = j * 64 + lane; L.e[j] = i < nvec ? vp[i] : dbl2{0.0, 0.0}; }
+  const dbl2 *sp = a.slot + g * (long)(a.epg / 16);
+  const dbl2 *rp = a.rec + g * 60L;
+  L.e[14] = lane < a.epg / 16 ? sp[lane] : dbl2{0.0, 0.0};
+  L.e[15] = lane < 60 ? rp[lane] : dbl2{0.0, 0.0};
+  // panel rows: box (sx + 2) x (sy + 2) x (sz + 2); later groups of a run: only its last sz planes
+  const int wx = a.sx + 2, wy = a.sy + 2, wz = a.sz + 2;
+  const int z0 = first ? 0 : 2, nwin = wx * wy * (wz - z0);
+#pragma unroll
+  for (int j = 0; j < 18; ++j) {
+    const int r = j * 8 + (lane >> 3);
+    L.xr[j] = dbl2{0.0, 0.0};
+    if (r < nwin) {
+      const int dx = r % wx, dy = (r / wx) % wy, dz = z0 + r / (wx * wy);
+      int x = tx * a.sx - 1 + dx, y = ty * a.sy - 1 + dy, z = tz * a.sz - 1 + dz;
+      x = x < 0 ? 0 : (x >= n1 ? n1 - 1 : x); y = y < 0 ? 0 : (y >= n1 ? n1 - 1 : y); z = z < 0 ? 0 : (z >= n1 ? n1 - 1 : z);
+      const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
+      L.xr[j] = a.X[row * 8 + (lane & 7)];
+    }
+  }
+}
+__device__ __forceinline__ void slide_fold(const SlideArgs &s, int tx, int ty, int tz, int lane, const SlideLoads &L) {
+  const TwinArgs &a = s.t;
+  dbl2 acc = {0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { acc.x += L.e[j].x; acc.y += L.e[j].y; }
+#pragma unroll
+  for (int j = 0; j < 18; ++j) { acc.x += L.xr[j].x; acc.y += L.xr[j].y; }
+  const int rows = a.sx * a.sy * a.sz, n1 = a.n1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = j * 8 + (lane >> 3);
+    if (r < rows) {
+      const int x = tx * a.sx + r % a.sx, y = ty * a.sy + (r / a.sx) % a.sy, z = tz * a.sz + r / (a.sx * a.sy);
+      const long row = (long)x + (long)n1 * ((long)y + (long)n1 * z);
+      a.Y[row * 8 + (lane & 7)] = acc;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_spmm_slide(SlideArgs s) {
+  const TwinArgs &a = s.t;
+  const int lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7;
+  const long waves_per_xcd = a.waves_total / 8;
+  const long w_in_xcd = (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+  if ((long)blockIdx.x * 4 + (threadIdx.x >> 6) >= a.waves_total) return;
+  const long r0 = s.runs * xcd / 8, r1 = s.runs * (xcd + 1) / 8;
+  const long nlines = (long)a.tiles_x * a.tiles_y;
+  for (long run = r0 + w_in_xcd; run < r1; run += waves_per_xcd) {
+    const long line = run % nlines, piece = run / nlines;
+    const int tx = (int)(line % a.tiles_x), ty = (int)(line / a.tiles_x);
+    const int tz0 = (int)piece * s.run_len;
+    const int len = tz0 + s.run_len <= a.tiles_z ? s.run_len : a.tiles_z - tz0;
+    if (len <= 0) continue;
+    const long gbase = ((long)piece * nlines + line) * s.run_len;      // records of a run are consecutive
+    SlideLoads A, B;
+    slide_issue(s, gbase, tx, ty, tz0, true, lane, A);
+    for (int t = 0; t < len; ++t) {
+      if (s.ahead) {
+        if (t + 1 < len) slide_issue(s, gbase + t + 1, tx, ty, tz0 + t + 1, false, lane, B);
+        slide_fold(s, tx, ty, tz0 + t, lane, A);
+        A = B;
+      } else {
+        slide_fold(s, tx, ty, tz0 + t, lane, A);
+        if (t + 1 < len) slide_issue(s, gbase + t + 1, tx, ty, tz0 + t + 1, false, lane, A);
+      }
+    }
+  }
+}
+static void spmmslide_main(int n1) {
+  SlideArgs s;
+  TwinArgs &a = s.t;
+  a.sx = 4; a.sy = 4; a.sz = 2;
+  a.n1 = n1; a.tiles_x = n1 / 4; a.tiles_y = n1 / 4; a.tiles_z = n1 / 2;
+  a.groups = (long)a.tiles_x * a.tiles_y * a.tiles_z;
+  a.epg = 27 * 32; a.pencil = 4; a.entries = 1; a.xrows = 1;
+  const long n = (long)n1 * n1 * n1;
+  double *val, *slot, *rec, *X, *Y;
+  const long gpad = a.groups + a.groups / 8 + 64;                     // records padded to whole runs
+  CK(hipMalloc(&val, gpad * a.epg * 8)); CK(hipMalloc(&slot, gpad * a.epg)); CK(hipMalloc(&rec, gpad * 1920));
+  CK(hipMalloc(&X, n * 128)); CK(hipMalloc(&Y, n * 128));
+  CK(hipMemset(val, 0, gpad * a.epg * 8)); CK(hipMemset(slot, 0, gpad * a.epg)); CK(hipMemset(rec, 0, gpad * 1920));
+  CK(hipMemset(X, 0, n * 128)); CK(hipMemset(Y, 0, n * 128));
+  a.val = (const dbl2 *)val; a.slot = (const dbl2 *)slot; a.rec = (const dbl2 *)rec; a.X = (const dbl2 *)X; a.Y = (dbl2 *)Y;
+  const double alg = 12.0 * 27.0 * n + 4.0 * (n + 1) + 2.0 * 128.0 * n;
+  printf("tile SpMM twin, SLIDING windows: %d^3 rows, 4 x 4 x 2 tiles walked along z in runs; per group 9 B per entry + 960 B of records, 72 new panel rows (144 at the start of a run), 32 rows of Y; algorithmic (SURVEY 8d) %.3f GB\n", n1, alg / 1e9);
+  for (int run_len : {27, 54, 108}) {
+    s.pieces = (a.tiles_z + run_len - 1) / run_len;
+    s.run_len = (a.tiles_z + s.pieces - 1) / s.pieces;
+    s.runs = (long)a.tiles_x * a.tiles_y * s.pieces;
+    for (int ahead = 0; ahead < 2; ++ahead) {
+      s.ahead = ahead;
+      for (int wpc : {4, 8, 10, 12, 16}) {
+        a.waves_total = 256 * wpc;
+        const int blocks = a.waves_total / 4;
+        const float ms = timeit([&] { hipLaunchKernelGGL(k_spmm_slide, dim3(blocks), dim3(256), 0, 0, s); }, 10);
+        printf("runs of %3d groups  %-26s waves/CU=%2d  %.3f ms  (algorithmic bytes / time = %.0f GB/s = %.3f of 8 TB/s)\n", s.run_len,
+               ahead ? "next group issued first" : "one group at a time", wpc, ms, alg / ms / 1e6, alg / ms / 1e6 / 8000.0);
+        fflush(stdout);
+      }
+    }
+  }
+  CK(hipFree(val)); CK(hipFree(slot)); CK(hipFree(rec)); CK(hipFree(X)); CK(hipFree(Y));
+}
+
 // ------------------------------------------------------------------------------------------------ cg! update folded into the SpMV?
 // fold `x += alpha p_old` and `p = r + beta p_old` into the SpMV of the NEXT iteration (the
 // product gathers r and p_old instead of p, writes p_new, Ap and x): matrix + 72n instead of matrix + 80n bytes per iteration.
@@ -273,7 +397,8 @@ int main(int argc, char **argv) {
   const char *mode = argc > 1 ? argv[1] : "panel";
   if (strcmp(mode, "panel") == 0) panel_main(argc > 2 ? atol(argv[2]) : 10077696L, 16);
   else if (strcmp(mode, "spmm") == 0) spmm_main(argc > 2 ? atoi(argv[2]) : 216);
+  else if (strcmp(mode, "spmmslide") == 0) spmmslide_main(argc > 2 ? atoi(argv[2]) : 216);
   else if (strcmp(mode, "cgfold") == 0) cgfold_main(argc > 2 ? atoi(argv[2]) : 512);
-  else { printf("usage: streamfloor panel [rows] | spmm [n1] | cgfold [n1]\n"); return 2; }
+  else { printf("usage: streamfloor panel [rows] | spmm [n1] | spmmslide [n1] | cgfold [n1]\n"); return 2; }
   return 0;
 }
