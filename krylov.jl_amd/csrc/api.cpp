@@ -480,19 +480,22 @@ int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes) {
   return KHIP_OK;
 }
 
-int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms) {
-  KHIP_REQUIRE(ctx && launches && total_ms, "profile_spmv: null argument");
+int khip_profile_kernels(khip_ctx *ctx, int ntags, int64_t *launches, double *total_ms) {
+  KHIP_REQUIRE(ctx && launches && total_ms && ntags >= 1, "profile_kernels: bad argument");
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  double tot = 0;
+  for (int t = 0; t < ntags; ++t) { launches[t] = 0; total_ms[t] = 0.0; }
   for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
     float ms = 0;
     KHIP_CHECK_HIP(hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
-    tot += ms;
+    const int tag = i / 2 < ctx->prof_tags.size() ? ctx->prof_tags[i / 2] : 0;
+    if (tag < ntags) { launches[tag] += 1; total_ms[tag] += ms; }
   }
-  *launches = (int64_t)(ctx->prof_used / 2);
-  *total_ms = tot;
   ctx->prof_used = 0;
   return KHIP_OK;
+}
+
+int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms) {      // the SpMV brackets alone (tag 0); resets every counter
+  return khip_profile_kernels(ctx, 1, launches, total_ms);
 }
 
 int khip_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, int p) {

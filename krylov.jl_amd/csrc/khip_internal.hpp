@@ -181,6 +181,7 @@ struct khip_ctx {
   void *panel_scratch = nullptr;       // panel.hip: V^T Q partial tiles + Psi staging ring
   // SpMV launch profiling (events recorded on `stream`, resolved lazily)
   std::vector<hipEvent_t> prof_events;   // pairs: start, stop
+  std::vector<int> prof_tags;            // one per pair: which kernel family the bracket belongs to (ProfTag)
   size_t prof_used = 0;
 };
 
@@ -402,4 +403,28 @@ inline int64_t global_rows(khip_ctx *ctx, const khip_operator *A, int64_t n_loca
   return n_local;
 }
 
+
+// HIP-event brackets around single kernel launches on the context's stream (ctx option "profile_spmv" = 1; khip_profile_spmv /
+// khip_profile_kernels read them): bench.py's roofline figures are averages of these, measured inside the timed solve.
+enum ProfTag { kProfSpmv = 0, kProfSpmm = 1, kProfPanelTn = 2, kProfPanelNnTn = 3, kProfPanelMultiNn = 4, kProfPanelNn = 5, kProfPanelQr = 6, kProfTags = 7 };
+struct ProfScope {
+  khip_ctx *ctx;
+  hipEvent_t stop = nullptr;
+  ProfScope(khip_ctx *c, int tag) : ctx(c) {
+    if (!c->tune.profile_spmv) return;
+    if (c->prof_used + 2 > c->prof_events.size()) {
+      for (int i = 0; i < 64; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->prof_events.push_back(e);
+      }
+    }
+    if (c->prof_tags.size() < c->prof_events.size() / 2) c->prof_tags.resize(c->prof_events.size() / 2, 0);
+    if (hipEventRecord(c->prof_events[c->prof_used], c->stream) != hipSuccess) return;
+    stop = c->prof_events[c->prof_used + 1];
+    c->prof_tags[c->prof_used / 2] = tag;
+    c->prof_used += 2;
+  }
+  ~ProfScope() { if (stop) (void)hipEventRecord(stop, ctx->stream); }
+};
 }  // namespace khip

@@ -395,7 +395,9 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
 // they meet at a barrier when the copies have landed, and each runs the products of half of the group's row passes (L = 4: one
 // pass of 16 rows each) -- twice the waves per CU on the same LDS, half the serial work per wave and group.  The record / entry
 // prefetch pipeline is per wave as before.  Same arithmetic, same order per row: Y bit-identical.
-template <int L, bool DIST, int NL>
+// AHEAD (round 6) is a separate instantiation: the look-ahead loop keeps three records and two entry sets live across a
+// barrier and would cost the round-4 loop its fourth wave per SIMD if both sat in one kernel (161 instead of 120 VGPRs at NL = 3).
+template <int L, bool DIST, int NL, bool AHEAD>
 __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w) {
   using S = TileShape<L>;
   static_assert(S::NPASS >= 2, "two waves per window need two row passes per group");
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w)
   load_rec(g1, r1);
   load_ent(g, r0, e0);
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  if (slide && w.ahead) {
+  if constexpr (AHEAD) {
     // LOOK-AHEAD ON SLIDING WINDOWS (round 6).  Per group: everything this wave has in flight has landed (vmcnt(0): the copies of
     // g, its entries, the record of g + 1) -> ONE barrier (the partner's half of the copies has landed too, and both waves are
     // past the products of g - 1) -> issue the copies of g + 1 (its new rows avoid every slot g reads: record flag `look`), its
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w)
       r0 = r1; e0 = e1; r1 = r2;
     }
     return;
-  }
+  } else {
   for (;;) {
     const bool direct = __builtin_amdgcn_readfirstlane(r0.flag) != 0;      // the same for both waves: barriers stay matched
     const unsigned mask = slide ? (unsigned)__builtin_amdgcn_readfirstlane(r0.mask) : 0xffffffffu;
@@ -595,6 +597,7 @@ __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w)
     if (g >= gend) break;
     if (!direct) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both waves are done with the window before the next copies
     r0 = r1; e0 = e1; r1 = r2;
+  }
   }
 }
 
@@ -1167,7 +1170,18 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
     // two waves per window (spmm_tile2_kernel): the residency is counted in windows as before, every window now carries two waves
     const size_t lds1 = (size_t)w.cap * 32 * L;
     int wg_per_cu = (int)((size_t)(160 * 1024) / lds1);
-    if (wg_per_cu >= 5 && !w.ahead) --wg_per_cu;
+    if (w.ahead) {
+      // the look-ahead kernel holds more registers: ask the runtime how many of its workgroups a CU takes (LDS and VGPRs), and
+      // keep the waves a multiple of the four SIMDs (5 workgroups = 10 waves ran 45 % slower than 4, profiles/r06b_spmm_ahead_ab.jsonl)
+      int nb = 0;
+      const void *fn = nullptr;
+#define KHIP_TILE2_FN(D, N) fn = (const void *)spmm_tile2_kernel<(L >= 4 ? L : 4), D, N, true>
+      if (dist) { switch (NL) { case 1: KHIP_TILE2_FN(true, 1); break; case 2: KHIP_TILE2_FN(true, 2); break; case 3: KHIP_TILE2_FN(true, 3); break; default: KHIP_TILE2_FN(true, 4); break; } }
+      else      { switch (NL) { case 1: KHIP_TILE2_FN(false, 1); break; case 2: KHIP_TILE2_FN(false, 2); break; case 3: KHIP_TILE2_FN(false, 3); break; default: KHIP_TILE2_FN(false, 4); break; } }
+#undef KHIP_TILE2_FN
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 128, lds1) == hipSuccess && nb > 0 && nb < wg_per_cu) wg_per_cu = nb;
+      if (wg_per_cu > 2) wg_per_cu &= ~1;
+    } else if (wg_per_cu >= 5) --wg_per_cu;
     if (wg_per_cu > 8) wg_per_cu = 8;
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t grid2 = ctx->tune.spmm_tile_grid > 0 ? ctx->tune.spmm_tile_grid : (int64_t)ctx->num_cu * wg_per_cu;
@@ -1180,7 +1194,11 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
     if (grid2 > w.groups) grid2 = w.groups;
     if (grid2 >= 64) grid2 &= ~(int64_t)7;
     const dim3 gd2((unsigned)grid2), bd2(128);
-#define KHIP_TILE2(D, N) hipLaunchKernelGGL((spmm_tile2_kernel<(L >= 4 ? L : 4), D, N>), gd2, bd2, lds1, ctx->stream, a, w)
+#define KHIP_TILE2(D, N)                                                                                                     \
+  do {                                                                                                                       \
+    if (w.ahead) hipLaunchKernelGGL((spmm_tile2_kernel<(L >= 4 ? L : 4), D, N, true>), gd2, bd2, lds1, ctx->stream, a, w);   \
+    else hipLaunchKernelGGL((spmm_tile2_kernel<(L >= 4 ? L : 4), D, N, false>), gd2, bd2, lds1, ctx->stream, a, w);          \
+  } while (0)
     if (dist) { switch (NL) { case 1: KHIP_TILE2(true, 1); break; case 2: KHIP_TILE2(true, 2); break; case 3: KHIP_TILE2(true, 3); break; default: KHIP_TILE2(true, 4); break; } }
     else      { switch (NL) { case 1: KHIP_TILE2(false, 1); break; case 2: KHIP_TILE2(false, 2); break; case 3: KHIP_TILE2(false, 3); break; default: KHIP_TILE2(false, 4); break; } }
 #undef KHIP_TILE2

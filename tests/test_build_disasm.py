@@ -60,6 +60,16 @@ def test_tile_spmm_wait_counts_match_the_emitted_loads():
         assert any("global_load_lds_dwordx4" in l for l in ins), name              # the copies are LDS-DMA
         waits = _waits_after_dma(ins)
         assert waits, name
+        if kind == "spmm_tile2_kernel" and re.search(r"ELi\d+ELb1EEEv", name):
+            # The look-ahead instantiation (round 6) has no counted wait of its own: before the one barrier of a group it waits for
+            # EVERYTHING it has in flight -- `s_waitcnt vmcnt(0)` (+ lgkmcnt(0)) then `s_barrier` -- and the copies it issues
+            # afterwards go to window slots the current group does not read (tests/test_gpu_block.py checks the bits).  hipcc's own
+            # counted waits behind a copy only ever over-wait (the asm copies are not in its count).
+            top = [i for i, l in enumerate(ins) if re.match(r"s_waitcnt vmcnt\(0\)", l) and any(x.startswith("s_barrier") for x in ins[i + 1:i + 4])]
+            assert top, f"{name}: no vmcnt(0) + s_barrier pair"
+            assert sum(1 for l in ins if l.startswith("s_barrier")) >= 2, name
+            seen["ahead"] = seen.get("ahead", 0) + 1
+            continue
         for n, cnt, _barrier in waits:
             # at least n younger vector-memory instructions: vmcnt(n) then implies every copy has landed
             assert cnt >= n, f"{name}: s_waitcnt vmcnt({n}) with only {cnt} vector-memory instructions after the last LDS-DMA copy"
@@ -69,4 +79,4 @@ def test_tile_spmm_wait_counts_match_the_emitted_loads():
         if kind == "spmm_tile2_kernel":
             assert any(b for _n, _c, b in exact), f"{name}: the wait before the s_barrier is not the exact one: {waits}"
         seen[kind] += 1
-    assert seen["spmm_tile_kernel"] >= 16 and seen["spmm_tile2_kernel"] >= 8, seen
+    assert seen["spmm_tile_kernel"] >= 16 and seen["spmm_tile2_kernel"] >= 8 and seen.get("ahead", 0) >= 8, seen

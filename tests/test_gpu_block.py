@@ -423,7 +423,8 @@ def test_spmm_tile_grid_operators_bit_identical(K, ctx, oracle, kind, dims):
         ref = np.stack([A.matvec(np.ascontiguousarray(X[:, j])) for j in range(16)], axis=1)
         assert np.array_equal(Yt, ref)
     if kind == "poisson" and n3 > 1:
-        assert info["window"] <= 6 * 4 * 4 + 8, info          # 7-point tile: far fewer than the 6 x 6 x 4 box
+        # 7-point tile: far fewer than the 6 x 6 x 4 box; half a window more where the sliding windows look one group ahead
+        assert info["window"] <= (6 * 4 * 4 + 8) * 3 // 2, info
 
 
 @pytest.mark.parametrize("p", [8, 16, 32])

@@ -229,22 +229,23 @@ struct SlideArgs {
   long runs;
   int ahead;
 };
-struct SlideLoads { dbl2 e[16]; dbl2 xr[18]; };
-__device__ __forceinline__ void slide_issue(const SlideArgs &s, long g, int tx, int ty, int tz, bool first, int lane, SlideLoads &L) {
+template <int NX> struct SlideLoads { dbl2 e[9]; dbl2 xr[NX]; };      // 4 x 4 x 2 tiles: 432 value vectors = 7 per lane, + slots + record
+template <int NX>
+__device__ __forceinline__ void slide_issue(const SlideArgs &s, long g, int tx, int ty, int tz, int lane, SlideLoads<NX> &L) {
   const TwinArgs &a = s.t;
   const int nvec = a.epg / 2, n1 = a.n1;
   const dbl2 *vp = a.val + g * (long)nvec;
 #pragma unroll
-  for (int j = 0; j < 14; ++j) { const int i = j * 64 + lane; L.e[j] = i < nvec ? vp[i] : dbl2{0.0, 0.0}; }
+  for (int j = 0; j < 7; ++j) { const int i = j * 64 + lane; L.e[j] = i < nvec ? vp[i] : dbl2{0.0, 0.0}; }
   const dbl2 *sp = a.slot + g * (long)(a.epg / 16);
   const dbl2 *rp = a.rec + g * 60L;
-  L.e[14] = lane < a.epg / 16 ? sp[lane] : dbl2{0.0, 0.0};
-  L.e[15] = lane < 60 ? rp[lane] : dbl2{0.0, 0.0};
-  // panel rows: box (sx + 2) x (sy + 2) x (sz + 2); later groups of a run: only its last sz planes
+  L.e[7] = lane < a.epg / 16 ? sp[lane] : dbl2{0.0, 0.0};
+  L.e[8] = lane < 60 ? rp[lane] : dbl2{0.0, 0.0};
+  // panel rows: box (sx + 2) x (sy + 2) x (sz + 2), NX = 18: all of it (first group of a run); NX = 9: only its last sz planes
   const int wx = a.sx + 2, wy = a.sy + 2, wz = a.sz + 2;
-  const int z0 = first ? 0 : 2, nwin = wx * wy * (wz - z0);
+  const int z0 = NX == 18 ? 0 : 2, nwin = wx * wy * (wz - z0);
 #pragma unroll
-  for (int j = 0; j < 18; ++j) {
+  for (int j = 0; j < NX; ++j) {
     const int r = j * 8 + (lane >> 3);
     L.xr[j] = dbl2{0.0, 0.0};
     if (r < nwin) {
@@ -256,13 +257,14 @@ __device__ __forceinline__ void slide_issue(const SlideArgs &s, long g, int tx, 
     }
   }
 }
-__device__ __forceinline__ void slide_fold(const SlideArgs &s, int tx, int ty, int tz, int lane, const SlideLoads &L) {
+template <int NX>
+__device__ __forceinline__ void slide_fold(const SlideArgs &s, int tx, int ty, int tz, int lane, const SlideLoads<NX> &L) {
   const TwinArgs &a = s.t;
   dbl2 acc = {0.0, 0.0};
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { acc.x += L.e[j].x; acc.y += L.e[j].y; }
+  for (int j = 0; j < 9; ++j) { acc.x += L.e[j].x; acc.y += L.e[j].y; }
 #pragma unroll
-  for (int j = 0; j < 18; ++j) { acc.x += L.xr[j].x; acc.y += L.xr[j].y; }
+  for (int j = 0; j < NX; ++j) { acc.x += L.xr[j].x; acc.y += L.xr[j].y; }
   const int rows = a.sx * a.sy * a.sz, n1 = a.n1;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -274,6 +276,7 @@ __device__ __forceinline__ void slide_fold(const SlideArgs &s, int tx, int ty, i
     }
   }
 }
+template <bool AHEAD>
 __global__ __launch_bounds__(256) void k_spmm_slide(SlideArgs s) {
   const TwinArgs &a = s.t;
   const int lane = threadIdx.x & 63;
@@ -290,16 +293,28 @@ __global__ __launch_bounds__(256) void k_spmm_slide(SlideArgs s) {
     const int len = tz0 + s.run_len <= a.tiles_z ? s.run_len : a.tiles_z - tz0;
     if (len <= 0) continue;
     const long gbase = ((long)piece * nlines + line) * s.run_len;      // records of a run are consecutive
-    SlideLoads A, B;
-    slide_issue(s, gbase, tx, ty, tz0, true, lane, A);
-    for (int t = 0; t < len; ++t) {
-      if (s.ahead) {
-        if (t + 1 < len) slide_issue(s, gbase + t + 1, tx, ty, tz0 + t + 1, false, lane, B);
-        slide_fold(s, tx, ty, tz0 + t, lane, A);
-        A = B;
-      } else {
-        slide_fold(s, tx, ty, tz0 + t, lane, A);
-        if (t + 1 < len) slide_issue(s, gbase + t + 1, tx, ty, tz0 + t + 1, false, lane, A);
+    SlideLoads<9> A;
+    {
+      SlideLoads<18> F;                                                // the first group of a run fills the window
+      slide_issue<18>(s, gbase, tx, ty, tz0, lane, F);
+      if (AHEAD && len > 1) slide_issue<9>(s, gbase + 1, tx, ty, tz0 + 1, lane, A);
+      slide_fold<18>(s, tx, ty, tz0, lane, F);
+      if (!AHEAD && len > 1) slide_issue<9>(s, gbase + 1, tx, ty, tz0 + 1, lane, A);
+    }
+    if (AHEAD) {
+      SlideLoads<9> B;
+      for (int t = 1; t < len; t += 2) {                   // two groups per trip: the buffers swap roles without a copy
+        if (t + 1 < len) slide_issue<9>(s, gbase + t + 1, tx, ty, tz0 + t + 1, lane, B);
+        slide_fold<9>(s, tx, ty, tz0 + t, lane, A);
+        if (t + 1 < len) {
+          if (t + 2 < len) slide_issue<9>(s, gbase + t + 2, tx, ty, tz0 + t + 2, lane, A);
+          slide_fold<9>(s, tx, ty, tz0 + t + 1, lane, B);
+        }
+      }
+    } else {
+      for (int t = 1; t < len; ++t) {
+        slide_fold<9>(s, tx, ty, tz0 + t, lane, A);
+        if (t + 1 < len) slide_issue<9>(s, gbase + t + 1, tx, ty, tz0 + t + 1, lane, A);
       }
     }
   }
@@ -330,7 +345,8 @@ static void spmmslide_main(int n1) {
       for (int wpc : {4, 8, 10, 12, 16}) {
         a.waves_total = 256 * wpc;
         const int blocks = a.waves_total / 4;
-        const float ms = timeit([&] { hipLaunchKernelGGL(k_spmm_slide, dim3(blocks), dim3(256), 0, 0, s); }, 10);
+        const float ms = ahead ? timeit([&] { hipLaunchKernelGGL(k_spmm_slide<true>, dim3(blocks), dim3(256), 0, 0, s); }, 10)
+                               : timeit([&] { hipLaunchKernelGGL(k_spmm_slide<false>, dim3(blocks), dim3(256), 0, 0, s); }, 10);
         printf("runs of %3d groups  %-26s waves/CU=%2d  %.3f ms  (algorithmic bytes / time = %.0f GB/s = %.3f of 8 TB/s)\n", s.run_len,
                ahead ? "next group issued first" : "one group at a time", wpc, ms, alg / ms / 1e6, alg / ms / 1e6 / 8000.0);
         fflush(stdout);
