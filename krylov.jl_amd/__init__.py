@@ -98,6 +98,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "khip_csr_halo_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(_i64), C.POINTER(_i64)]),
     "khip_profile_spmv": (_int, [_vp, C.POINTER(_i64), C.POINTER(_dbl)]),
+    "khip_profile_kernels": (_int, [_vp, _int, C.POINTER(_i64), C.POINTER(_dbl)]),
     "khip_dot": (_int, [_vp, _i64, _vp, _vp, c_double_p]),
     "khip_nrm2": (_int, [_vp, _i64, _vp, c_double_p]),
     "khip_scal": (_int, [_vp, _i64, _dbl, _vp]),
@@ -335,6 +336,16 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         _ck(lib().khip_profile_spmv(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    PROFILE_TAGS = ("spmv", "spmm", "panel_gemm_tn", "panel_nn_tn", "panel_multi_nn", "panel_gemm_nn", "panel_qr_scale_gram")
+
+    def profile_kernels(self):
+        """{family: (launches, total_ms)} of the HIP-event brackets recorded since the last call (option profile_spmv = 1):
+        khip_profile_kernels -- SpMV, SpMM, and the panel kernels of block_gmres!."""
+        k = len(self.PROFILE_TAGS)
+        n, ms = (C.c_int64 * k)(), (C.c_double * k)()
+        _ck(lib().khip_profile_kernels(self._h, k, n, ms))
+        return {t: (int(n[i]), float(ms[i])) for i, t in enumerate(self.PROFILE_TAGS)}
 
     # --- multi-GPU (one process per GPU) ---
     @staticmethod

@@ -637,6 +637,7 @@ int launch_spmm(khip_ctx *ctx, const khip_csr *A, const double *X, double *Y, in
   }
   a.row_lo = 0; a.row_hi = A->m; a.xcd_remap = 0; a.nt_y = 0; a.dot_early = 0; a.fake_gather = 0; a.tiles_per_block = 1;
   a.nnz_bound = A->nnz + kPad;
+  ProfScope prof_scope(ctx, kProfSpmm);             // ctx option profile_spmv: HIP events around the product's kernels (after the halo exchange)
   int P = 4;
   while (P < p) P <<= 1;
   const int rpb = kBlock / P;

@@ -512,13 +512,17 @@ void launch_gemm_nn(khip_ctx *ctx, int64_t np, int p, double alpha, const double
     const int64_t per_wg = (int64_t)kWavesPerBlock * T;
     const unsigned g = (unsigned)((tiles + per_wg - 1) / per_wg);
     const size_t lds = sizeof(double) * (size_t)p * p;
+    { ProfScope prof_scope(ctx, kProfPanelNn);
     if (p <= 16) hipLaunchKernelGGL((panel_multi_nn_lds_kernel<1>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, 1, a, Psi_dev, alpha, beta, Q, T);
     else hipLaunchKernelGGL((panel_multi_nn_lds_kernel<2>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, 1, a, Psi_dev, alpha, beta, Q, T);
+    }
     return;
   }
   const unsigned g = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  { ProfScope prof_scope(ctx, kProfPanelNn);
   if (p <= 16) hipLaunchKernelGGL((panel_gemm_nn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, Psi_dev, beta, Q);
   else hipLaunchKernelGGL((panel_gemm_nn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, alpha, V, Psi_dev, beta, Q);
+  }
 }
 
 constexpr int kPsiSlots = 64;    // staging ring for the p x p factors of Q += V Psi
@@ -774,8 +778,10 @@ static void tn_reduce(khip_ctx *ctx, const TnPlan &t, int p, double *psi_out) {
 static int tn_enqueue(khip_ctx *ctx, int64_t np, int p, const double *V, const double *Q, double *psi_out) {
   const TnPlan t = tn_plan(np, p);
   KHIP_TRY(ensure_panel_scratch(ctx, 2 * (size_t)t.blocks * t.tile_elems));
+  { ProfScope prof_scope(ctx, kProfPanelTn);
   if (t.NT == 1) hipLaunchKernelGGL((panel_gemm_tn_kernel<1>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, V, Q, g_ps.partials);
   else hipLaunchKernelGGL((panel_gemm_tn_kernel<2>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, V, Q, g_ps.partials);
+  }
   tn_reduce(ctx, t, p, psi_out);
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
@@ -808,8 +814,10 @@ int khip::panel_scale_gram(khip_ctx *ctx, int64_t n, int p, double *Q, const dou
   double *psi_h = g_ps.psi_pinned + (size_t)slot * 1024, *psi_d = g_ps.psi_dev + (size_t)slot * 1024;
   memcpy(psi_h, Ri_host, sizeof(double) * (size_t)p * p);
   KHIP_CHECK_HIP(hipMemcpyAsync(psi_d, psi_h, sizeof(double) * (size_t)p * p, hipMemcpyHostToDevice, ctx->stream));
+  { ProfScope prof_scope(ctx, kProfPanelQr);
   if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
   else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, 1.0, Q, psi_d, 0.0, nullptr, Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
+  }
   tn_reduce(ctx, t, p, g_ps.psi_dev);
   KHIP_CHECK_HIP(hipGetLastError());
   KHIP_CHECK_HIP(hipMemcpyAsync(g_ps.psi_pinned, g_ps.psi_dev, sizeof(double) * (size_t)p * p, hipMemcpyDeviceToHost, ctx->stream));
@@ -851,14 +859,18 @@ int khip::panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *c
   if (T > 0 && lds <= 48 * 1024) {            // factors in LDS, T tiles per wave
     const int64_t per_wg = (int64_t)kWavesPerBlock * T;
     const unsigned g = (unsigned)((tiles + per_wg - 1) / per_wg);
+    { ProfScope prof_scope(ctx, kProfPanelMultiNn);
     if (p <= 16) hipLaunchKernelGGL((panel_multi_nn_lds_kernel<1>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, 1.0, beta, X, T);
     else hipLaunchKernelGGL((panel_multi_nn_lds_kernel<2>), dim3(g), dim3(kBlock), lds, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, 1.0, beta, X, T);
+    }
     KHIP_CHECK_HIP(hipGetLastError());
     return KHIP_OK;
   }
   const unsigned g = (unsigned)((tiles + kWavesPerBlock - 1) / kWavesPerBlock);
+  { ProfScope prof_scope(ctx, kProfPanelMultiNn);
   if (p <= 16) hipLaunchKernelGGL((panel_multi_nn_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, beta, X);
   else hipLaunchKernelGGL((panel_multi_nn_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, np, p, k, a, g_ps.psi_dev + 1024, beta, X);
+  }
   KHIP_CHECK_HIP(hipGetLastError());
   return KHIP_OK;
 }
@@ -906,14 +918,18 @@ int khip::panel_mgs_gram(khip_ctx *ctx, int64_t n, int p, int k, const double *c
     double *psi_i = g_ps.psi_dev + (size_t)(i + 1) * 1024;
     if (i + 1 < k) {
       double *psi_n = g_ps.psi_dev + (size_t)(i + 2) * 1024;
+      { ProfScope prof_scope(ctx, kProfPanelNnTn);
       if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
       else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, false>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, V_host[i + 1], Q, g_ps.partials, (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0));
+      }
       tn_reduce(ctx, t, p, psi_n);
     } else if (tiles > 0 && want_gram) {
       double *psi_g = g_ps.psi_dev + (size_t)(k + 1) * 1024;
       const int flags = (ctx->tune.panel_a_lds ? 1 : 0) | (panel_nt(ctx, np, p) ? 2 : 0);
+      { ProfScope prof_scope(ctx, kProfPanelNnTn);
       if (t.NT == 1) hipLaunchKernelGGL((panel_nn_tn_kernel<1, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, nullptr, Q, g_ps.partials, flags);
       else hipLaunchKernelGGL((panel_nn_tn_kernel<2, 2, true>), dim3(t.blocks), dim3(kBlock), 0, ctx->stream, np, p, -1.0, V_host[i], psi_i, 1.0, nullptr, Q, g_ps.partials, flags);
+      }
       tn_reduce(ctx, t, p, psi_g);
     } else if (tiles > 0) {
       launch_gemm_nn(ctx, np, p, -1.0, V_host[i], psi_i, 1.0, Q);

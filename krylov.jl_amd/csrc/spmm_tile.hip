@@ -25,6 +25,7 @@
 // Groups with a row longer than 32 entries or more distinct columns than the window takes are flagged at build time and
 // go down a direct-gather path inside the same kernel.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "spmv_common.hpp"
@@ -128,9 +129,69 @@ __device__ __forceinline__ void tile_batch(const dbl2 (&v)[TileShape<L>::F], con
   if (n > 6) tile_entry<L, 8 * B + 6, MASK>(v, sw, xa, xb_, len, acc);
   if (n > 7) tile_entry<L, 8 * B + 7, MASK>(v, sw, xa, xb_, len, acc);
 }
+// CHUNKS (round 6).  The entry-by-entry form above exposes one LDS round trip per entry: two ds_read_b128, a wait, four products,
+// four adds, a scalar branch (profiles/r06c: ~170 cycles per entry and wave, ~2 us per group -- a quarter of the 8 us a
+// workgroup spends per group).  Where all rows of a pass have the same length (wave-uniform n, no masks) the entries are taken
+// C at a time: the C (val, slot) broadcasts, then all 2 C window reads, then the 4 C products and adds IN STORED ORDER -- the same
+// rounded operations per row and column, so Y stays bit-identical; one LDS round trip per C entries.
+#ifndef KHIP_TILE_CHUNK
+#define KHIP_TILE_CHUNK 4
+#endif
+template <int L, int T0, int C>
+__device__ __forceinline__ void tile_chunk(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
+                                           const char *xb_, double (&acc)[4]) {
+  using S = TileShape<L>;
+  constexpr int bpl = 4 * S::SW;
+  double vv[C];
+  dbl2 x0[C], x1[C];
+  int off[C];
+  auto one = [&](auto kc) {
+    constexpr int k = decltype(kc)::value, T = T0 + k, f = T / (2 * L), e = T % (2 * L);
+    vv[k] = tile_bcast<L, e / 2>((e & 1) ? v[f].y : v[f].x);
+    const int word = tile_bcast<L, T / bpl>(sw[(T % bpl) / 4]);
+    off[k] = (int)(((unsigned)word >> (8 * (T & 3))) & 0xffu) << S::SHIFT;
+  };
+  one(std::integral_constant<int, 0>{});
+  if constexpr (C > 1) one(std::integral_constant<int, 1>{});
+  if constexpr (C > 2) one(std::integral_constant<int, 2>{});
+  if constexpr (C > 3) one(std::integral_constant<int, 3>{});
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    x0[k] = *reinterpret_cast<const dbl2 *>(xa + off[k]);
+    x1[k] = *reinterpret_cast<const dbl2 *>(xb_ + off[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const double p0 = vv[k] * x0[k].x, p1 = vv[k] * x0[k].y, p2 = vv[k] * x1[k].x, p3 = vv[k] * x1[k].y;
+    acc[0] = acc[0] + p0;
+    acc[1] = acc[1] + p1;
+    acc[2] = acc[2] + p2;
+    acc[3] = acc[3] + p3;
+  }
+}
+template <int L, int Q>        // entries C Q .. of a pass whose rows all have n entries (wave-uniform): whole chunks, then the rest of the last one
+__device__ __forceinline__ void tile_chunks_from(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
+                                                 const char *xb_, int n, double (&acc)[4]) {
+  constexpr int C = KHIP_TILE_CHUNK, T0 = C * Q;
+  if constexpr (T0 < kTileLen) {
+    if (n >= T0 + C) {
+      tile_chunk<L, T0, C>(v, sw, xa, xb_, acc);
+      tile_chunks_from<L, Q + 1>(v, sw, xa, xb_, n, acc);
+    } else {
+      const int r = n - T0;
+      if (r == 1) tile_chunk<L, T0, 1>(v, sw, xa, xb_, acc);
+      if constexpr (C > 2) { if (r == 2) tile_chunk<L, T0, 2>(v, sw, xa, xb_, acc); }
+      if constexpr (C > 3) { if (r == 3) tile_chunk<L, T0, 3>(v, sw, xa, xb_, acc); }
+    }
+  }
+}
 template <int L, bool MASK>
 __device__ __forceinline__ void tile_rows(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
                                           const char *xb_, int len, int nmax, double (&acc)[4]) {
+  if constexpr (!MASK && KHIP_TILE_CHUNK > 1) {
+    tile_chunks_from<L, 0>(v, sw, xa, xb_, nmax, acc);
+    return;
+  }
   if (nmax > 0) tile_batch<L, 0, MASK>(v, sw, xa, xb_, len, nmax < 8 ? nmax : 8, acc);
   if (nmax > 8) tile_batch<L, 1, MASK>(v, sw, xa, xb_, len, nmax < 16 ? nmax - 8 : 8, acc);
   if (nmax > 16) tile_batch<L, 2, MASK>(v, sw, xa, xb_, len, nmax < 24 ? nmax - 16 : 8, acc);
@@ -267,7 +328,7 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
           rr = own ? rr : rr - (uint64_t)a.n_owned;
         }
         const char *gsrc = src + (rr << w.gshift) + w.coff + 16 * (lane % (2 * L));
-        const unsigned dst = win_lds + wbase + 1024u * (unsigned)wq;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(win_lds + wbase + 1024u * (unsigned)wq));   // wave-uniform by construction; the "s" operand needs the compiler to know it
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
@@ -397,8 +458,13 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
 // prefetch pipeline is per wave as before.  Same arithmetic, same order per row: Y bit-identical.
 // AHEAD (round 6) is a separate instantiation: the look-ahead loop keeps three records and two entry sets live across a
 // barrier and would cost the round-4 loop its fourth wave per SIMD if both sat in one kernel (161 instead of 120 VGPRs at NL = 3).
+#ifdef KHIP_TILE_WPE                 // experiment build: ask for KHIP_TILE_WPE waves per SIMD (a register budget of 512 / WPE)
+#define KHIP_TILE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(KHIP_TILE_WPE, KHIP_TILE_WPE)))
+#else
+#define KHIP_TILE_WPE_ATTR
+#endif
 template <int L, bool DIST, int NL, bool AHEAD>
-__global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w) {
+__global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(SpmvArgs a, TileArgs w) {
   using S = TileShape<L>;
   static_assert(S::NPASS >= 2, "two waves per window need two row passes per group");
   constexpr int NP = S::NPASS / 2;                   // row passes per wave
@@ -495,7 +561,7 @@ __global__ __launch_bounds__(128) void spmm_tile2_kernel(SpmvArgs a, TileArgs w)
           rr = own ? rr : rr - (uint64_t)a.n_owned;
         }
         const char *gsrc = src + (rr << w.gshift) + w.coff + 16 * (lane % (2 * L));
-        const unsigned dst = win_lds + 1024u * (unsigned)wq;
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(win_lds + 1024u * (unsigned)wq));
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
@@ -1170,18 +1236,21 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
     // two waves per window (spmm_tile2_kernel): the residency is counted in windows as before, every window now carries two waves
     const size_t lds1 = (size_t)w.cap * 32 * L;
     int wg_per_cu = (int)((size_t)(160 * 1024) / lds1);
-    if (w.ahead) {
-      // the look-ahead kernel holds more registers: ask the runtime how many of its workgroups a CU takes (LDS and VGPRs), and
-      // keep the waves a multiple of the four SIMDs (5 workgroups = 10 waves ran 45 % slower than 4, profiles/r06b_spmm_ahead_ab.jsonl)
+    {
+      // how many of the kernel's workgroups a CU takes (LDS AND registers: the chunked product loop of round 6 holds 141 VGPRs at
+      // NL = 3, three waves per SIMD) -- a persistent grid larger than that leaves whole workgroups waiting for a slot.  The
+      // look-ahead kernel keeps its waves a multiple of the four SIMDs (5 workgroups = 10 waves ran 45 % slower than 4,
+      // profiles/r06b_spmm_ahead_ab.jsonl); the round-4 loop stays one workgroup short of an LDS limit of 5 and more (3 % faster).
       int nb = 0;
       const void *fn = nullptr;
-#define KHIP_TILE2_FN(D, N) fn = (const void *)spmm_tile2_kernel<(L >= 4 ? L : 4), D, N, true>
+#define KHIP_TILE2_FN(D, N) fn = w.ahead ? (const void *)spmm_tile2_kernel<(L >= 4 ? L : 4), D, N, true> : (const void *)spmm_tile2_kernel<(L >= 4 ? L : 4), D, N, false>
       if (dist) { switch (NL) { case 1: KHIP_TILE2_FN(true, 1); break; case 2: KHIP_TILE2_FN(true, 2); break; case 3: KHIP_TILE2_FN(true, 3); break; default: KHIP_TILE2_FN(true, 4); break; } }
       else      { switch (NL) { case 1: KHIP_TILE2_FN(false, 1); break; case 2: KHIP_TILE2_FN(false, 2); break; case 3: KHIP_TILE2_FN(false, 3); break; default: KHIP_TILE2_FN(false, 4); break; } }
 #undef KHIP_TILE2_FN
+      if (!w.ahead && wg_per_cu >= 5) --wg_per_cu;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 128, lds1) == hipSuccess && nb > 0 && nb < wg_per_cu) wg_per_cu = nb;
-      if (wg_per_cu > 2) wg_per_cu &= ~1;
-    } else if (wg_per_cu >= 5) --wg_per_cu;
+      if (w.ahead && wg_per_cu > 2) wg_per_cu &= ~1;
+    }
     if (wg_per_cu > 8) wg_per_cu = 8;
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t grid2 = ctx->tune.spmm_tile_grid > 0 ? ctx->tune.spmm_tile_grid : (int64_t)ctx->num_cu * wg_per_cu;
