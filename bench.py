@@ -117,6 +117,138 @@ def parity_vs_oracle(n1, residuals, full=None):
     return out
 
 
+def _prefix_dev(hist, golden_file, x=None):
+    """max relative deviation of a residual history from a golden oracle history (tests/golden/<file>), and of the solution sample."""
+    path = os.path.join(ROOT, "tests", "golden", golden_file)
+    if not os.path.exists(path):
+        return None
+    g = json.load(open(path))
+    href = g["residuals"]
+    k = min(len(hist), len(href))
+    dev = max(abs(float(hist[i]) - href[i]) / href[i] for i in range(k) if href[i] != 0.0)
+    out = {"against": f"tests/golden/{golden_file} ({g['oracle']})", "iterations_compared": k - 1, "max_rel_dev": dev,
+           "tolerance": 1e-12, "ok": bool(dev <= 1e-12 and len(hist) == len(href))}
+    if x is not None:
+        xg = g["x_sample"]
+        import numpy as np
+        xs = np.asarray(x)[g["x_index"]]
+        out["x_sample_max_rel_dev"] = float(np.max(np.abs(xs - np.asarray(xg))) / np.max(np.abs(np.asarray(xg))))
+    return out
+
+
+def other_configs(K, ctx, log):
+    """BASELINE cfg 3 and cfg 5 on the driver-run line: nested, labelled, NOT part of `value`.  Each leg: an
+    untimed parity solve against the oracle's golden history, then a timed run with HIP-event brackets around every kernel of the
+    families that carry the bytes (khip_profile_kernels), fractions of the 8 TB/s peak on ALGORITHMIC bytes."""
+    import numpy as np
+    out = {}
+    # ---------------- cfg 3: gmres!(memory = 30, restart = true) on kron_unsymmetric(256), b = A * ones ----------------
+    t_leg = time.time()
+    n1 = 256
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "kron_unsymmetric", n1)
+    ones = ctx.empty(n); K.kfill_(ones, 1.0)
+    b = ctx.empty(n); A.matvec(ones, b)
+    ws = K.GmresWorkspace(ctx, n, n, memory=30)
+    K.gmres_(ws, A, b, restart=True, atol=0.0, rtol=0.0, itmax=45, history=True)                   # the golden's 45 iterations
+    parity = _prefix_dev(ws.stats.residuals, "oracle_cfg3_gmres256.json", ws.x.to_host())
+    K.gmres_(ws, A, b, restart=True, itmax=30, atol=0.0, rtol=0.0)                                 # warm-up cycle
+    ctx.set_option("profile_spmv", 1); ctx.profile_kernels()
+    ctx.sync(); t0 = time.perf_counter()
+    K.gmres_(ws, A, b, restart=True, itmax=90, atol=0.0, rtol=0.0)                                 # three whole cycles
+    ctx.sync(); dt = time.perf_counter() - t0
+    prof = ctx.profile_kernels(); ctx.set_option("profile_spmv", 0)
+    it = ws.stats.niter
+    sb = A.spmv_bytes
+    # one 30-step cycle as the reference issues it (src/gmres.jl:236-330): per inner iteration k the product, k x (kdot 16n +
+    # kaxpy 24n), knorm 8n, kdivcopy 16n; per cycle the residual (product + kaxpby 24n), its norm and scaling (8n + 16n), and the
+    # solution update (30 kaxpy of 24n)
+    cyc_ref = sum(sb + k * 40 * n + 24 * n for k in range(1, 31)) + 30 * 24 * n + sb + 24 * n + 24 * n
+    # ... and with the legal fusions this library applies: product; per basis vector ONE pass (read V_i and q, write q: 24n, the
+    # coefficient of the next vector folded in) -- the last one also yields ||q||^2; scaling 16n; per cycle the residual product
+    # with its update fused (sb + 16n), and the solution update as one multi-axpy ((30 + 2) 8n)
+    cyc_fused = sum(sb + k * 24 * n + 16 * n for k in range(1, 31)) + sb + 16 * n + 32 * 8 * n
+    cycles = it / 30.0
+    spmv_l, spmv_ms = prof["spmv"]
+    out["cfg3_gmres"] = {
+        "NOT_THE_HEADLINE": "BASELINE cfg 3, untimed for `value`: gmres!(memory = 30, restart = true) on kron_unsymmetric(256) CSR (117,047,296 entries), "
+                            "b = A * ones, atol = rtol = 0, khip_gmres_solve on an adopted workspace, fused = 2",
+        "inner_iterations": int(it), "seconds": dt, "ms_per_inner_iteration": 1e3 * dt / it, "inner_iterations_per_sec": it / dt,
+        "bytes_per_cycle_reference_sequence": cyc_ref, "bytes_per_cycle_fused": cyc_fused,
+        "achieved_reference_sequence": cyc_ref * cycles / dt / 1e9, "frac_reference_sequence": cyc_ref * cycles / dt / 1e9 / HBM_PEAK_GBPS,
+        "achieved_fused": cyc_fused * cycles / dt / 1e9, "frac_fused": cyc_fused * cycles / dt / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+        "frac_note": "algorithmic bytes / time / 8 TB/s; at 256^3 a vector is 134 MB: the basis vector and q of a Gram-Schmidt pass come partly "
+                     "out of the 256 MB Infinity Cache, so the fractions are not HBM fractions (DESIGN.md 3.2)",
+        "spmv": {"launches": spmv_l, "avg_ms": spmv_ms / max(spmv_l, 1), "bytes_per_launch": sb,
+                 "frac": (sb / (spmv_ms / max(spmv_l, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS) if spmv_ms > 0 else None,
+                 "kernel": f"SpMV kernel {A.spmv_kernel_choice}, code_info {list(A.code_info)}"},
+        "parity": parity, "leg_seconds": None}
+    del ws, A, b, ones
+    out["cfg3_gmres"]["leg_seconds"] = time.time() - t_leg
+    log(f"[bench] cfg 3 leg {out['cfg3_gmres']['leg_seconds']:.1f} s: {out['cfg3_gmres']['ms_per_inner_iteration']:.3f} ms per inner iteration")
+
+    # ---------------- cfg 5: block_gmres!(memory = 5, restart = true), p = 16, 27-point 216^3 ----------------
+    t_leg = time.time()
+    n1, p = 216, 16
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "stencil27", n1)
+    t = (np.arange(n) + 1.0) / n
+    Xt = np.stack([np.cos(j * np.pi * t) + 0.1 * j for j in range(p)], axis=1)                     # tests/golden/make_scale_golden.py cfg5_xtrue
+    dXt = K.Panel.from_host(ctx, Xt)
+    dB = K.Panel(ctx, n, p)
+    K.spmm_(A, dXt, dB)                                                                            # B = A * X_true (also builds the tile records)
+    del Xt, dXt
+    ws = K.BlockGmresWorkspace(ctx, n, n, p, memory=5)
+    K.block_gmres_(ws, A, dB, restart=True, atol=0.0, rtol=0.0, itmax=7, history=True)             # the golden's 7 iterations
+    parity = _prefix_dev(ws.stats.residuals, "oracle_cfg5_block216.json", ws.X)
+    ctx.set_option("profile_spmv", 1); ctx.profile_kernels()
+    ctx.sync(); t0 = time.perf_counter()
+    K.block_gmres_(ws, A, dB, restart=True, itmax=20, atol=0.0, rtol=0.0)                          # four whole cycles of 5
+    ctx.sync(); dt = time.perf_counter() - t0
+    prof = ctx.profile_kernels(); ctx.set_option("profile_spmv", 0)
+    it = ws.stats.niter
+    pb = 8 * n * p                                                                                 # bytes of one n x p panel
+    spmm_b = 12 * A.nnz + 4 * n + 2 * pb
+    # one iteration k (1..5) of a cycle as the reference issues it (src/block_gmres.jl:236-310): mul!(W, A, P) = SpMM; k x
+    # (mul!(R, V_i', Q): 2 panels read; mul!(Q, V_i, R, -1, 1): 2 read + 1 written); householder!(Q): geqrf + orgqr, two panel
+    # passes of read + write.  Mean over k = 1..5 (k = 3), plus per cycle the residual SpMM (+ 3 panels) and X += sum V_i Y_i (5 x 3 panels)
+    it_ref = spmm_b + 3 * 5 * pb + 4 * pb
+    cyc_extra_ref = spmm_b + 3 * pb + 5 * 3 * pb
+    # with this library's fusions: SpMM; V_1' Q (2 panels); k fused steps Q -= V_i Psi_i ; Psi_{i+1} = V_{i+1}' Q (3 read + 1 written);
+    # CholeskyQR2 (5 panel passes); per cycle the residual SpMM + 3 panels and ONE pass X += sum V_i Y_i (5 + 2 panels)
+    it_fused = spmm_b + 2 * pb + 3 * 4 * pb + 5 * pb
+    cyc_extra_fused = spmm_b + 3 * pb + 7 * pb
+    tot_ref = it * it_ref + (it / 5.0) * cyc_extra_ref
+    tot_fused = it * it_fused + (it / 5.0) * cyc_extra_fused
+
+    def fam(tag, nbytes):
+        l, ms = prof[tag]
+        avg = ms / max(l, 1)
+        return {"launches": l, "avg_ms": avg, "bytes_per_launch": nbytes, "achieved": (nbytes / (avg * 1e-3) / 1e9) if avg > 0 else None,
+                "frac": (nbytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS) if avg > 0 else None}
+    info = A.tile_info
+    out["cfg5_block_gmres"] = {
+        "NOT_THE_HEADLINE": "BASELINE cfg 5, untimed for `value`: block_gmres!(memory = 5, restart = true), p = 16, on the 27-point 216^3 operator "
+                            "(10,077,696 rows, 269,586,136 entries: the SuiteSparse-shaped stand-in, no network), B = A * X_true, atol = rtol = 0, "
+                            "khip_block_gmres_solve_panel on an adopted workspace",
+        "iterations": int(it), "seconds": dt, "ms_per_iteration": 1e3 * dt / it,
+        "bytes_per_iteration_reference_sequence": tot_ref / it, "bytes_per_iteration_fused": tot_fused / it,
+        "achieved_reference_sequence": tot_ref / dt / 1e9, "frac_reference_sequence": tot_ref / dt / 1e9 / HBM_PEAK_GBPS,
+        "achieved_fused": tot_fused / dt / 1e9, "frac_fused": tot_fused / dt / 1e9 / HBM_PEAK_GBPS, "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+        "kernels_hip_events": {
+            "spmm_tile (mul!(W, A, P), src/block_gmres.jl:242)": dict(fam("spmm", spmm_b), window=info["window"], groups=info["groups"]),
+            "panel_nn_tn (Q -= V Psi ; Psi' = V'^T Q, :244-247)": fam("panel_nn_tn", 4 * pb),
+            "panel_gemm_tn (Psi = V^T Q, :245)": fam("panel_gemm_tn", 2 * pb),
+            "panel_multi_nn (X += sum V_i Y_i, :324-326; k = 5)": fam("panel_multi_nn", 7 * pb),
+            "panel_gemm_nn (Q <- Q R^-1 of the QR)": fam("panel_gemm_nn", 2 * pb),
+            "panel_scale_gram (scale + Gram of CholeskyQR2)": fam("panel_qr_scale_gram", 2 * pb)},
+        "parity": parity, "leg_seconds": None}
+    del ws, A, dB
+    out["cfg5_block_gmres"]["leg_seconds"] = time.time() - t_leg
+    log(f"[bench] cfg 5 leg {out['cfg5_block_gmres']['leg_seconds']:.1f} s: {out['cfg5_block_gmres']['ms_per_iteration']:.3f} ms per iteration")
+    return out
+
+
 def self_consistency(n1, residuals):
     """Same history against the 1-GPU run of the UNFUSED primitive sequence (GPU vs GPU: says the fused / partitioned
     path equals the plain one, nothing about the reference)."""
@@ -233,6 +365,33 @@ def launch_ranks(args, argv):
     return worst
 
 
+PHASES = ("halo_pack", "halo_transfer", "spmv", "spmv_boundary", "dot_allgather_combine")
+
+
+def summarize_phases(profiles, steps):
+    """Per-rank phase times of one iteration from the HIP-event brackets of the timed solve (Context.profile_kernels on every rank,
+    gathered over the control plane): the pack kernel, the halo transfer on its own stream, the interior and the boundary launch of
+    the product, each dot's 16-byte all-gather + combine.  `checks` evaluates the falsifiers DESIGN.md section 5 names for the
+    8-GPU prediction, so that the one scaling run the driver may get explains itself."""
+    rows = []
+    for r, prof in enumerate(profiles):
+        row = {"rank": r}
+        for k in PHASES:
+            l, ms = prof.get(k, (0, 0.0))
+            row[k] = {"launches_per_iteration": l / max(steps, 1), "ms_per_iteration": ms / max(steps, 1), "avg_us": (1e3 * ms / l) if l else None}
+        rows.append(row)
+    dots = [x["dot_allgather_combine"]["avg_us"] for x in rows if x["dot_allgather_combine"]["avg_us"] is not None]
+    xfer = [x["halo_transfer"]["avg_us"] for x in rows if x["halo_transfer"]["avg_us"] is not None]
+    inter = [x["spmv"]["avg_us"] for x in rows if x["spmv"]["avg_us"] is not None]
+    checks = {"dot_allgather_combine_avg_us_max": max(dots) if dots else None,
+              "falsifier_allgather_above_50us": bool(dots and max(dots) > 50.0),
+              "halo_transfer_avg_us_max": max(xfer) if xfer else None, "spmv_interior_avg_us_min": min(inter) if inter else None,
+              "falsifier_halo_longer_than_interior_product": bool(xfer and inter and max(xfer) > min(inter)),
+              "reading": "DESIGN.md 5: the N = 8 prediction (0.53-0.57 ms per iteration) fails if an 8-rank 16-byte all-gather + combine costs "
+                         "more than ~50 us (two per iteration), or if the halo transfer does not finish under the interior product"}
+    return {"per_rank": rows, "checks": checks}
+
+
 def dry_launch(rank, world, json_fd):
     """--dry-launch: the launch path without the GPU -- every rank joins the gloo group (the control plane of the real run)
     and the ranks are counted by an all-reduce; rank 0 prints the one JSON line."""
@@ -249,10 +408,17 @@ def dry_launch(rank, world, json_fd):
     dist.all_reduce(t)
     ranks = [None] * world
     dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "-1")), os.getpid()))
+    # the per-rank phase report of the real run, on synthetic brackets (no GPU here): same gather, same summary
+    steps = 10
+    fake = {"spmv": (steps, 2.5 * steps), "spmv_boundary": (steps, 0.01 * steps), "halo_pack": (steps, 0.004 * steps),
+            "halo_transfer": (steps, (0.2 + 0.01 * rank) * steps), "dot_allgather_combine": (2 * steps, 0.02 * (rank + 1) * 2 * steps)}
+    profs = [None] * world
+    dist.all_gather_object(profs, fake if world > 1 else {"spmv": (steps, 2.5 * steps)})
     dist.barrier()
     if rank == 0:
         os.write(json_fd, (json.dumps({"dry_launch": True, "n_gpus": world, "ranks_rendezvoused": int(t.item()),
-                                       "ranks": [list(r) for r in ranks],
+                                       "ranks": [list(r) for r in ranks], "phases": summarize_phases(profs, steps),
+                                       "ab": {k: None for k in ("overlap_halo_0", "comm_priority_0")},
                                        "launcher": "bench.py" if os.environ.get("KHIP_BENCH_SELF_LAUNCHED") else "external"}) + "\n").encode())
     dist.destroy_process_group()
 
@@ -272,6 +438,9 @@ def main():
                     help="NOT the headline: 1 = single-reduction CG (one all-reduce per iteration; different rounding)")
     ap.add_argument("--opt", action="append", default=[], help="tuning knob key=value (khip_ctx_set_option)")
     ap.add_argument("--no-full-parity", action="store_true", help="skip the (untimed) full solve to rtol 1e-8 of the parity leg")
+    ap.add_argument("--no-ab", action="store_true", help="N > 1: skip the A/B legs (overlap_halo = 0, comm_priority = 0)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the (untimed for `value`) legs of BASELINE cfg 3 (gmres!) and cfg 5 (block_gmres!)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="exercise only the N-rank launch + rendezvous (gloo), no GPU work: tests/test_bench_launch.py")
     ap.add_argument("--also-variant1", action="store_true",
@@ -365,7 +534,7 @@ def main():
     if args.warmup > 0:
         K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.warmup, fused=args.fused, variant=args.variant)
     ctx.set_option("profile_spmv", 1)
-    ctx.profile_spmv()
+    ctx.profile_kernels()
     barrier()
     t0 = time.perf_counter()
     done, first_hist, solves = 0, None, 0
@@ -381,8 +550,41 @@ def main():
     elapsed = time.perf_counter() - t0
     st = ws.stats
     assert done == args.steps, (done, st.status)
-    launches, spmv_ms = ctx.profile_spmv()
+    prof_main = ctx.profile_kernels()
+    launches = prof_main["spmv"][0] + prof_main["spmv_boundary"][0]        # interior + boundary launches of a row-partitioned product
+    spmv_ms = prof_main["spmv"][1] + prof_main["spmv_boundary"][1]
     ctx.set_option("profile_spmv", 0)
+    # N > 1: every rank's phase times to rank 0; then the same K iterations with the halo overlap off and with the communication
+    # stream at default priority (an A/B inside ONE launch: the one scaling run the driver may get should explain itself)
+    phases, ab = None, None
+    if use_comm:
+        profs = [prof_main]
+        if dist is not None and world > 1:
+            profs = [None] * world
+            dist.all_gather_object(profs, prof_main)
+        phases = summarize_phases(profs, args.steps)
+        ab = {}
+        if args.variant == 0 and not args.no_ab:
+            for name, key, val in (("overlap_halo_0", "overlap_halo", 0), ("comm_priority_0", "comm_priority", 0)):
+                old_val = ctx.get_option(key)
+                ctx.set_option(key, val)
+                try:
+                    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=max(min(args.warmup, 5), 1), fused=args.fused)
+                    barrier()
+                    ta = time.perf_counter()
+                    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.steps, fused=args.fused)
+                    barrier()
+                    el = time.perf_counter() - ta
+                    its_ab = ws.stats.niter
+                finally:
+                    ctx.set_option(key, old_val)
+                if dist is not None and world > 1:
+                    import torch
+                    tt = torch.tensor([el], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    el = float(tt.item())
+                ab[name] = {"value": its_ab / el, "unit": "iter/s", "steps": int(its_ab), "ms_per_step": 1e3 * el / max(its_ab, 1),
+                            "setting": f"{key} = {val} (the headline runs with {key} = {old_val})"}
     # parity leg (untimed): the first PARITY_ITERS residual norms of a fresh solve against the CPU oracle's
     parity_hist = first_hist
     if n1 == 512 and len(first_hist) <= PARITY_ITERS:
@@ -443,6 +645,12 @@ def main():
         finally:
             for k, v in saved.items():
                 ctx.set_option(k, v)
+    others = None
+    if world == 1 and n1 == 512 and args.variant == 0 and not args.no_other_configs and not templates:
+        try:
+            others = other_configs(K, ctx, log)
+        except Exception as e:          # never lose the headline line to a side leg
+            others = {"error": f"{type(e).__name__}: {e}"}
     rccl_ranks = ctx.comm_info()["rccl_ranks"] if use_comm else 0
     if dist is not None:
         import torch
@@ -487,8 +695,12 @@ def main():
             "parity": parity_vs_oracle(n1, parity_hist, full),
             "self_consistency": self_consistency(n1, parity_hist),
             "rccl_ranks_seen": rccl_ranks,
+            "comm": (dict(ctx.comm_info(), halo=dict(zip(("gather_mode", "n_ghost", "n_send"), A.halo_info))) if use_comm else None),
+            "phases": phases, "ab": ab,
             "single_reduction_cg": sr,
             "roofline_int32_csr": int32_leg,
+            "cfg3_gmres": (others or {}).get("cfg3_gmres"), "cfg5_block_gmres": (others or {}).get("cfg5_block_gmres"),
+            "other_configs_error": (others or {}).get("error"),
             "roofline": {"bound": "hbm", "kernel": kern + " (SpMV fused with p.Ap)",
                          "achieved": spmv_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": spmv_gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_note": traffic_note,

@@ -175,7 +175,9 @@ int khip_profile_spmv(khip_ctx *ctx, int64_t *launches, double *total_ms);
 /* The same brackets by kernel family (what bench.py's cfg-3 / cfg-5 legs report): launches[t] and total_ms[t] for t < ntags of
  * 0 = SpMV, 1 = SpMM (khip_spmm: the main kernel of a launch), 2 = panel_gemm_tn (V' Q), 3 = panel_nn_tn (the fused block
  * Gram-Schmidt step Q -= V Psi ; Psi' = V' Q), 4 = panel_multi_nn (X += sum V_i Y_i), 5 = panel_gemm_nn, 6 = the panel QR's passes
- * (scale + Gram); at most 7 families.  Synchronises and resets every counter. */
+ * (scale + Gram), 7 = halo pack kernel, 8 = halo transfer (grouped ncclSend / ncclRecv or the all-gather of x, bracketed on the
+ * stream it runs on), 9 = a dot's 16-byte all-gather + combine kernel, 10 = the boundary rows' SpMV launch of a row-partitioned
+ * product (tag 0 then is the interior launch); at most 11 families.  Synchronises the context's streams and resets every counter. */
 int khip_profile_kernels(khip_ctx *ctx, int ntags, int64_t *launches, double *total_ms);
 
 /* ------------------------------------------------ BLAS-1 shim ---------------- */

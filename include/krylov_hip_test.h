@@ -23,6 +23,12 @@ int khip_test_roots_quadratic(double q2, double q1, double q0, int nitref, doubl
 int khip_test_to_boundary(khip_ctx *ctx, int64_t n, const double *x, const double *d, double radius, int flip,
                           double *sigma1, double *sigma2);
 
+/* test-only measurement hook (tools/slab_iteration.py, tests/test_gpu_self_halo.py): a ONE-rank RCCL communicator whose slab's
+ * off-slab columns wrap onto its own rows and travel through the real exchange plan (pack kernel, grouped ncclSend / ncclRecv to
+ * itself on the halo stream, interior / boundary split, 16-byte all-gather + combine).  Set before khip_comm_init / the handle's
+ * creation.  Not an option of khip_ctx_set_option: it changes the operator (periodic slab). */
+int khip_test_set_halo_self(khip_ctx *ctx, int enable);
+
 /* test-only, host-only: the analysis behind the block schedule on a CSR pattern in host memory (no device; checks that
  * every row lands in exactly one block and no block depends on a later one).  mode 1 = as khip_ilu0_create, 3 = level
  * sequence.  out10 = grid dims[3], skewed basis, blocks lower / upper, largest face list, 48-byte records possible,

@@ -207,6 +207,7 @@ SIGNATURES = {
     "khip_test_householder_r": (_int, [_int, _int, c_double_p, c_double_p]),
     "khip_test_householder_signs": (_int, [_int, _i64, c_double_p, c_double_p, c_double_p]),
     "khip_test_optional_build_failures": (_int, [C.POINTER(_int)]),
+    "khip_test_set_halo_self": (_int, [_vp, _int]),
     "khip_test_sym_givens": (_int, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     "khip_test_roots_quadratic": (_int, [C.c_double, C.c_double, C.c_double, _int, c_double_p, c_double_p]),
     "khip_test_to_boundary": (_int, [_vp, _i64, _vp, _vp, C.c_double, _int, c_double_p, c_double_p]),
@@ -317,6 +318,10 @@ class Context:
     def set_option(self, key: str, value: int):
         _ck(lib().khip_ctx_set_option(self._h, key.encode(), int(value)))
 
+    def test_set_halo_self(self, enable: int = 1):
+        """TEST-ONLY measurement hook (include/krylov_hip_test.h): a one-rank RCCL communicator exchanges its halo with itself."""
+        _ck(lib().khip_test_set_halo_self(self._h, int(enable)))
+
     def get_option(self, key: str) -> int:
         v = C.c_int()
         _ck(lib().khip_ctx_get_option(self._h, key.encode(), C.byref(v)))
@@ -337,7 +342,8 @@ class Context:
         _ck(lib().khip_profile_spmv(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
-    PROFILE_TAGS = ("spmv", "spmm", "panel_gemm_tn", "panel_nn_tn", "panel_multi_nn", "panel_gemm_nn", "panel_qr_scale_gram")
+    PROFILE_TAGS = ("spmv", "spmm", "panel_gemm_tn", "panel_nn_tn", "panel_multi_nn", "panel_gemm_nn", "panel_qr_scale_gram",
+                    "halo_pack", "halo_transfer", "dot_allgather_combine", "spmv_boundary")
 
     def profile_kernels(self):
         """{family: (launches, total_ms)} of the HIP-event brackets recorded since the last call (option profile_spmv = 1):

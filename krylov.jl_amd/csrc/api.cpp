@@ -28,6 +28,13 @@ void optional_build(int rc) {
 
 extern "C" {
 
+// test-only (include/krylov_hip_test.h): the self-halo measurement hook is not an option of the product
+int khip_test_set_halo_self(khip_ctx *ctx, int enable) {
+  KHIP_REQUIRE(ctx, "test_set_halo_self: null context");
+  ctx->tune.halo_self = enable ? 1 : 0;
+  return KHIP_OK;
+}
+
 int khip_test_optional_build_failures(int *count) {
   KHIP_REQUIRE(count, "test_optional_build_failures: null output");
   *count = khip::g_optional_build_failures;
@@ -80,16 +87,19 @@ int khip_ctx_create(int device, void *stream, khip_ctx **out) {
   // drains (rocprofv3 trace of the N = 8 slab iteration, profiles/r05b_slab8_one_iteration_trace.txt: 260 us under a 263 us
   // product) -- i.e. the transfer would start late on real links.  Highest priority lets its workgroups in first.
   // KHIP_COMM_PRIORITY=0 keeps the default priority (A/B).
+  // Both streams exist; ctx option "comm_priority" (1 / 0) picks the one in use, so that bench.py can A/B it inside one launch.
   {
     int least = 0, greatest = 0;
     const char *pe = getenv("KHIP_COMM_PRIORITY");
-    const bool high = !pe || atoi(pe) != 0;
-    if (high && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
-      KHIP_CHECK_HIP(hipStreamCreateWithPriority(&ctx->comm_stream, hipStreamNonBlocking, greatest));
+    ctx->tune.comm_priority = (!pe || atoi(pe) != 0) ? 1 : 0;
+    KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->comm_stream_lo, hipStreamNonBlocking));
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+      KHIP_CHECK_HIP(hipStreamCreateWithPriority(&ctx->comm_stream_hi, hipStreamNonBlocking, greatest));
     } else {
       (void)hipGetLastError();
-      KHIP_CHECK_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+      ctx->comm_stream_hi = ctx->comm_stream_lo;
     }
+    ctx->comm_stream = ctx->tune.comm_priority ? ctx->comm_stream_hi : ctx->comm_stream_lo;
   }
   for (int i = 0; i < khip_ctx::kEvRing; ++i) {
     KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_a[i], hipEventDisableTiming));
@@ -130,7 +140,8 @@ int khip_ctx_destroy(khip_ctx *ctx) {
     if (ctx->ev_a[i]) (void)hipEventDestroy(ctx->ev_a[i]);
     if (ctx->ev_b[i]) (void)hipEventDestroy(ctx->ev_b[i]);
   }
-  (void)hipStreamDestroy(ctx->comm_stream);
+  if (ctx->comm_stream_hi && ctx->comm_stream_hi != ctx->comm_stream_lo) (void)hipStreamDestroy(ctx->comm_stream_hi);
+  if (ctx->comm_stream_lo) (void)hipStreamDestroy(ctx->comm_stream_lo);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return KHIP_OK;
@@ -150,7 +161,7 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
       {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_delta", &t.spmv_delta}, {"spmv_blk_pub", &t.spmv_blk_pub}, {"spmv_stream_nt", &t.spmv_stream_nt}, {"cg_setup_fused", &t.cg_setup_fused}, {"spmv_wide", &t.spmv_wide}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"halo_self", &t.halo_self}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_slide", &t.spmm_tile_slide}, {"spmm_tile_ahead", &t.spmm_tile_ahead}, {"spmm_tile_dbuf", &t.spmm_tile_dbuf}, {"spmm_tile_pair", &t.spmm_tile_pair}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
+      {"profile_spmv", &t.profile_spmv}, {"comm_priority", &t.comm_priority}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_delta", &t.spmv_delta}, {"spmv_blk_pub", &t.spmv_blk_pub}, {"spmv_stream_nt", &t.spmv_stream_nt}, {"cg_setup_fused", &t.cg_setup_fused}, {"spmv_wide", &t.spmv_wide}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_slide", &t.spmm_tile_slide}, {"spmm_tile_ahead", &t.spmm_tile_ahead}, {"spmm_tile_dbuf", &t.spmm_tile_dbuf}, {"spmm_tile_pair", &t.spmm_tile_pair}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;
@@ -161,6 +172,12 @@ int khip_ctx_set_option(khip_ctx *ctx, const char *key, int value) {
   int *p = tuning_field(ctx, key);
   KHIP_REQUIRE(p, "set_option: unknown key '%s'", key);
   *p = value;
+  if (p == &ctx->tune.comm_priority) {            // switch the communication stream (everything on both has drained first)
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->comm_stream_hi));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->comm_stream_lo));
+    ctx->comm_stream = value ? ctx->comm_stream_hi : ctx->comm_stream_lo;
+  }
   return KHIP_OK;
 }
 
@@ -433,7 +450,10 @@ int khip::spmv_any(khip_ctx *ctx, const khip_csr *A, const double *x, double *y,
   KHIP_TRY(comm_halo_exchange_end(ctx, A));
   // the two boundary ranges [0, interior_lo) and [interior_hi, m) as ONE launch where the kernel takes two ranges (round 5: one
   // launch and ~10 us less per product at the N = 8 slab shape); same partials in the same order: the fused dot is unchanged
-  return launch_spmv(ctx, A, x, y, dot_slot, 0, A->m, &cursor, true, dotw, dot_sq, A->interior_lo, A->interior_hi);
+  ctx->prof_spmv_tag = kProfSpmvBoundary;
+  const int rc_b = launch_spmv(ctx, A, x, y, dot_slot, 0, A->m, &cursor, true, dotw, dot_sq, A->interior_lo, A->interior_hi);
+  ctx->prof_spmv_tag = kProfSpmv;
+  return rc_b;
 }
 extern "C" {
 
@@ -483,6 +503,7 @@ int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes) {
 int khip_profile_kernels(khip_ctx *ctx, int ntags, int64_t *launches, double *total_ms) {
   KHIP_REQUIRE(ctx && launches && total_ms && ntags >= 1, "profile_kernels: bad argument");
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) KHIP_CHECK_HIP(hipStreamSynchronize(ctx->comm_stream));      // halo / dot brackets live there
   for (int t = 0; t < ntags; ++t) { launches[t] = 0; total_ms[t] = 0.0; }
   for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
     float ms = 0;

@@ -583,11 +583,17 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
       KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a[ctx->ev_cur], ctx->stream));
       KHIP_CHECK_HIP(hipStreamWaitEvent(gs, ctx->ev_a[ctx->ev_cur], 0));
     }
-    KHIP_CHECK_NCCL(g_rccl.AllGather(src, ghost, (size_t)maxm * w, ncclFloat64, c->halo_comm, gs));
+    {
+      ProfScope prof_scope(ctx, kProfHaloXfer, gs);
+      KHIP_CHECK_NCCL(g_rccl.AllGather(src, ghost, (size_t)maxm * w, ncclFloat64, c->halo_comm, gs));
+    }
     if (gs != ctx->stream) KHIP_CHECK_HIP(hipEventRecord(ctx->ev_b[ctx->ev_cur], gs));
     return KHIP_OK;
   }
-  KHIP_TRY(launch_gather(ctx, A->n_send, A->send_idx, x, sendbuf, width));
+  {
+    ProfScope prof_scope(ctx, kProfHaloPack);
+    KHIP_TRY(launch_gather(ctx, A->n_send, A->send_idx, x, sendbuf, width));
+  }
   if (c->hub) {
     LocalHub *h = c->hub;
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));          // my send buffer is packed
@@ -609,6 +615,7 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
     KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a[ctx->ev_cur], ctx->stream));
     KHIP_CHECK_HIP(hipStreamWaitEvent(cs, ctx->ev_a[ctx->ev_cur], 0));
   }
+  ProfScope prof_xfer(ctx, kProfHaloXfer, cs);
   KHIP_CHECK_NCCL(g_rccl.GroupStart());
   for (int r = 0; r < c->nranks; ++r) {
     if (r == c->rank && !A->self_halo) continue;
@@ -618,6 +625,7 @@ int comm_halo_exchange_begin(khip_ctx *ctx, const khip_csr *A_in, const double *
     if (nr > 0) KHIP_CHECK_NCCL(g_rccl.Recv(ghost + A->recv_off[r] * w, (size_t)nr * w, ncclFloat64, r, c->halo_comm, cs));
   }
   KHIP_CHECK_NCCL(g_rccl.GroupEnd());
+  if (prof_xfer.stop) { (void)hipEventRecord(prof_xfer.stop, cs); prof_xfer.stop = nullptr; }      // the bracket closes behind the transfer, not at the end of this scope
   if (cs != ctx->stream) KHIP_CHECK_HIP(hipEventRecord(ctx->ev_b[ctx->ev_cur], cs));
   return KHIP_OK;
 }
@@ -700,6 +708,7 @@ int comm_allreduce_dd_device(khip_ctx *ctx, int slot, int count) {
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));      // vals lives on this stack frame
     return launch_epilogue_only(ctx, slot);
   }
+  ProfScope prof_scope(ctx, kProfDotGather);
   KHIP_CHECK_NCCL(g_rccl.AllGather(ctx->results_dd + slot, c->gather_dev, (size_t)count * 2, ncclFloat64, c->comm, ctx->stream));
   return launch_combine(ctx, c->gather_dev, c->nranks, count, slot);
 }
@@ -716,8 +725,11 @@ int comm_allreduce_dd_device_begin(khip_ctx *ctx, int slot, int count) {
   ctx->ev_cur = (ctx->ev_cur + 1) % khip_ctx::kEvRing;
   KHIP_CHECK_HIP(hipEventRecord(ctx->ev_a[ctx->ev_cur], ctx->stream));
   KHIP_CHECK_HIP(hipStreamWaitEvent(cs, ctx->ev_a[ctx->ev_cur], 0));
-  KHIP_CHECK_NCCL(g_rccl.AllGather(ctx->results_dd + slot, c->gather_dev, (size_t)count * 2, ncclFloat64, c->halo_comm, cs));
-  KHIP_TRY(launch_combine(ctx, c->gather_dev, c->nranks, count, slot, cs));
+  {
+    ProfScope prof_scope(ctx, kProfDotGather, cs);
+    KHIP_CHECK_NCCL(g_rccl.AllGather(ctx->results_dd + slot, c->gather_dev, (size_t)count * 2, ncclFloat64, c->halo_comm, cs));
+    KHIP_TRY(launch_combine(ctx, c->gather_dev, c->nranks, count, slot, cs));
+  }
   if (!ctx->ev_red) KHIP_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_red, hipEventDisableTiming));
   KHIP_CHECK_HIP(hipEventRecord(ctx->ev_red, cs));
   ctx->allreduce_pending = true;      // state of THIS context, next to ev_red

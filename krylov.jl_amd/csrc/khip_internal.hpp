@@ -137,6 +137,7 @@ struct Tuning {
   int halo_mode = 0;        // distributed operators: 1 = exchange only the needed remote x entries (neighbour Send/Recv), 2 = all-gather x before every product, 0 = choose per operator (gather when a rank needs more than halo_gather_pct % of its own row count from its peers)
   int halo_gather_pct = 50; // see halo_mode
   int halo_self = 0;        // TEST / MEASUREMENT hook: with a ONE-rank communicator, a row slab [row0, row0 + m) of a larger operator gets a real halo plan whose off-slab columns wrap onto the slab's own rows (the slab becomes periodic) and are exchanged with grouped ncclSend / ncclRecv to the rank ITSELF: pack kernel, grouped call on the halo stream, interior / boundary split, 16-byte all-gather + combine all run as on N ranks (tools/slab_iteration.py).  Set BEFORE khip_comm_init
+  int comm_priority = 1;    // 1: the communication stream has the highest stream priority (default; env KHIP_COMM_PRIORITY=0 starts with 0); 0: default priority
   int profile_spmv = 0;     // record HIP events around every SpMV launch (bench.py roofline leg)
 };
 
@@ -154,7 +155,8 @@ struct khip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t comm_stream = nullptr;
+  hipStream_t comm_stream = nullptr;     // = comm_stream_hi or comm_stream_lo (ctx option comm_priority; both exist for an A/B inside one process)
+  hipStream_t comm_stream_hi = nullptr, comm_stream_lo = nullptr;
   // halo exchange hand-off events main stream <-> comm stream: a ring, so that an exchange enqueued while
   // earlier ones are still pending (device-resident loops run several iterations ahead) never re-records
   // an event something still waits on
@@ -182,6 +184,7 @@ struct khip_ctx {
   // SpMV launch profiling (events recorded on `stream`, resolved lazily)
   std::vector<hipEvent_t> prof_events;   // pairs: start, stop
   std::vector<int> prof_tags;            // one per pair: which kernel family the bracket belongs to (ProfTag)
+  int prof_spmv_tag = 0;                 // tag of the next SpMV launch's bracket (kProfSpmv; kProfSpmvBoundary for the boundary rows)
   size_t prof_used = 0;
 };
 
@@ -406,11 +409,18 @@ inline int64_t global_rows(khip_ctx *ctx, const khip_operator *A, int64_t n_loca
 
 // HIP-event brackets around single kernel launches on the context's stream (ctx option "profile_spmv" = 1; khip_profile_spmv /
 // khip_profile_kernels read them): bench.py's roofline figures are averages of these, measured inside the timed solve.
-enum ProfTag { kProfSpmv = 0, kProfSpmm = 1, kProfPanelTn = 2, kProfPanelNnTn = 3, kProfPanelMultiNn = 4, kProfPanelNn = 5, kProfPanelQr = 6, kProfTags = 7 };
+enum ProfTag { kProfSpmv = 0, kProfSpmm = 1, kProfPanelTn = 2, kProfPanelNnTn = 3, kProfPanelMultiNn = 4, kProfPanelNn = 5, kProfPanelQr = 6,
+               kProfHaloPack = 7,       // pack kernel of the neighbour exchange (main stream)
+               kProfHaloXfer = 8,       // grouped ncclSend / ncclRecv (or the all-gather of x), on the stream it runs on
+               kProfDotGather = 9,      // 16-byte all-gather of a dot's (hi, lo) partials + combine kernel
+               kProfSpmvBoundary = 10,  // the boundary rows' launch of a row-partitioned product (after the halo has arrived)
+               kProfTags = 11 };
 struct ProfScope {
   khip_ctx *ctx;
   hipEvent_t stop = nullptr;
-  ProfScope(khip_ctx *c, int tag) : ctx(c) {
+  hipStream_t stream = nullptr;
+  ProfScope(khip_ctx *c, int tag, hipStream_t st = nullptr) : ctx(c) {
+    stream = st ? st : c->stream;
     if (!c->tune.profile_spmv) return;
     if (c->prof_used + 2 > c->prof_events.size()) {
       for (int i = 0; i < 64; ++i) {
@@ -420,11 +430,11 @@ struct ProfScope {
       }
     }
     if (c->prof_tags.size() < c->prof_events.size() / 2) c->prof_tags.resize(c->prof_events.size() / 2, 0);
-    if (hipEventRecord(c->prof_events[c->prof_used], c->stream) != hipSuccess) return;
+    if (hipEventRecord(c->prof_events[c->prof_used], stream) != hipSuccess) return;
     stop = c->prof_events[c->prof_used + 1];
     c->prof_tags[c->prof_used / 2] = tag;
     c->prof_used += 2;
   }
-  ~ProfScope() { if (stop) (void)hipEventRecord(stop, ctx->stream); }
+  ~ProfScope() { if (stop) (void)hipEventRecord(stop, stream); }
 };
 }  // namespace khip

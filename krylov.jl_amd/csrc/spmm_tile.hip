@@ -188,7 +188,7 @@ __device__ __forceinline__ void tile_chunks_from(const dbl2 (&v)[TileShape<L>::F
 template <int L, bool MASK>
 __device__ __forceinline__ void tile_rows(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
                                           const char *xb_, int len, int nmax, double (&acc)[4]) {
-  if constexpr (!MASK && KHIP_TILE_CHUNK > 1) {
+  if constexpr (!MASK && KHIP_TILE_CHUNK > 1 && L == 4) {       // p = 16 (and its column slices) only: at p = 8 the chunks cost 17 % (0.96 -> 1.12 ms, profiles/r06e_spmm_chunk_ab.log)
     tile_chunks_from<L, 0>(v, sw, xa, xb_, nmax, acc);
     return;
   }
@@ -1254,10 +1254,14 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
     if (wg_per_cu > 8) wg_per_cu = 8;
     if (wg_per_cu < 1) wg_per_cu = 1;
     int64_t grid2 = ctx->tune.spmm_tile_grid > 0 ? ctx->tune.spmm_tile_grid : (int64_t)ctx->num_cu * wg_per_cu;
-    if (w.run_len > 0 && ctx->tune.spmm_tile_grid <= 0) {               // sliding windows: equally many runs per workgroup
+    if (w.run_len > 0 && ctx->tune.spmm_tile_grid <= 0) {
+      // sliding windows: a workgroup takes whole runs.  With few runs per workgroup they must get equally many (the grid shrinks to
+      // the largest one that does it); from four runs per workgroup on, every slot of every CU filled is worth more than an even
+      // last round (cfg 5, 6 workgroups per CU: 1536 workgroups of 7 or 8 runs 1.140 ms, 1464 of 8 runs each 1.190 ms,
+      // profiles/r06e_spmm_chunk_ab.log)
       const int64_t per_x = w.runs_per_xcd, max_wx = grid2 / 8 > 0 ? grid2 / 8 : 1;
       const int64_t kk = (per_x + max_wx - 1) / max_wx;
-      grid2 = 8 * ((per_x + kk - 1) / kk);
+      if (kk < 4) grid2 = 8 * ((per_x + kk - 1) / kk);
     }
     if (w.run_len > 0 && grid2 > w.runs) grid2 = w.runs;
     if (grid2 > w.groups) grid2 = w.groups;

@@ -1286,7 +1286,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     KHIP_CHECK_HIP(hipEventRecord(ctx->prof_events[ctx->prof_used], ctx->stream));
     ev_stop = ctx->prof_events[ctx->prof_used + 1];
     if (ctx->prof_tags.size() < ctx->prof_events.size() / 2) ctx->prof_tags.resize(ctx->prof_events.size() / 2, 0);
-    ctx->prof_tags[ctx->prof_used / 2] = kProfSpmv;
+    ctx->prof_tags[ctx->prof_used / 2] = ctx->prof_spmv_tag;
     ctx->prof_used += 2;
   }
 

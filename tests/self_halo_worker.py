@@ -1,4 +1,4 @@
-"""One process, ONE RCCL rank that exchanges its halo with ITSELF (ctx option "halo_self", csrc/comm.cpp): a slab of planes of the
+"""One process, ONE RCCL rank that exchanges its halo with ITSELF (test hook khip_test_set_halo_self, csrc/comm.cpp): a slab of planes of the
 7-point grid whose off-slab columns wrap onto the slab (a periodic slab), against the same periodic operator as a plain
 single-GPU CSR.  Driven by tests/test_gpu_self_halo.py (own process: a hang of the self Send/Recv must not take the suite down).
 argv: n1 k0 k1 out.json"""
@@ -20,7 +20,7 @@ def main():
     m = r1 - r0
     res = {}
     ctx = K.Context(0)
-    ctx.set_option("halo_self", 1)                    # before the communicator: it splits off the halo communicator for one rank too
+    ctx.test_set_halo_self(1)                    # before the communicator: it splits off the halo communicator for one rank too
     ctx.comm_init(0, 1, K.Context.comm_unique_id())
     info = ctx.comm_info()
     res["rccl_ranks"] = info["rccl_ranks"]

@@ -36,6 +36,36 @@ def test_bench_gpus_n_launches_n_ranks_itself(n):
     assert sorted(r[0] for r in d["ranks"]) == list(range(n))              # ranks 0..n-1, each once
     assert [r[1] for r in sorted(d["ranks"])] == list(range(n))            # LOCAL_RANK = rank: one device each
     assert len({r[2] for r in d["ranks"]}) == n                            # n distinct processes
+    # the per-rank phase report of a real N > 1 run, gathered and summarised by the same code on synthetic
+    # brackets: one row per rank, every phase with launches / ms per iteration / average, and the falsifier checks of DESIGN.md 5
+    ph = d["phases"]
+    assert [row["rank"] for row in ph["per_rank"]] == list(range(n))
+    for row in ph["per_rank"]:
+        for k in ("halo_pack", "halo_transfer", "spmv", "spmv_boundary", "dot_allgather_combine"):
+            assert set(row[k]) == {"launches_per_iteration", "ms_per_iteration", "avg_us"}, row
+        assert row["dot_allgather_combine"]["launches_per_iteration"] == 2.0
+    c = ph["checks"]
+    assert c["dot_allgather_combine_avg_us_max"] == pytest.approx(20.0 * n)          # the slowest rank's average
+    assert c["falsifier_allgather_above_50us"] == (20.0 * n > 50.0)
+    assert c["falsifier_halo_longer_than_interior_product"] is False
+    assert set(d["ab"]) == {"overlap_halo_0", "comm_priority_0"}
+
+
+def test_phase_summary_flags_the_falsifiers():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    steps = 20
+    profs = [{"spmv": (steps, 0.26 * steps), "spmv_boundary": (steps, 0.01 * steps), "halo_pack": (steps, 0.004 * steps),
+              "halo_transfer": (steps, 0.30 * steps), "dot_allgather_combine": (2 * steps, 0.06 * 2 * steps)} for _ in range(8)]
+    out = bench.summarize_phases(profs, steps)
+    assert len(out["per_rank"]) == 8
+    assert out["checks"]["falsifier_allgather_above_50us"] and out["checks"]["falsifier_halo_longer_than_interior_product"]
+    assert out["per_rank"][3]["halo_transfer"]["avg_us"] == pytest.approx(300.0)
+    # a single-GPU profile has no communication phases
+    one = bench.summarize_phases([{"spmv": (steps, 2.2 * steps)}], steps)
+    assert one["per_rank"][0]["halo_transfer"]["avg_us"] is None and one["checks"]["falsifier_allgather_above_50us"] is False
 
 
 def test_bench_under_torch_distributed_run_still_works():

@@ -3,7 +3,7 @@
 exchange code.
 
 N = 1 is the plain single-GPU solve.  For N > 1 the rank owns 512 / N interior planes and runs the distributed path against a
-ONE-rank RCCL communicator with ctx option "halo_self": pack kernel -> grouped ncclSend / ncclRecv of the two boundary planes (to
+ONE-rank RCCL communicator with test hook khip_test_set_halo_self: pack kernel -> grouped ncclSend / ncclRecv of the two boundary planes (to
 itself) on the halo stream and communicator -> interior rows -> boundary ranges -> 16-byte all-gather of the (hi, lo) dot
 partials + combine kernel.  Everything an interior rank of an N-GPU run launches is launched; what is missing is the xGMI
 transfer itself (2 planes x 2 MB at >= 50 GB/s: <= 0.1 ms, overlapped with the interior rows) and the skew between ranks.  So
@@ -34,7 +34,7 @@ def run(n1, N, iters, fused, variant=0, opts=()):
         info = {"rccl_ranks": 0, "halo_comm_separate": 0}
         halo = (0, 0, 0)
     else:
-        ctx.set_option("halo_self", 1)
+        ctx.test_set_halo_self(1)
         ctx.comm_init(0, 1, K.Context.comm_unique_id())
         info = ctx.comm_info()
         planes = n1 // N
