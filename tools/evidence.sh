@@ -14,6 +14,8 @@
 #   newtests  the GPU tests added last
 #   ilu       tools/bench_ilu.py 64 128 256
 #   adopt     tests/c/adopt_sequence 64 512
+#   spmmirr   rocprofv3 --pmc passes + synthetic twin of the tile SpMM on the banded + random operator
+#   spmmab    tile SpMM variants (tools/spmm_ahead_ab.py --sweep) + the twins of its traffic on the same box
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD; TAG=${1:-r05}; shift; mkdir -p gpurun_out; export TMPDIR=/tmp
 for stage in "$@"; do
@@ -57,6 +59,12 @@ for stage in "$@"; do
       timeout 400 python tools/bench_ilu.py 64 128 256 > gpurun_out/${TAG}_bench_ilu.jsonl 2> gpurun_out/${TAG}_bench_ilu.err; cut -c1-500 gpurun_out/${TAG}_bench_ilu.jsonl ;;
     adopt)
       timeout 300 tests/c/adopt_sequence 64 512 2>&1 | tail -12 ;;
+    spmmirr)     # counters + twin of the tile SpMM on the banded + random operator
+      bash tools/gpu_prof_spmm_irregular.sh ${TAG} 2>&1 | tail -60 ;;
+    spmmab)      # tile SpMM variants on one box (look-ahead, chunked product loop, grids) + the twins of its traffic
+      timeout 300 python tools/spmm_ahead_ab.py --sweep > gpurun_out/${TAG}_spmm_ahead_ab.jsonl 2> gpurun_out/${TAG}_spmm_ahead_ab.err; cut -c1-170 gpurun_out/${TAG}_spmm_ahead_ab.jsonl
+      [ -x tools/streamfloor ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/streamfloor tools/streamfloor.hip
+      (timeout 100 tools/streamfloor spmmslide | grep "waves/CU= 4"; timeout 100 tools/streamfloor spmm | grep "twin:\|entries + records + panel rows + Y waves/CU= 4") 2>&1 | cut -c1-150 | tee gpurun_out/${TAG}_spmm_twins.log ;;
     *) echo "unknown stage $stage" ;;
   esac
 done

@@ -356,6 +356,79 @@ static void spmmslide_main(int n1) {
   CK(hipFree(val)); CK(hipFree(slot)); CK(hipFree(rec)); CK(hipFree(X)); CK(hipFree(Y));
 }
 
+// ------------------------------------------------------------------------------------------------ tile SpMM twin, banded + random operator
+// The traffic of the tile SpMM on the non-stencil benchmark operator (csrc/gen_irregular.cpp: band of half-width 13, three
+// links per row to partners inside its block of 2^20 rows; 10.5 M rows, p = 16): groups of 32 consecutive rows; per group the
+// matrix stream (9 B per entry, 27 entries per row here; records), the 32 + 26 consecutive panel rows of the band, 96 panel rows
+// at hashed positions inside the group's block of 2^20 rows (one 128-byte line each: a panel row IS a line at p = 16), 32 rows
+// of Y.  A wave takes whole groups with every load in flight, as k_spmm_twin.  links = 0 / 1 switches the hashed rows off / on.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull; z ^= z >> 27; z *= 0x94d049bb133111ebull; z ^= z >> 31; return z;
+}
+__global__ __launch_bounds__(256) void k_spmm_irr(TwinArgs a, long n, int links) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= a.waves_total) return;
+  const int xcd = blockIdx.x & 7;
+  const long waves_per_xcd = a.waves_total / 8;
+  const long w_in_xcd = (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+  const long g0 = a.groups * xcd / 8, g1 = a.groups * (xcd + 1) / 8;
+  for (long g = g0 + w_in_xcd; g < g1; g += waves_per_xcd) {
+    dbl2 e[9], xr[20];
+    const int nvec = a.epg / 2;
+    const dbl2 *vp = a.val + g * (long)nvec;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const int i = j * 64 + lane; e[j] = i < nvec ? vp[i] : dbl2{0.0, 0.0}; }
+    e[7] = lane < a.epg / 16 ? (a.slot + g * (long)(a.epg / 16))[lane] : dbl2{0.0, 0.0};
+    e[8] = lane < 60 ? (a.rec + g * 60L)[lane] : dbl2{0.0, 0.0};
+    const long row0 = g * 32;
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {
+      const int r = j * 8 + (lane >> 3);                 // 0..57: the band; 58..153: the links
+      xr[j] = dbl2{0.0, 0.0};
+      long row = -1;
+      if (r < 58) row = row0 - 13 + r;
+      else if (r < 154 && links) row = (row0 & ~((1L << 20) - 1)) | (long)(mix64((unsigned long long)(g * 96 + (r - 58))) & ((1ull << 20) - 1));
+      if (row >= 0 && row < n) xr[j] = a.X[row * 8 + (lane & 7)];
+    }
+    dbl2 acc = {0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { acc.x += e[j].x; acc.y += e[j].y; }
+#pragma unroll
+    for (int j = 0; j < 20; ++j) { acc.x += xr[j].x; acc.y += xr[j].y; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long row = row0 + j * 8 + (lane >> 3);
+      if (row < n) a.Y[row * 8 + (lane & 7)] = acc;
+    }
+  }
+}
+static void spmmirr_main() {
+  TwinArgs a;
+  const long n = 10L * (1 << 20);
+  a.groups = n / 32; a.epg = 27 * 32; a.n1 = 0; a.sx = a.sy = a.sz = 0;
+  double *val, *slot, *rec, *X, *Y;
+  CK(hipMalloc(&val, a.groups * a.epg * 8)); CK(hipMalloc(&slot, a.groups * a.epg)); CK(hipMalloc(&rec, a.groups * 1920));
+  CK(hipMalloc(&X, n * 128)); CK(hipMalloc(&Y, n * 128));
+  CK(hipMemset(val, 0, a.groups * a.epg * 8)); CK(hipMemset(slot, 0, a.groups * a.epg)); CK(hipMemset(rec, 0, a.groups * 1920));
+  CK(hipMemset(X, 0, n * 128)); CK(hipMemset(Y, 0, n * 128));
+  a.val = (const dbl2 *)val; a.slot = (const dbl2 *)slot; a.rec = (const dbl2 *)rec; a.X = (const dbl2 *)X; a.Y = (dbl2 *)Y;
+  const double nnz = 27.0 * n, alg = 12.0 * nnz + 4.0 * (n + 1) + 2.0 * 128.0 * n;
+  const double moved0 = (double)a.groups * (a.epg * 9.0 + 960.0) + 2.0 * 128.0 * n, moved1 = moved0 + (double)a.groups * 96.0 * 128.0;
+  printf("tile SpMM twin, banded + random: %ld rows, p = 16; algorithmic (SURVEY 8d, 27 entries per row) %.3f GB; bytes requested without the links %.3f GB, with the 96 hashed panel rows per group %.3f GB\n",
+         n, alg / 1e9, moved0 / 1e9, moved1 / 1e9);
+  for (int links = 0; links < 2; ++links)
+    for (int wpc : {4, 8, 12, 16}) {
+      a.waves_total = 256 * wpc;
+      const int blocks = a.waves_total / 4;
+      const float ms = timeit([&] { hipLaunchKernelGGL(k_spmm_irr, dim3(blocks), dim3(256), 0, 0, a, n, links); }, 10);
+      printf("%-28s waves/CU=%2d  %.3f ms  (algorithmic bytes / time = %.0f GB/s = %.3f of 8 TB/s; requested bytes / time = %.0f GB/s)\n",
+             links ? "band + links" : "band only", wpc, ms, alg / ms / 1e6, alg / ms / 1e6 / 8000.0, (links ? moved1 : moved0) / ms / 1e6);
+      fflush(stdout);
+    }
+  CK(hipFree(val)); CK(hipFree(slot)); CK(hipFree(rec)); CK(hipFree(X)); CK(hipFree(Y));
+}
+
 // ------------------------------------------------------------------------------------------------ cg! update folded into the SpMV?
 // fold `x += alpha p_old` and `p = r + beta p_old` into the SpMV of the NEXT iteration (the
 // product gathers r and p_old instead of p, writes p_new, Ap and x): matrix + 72n instead of matrix + 80n bytes per iteration.
@@ -413,8 +486,9 @@ int main(int argc, char **argv) {
   const char *mode = argc > 1 ? argv[1] : "panel";
   if (strcmp(mode, "panel") == 0) panel_main(argc > 2 ? atol(argv[2]) : 10077696L, 16);
   else if (strcmp(mode, "spmm") == 0) spmm_main(argc > 2 ? atoi(argv[2]) : 216);
+  else if (strcmp(mode, "spmmirr") == 0) spmmirr_main();
   else if (strcmp(mode, "spmmslide") == 0) spmmslide_main(argc > 2 ? atoi(argv[2]) : 216);
   else if (strcmp(mode, "cgfold") == 0) cgfold_main(argc > 2 ? atoi(argv[2]) : 512);
-  else { printf("usage: streamfloor panel [rows] | spmm [n1] | spmmslide [n1] | cgfold [n1]\n"); return 2; }
+  else { printf("usage: streamfloor panel [rows] | spmm [n1] | spmmslide [n1] | spmmirr | cgfold [n1]\n"); return 2; }
   return 0;
 }
