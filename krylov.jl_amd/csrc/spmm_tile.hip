@@ -1210,6 +1210,12 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   // (profiles/r04r_spmm_dbuf.log).  spmm_tile_dbuf: -1 by that rule, 0 never, 1 always.  (Sliding windows carry ONE window.)
   const int dbuf_opt = ctx->tune.spmm_tile_dbuf;
   const bool use_pair = ctx->tune.spmm_tile_pair && L >= 4 && !ctx->tune.spmm_tile_nt;
+  {
+    // the order of the groups over the XCDs rides on bit 3 of w.exp (the kernels' round-robin switch)
+    const int xo = ctx->tune.spmm_tile_xcd;
+    const bool rr = xo > 0 || (xo < 0 && A->tile_grid == 0 && A->tile_run_len == 0);
+    if (rr) w.exp |= 8;
+  }
   w.ahead = (use_pair && A->tile_ahead && w.run_len > 0 && ctx->tune.spmm_tile_ahead != 0) ? 1 : 0;
   w.dbuf = (!use_pair && (dbuf_opt > 0 || (dbuf_opt < 0 && (size_t)w.cap * 32 * L * 2 <= (size_t)26 * 1024))) ? 1 : 0;
   if (w.dbuf) w.run_len = 0;      // records built for sliding windows serve every other scheme too: their list names the column of EVERY slot, so a kernel that copies all octets of every group (in any order of the groups) fills a consistent window

@@ -116,6 +116,8 @@ def test_bench_with_one_rank_communicator_equals_the_plain_path():
         outs[force] = json.loads(lines[0])
     plain, comm = outs["0"], outs["1"]
     assert plain["rccl_ranks_seen"] == 0 and comm["rccl_ranks_seen"] == 1
+    assert plain["phases"] is None and comm["phases"]["per_rank"][0]["dot_allgather_combine"]["launches_per_iteration"] == 2.0
+    assert set(comm["ab"]) == {"overlap_halo_0", "comm_priority_0"}
     assert comm["final_residual_norm"] == plain["final_residual_norm"]                  # same bits through the communicator
     assert comm["steps"] == plain["steps"] == 30 and comm["n_gpus"] == 1
     for o in (plain, comm):
@@ -146,3 +148,11 @@ def test_bench_gpus_n_runs_n_rccl_ranks(world):
     assert o["self_consistency"]["max_rel_dev"] == 0.0 and o["self_consistency"]["iterations_compared"] == 100
     assert o["parity"]["ok"] and o["parity"]["max_rel_dev"] <= 1e-12
     assert o["value"] > 0 and o["config"]["partition"] == f"1-D rows over {world} GPU(s)"
+    # the run explains itself: per-rank phase times from HIP events, the link / communicator facts, the A/B legs
+    assert [row["rank"] for row in o["phases"]["per_rank"]] == list(range(world))
+    for row in o["phases"]["per_rank"]:
+        assert row["halo_transfer"]["launches_per_iteration"] == 1.0 and row["halo_pack"]["launches_per_iteration"] == 1.0
+        assert row["spmv"]["launches_per_iteration"] == 1.0 and row["spmv_boundary"]["launches_per_iteration"] == 1.0
+        assert row["dot_allgather_combine"]["launches_per_iteration"] == 2.0 and row["dot_allgather_combine"]["avg_us"] > 0
+    assert o["comm"]["rccl_ranks"] == world and o["comm"]["halo"]["gather_mode"] == 0 and o["comm"]["halo"]["n_ghost"] > 0
+    assert set(o["ab"]) == {"overlap_halo_0", "comm_priority_0"} and all(v["value"] > 0 for v in o["ab"].values())
