@@ -185,10 +185,10 @@ __device__ __forceinline__ void tile_chunks_from(const dbl2 (&v)[TileShape<L>::F
     }
   }
 }
-template <int L, bool MASK>
+template <int L, bool MASK, bool CHUNKED = false>        // CHUNKED: the two-wave kernel (the one-wave kernel keeps its 4 waves per SIMD with the entry-by-entry loop)
 __device__ __forceinline__ void tile_rows(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
                                           const char *xb_, int len, int nmax, double (&acc)[4]) {
-  if constexpr (!MASK && KHIP_TILE_CHUNK > 1 && L == 4) {       // p = 16 (and its column slices) only: at p = 8 the chunks cost 17 % (0.96 -> 1.12 ms, profiles/r06e_spmm_chunk_ab.log)
+  if constexpr (CHUNKED && !MASK && KHIP_TILE_CHUNK > 1 && L == 4) {       // p = 16 (and its column slices) only: at p = 8 the chunks cost 17 % (0.96 -> 1.12 ms, profiles/r06e_spmm_chunk_ab.log)
     tile_chunks_from<L, 0>(v, sw, xa, xb_, nmax, acc);
     return;
   }
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
       const int len0 = __builtin_amdgcn_readfirstlane(len);
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
       if (__ballot(len != len0) == 0) {
-        tile_rows<L, false>(e.v[q], e.sw[q], xa, xb_, len, len0, acc);
+        tile_rows<L, false, true>(e.v[q], e.sw[q], xa, xb_, len, len0, acc);
       } else {
         int nmax = len;
 #pragma unroll
