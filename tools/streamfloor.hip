@@ -365,15 +365,17 @@ static void spmmslide_main(int n1) {
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull; z ^= z >> 27; z *= 0x94d049bb133111ebull; z ^= z >> 31; return z;
 }
-__global__ __launch_bounds__(256) void k_spmm_irr(TwinArgs a, long n, int links) {
+__global__ __launch_bounds__(256) void k_spmm_irr(TwinArgs a, long n, int links, int round_robin) {
   const int lane = threadIdx.x & 63;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wave >= a.waves_total) return;
   const int xcd = blockIdx.x & 7;
   const long waves_per_xcd = a.waves_total / 8;
   const long w_in_xcd = (long)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
-  const long g0 = a.groups * xcd / 8, g1 = a.groups * (xcd + 1) / 8;
-  for (long g = g0 + w_in_xcd; g < g1; g += waves_per_xcd) {
+  // round_robin = 0: XCD x takes the x-th eighth of the groups (eight fronts); 1: one front over the matrix, the groups dealt to all waves in turn
+  const long g0 = round_robin ? 0 : a.groups * xcd / 8, g1 = round_robin ? a.groups : a.groups * (xcd + 1) / 8;
+  const long gstart = round_robin ? wave : g0 + w_in_xcd, gstep = round_robin ? a.waves_total : waves_per_xcd;
+  for (long g = gstart; g < g1; g += gstep) {
     dbl2 e[9], xr[20];
     const int nvec = a.epg / 2;
     const dbl2 *vp = a.val + g * (long)nvec;
@@ -418,14 +420,16 @@ static void spmmirr_main() {
   printf("tile SpMM twin, banded + random: %ld rows, p = 16; algorithmic (SURVEY 8d, 27 entries per row) %.3f GB; bytes requested without the links %.3f GB, with the 96 hashed panel rows per group %.3f GB\n",
          n, alg / 1e9, moved0 / 1e9, moved1 / 1e9);
   for (int links = 0; links < 2; ++links)
-    for (int wpc : {4, 8, 12, 16}) {
-      a.waves_total = 256 * wpc;
-      const int blocks = a.waves_total / 4;
-      const float ms = timeit([&] { hipLaunchKernelGGL(k_spmm_irr, dim3(blocks), dim3(256), 0, 0, a, n, links); }, 10);
-      printf("%-28s waves/CU=%2d  %.3f ms  (algorithmic bytes / time = %.0f GB/s = %.3f of 8 TB/s; requested bytes / time = %.0f GB/s)\n",
-             links ? "band + links" : "band only", wpc, ms, alg / ms / 1e6, alg / ms / 1e6 / 8000.0, (links ? moved1 : moved0) / ms / 1e6);
-      fflush(stdout);
-    }
+    for (int rr = 0; rr < 2; ++rr)
+      for (int wpc : {4, 8, 16}) {
+        a.waves_total = 256 * wpc;
+        const int blocks = a.waves_total / 4;
+        const float ms = timeit([&] { hipLaunchKernelGGL(k_spmm_irr, dim3(blocks), dim3(256), 0, 0, a, n, links, rr); }, 10);
+        printf("%-13s %-28s waves/CU=%2d  %.3f ms  (algorithmic bytes / time = %.0f GB/s = %.3f of 8 TB/s; requested bytes / time = %.0f GB/s)\n",
+               links ? "band + links" : "band only", rr ? "one front (round-robin)" : "eight fronts (XCD eighths)", wpc, ms, alg / ms / 1e6, alg / ms / 1e6 / 8000.0,
+               (links ? moved1 : moved0) / ms / 1e6);
+        fflush(stdout);
+      }
   CK(hipFree(val)); CK(hipFree(slot)); CK(hipFree(rec)); CK(hipFree(X)); CK(hipFree(Y));
 }
 
