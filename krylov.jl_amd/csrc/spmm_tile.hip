@@ -529,6 +529,7 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
       for (int f = 0; f < S::F; ++f) {
         int64_t i0 = (int64_t)r.d[q].y + 2 * c + 2 * L * f;
         i0 = i0 < vlast ? i0 : vlast;
+        if (w.exp & 4) i0 = 2 * c + 2 * L * f;                             // phase experiment: no entry stream
         e.v[q][f] = *reinterpret_cast<const dbl2u *>(a.val + i0);
       }
       const char *sp = slots + ((wv * NP + q) * S::RP + sub) * kTileLen + 4 * S::SW * c;
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
 #pragma unroll
     for (int wq = 0; wq < NL * PER; ++wq) {
       constexpr unsigned OCT = S::EPI >= 8 ? (1u << (S::EPI / 8)) - 1u : 1u;
-      if ((wq & 1) == wv && S::EPI * wq < w.cap && ((mask >> ((S::EPI * wq) >> 3)) & OCT) != 0) {
+      if ((wq & 1) == wv && S::EPI * wq < w.cap && !(w.exp & 1) && ((mask >> ((S::EPI * wq) >> 3)) & OCT) != 0) {
         const char *src = reinterpret_cast<const char *>(a.x);
         uint64_t rr = (unsigned)col[wq];
         if (DIST) {
@@ -575,7 +576,9 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
       const int len = d.z;
       const int len0 = __builtin_amdgcn_readfirstlane(len);
       double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      if (__ballot(len != len0) == 0) {
+      if (w.exp & 2) {                                                      // phase experiment: no products
+        acc[0] = e.v[q][0].x + e.v[q][S::F - 1].y + (double)e.sw[q][0];
+      } else if (__ballot(len != len0) == 0) {
         tile_rows<L, false, true>(e.v[q], e.sw[q], xa, xb_, len, len0, acc);
       } else {
         int nmax = len;

@@ -57,12 +57,19 @@ def run(n1, N, iters, fused, variant=0, opts=()):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     st = ws.stats
+    # the phases of one iteration from the HIP-event brackets bench.py reports per rank at N > 1 (khip_profile_kernels): pack kernel,
+    # halo transfer on its stream, interior and boundary launch of the product, each dot's 16-byte all-gather + combine
+    ctx.set_option("profile_spmv", 1); ctx.profile_kernels()
+    K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=iters, fused=fused, variant=variant)
+    prof = ctx.profile_kernels(); ctx.set_option("profile_spmv", 0)
+    it_p = max(ws.stats.niter, 1)
+    phases = {k: {"launches_per_iteration": l / it_p, "avg_us": 1e3 * ms / l} for k, (l, ms) in prof.items() if l}
     bits, diags = A.code_info
     rec = {"n1": n1, "N": N, "planes": n1 // N, "rows": m, "iters": int(st.niter), "fused": fused, "variant": variant,
            "ms_per_iteration": 1e3 * best / max(st.niter, 1), "rccl_ranks": info["rccl_ranks"],
            "halo_comm_separate": info["halo_comm_separate"], "halo_entries_recv": halo[1], "halo_entries_sent": halo[2],
            "column_code_bits": bits, "spmv_bytes_algorithmic": A.spmv_bytes, "residual_last": float(st.residuals[-1]),
-           "opts": dict(opts)}
+           "opts": dict(opts), "phases_hip_events": phases}
     ctx.close()
     return rec
 
@@ -81,7 +88,7 @@ def main():
     for N in ([args.only] if args.only else [1, 2, 4, 8]):
         cases = [dict(variant=0, opts=())]
         if args.variants and N > 1:
-            cases += [dict(variant=1, opts=()), dict(variant=0, opts=(("overlap_halo", 0),))]
+            cases += [dict(variant=1, opts=()), dict(variant=0, opts=(("overlap_halo", 0),)), dict(variant=0, opts=(("comm_priority", 0),))]
         for c in cases:
             r = run(args.n1, N, args.iters, args.fused, **c)
             recs.append(r)
