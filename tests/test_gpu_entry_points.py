@@ -131,3 +131,45 @@ def test_verbose_log_of_a_forwarded_solve_goes_to_iostream(K, ctx, tmp_path):
     assert ws.last_path == 1                                         # the log rows need the scalars on the host
     txt = open(path, encoding="utf-8").read()
     assert txt.startswith("CG: system of %d equations in %d variables" % (n, n)) and txt.count("\n") >= st.niter
+
+
+def test_profile_kernels_brackets_every_family(K, ctx):
+    """khip_profile_kernels (bench.py's cfg-3 / cfg-5 legs and the N > 1 phase report): with ctx option profile_spmv = 1 every SpMV /
+    SpMM launch and every panel kernel of block_gmres! is bracketed by HIP events on the stream it runs on; the call returns
+    (launches, total ms) per family and resets."""
+    import time
+    n1, p = 24, 16
+    n = n1 ** 3
+    A = K.CsrMatrix.stencil(ctx, "stencil27", n1)
+    t = (np.arange(n) + 1.0) / n
+    Xt = np.stack([np.cos(j * np.pi * t) + 0.1 * j for j in range(p)], axis=1)
+    dB = K.Panel(ctx, n, p)
+    K.spmm_(A, K.Panel.from_host(ctx, Xt), dB)
+    ws = K.BlockGmresWorkspace(ctx, n, n, p, memory=5)
+    K.block_gmres_(ws, A, dB, restart=True, atol=0.0, rtol=0.0, itmax=5)                 # warm-up (lazy builds)
+    assert set(K.Context.PROFILE_TAGS) >= {"spmv", "spmm", "panel_nn_tn", "panel_gemm_tn", "panel_multi_nn", "halo_transfer", "spmv_boundary"}
+    ctx.set_option("profile_spmv", 1)
+    ctx.profile_kernels()
+    ctx.sync(); t0 = time.perf_counter()
+    K.block_gmres_(ws, A, dB, restart=True, atol=0.0, rtol=0.0, itmax=10)                # two cycles of five
+    ctx.sync(); wall_ms = 1e3 * (time.perf_counter() - t0)
+    prof = ctx.profile_kernels()
+    ctx.set_option("profile_spmv", 0)
+    assert ws.stats.niter == 10
+    assert prof["spmm"][0] == 10 + 1                                                       # one product per iteration + the restart's residual
+    assert prof["panel_nn_tn"][0] == 2 * (1 + 2 + 3 + 4 + 5)                               # k fused Gram-Schmidt steps in iteration k
+    assert prof["panel_gemm_tn"][0] >= 10 and prof["panel_multi_nn"][0] == 2               # X += sum V_i Y_i once per cycle
+    assert prof["spmv"][0] == 0 and prof["halo_transfer"][0] == 0
+    total = sum(ms for _l, ms in prof.values())
+    assert 0.0 < total <= wall_ms, (total, wall_ms)
+    assert all(l == 0 and ms == 0.0 for l, ms in ctx.profile_kernels().values())           # reset
+    # SpMV brackets through a cg! solve: one launch per iteration (+ set-up), none of the panel families
+    b = ctx.array(np.linspace(0.5, 1.5, n))
+    P = K.CsrMatrix.stencil(ctx, "poisson", n1)
+    w2 = K.CgWorkspace(ctx, n, n)
+    K.cg_(w2, P, b, atol=0.0, rtol=0.0, itmax=3)
+    ctx.set_option("profile_spmv", 1); ctx.profile_kernels()
+    K.cg_(w2, P, b, atol=0.0, rtol=0.0, itmax=12)
+    prof = ctx.profile_kernels(); ctx.set_option("profile_spmv", 0)
+    assert prof["spmv"][0] in (12, 13) and prof["spmm"][0] == 0 and prof["panel_nn_tn"][0] == 0
+    assert ctx.profile_spmv() == (0, 0.0)
