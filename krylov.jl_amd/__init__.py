@@ -1756,6 +1756,11 @@ def block_gmres_(ws: BlockGmresWorkspace, A, B_colmajor: DeviceVector, M=None, N
         keep.append(Bp)
         rc = lib().khip_block_gmres_solve_panel(ws._h, *ops, Bp.buf.ptr, C.byref(opts))
     else:
+        if isinstance(B_colmajor, Panel):            # a library-owned workspace takes B column-major (khip_block_gmres_solve)
+            col = ws.ctx.empty(ws.n * ws.p)
+            _ck(lib().khip_panel_to_colmajor(ws.ctx._h, ws.n, ws.p, B_colmajor.buf.ptr, col.ptr))
+            keep.append(col)
+            B_colmajor = col
         rc = lib().khip_block_gmres_solve(ws._h, *ops, _p(B_colmajor), C.byref(opts))
     return _finish(ws, rc)
 
