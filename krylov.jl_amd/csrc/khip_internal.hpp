@@ -122,7 +122,7 @@ struct Tuning {
   int spmm_tile_grid = 0;   // ... or this many waves outright
   int spmm_tile_pair = 1;   // two waves per window (spmm_tile2_kernel, p >= 16): twice the waves per CU on the same LDS, each wave half of a group's row passes; 0: one wave per window
   int spmm_tile_dbuf = -1;  // two windows per wave, the copies of the next group overlap this group's products: -1 = where six waves per CU still fit (small windows), 0 never, 1 always
-  int spmm_tile_xcd = -1;   // which XCD takes which groups of the tile SpMM: 0 = XCD x the x-th eighth (neighbouring groups share an L2: grid tiles), 1 = round-robin over all persistent workgroups (ONE front over the matrix: long-range columns find their panel rows in the Infinity Cache; banded + random 1.90 -> 1.55 ms, profiles/r06h_spmm_xcd_order.log), -1 = 1 for handles without a grid and without runs, else 0
+  int spmm_tile_xcd = -1;   // which XCD takes which groups of the tile SpMM: 0 = XCD x the x-th eighth (neighbouring groups share an L2: grid tiles), 1 = round-robin over all persistent workgroups (ONE front over the matrix: long-range columns find their panel rows in the Infinity Cache; banded + random 1.90 -> 1.55 ms, profiles/r06h_spmm_xcd_order.log), 2 = one front in chunks (per sweep of G groups XCD x takes the x-th chunk of G / 8: within 1 % of 1 without a grid, worse on grid tiles), -1 = 1 for handles without a grid and without runs, else 0
   int spmm_tile_ahead = 0;  // sliding windows with ONE GROUP OF LOOK-AHEAD (round 6): the new panel rows of group g + 1 take window slots that neither g nor g + 1 needs, so their copies are issued BEFORE the products of g and land while they run (windows of |g| + |new(g + 1)| rows: 216 instead of 144 at cfg 5); -1 = where the records have runs and two waves share a window; 0 never; 1 = as -1 (read at build time for the window size, at launch for the loop)
   int spmm_tile_slide = -1; // sliding windows: a wave (pair) walks a run of groups along the slowest grid direction and copies only the panel rows its window does not hold yet; -1 = runs of <= 27 groups on grid operators, none otherwise; 0 never; 1 whole grid lines; N > 1 runs of N groups (also without a grid)
   int spmm_tile_pencil = 0; // tile rows per pencil in the group order of grid operators (0 = 4)

@@ -472,8 +472,15 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
   typedef __attribute__((address_space(3))) char lds_char;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane / L, c = lane % L;
   const int64_t last = w.groups - 1;
-  int64_t G = gridDim.x, g = blockIdx.x, gend = w.groups;
-  if (!(w.exp & 8) && (gridDim.x & 7) == 0) {
+  // Which workgroup takes which groups (runs).  Workgroup b runs on XCD b % 8.  Three orders:
+  //   eighths (default on grid tiles until round 6): XCD x walks the x-th eighth of the groups -- eight fronts, neighbours share an L2;
+  //   exp & 8   : plain round-robin, workgroup b takes b, b + G, ... -- ONE front, neighbours on different XCDs;
+  //   exp & 128 : one front in chunks -- per sweep of G groups XCD x takes the x-th contiguous chunk of G / 8, so that neighbours
+  //               share an L2 AND all XCDs stay within G consecutive groups (their common panel rows meet in the Infinity Cache).
+  const bool eighths = !(w.exp & (8 | 128)) && (gridDim.x & 7) == 0;
+  const int64_t lin = ((w.exp & 128) && (gridDim.x & 7) == 0) ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  int64_t G = gridDim.x, g = lin, gend = w.groups;
+  if (eighths) {
     const int64_t x = blockIdx.x & 7;
     G = gridDim.x >> 3;
     g = x * w.per_xcd + (blockIdx.x >> 3);
@@ -486,10 +493,9 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
   int tpos = 0;
   if (slide) {
     const int64_t x = blockIdx.x & 7;
-    const bool by_xcd = (gridDim.x & 7) == 0;
-    G = by_xcd ? (gridDim.x >> 3) : gridDim.x;
-    run = by_xcd ? x * w.runs_per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-    const int64_t run_end = by_xcd ? ((x + 1) * w.runs_per_xcd < w.runs ? (x + 1) * w.runs_per_xcd : w.runs) : w.runs;
+    G = eighths ? (gridDim.x >> 3) : gridDim.x;
+    run = eighths ? x * w.runs_per_xcd + (blockIdx.x >> 3) : lin;
+    const int64_t run_end = eighths ? ((x + 1) * w.runs_per_xcd < w.runs ? (x + 1) * w.runs_per_xcd : w.runs) : w.runs;
     g = run * w.run_len;
     gend = run_end * w.run_len;
   }
@@ -1216,8 +1222,8 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   {
     // the order of the groups over the XCDs rides on bit 3 of w.exp (the kernels' round-robin switch)
     const int xo = ctx->tune.spmm_tile_xcd;
-    const bool rr = xo > 0 || (xo < 0 && A->tile_grid == 0 && A->tile_run_len == 0);
-    if (rr) w.exp |= 8;
+    if (xo == 2) w.exp |= 128;                       // one front in chunks of G / 8 per XCD
+    else if (xo == 1 || (xo < 0 && A->tile_grid == 0 && A->tile_run_len == 0)) w.exp |= 8;
   }
   w.ahead = (use_pair && A->tile_ahead && w.run_len > 0 && ctx->tune.spmm_tile_ahead != 0) ? 1 : 0;
   w.dbuf = (!use_pair && (dbuf_opt > 0 || (dbuf_opt < 0 && (size_t)w.cap * 32 * L * 2 <= (size_t)26 * 1024))) ? 1 : 0;

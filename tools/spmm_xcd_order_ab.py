@@ -34,8 +34,9 @@ for name, make in ops:
     ctx.set_option("spmm_tile", 0); ctx.set_option("spmm_window", 0); K.spmm_(A, X, Y); ctx.sync(); ref = Y.buf.to_host()
     ctx.set_option("spmm_tile", 2); ctx.set_option("spmm_window", 1)
     alg = 12 * A.nnz + 4 * A.n + 16 * A.n * p
-    for opts in ({}, {"spmm_tile_xcd": 0}, {"spmm_tile_xcd": 1}, {"spmm_tile_xcd": 1, "spmm_tile_pair": 0}, {"spmm_tile_xcd": 1, "spmm_tile_pair": 0, "spmm_tile_nt": 1},
-                 {"spmm_tile_xcd": 0, "spmm_tile_pair": 0, "spmm_tile_nt": 1}):
+    # spmm_tile_xcd: 0 = XCD x takes the x-th eighth of the groups, 1 = round-robin (one front), 2 = one front in chunks of G / 8 per XCD
+    for opts in ({}, {"spmm_tile_xcd": 0}, {"spmm_tile_xcd": 1}, {"spmm_tile_xcd": 2}, {"spmm_tile_xcd": 0}, {"spmm_tile_xcd": 1}, {"spmm_tile_xcd": 2},
+                 {"spmm_tile_xcd": 1, "spmm_tile_pair": 0}):
         for k, v in opts.items(): ctx.set_option(k, v)
         t = timed(A, X, Y)
         print(json.dumps(dict(op=name, opts=opts, ms=round(t * 1e3, 4), frac=round(alg / t / 8e12, 4), same=bool(np.array_equal(ref, Y.buf.to_host())),
