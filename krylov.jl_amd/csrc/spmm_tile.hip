@@ -134,8 +134,12 @@ __device__ __forceinline__ void tile_batch(const dbl2 (&v)[TileShape<L>::F], con
 // workgroup spends per group).  Where all rows of a pass have the same length (wave-uniform n, no masks) the entries are taken
 // C at a time: the C (val, slot) broadcasts, then all 2 C window reads, then the 4 C products and adds IN STORED ORDER -- the same
 // rounded operations per row and column, so Y stays bit-identical; one LDS round trip per C entries.
+// Measured (profiles/r06e_spmm_chunk_ab.log, r06t_spmm_grid_attribution.log): the chunks cost registers (120 -> 141 VGPRs at NL = 3: 6
+// instead of 7 workgroups per CU) and the products they speed up are hidden anyway (the kernel is 1.6 % faster with NO products at all,
+// r06m_spmm_phases.log): chunks of 4 run 2-4 % SLOWER than the entry-by-entry loop on the same grid.  The library is built with 1 (off);
+// -DKHIP_TILE_CHUNK=2 / 4 builds the variants (tools/spmm_chunk_ab.sh).
 #ifndef KHIP_TILE_CHUNK
-#define KHIP_TILE_CHUNK 4
+#define KHIP_TILE_CHUNK 1
 #endif
 template <int L, int T0, int C>
 __device__ __forceinline__ void tile_chunk(const dbl2 (&v)[TileShape<L>::F], const int (&sw)[TileShape<L>::SW], const char *xa,
