@@ -1236,6 +1236,20 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
   int per_cu = (int)((size_t)(160 * 1024) / lds);                    // LDS-limited residency of the one-wave workgroups
   if (per_cu >= 5) --per_cu;                                         // one wave short of the LDS limit measures 3 % faster (7 instead of 8 at 144 panel rows)
   if (per_cu > 16) per_cu = 16;
+  if (!use_pair) {
+    // ... and the registers: the one-wave kernel holds 216-344 VGPRs (one or two waves per SIMD); a persistent grid beyond what
+    // a CU takes leaves whole workgroups waiting for a slot (round 6; the two-wave kernel asks the same question below)
+    const bool dist0 = a.ghost != a.x, nt0 = ctx->tune.spmm_tile_nt != 0;
+    const int NL0 = (w.cap + 63) / 64;
+    const void *fn = nullptr;
+#define KHIP_TILE1_FN(D, N) fn = nt0 ? (const void *)spmm_tile_kernel<L, D, N, true> : (const void *)spmm_tile_kernel<L, D, N, false>
+    if (dist0) { switch (NL0) { case 1: KHIP_TILE1_FN(true, 1); break; case 2: KHIP_TILE1_FN(true, 2); break; case 3: KHIP_TILE1_FN(true, 3); break; default: KHIP_TILE1_FN(true, 4); break; } }
+    else       { switch (NL0) { case 1: KHIP_TILE1_FN(false, 1); break; case 2: KHIP_TILE1_FN(false, 2); break; case 3: KHIP_TILE1_FN(false, 3); break; default: KHIP_TILE1_FN(false, 4); break; } }
+#undef KHIP_TILE1_FN
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64, lds) == hipSuccess && nb > 0 && nb < per_cu) per_cu = nb;
+  }
   if (per_cu < 1) per_cu = 1;
   int64_t grid = (int64_t)ctx->num_cu * per_cu * (ctx->tune.spmm_tile_waves > 0 ? ctx->tune.spmm_tile_waves : 1);
   if (ctx->tune.spmm_tile_grid > 0) grid = ctx->tune.spmm_tile_grid;
@@ -1245,7 +1259,7 @@ static int launch_tile_L(khip_ctx *ctx, const khip_csr *A, const SpmvArgs &a, in
     // limit that gives every wave of an XCD ceil(runs per XCD / waves per XCD) runs with no wave left half empty
     const int64_t per_x = w.runs_per_xcd, max_wx = grid / 8 > 0 ? grid / 8 : 1;
     const int64_t k = (per_x + max_wx - 1) / max_wx;                 // runs per wave
-    grid = 8 * ((per_x + k - 1) / k);
+    if (k < 4) grid = 8 * ((per_x + k - 1) / k);                     // from four runs per wave on: the full grid (as for the two-wave kernel below)
   }
   if (w.run_len > 0 && grid > w.runs) grid = w.runs;
   if (grid >= 64) grid &= ~(int64_t)7;                               // whole waves per XCD
