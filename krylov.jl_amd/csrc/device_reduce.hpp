@@ -191,8 +191,23 @@ __global__ __launch_bounds__(kBlock) void reduce_finish_kernel(RedArgs ra, int64
   dd acc[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
+    // A thread folds its partials i = lo + tid, + 256, ... IN THAT ORDER (the result's bits depend on it).  The loads are issued
+    // eight at a time before the first merge (round 6): the loop used to wait for every 16-byte load before issuing the next --
+    // eight dependent round trips through L2 per launch (launch_finish gives a thread 8 partials), 11 us per finish kernel where
+    // the MGS step it follows takes 70 us at 256^3 (profiles/r06_rocprofv3_kernel_stats.csv).
     dd a = {0.0, 0.0};
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) a = dd_merge(a, ra.wave_partials[(size_t)o * ra.cap + i]);
+    const dd *src = ra.wave_partials + (size_t)o * ra.cap;
+    for (int64_t base = lo + threadIdx.x; base < hi; base += (int64_t)kBlock * 8) {
+      dd v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + (int64_t)j * kBlock;
+        v[j] = src[i < hi ? i : base];                 // (a clamped index: the value is not merged)
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (base + (int64_t)j * kBlock < hi) a = dd_merge(a, v[j]);
+    }
     acc[o] = a;
   }
   block_reduce<NOUT>(acc, s_w);
