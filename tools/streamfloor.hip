@@ -228,15 +228,31 @@ struct SlideArgs {
   int run_len, pieces;   // groups per run, runs per line of tiles along z
   long runs;
   int ahead;
+  int csr_val;           // 1: the value stream in CSR row order, read as the kernel reads it (strided 64-byte pieces); 0: contiguous per group
 };
 template <int NX> struct SlideLoads { dbl2 e[9]; dbl2 xr[NX]; };      // 4 x 4 x 2 tiles: 432 value vectors = 7 per lane, + slots + record
+typedef double dbl2u8 __attribute__((ext_vector_type(2), aligned(8)));
 template <int NX>
 __device__ __forceinline__ void slide_issue(const SlideArgs &s, long g, int tx, int ty, int tz, int lane, SlideLoads<NX> &L) {
   const TwinArgs &a = s.t;
   const int nvec = a.epg / 2, n1 = a.n1;
   const dbl2 *vp = a.val + g * (long)nvec;
+  if (s.csr_val) {
+    // the value stream as the KERNEL reads it out of the CSR arrays: 27 doubles per row in row order; per instruction 16 rows of the tile
+    // (4 consecutive rows x 4 lines), 4 lanes per row, 64 bytes of each row (entries 8 f .. 8 f + 7) -- 16 pieces of 64 B at 216-byte
+    // and line / plane strides instead of one contiguous KiB (7 of the 8 instructions of a group modelled: f = 3 reads the last 3 entries)
+    const double *v0 = reinterpret_cast<const double *>(a.val);
 #pragma unroll
-  for (int j = 0; j < 7; ++j) { const int i = j * 64 + lane; L.e[j] = i < nvec ? vp[i] : dbl2{0.0, 0.0}; }
+    for (int j = 0; j < 7; ++j) {
+      const int q = j >> 2, f = j & 3, sub = lane >> 2, c = lane & 3, row = q * 16 + sub;
+      const int di = row & 3, dj = (row >> 2) & 3, dk = row >> 4;
+      const long R = (long)(tx * a.sx + di) + (long)n1 * ((long)(ty * a.sy + dj) + (long)n1 * (tz * a.sz + dk));
+      L.e[j] = *reinterpret_cast<const dbl2u8 *>(v0 + R * 27 + 2 * c + 8 * f);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const int i = j * 64 + lane; L.e[j] = i < nvec ? vp[i] : dbl2{0.0, 0.0}; }
+  }
   const dbl2 *sp = a.slot + g * (long)(a.epg / 16);
   const dbl2 *rp = a.rec + g * 60L;
   L.e[7] = lane < a.epg / 16 ? sp[lane] : dbl2{0.0, 0.0};
@@ -328,7 +344,7 @@ static void spmmslide_main(int n1) {
   a.epg = 27 * 32; a.pencil = 4; a.entries = 1; a.xrows = 1;
   const long n = (long)n1 * n1 * n1;
   double *val, *slot, *rec, *X, *Y;
-  const long gpad = a.groups + a.groups / 8 + 64;                     // records padded to whole runs
+  const long gpad = a.groups + a.groups / 8 + 64;                     // records padded to whole runs (>= n * 27 doubles + slack for the CSR-order reads)
   CK(hipMalloc(&val, gpad * a.epg * 8)); CK(hipMalloc(&slot, gpad * a.epg)); CK(hipMalloc(&rec, gpad * 1920));
   CK(hipMalloc(&X, n * 128)); CK(hipMalloc(&Y, n * 128));
   CK(hipMemset(val, 0, gpad * a.epg * 8)); CK(hipMemset(slot, 0, gpad * a.epg)); CK(hipMemset(rec, 0, gpad * 1920));
@@ -336,7 +352,9 @@ static void spmmslide_main(int n1) {
   a.val = (const dbl2 *)val; a.slot = (const dbl2 *)slot; a.rec = (const dbl2 *)rec; a.X = (const dbl2 *)X; a.Y = (dbl2 *)Y;
   const double alg = 12.0 * 27.0 * n + 4.0 * (n + 1) + 2.0 * 128.0 * n;
   printf("tile SpMM twin, SLIDING windows: %d^3 rows, 4 x 4 x 2 tiles walked along z in runs; per group 9 B per entry + 960 B of records, 72 new panel rows (144 at the start of a run), 32 rows of Y; algorithmic (SURVEY 8d) %.3f GB\n", n1, alg / 1e9);
-  for (int run_len : {27, 54, 108}) {
+  s.csr_val = 0;
+  for (int run_len : {27, 54, 108, -27}) {
+    if (run_len < 0) { s.csr_val = 1; run_len = -run_len; printf("the same with the value stream in CSR row order, read in the kernel's 64-byte pieces (2.18 GB of values + 27 doubles of slack):\n"); }
     s.pieces = (a.tiles_z + run_len - 1) / run_len;
     s.run_len = (a.tiles_z + s.pieces - 1) / s.pieces;
     s.runs = (long)a.tiles_x * a.tiles_y * s.pieces;
