@@ -550,3 +550,57 @@ def test_adjoint_of_the_julia_operator_is_cached_and_finalised():
     body = re.search(r"function Base\.adjoint\(A::HIPCsr\)\n(.*?)\nend\n", glue, flags=re.S).group(1)
     assert "A.adj === nothing || return A.adj" in body and "finalizer(destroy_csr" in body and "A.adj = At" in body
     assert body.count("khip_csr_transpose") == 1
+
+
+# ---- a structural check of the Julia sources (no Julia here): brackets and block keywords balance ------------------------------
+def _julia_strip(src):
+    """Julia source without string / character literals and comments (postfix ' = adjoint stays out of the way)."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith('"""', i):
+            j = src.find('"""', i + 3); i = (j + 3) if j >= 0 else n; out.append('""'); continue
+        if c == '"':
+            j = i + 1
+            while j < n and src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            out.append('""'); i = j + 1; continue
+        if c == "'":
+            prev = out[-1] if out else " "
+            if prev.isalnum() or prev in "_)]}'":
+                out.append(" "); i += 1; continue
+            j = i + 1
+            if j < n and src[j] == "\\":
+                j += 1
+            j = src.find("'", j + 1); out.append("' '"); i = j + 1; continue
+        if c == "#":
+            if src.startswith("#=", i):
+                j = src.find("=#", i + 2); i = (j + 2) if j >= 0 else n; continue
+            j = src.find("\n", i); i = j if j >= 0 else n; continue
+        out.append(c); i += 1
+    return "".join(out)
+
+
+@pytest.mark.parametrize("rel", ["src/KrylovHIP.jl", "test/runtests.jl", "examples/mpi_krylov_hip.jl"])
+def test_julia_sources_are_structurally_balanced(rel):
+    """The package cannot be parsed by Julia here.  What can be checked without it: every bracket closes in order, and the block
+    openers (function / do / begin / let / struct / module / try / quote / macro anywhere; if / for / while at the start of a
+    statement -- comprehensions and generators have no `end`) are as many as the `end`s.  Catches a lost `end` or parenthesis of an
+    edit; it is not a parser."""
+    s = _julia_strip(open(os.path.join(ROOT, "julia", "KrylovHIP", rel)).read())
+    stack, pairs = [], {")": "(", "]": "[", "}": "{"}
+    for ln, line in enumerate(s.split("\n"), 1):
+        for ch in line:
+            if ch in "([{":
+                stack.append((ch, ln))
+            elif ch in ")]}":
+                assert stack and stack[-1][0] == pairs[ch], f"{rel}:{ln}: unbalanced {ch}"
+                stack.pop()
+    assert not stack, f"{rel}: unclosed {stack[-1]}"
+    s2 = re.sub(r"\bmutable\s+struct\b", "struct", s)
+    opens = 0
+    for line in s2.split("\n"):
+        opens += len(re.findall(r"\b(function|do|begin|let|struct|module|try|quote|macro)\b", line))
+        opens += len(re.findall(r"(?:^|;|=|\breturn\b|\bbegin\b|\bdo\b|\belse\b)\s*(if|for|while)\b", line))
+    ends = len(re.findall(r"\bend\b", s2))
+    assert opens == ends, f"{rel}: {opens} block openers, {ends} `end`"
