@@ -462,6 +462,15 @@ __global__ __launch_bounds__(64) void spmm_tile_kernel(SpmvArgs a, TileArgs w) {
 // prefetch pipeline is per wave as before.  Same arithmetic, same order per row: Y bit-identical.
 // AHEAD (round 6) is a separate instantiation: the look-ahead loop keeps three records and two entry sets live across a
 // barrier and would cost the round-4 loop its fourth wave per SIMD if both sat in one kernel (161 instead of 120 VGPRs at NL = 3).
+// experiment build (-DKHIP_TILE2_NT=1): the two-wave kernel's matrix-side streams (records, entries) and its Y stores carry the
+// non-temporal hint, so that they do not push the panel rows out of the Infinity Cache (tools/spmm_chunk_ab.sh builds it as build_nt)
+#ifdef KHIP_TILE2_NT
+#define KHIP_T2_LD(ptr) __builtin_nontemporal_load(ptr)
+#define KHIP_T2_ST(ptr, val) __builtin_nontemporal_store(val, ptr)
+#else
+#define KHIP_T2_LD(ptr) (*(ptr))
+#define KHIP_T2_ST(ptr, val) (*(ptr) = (val))
+#endif
 #ifdef KHIP_TILE_WPE                 // experiment build: ask for KHIP_TILE_WPE waves per SIMD (a register budget of 512 / WPE)
 #define KHIP_TILE_WPE_ATTR __attribute__((amdgpu_waves_per_eu(KHIP_TILE_WPE, KHIP_TILE_WPE)))
 #else
@@ -521,11 +530,11 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
     const int4v *desc = reinterpret_cast<const int4v *>(rec);
     const int32_t *lst = reinterpret_cast<const int32_t *>(rec + kTileDescBytes);
 #pragma unroll
-    for (int q = 0; q < NP; ++q) r.d[q] = desc[(wv * NP + q) * S::RP + sub];
+    for (int q = 0; q < NP; ++q) r.d[q] = KHIP_T2_LD(desc + (wv * NP + q) * S::RP + sub);
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const int q = lane + 64 * j;
-      r.lw[j] = lst[q < w.cap ? q : w.cap - 1];
+      r.lw[j] = KHIP_T2_LD(lst + (q < w.cap ? q : w.cap - 1));
     }
     r.flag = reinterpret_cast<const int *>(rec)[7];                      // aux word of row slot 1: the group's direct-path flag
     r.mask = reinterpret_cast<const int *>(rec)[11];                     // ... of row slot 2: the octets of slots to copy (sliding windows)
@@ -540,13 +549,13 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
         int64_t i0 = (int64_t)r.d[q].y + 2 * c + 2 * L * f;
         i0 = i0 < vlast ? i0 : vlast;
         if (w.exp & 4) i0 = 2 * c + 2 * L * f;                             // phase experiment: no entry stream
-        e.v[q][f] = *reinterpret_cast<const dbl2u *>(a.val + i0);
+        e.v[q][f] = KHIP_T2_LD(reinterpret_cast<const dbl2u *>(a.val + i0));
       }
       const char *sp = slots + ((wv * NP + q) * S::RP + sub) * kTileLen + 4 * S::SW * c;
       if (S::SW == 1) {
-        e.sw[q][0] = *reinterpret_cast<const int *>(sp);
+        e.sw[q][0] = KHIP_T2_LD(reinterpret_cast<const int *>(sp));
       } else {
-        const int2v t = *reinterpret_cast<const int2v *>(sp);
+        const int2v t = KHIP_T2_LD(reinterpret_cast<const int2v *>(sp));
         e.sw[q][0] = t.x; e.sw[q][S::SW - 1] = t.y;
       }
     }
@@ -599,8 +608,8 @@ __global__ __launch_bounds__(128) KHIP_TILE_WPE_ATTR void spmm_tile2_kernel(Spmv
       }
       if (d.x >= 0) {
         double *yr = a.y + ((int64_t)d.x << (w.gshift - 3)) + (w.coff >> 3) + 2 * c;
-        *reinterpret_cast<dbl2 *>(yr + (hq >> 3)) = dbl2{acc[0], acc[1]};
-        *reinterpret_cast<dbl2 *>(yr + 2 * L - (hq >> 3)) = dbl2{acc[2], acc[3]};
+        KHIP_T2_ST(reinterpret_cast<dbl2 *>(yr + (hq >> 3)), (dbl2{acc[0], acc[1]}));
+        KHIP_T2_ST(reinterpret_cast<dbl2 *>(yr + 2 * L - (hq >> 3)), (dbl2{acc[2], acc[3]}));
       }
     }
   };
