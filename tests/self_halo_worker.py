@@ -45,6 +45,18 @@ def main():
         ys2 = A.matvec(ctx.array(xh)).to_host()
         res[f"spmv_overlap{overlap}_bit_identical"] = bool(np.array_equal(ys2, yp))
     ctx.set_option("overlap_halo", 1)
+    # round 6: the communication stream's priority is switchable between solves (bench.py's A/B at N > 1), and the exchange's phases are
+    # bracketed by HIP events on the stream each runs on (khip_profile_kernels): same bits either way, every phase seen once per product
+    ctx.set_option("comm_priority", 0)
+    res["spmv_priority0_bit_identical"] = bool(np.array_equal(A.matvec(ctx.array(xh)).to_host(), yp))
+    ctx.set_option("comm_priority", 1)
+    ctx.set_option("profile_spmv", 1); ctx.profile_kernels()
+    xd = ctx.array(xh); yd = ctx.empty(m)
+    for _ in range(3):
+        A.matvec(xd, yd)
+    prof = ctx.profile_kernels(); ctx.set_option("profile_spmv", 0)
+    res["phase_launches"] = {k: prof[k][0] for k in ("halo_pack", "halo_transfer", "spmv", "spmv_boundary", "dot_allgather_combine")}
+    res["phase_ms_positive"] = bool(all(prof[k][1] > 0 for k in ("halo_pack", "halo_transfer", "spmv", "spmv_boundary")))
     b = ctx.array(np.ones(m)); b2 = ctx2.array(np.ones(m))
     for fused in (0, 2):
         ws, ws2 = K.CgWorkspace(ctx, m, m), K.CgWorkspace(ctx2, m, m)

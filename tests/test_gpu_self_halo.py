@@ -30,6 +30,12 @@ def test_self_halo_slab_equals_the_periodic_operator(n1, k0, k1):
     assert r["n_ghost"] == 2 * n1 * n1 == r["n_send"]                  # the two neighbouring planes, SURVEY 8e
     assert r["spmv_uses_halo"]
     assert r["spmv_bit_identical"] and r["spmv_overlap1_bit_identical"] and r["spmv_overlap0_bit_identical"]
+    assert r["spmv_priority0_bit_identical"]                            # communication stream at default priority (ctx option comm_priority)
+    # the phases of three products, each bracketed once per product on the stream it runs on (khip_profile_kernels)
+    pl = r["phase_launches"]
+    assert (pl["halo_pack"], pl["halo_transfer"], pl["spmv"], pl["dot_allgather_combine"]) == (3, 3, 3, 0)
+    assert pl["spmv_boundary"] in (3, 6)            # the two boundary ranges are ONE launch where the staged / coded kernel takes them, two otherwise
+    assert r["phase_ms_positive"]
     for fused in (0, 2):
         assert r[f"cg_fused{fused}_niter"][0] == r[f"cg_fused{fused}_niter"][1]
         # same kernels on the same values; the dots go through one more (1-rank) combine step: <= 1 ulp per dot
