@@ -1016,7 +1016,8 @@ int ensure_reduction_scratch(khip_ctx *ctx, int64_t nwaves, int nout) {
 int launch_finish(khip_ctx *ctx, int64_t nwaves, int nout, int slot) {
   RedArgs ra = make_red_args(ctx, slot);
   if (ctx->comm) ra.epi = EPI_NONE;      // the cross-rank combine kernel owns the epilogue
-  int64_t want = (nwaves + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+  static const int per_thread = [] { const char *e = getenv("KHIP_FINISH_PER_THREAD"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();   // partials a thread folds (experiments: 4 / 8 / 16)
+  int64_t want = (nwaves + (int64_t)kBlock * per_thread - 1) / ((int64_t)kBlock * per_thread);
   const unsigned g = (unsigned)(want < 1 ? 1 : (want > kFinishMaxBlocks ? kFinishMaxBlocks : want));
   if (nout == 1) hipLaunchKernelGGL((reduce_finish_kernel<1>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);
   else if (nout == 2) hipLaunchKernelGGL((reduce_finish_kernel<2>), dim3(g), dim3(kBlock), 0, ctx->stream, ra, nwaves);
