@@ -31,13 +31,14 @@ template <typename T> struct Acc;
 template <> struct Acc<double> { static __device__ double mad(double a, double b, double c) { return fma(a, b, c); } };
 template <> struct Acc<dbl2> { static __device__ dbl2 mad(dbl2 a, dbl2 b, dbl2 c) { dbl2 o; o.x = fma(a.x, b.x, c.x); o.y = fma(a.y, b.y, c.y); return o; } };
 
-// q <- q + 0.5 v [+ 0.25 u]; NR = 2: reads v, q; NR = 3: reads v, q, u.  WRITE = false: reads only (the TN product's mix).
+// q <- q + 0.5 v [+ 0.25 u]; NR = 2: reads v, q; NR = 3: reads v, q, u; NR = 1: q <- 1.5 q IN PLACE (one read + one write of the same panel: the
+// scalings Q <- Q R^-1 of the panel QR).  WRITE = false: reads only (the TN product's mix).
 template <typename T, int NR, int U, bool WRITE, bool NTS>
 __global__ __launch_bounds__(256) void k_panel(const T *v, T *q, const T *u, long nv, double *sink) {
   const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
   T a[U], b[U], c[U];
 #pragma unroll
-  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < nv) { a[j] = v[i]; b[j] = q[i]; if (NR == 3) c[j] = u[i]; } }
+  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < nv) { b[j] = q[i]; a[j] = NR == 1 ? b[j] : v[i]; if (NR == 3) c[j] = u[i]; } }
   T half, quarter, acc;
   memset(&acc, 0, sizeof(T));
   if constexpr (sizeof(T) == 8) { half = 0.5; quarter = 0.25; } else { half = dbl2{0.5, 0.5}; quarter = dbl2{0.25, 0.25}; }
@@ -74,6 +75,8 @@ static void panel_main(long rows, int p) {
   run_panel<double, NR, 16, WRITE, NTS>(NAME, v, q, u, n, sink); \
   run_panel<dbl2, NR, 2, WRITE, NTS>(NAME, v, q, u, n, sink); run_panel<dbl2, NR, 4, WRITE, NTS>(NAME, v, q, u, n, sink); \
   run_panel<dbl2, NR, 8, WRITE, NTS>(NAME, v, q, u, n, sink)
+  BOTH("1R+1W", 1, true, false);          // in place
+  BOTH("1R+1W", 1, true, true);
   BOTH("2R", 2, false, false);
   BOTH("2R+1W", 2, true, false);
   BOTH("2R+1W", 2, true, true);
