@@ -64,6 +64,42 @@ static void run_panel(const char *name, double *v, double *q, double *u, long n,
   fflush(stdout);
 }
 
+// X <- X + sum_i c_i V_i, K read streams + X read and written in place: the mix of panel_multi_nn (X += sum V_i Y_i, k = 5: 6 reads + 1 write)
+struct MultiPtrs { const double *v[8]; };
+template <int K, int U>
+__global__ __launch_bounds__(256) void k_multi(MultiPtrs P, double *x, long n) {
+  const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
+  double a[K][U], b[U];
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < n) { b[j] = x[i];
+#pragma unroll
+      for (int k = 0; k < K; ++k) a[k][j] = P.v[k][i]; } }
+#pragma unroll
+  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < n) { double o = b[j];
+#pragma unroll
+      for (int k = 0; k < K; ++k) o = fma(0.125, a[k][j], o);
+      x[i] = o; } }
+}
+template <int K, int U>
+static void run_multi(double **v, double *x, long n) {
+  MultiPtrs P; for (int k = 0; k < 8; ++k) P.v[k] = v[k % K];
+  const long G = (n + 256L * U - 1) / (256L * U);
+  const float ms = timeit([&] { hipLaunchKernelGGL((k_multi<K, U>), dim3((unsigned)G), dim3(256), 0, 0, P, x, n); }, 10);
+  const double bytes = (double)(K + 2) * 8.0 * (double)n;
+  printf("%dR+1W (X in place + %d panels)  8 B/lane  U=%d  %.3f ms  %7.0f GB/s  %.3f of 8 TB/s\n", K + 1, K, U, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+  fflush(stdout);
+}
+static void multi_main(long rows, int p) {
+  const long n = ((rows + 15) / 16 * 16) * p;
+  double *v[5], *x;
+  for (auto &q : v) { CK(hipMalloc(&q, n * 8)); CK(hipMemset(q, 0, n * 8)); }
+  CK(hipMalloc(&x, n * 8)); CK(hipMemset(x, 0, n * 8));
+  printf("multi-panel update streams: %ld x %d doubles per panel (%.2f GB)\n", rows, p, n * 8 / 1e9);
+  run_multi<5, 1>(v, x, n); run_multi<5, 2>(v, x, n); run_multi<5, 4>(v, x, n);
+  run_multi<2, 2>(v, x, n); run_multi<2, 4>(v, x, n);
+  run_multi<1, 4>(v, x, n);
+}
+
 static void panel_main(long rows, int p) {
   const long n = ((rows + 15) / 16 * 16) * p;          // doubles of one panel (cfg 5: 10,077,696 x 16 = 1.29 GB)
   double *v, *q, *u, *sink;
@@ -511,9 +547,10 @@ int main(int argc, char **argv) {
   const char *mode = argc > 1 ? argv[1] : "panel";
   if (strcmp(mode, "panel") == 0) panel_main(argc > 2 ? atol(argv[2]) : 10077696L, 16);
   else if (strcmp(mode, "spmm") == 0) spmm_main(argc > 2 ? atoi(argv[2]) : 216);
+  else if (strcmp(mode, "multi") == 0) multi_main(argc > 2 ? atol(argv[2]) : 10077696L, 16);
   else if (strcmp(mode, "spmmirr") == 0) spmmirr_main();
   else if (strcmp(mode, "spmmslide") == 0) spmmslide_main(argc > 2 ? atoi(argv[2]) : 216);
   else if (strcmp(mode, "cgfold") == 0) cgfold_main(argc > 2 ? atoi(argv[2]) : 512);
-  else { printf("usage: streamfloor panel [rows] | spmm [n1] | spmmslide [n1] | spmmirr | cgfold [n1]\n"); return 2; }
+  else { printf("usage: streamfloor panel [rows] | multi [rows] | spmm [n1] | spmmslide [n1] | spmmirr | cgfold [n1]\n"); return 2; }
   return 0;
 }
