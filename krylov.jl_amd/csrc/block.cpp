@@ -683,6 +683,7 @@ static int block_gmres_solve_impl(khip_block_gmres_workspace *ws, const khip_ope
   if (!NisI && !ws->Pn) KB(alloc_panel(ctx, np, p, &ws->Pn));                      // :147
   double *Q = MisI ? W : ws->Qm, *R0 = MisI ? W : ws->Qm;
   double *Xr = restart ? dX : X;
+  bool xr_zeroed = true;            // Xr holds what the update of :324-326 accumulates into (X itself without restart)
 
   if (!B_is_panel) KB(khip_panel_from_colmajor(ctx, n, p, B_in, ws->Bp));
   KB(khip_fill(ctx, len, X, 0.0));                                                 // src/block_gmres.jl:155
@@ -724,7 +725,11 @@ static int block_gmres_solve_impl(khip_block_gmres_workspace *ws, const khip_ope
     for (auto &blk : Z) std::fill(blk.begin(), blk.end(), 0.0);
 
     if (restart) {
-      KB(khip_fill(ctx, len, Xr, 0.0));
+      // :198 zero-fills Xr here and :324-326 accumulate into it.  Nothing reads Xr in between, so the update below starts
+      // from beta = 0 instead (the panel kernels do not read X then: same bits as 1 * 0 + sum) and the fill + one panel read
+      // per cycle go away -- unless a callback could look at the workspace's dX during the cycle.
+      xr_zeroed = o.callback != nullptr;
+      if (xr_zeroed) KB(khip_fill(ctx, len, Xr, 0.0));
       if (npass >= 1) {
         // the residual block of a restart goes straight into V[1] (the copy of :211 is the only reader of R0)
         double *Wr = MisI ? V[0] : W;
@@ -895,7 +900,7 @@ static int block_gmres_solve_impl(khip_block_gmres_workspace *ws, const khip_ope
         Vp[i] = V[i];
         std::copy(Y[i].begin(), Y[i].begin() + pp, Yall.begin() + (size_t)i * pp);
       }
-      KB(panel_multi_nn(ctx, n, p, inner_iter, Vp.data(), Yall.data(), 1.0, Xr));
+      KB(panel_multi_nn(ctx, n, p, inner_iter, Vp.data(), Yall.data(), xr_zeroed ? 1.0 : 0.0, Xr));
     }
     if (!NisI) {                                                                   // :327-330
       KB(khip_copy(ctx, len, ws->Pn, Xr));
