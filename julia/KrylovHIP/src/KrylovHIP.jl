@@ -179,7 +179,8 @@ dptr(v::HIPVector) = isempty(v) ? Ptr{Cdouble}(C_NULL) : v.ptr
 native_precond(M) = M === I || M isa HIPOperator
 opref(M) = M === I ? Ptr{Operator}(C_NULL) : Base.unsafe_convert(Ptr{Operator}, M.op)
 # verbose log: the C loop writes with dprintf to a file descriptor (options.log_fd, 0 = stdout)
-logfd(io::IO) = io === Krylov.kstdout || io === stdout ? Cint(0) : (io isa IOStream ? Cint(fd(io)) : Cint(-1))
+# (`fd(::IOStream)` is an `Int` in older and a `RawFD` in newer Julia versions: `cconvert` takes both)
+logfd(io::IO) = (io === Krylov.kstdout || io === stdout) ? Cint(0) : (io isa IOStream ? Base.cconvert(Cint, fd(io))::Cint : Cint(-1))
 native_log(verbose, io) = verbose <= 0 || logfd(io) >= 0
 
 # ---- callbacks ------------------------------------------------------------------------------------------------------------
