@@ -450,9 +450,19 @@ function Base.copyto!(D::HIPMatrix, bc::Broadcast.Broadcasted{Broadcast.ArraySty
   D
 end
 # products (:242, :245, :246, :325)
-LinearAlgebra.mul!(W::HIPMatrix, A::HIPCsr, P::HIPMatrix) = (ck(ccall((:khip_spmm, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint), CTX[].h, A.h, P.ptr, W.ptr, P.k)); W)
-LinearAlgebra.mul!(Ψ::HIPMatrix, Vt::Adjoint{Float64,HIPMatrix}, Q::HIPMatrix) = (V = parent(Vt);
-  ck(ccall((:khip_panel_gemm_tn, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), CTX[].h, V.m, V.k, V.ptr, Q.ptr, Ψ.host)); Ψ)
+# (a system with n <= 4p keeps even X, W and V on the host: its products go column by column through the SpMV -- correctness only)
+function LinearAlgebra.mul!(W::HIPMatrix, A::HIPCsr, P::HIPMatrix)
+  if !tall(P)
+    for j in 1:P.k; W.host[:, j] = Vector(kmul!(HIPVector(undef, A.m), A, HIPVector(P.host[:, j]))); end
+    return W
+  end
+  ck(ccall((:khip_spmm, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint), CTX[].h, A.h, P.ptr, W.ptr, P.k)); W
+end
+function LinearAlgebra.mul!(Ψ::HIPMatrix, Vt::Adjoint{Float64,HIPMatrix}, Q::HIPMatrix)
+  V = parent(Vt)
+  tall(V) || return (mul!(Ψ.host, V.host', Q.host); Ψ)
+  ck(ccall((:khip_panel_gemm_tn, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), CTX[].h, V.m, V.k, V.ptr, Q.ptr, Ψ.host)); Ψ
+end
 function LinearAlgebra.mul!(Q::HIPMatrix, V::HIPMatrix, Ψ::HIPMatrix, α::Number, β::Number)
   tall(Q) || return (mul!(Q.host, V.host, Ψ.host, α, β); Q)                      # Y[i] -= R[pos] Y[j]   (:317)
   ck(ccall((:khip_panel_gemm_nn, lib), Cint, (Ptr{Cvoid}, Int64, Cint, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}), CTX[].h, V.m, V.k, α, V.ptr, Ψ.host, β, Q.ptr)); Q
