@@ -533,6 +533,41 @@ def main():
     # warm-up iterations (untimed)
     if args.warmup > 0:
         K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=args.warmup, fused=args.fused, variant=args.variant)
+    # Row-partitioned runs: should the halo exchange run UNDER the interior rows (overlap_halo = 1: two launches of the product and a
+    # cross-stream dependency, ~30-70 us of overhead per iteration on one rank, tools/slab_iteration.py) or BEFORE one launch over
+    # all rows (0)?  That depends on what the transfer costs on this node's links, which no 1-GPU box can show -- so it is probed
+    # here, untimed, during warm-up: a few iterations of each, max over ranks, and the headline runs with the faster one (the default
+    # unless the other is > 2 % faster).  y and the residual history are bit-identical either way; both probe times are in the line,
+    # and the A/B leg after the timed region repeats the OTHER setting over the full K iterations.
+    halo_probe = None
+    if use_comm and args.variant == 0 and not args.no_ab and not any(kv.startswith("overlap_halo=") for kv in args.opt):
+        default_overlap = ctx.get_option("overlap_halo")
+        probe_iters = max(5, min(args.steps, 20))
+        ms = {}
+        try:
+            for val in (1, 0):
+                ctx.set_option("overlap_halo", val)
+                K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=3, fused=args.fused)
+                barrier()
+                tp = time.perf_counter()
+                K.cg_(ws, A, b, atol=0.0, rtol=0.0, itmax=probe_iters, fused=args.fused)
+                barrier()
+                el = time.perf_counter() - tp
+                if dist is not None and world > 1:
+                    import torch
+                    tt = torch.tensor([el], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    el = float(tt.item())                      # the same number on every rank: the same choice on every rank
+                ms[val] = 1e3 * el / max(ws.stats.niter, 1)
+            other = 1 - default_overlap
+            chosen = other if ms[other] < 0.98 * ms[default_overlap] else default_overlap
+            halo_probe = {"chosen_overlap_halo": chosen, "default": default_overlap, "iterations_each": probe_iters,
+                          "ms_per_iteration": {f"overlap_halo_{v}": ms[v] for v in (1, 0)},
+                          "rule": "the non-default setting only if it is > 2 % faster (max over ranks)"}
+        except Exception as e:              # a probe must not cost the run: keep the default
+            chosen = default_overlap
+            halo_probe = {"chosen_overlap_halo": chosen, "default": default_overlap, "error": f"{type(e).__name__}: {e}"}
+        ctx.set_option("overlap_halo", chosen)
     ctx.set_option("profile_spmv", 1)
     ctx.profile_kernels()
     barrier()
@@ -565,7 +600,8 @@ def main():
         phases = summarize_phases(profs, args.steps)
         ab = {}
         if args.variant == 0 and not args.no_ab:
-            for name, key, val in (("overlap_halo_0", "overlap_halo", 0), ("comm_priority_0", "comm_priority", 0)):
+            other_overlap = 1 - ctx.get_option("overlap_halo")           # the setting the headline did NOT run with
+            for name, key, val in ((f"overlap_halo_{other_overlap}", "overlap_halo", other_overlap), ("comm_priority_0", "comm_priority", 0)):
                 old_val = ctx.get_option(key)
                 try:
                     ctx.set_option(key, val)
@@ -706,7 +742,7 @@ def main():
             "self_consistency": self_consistency(n1, parity_hist),
             "rccl_ranks_seen": rccl_ranks,
             "comm": (dict(ctx.comm_info(), halo=dict(zip(("gather_mode", "n_ghost", "n_send"), A.halo_info))) if use_comm else None),
-            "phases": phases, "ab": ab,
+            "phases": phases, "ab": ab, "halo_probe": halo_probe,
             "single_reduction_cg": sr,
             "roofline_int32_csr": int32_leg,
             "cfg3_gmres": (others or {}).get("cfg3_gmres"), "cfg5_block_gmres": (others or {}).get("cfg5_block_gmres"),

@@ -117,7 +117,9 @@ def test_bench_with_one_rank_communicator_equals_the_plain_path():
     plain, comm = outs["0"], outs["1"]
     assert plain["rccl_ranks_seen"] == 0 and comm["rccl_ranks_seen"] == 1
     assert plain["phases"] is None and comm["phases"]["per_rank"][0]["dot_allgather_combine"]["launches_per_iteration"] == 2.0
-    assert set(comm["ab"]) == {"overlap_halo_0", "comm_priority_0"}
+    chosen = comm["halo_probe"]["chosen_overlap_halo"]                    # the warm-up probe of the halo overlap ran (one rank: no halo, a tie)
+    assert chosen in (0, 1) and set(comm["halo_probe"]["ms_per_iteration"]) == {"overlap_halo_1", "overlap_halo_0"}
+    assert set(comm["ab"]) == {f"overlap_halo_{1 - chosen}", "comm_priority_0"} and plain["halo_probe"] is None
     assert comm["final_residual_norm"] == plain["final_residual_norm"]                  # same bits through the communicator
     assert comm["steps"] == plain["steps"] == 30 and comm["n_gpus"] == 1
     for o in (plain, comm):
@@ -155,4 +157,6 @@ def test_bench_gpus_n_runs_n_rccl_ranks(world):
         assert row["spmv"]["launches_per_iteration"] == 1.0 and row["spmv_boundary"]["launches_per_iteration"] == 1.0
         assert row["dot_allgather_combine"]["launches_per_iteration"] == 2.0 and row["dot_allgather_combine"]["avg_us"] > 0
     assert o["comm"]["rccl_ranks"] == world and o["comm"]["halo"]["gather_mode"] == 0 and o["comm"]["halo"]["n_ghost"] > 0
-    assert set(o["ab"]) == {"overlap_halo_0", "comm_priority_0"} and all(v["value"] > 0 for v in o["ab"].values())
+    chosen = o["halo_probe"]["chosen_overlap_halo"]
+    assert set(o["ab"]) == {f"overlap_halo_{1 - chosen}", "comm_priority_0"} and all(v["value"] > 0 for v in o["ab"].values())
+    assert all(v > 0 for v in o["halo_probe"]["ms_per_iteration"].values())
