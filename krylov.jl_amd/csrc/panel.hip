@@ -32,7 +32,10 @@ __device__ __forceinline__ T pld(const T *p, bool nt) { return nt ? __builtin_no
 template <typename T>
 __device__ __forceinline__ void pst(T *p, T v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 
-constexpr int kRowsPerWaveTN = 256;   // rows folded by one wave of the V^T Q kernel (64 MFMAs per tile pair)
+#ifndef KHIP_ROWS_PER_WAVE_TN
+#define KHIP_ROWS_PER_WAVE_TN 256      // experiment builds: -DKHIP_ROWS_PER_WAVE_TN=64 / 128 (tools/panel_front_ab.sh)
+#endif
+constexpr int kRowsPerWaveTN = KHIP_ROWS_PER_WAVE_TN;   // rows folded by one wave of the V^T Q kernel (64 MFMAs per tile pair)
 
 // ---------------------------------------------------------------- layout conversion ------
 // in: column-major n x p (ld = n); out: row-major n_pad x p (ld = p).  256 rows per workgroup via LDS.
@@ -234,8 +237,11 @@ __global__ __launch_bounds__(kBlock) void panel_gemm_nn_kernel(int64_t n_pad, in
 // panel_gemm_nn_kernel: Q and Psi_{i+1} are bit-identical to the two separate kernels; four panel passes instead of five.
 // SELF: the second product is the Gram matrix of the updated panel itself (Vn unused): round 1 of the CholeskyQR
 // (Q <- Q R^-1) fused with G = Q^T Q of round 2.
+#ifndef KHIP_NN_TN_WAVES
+#define KHIP_NN_TN_WAVES 1             // experiment builds: minimum waves per SIMD the register allocation must leave room for
+#endif
 template <int NT, int UNT, bool SELF>
-__global__ __launch_bounds__(kBlock) void panel_nn_tn_kernel(int64_t n_pad, int p, double alpha, const double *Vi,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(KHIP_NN_TN_WAVES, 8))) void panel_nn_tn_kernel(int64_t n_pad, int p, double alpha, const double *Vi,
                                                              const double *Psi_dev, double beta, const double *Vn, double *Q,
                                                              double *partials, int a_stage) {
   const int lane = threadIdx.x & 63;

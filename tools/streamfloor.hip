@@ -33,12 +33,15 @@ template <> struct Acc<dbl2> { static __device__ dbl2 mad(dbl2 a, dbl2 b, dbl2 c
 
 // q <- q + 0.5 v [+ 0.25 u]; NR = 2: reads v, q; NR = 3: reads v, q, u; NR = 1: q <- 1.5 q IN PLACE (one read + one write of the same panel: the
 // scalings Q <- Q R^-1 of the panel QR).  WRITE = false: reads only (the TN product's mix).
-template <typename T, int NR, int U, bool WRITE, bool NTS>
+// NTS = 2: non-temporal LOADS as well as stores (what the BLAS-1 kernels of csrc/blas1.hip do for long vectors)
+template <typename T, int NR, int U, bool WRITE, int NTS>
 __global__ __launch_bounds__(256) void k_panel(const T *v, T *q, const T *u, long nv, double *sink) {
   const long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
   T a[U], b[U], c[U];
 #pragma unroll
-  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < nv) { b[j] = q[i]; a[j] = NR == 1 ? b[j] : v[i]; if (NR == 3) c[j] = u[i]; } }
+  for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < nv) {
+      if (NTS == 2) { b[j] = __builtin_nontemporal_load(q + i); a[j] = NR == 1 ? b[j] : __builtin_nontemporal_load(v + i); if (NR == 3) c[j] = __builtin_nontemporal_load(u + i); }
+      else { b[j] = q[i]; a[j] = NR == 1 ? b[j] : v[i]; if (NR == 3) c[j] = u[i]; } } }
   T half, quarter, acc;
   memset(&acc, 0, sizeof(T));
   if constexpr (sizeof(T) == 8) { half = 0.5; quarter = 0.25; } else { half = dbl2{0.5, 0.5}; quarter = dbl2{0.25, 0.25}; }
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void k_panel(const T *v, T *q, const T *u, lon
   for (int j = 0; j < U; ++j) { const long i = base + j * 256; if (i < nv) {
       T o = Acc<T>::mad(half, a[j], b[j]);
       if (NR == 3) o = Acc<T>::mad(quarter, c[j], o);
-      if (WRITE) { if (NTS) __builtin_nontemporal_store(o, q + i); else q[i] = o; } else acc = Acc<T>::mad(o, o, acc);
+      if (WRITE) { if (NTS != 0) __builtin_nontemporal_store(o, q + i); else q[i] = o; } else acc = Acc<T>::mad(o, o, acc);
   } }
   if (!WRITE) {
     double s; if constexpr (sizeof(T) == 8) s = acc; else s = acc.x + acc.y;
@@ -54,13 +57,115 @@ __global__ __launch_bounds__(256) void k_panel(const T *v, T *q, const T *u, lon
   }
 }
 
-template <typename T, int NR, int U, bool WRITE, bool NTS>
+template <typename T, int NR, int U, bool WRITE, int NTS>
 static void run_panel(const char *name, double *v, double *q, double *u, long n, double *sink) {
   const long nv = n * 8 / (long)sizeof(T);
   const long G = (nv + 256L * U - 1) / (256L * U);
   const float ms = timeit([&] { hipLaunchKernelGGL((k_panel<T, NR, U, WRITE, NTS>), dim3((unsigned)G), dim3(256), 0, 0, (const T *)v, (T *)q, (const T *)u, nv, sink); }, 20);
   const double bytes = (double)(NR + (WRITE ? 1 : 0)) * 8.0 * (double)n;
   printf("%-10s %2d B/lane  U=%d  nts=%d  %.3f ms  %7.0f GB/s  %.3f of 8 TB/s\n", name, (int)sizeof(T), U, (int)NTS, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+  fflush(stdout);
+}
+
+// The fused Gram-Schmidt kernel's OWN access pattern without its arithmetic (csrc/panel.hip panel_nn_tn_kernel, p = 16): a wave walks RPW
+// consecutive rows in steps of UNT 16-row tiles; per tile two 16-byte loads of the V_i tile as it lies in memory, four 8-byte loads of
+// the Q tile and four of the V_{i+1} tile in operand order (row r0 + k + 4g, column i), four stores of the Q tile.  Says whether the
+// kernel's distance to the contiguous streams above is its access pattern (this twin is slow too) or its MFMA / LDS chain (this twin is fast).
+// BS = threads per workgroup (64 / 128 / 256); XCD = 1: workgroup j takes chunk (j mod 8) * (G / 8) + j / 8, i.e. each XCD walks its own eighth
+template <int RPW, int UNT, bool NTL, int BS = 256, int XCD = 0>
+__global__ __launch_bounds__(BS) void k_tilewalk(const double *Vi, double *Q, const double *Vn, long n_pad) {
+  const int lane = threadIdx.x & 63, i = lane & 15, k = lane >> 4;
+  long blk = blockIdx.x;
+  if (XCD) { const long G8 = gridDim.x / 8; if (blk < G8 * 8) blk = (blk & 7) * G8 + (blk >> 3); }
+  const long wid = blk * (BS / 64) + (threadIdx.x >> 6);
+  const long row_begin = wid * RPW;
+  if (row_begin >= n_pad) return;
+  const long row_end = row_begin + RPW < n_pad ? row_begin + RPW : n_pad;
+  for (long r = row_begin; r < row_end; r += 16 * UNT) {
+    dbl2 a[UNT][2]; double c[UNT][4], v[UNT][4];
+#pragma unroll
+    for (int t = 0; t < UNT; ++t) {
+      const long r0 = r + 16 * t;
+      if (r0 < row_end) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int c16 = lane + 64 * h, row = c16 >> 3, cc = c16 & 7;
+          const dbl2 *pa = reinterpret_cast<const dbl2 *>(Vi + (r0 + row) * 16 + 2 * cc); a[t][h] = NTL ? __builtin_nontemporal_load(pa) : *pa; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const double *pq = Q + (r0 + k + 4 * g) * 16 + i; c[t][g] = NTL ? __builtin_nontemporal_load(pq) : *pq; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const double *pv = Vn + (r0 + 4 * u + k) * 16 + i; v[t][u] = NTL ? __builtin_nontemporal_load(pv) : *pv; }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < UNT; ++t) {
+      const long r0 = r + 16 * t;
+      if (r0 < row_end) {
+        const double s = a[t][0].x + a[t][0].y + a[t][1].x + a[t][1].y;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const double o = fma(0.5, c[t][g], fma(0.25, v[t][g], s)); double *pq = Q + (r0 + k + 4 * g) * 16 + i;
+          if (NTL) __builtin_nontemporal_store(o, pq); else *pq = o; }
+      }
+    }
+  }
+}
+template <int RPW, int UNT, bool NTL, int BS = 256, int XCD = 0>
+static void run_tilewalk(double *v, double *q, double *u, long n) {
+  const long n_pad = n / 16;
+  const long per = (long)(BS / 64) * RPW;
+  const long G = (n_pad + per - 1) / per;
+  const float ms = timeit([&] { hipLaunchKernelGGL((k_tilewalk<RPW, UNT, NTL, BS, XCD>), dim3((unsigned)G), dim3(BS), 0, 0, v, q, u, n_pad); }, 20);
+  const double bytes = 4.0 * 8.0 * (double)n;
+  printf("3R+1W tile walk  rows/wave=%d  tiles/step=%d  ntl=%d  block=%d  xcd-eighths=%d  %.3f ms  %7.0f GB/s  %.3f of 8 TB/s\n", RPW, UNT, (int)NTL, BS, XCD, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
+  fflush(stdout);
+}
+
+// Cooperative tile loads: the four waves of a workgroup fetch ONE 16 x 16 tile of each stream together (thread t = element t: every wave's
+// instruction is 512 contiguous bytes, three loads in flight per lane -- the shape of the fastest contiguous stream above), park it in LDS
+// (double-buffered), and wave (tile mod 4) reads it back in MFMA operand order, runs the Gram-Schmidt step's two MFMA chains and stores the
+// Q tile.  STORE_ALL: the result goes back through LDS and all four waves store 512 bytes each.  T tiles per workgroup.
+typedef double dbl4v __attribute__((ext_vector_type(4)));
+template <int T, bool STORE_ALL>
+__global__ __launch_bounds__(256) void k_coop(const double *Vi, double *Q, const double *Vn, long tiles, double *sink) {
+  __shared__ double s[2][3][256];
+  __shared__ double so[2][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, k = lane >> 4;
+  const long t0 = (long)blockIdx.x * T;
+  if (t0 >= tiles) return;
+  const long t1 = t0 + T < tiles ? t0 + T : tiles;
+  dbl4v tn = {0.0, 0.0, 0.0, 0.0};
+  double a = __builtin_nontemporal_load(Vi + t0 * 256 + tid), c = __builtin_nontemporal_load(Q + t0 * 256 + tid), v = __builtin_nontemporal_load(Vn + t0 * 256 + tid);
+  for (long t = t0; t < t1; ++t) {
+    const int buf = (int)(t - t0) & 1;
+    s[buf][0][tid] = a; s[buf][1][tid] = c; s[buf][2][tid] = v;
+    if (t + 1 < t1) { a = __builtin_nontemporal_load(Vi + (t + 1) * 256 + tid); c = __builtin_nontemporal_load(Q + (t + 1) * 256 + tid); v = __builtin_nontemporal_load(Vn + (t + 1) * 256 + tid); }
+    __syncthreads();
+    if (w == (int)((t - t0) & 3)) {
+      dbl4v acc = {0.0, 0.0, 0.0, 0.0}, cin, wnew;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[buf][0][i * 16 + 4 * kk + k], 0.001 * (double)(kk + i), acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { cin[g] = s[buf][1][(k + 4 * g) * 16 + i]; wnew[g] = fma(-1.0, acc[g], cin[g]); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tn = __builtin_amdgcn_mfma_f64_16x16x4f64(s[buf][2][(4 * u + k) * 16 + i], wnew[u], tn, 0, 0, 0);
+      if (STORE_ALL) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) so[buf][(k + 4 * g) * 16 + i] = wnew[g];
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) __builtin_nontemporal_store(wnew[g], Q + t * 256 + (k + 4 * g) * 16 + i);
+      }
+    }
+    if (STORE_ALL) { __syncthreads(); __builtin_nontemporal_store(so[buf][tid], Q + t * 256 + tid); }
+  }
+  if (tn[0] + tn[1] + tn[2] + tn[3] == 12345.678) *sink = tn[0];
+}
+template <int T, bool STORE_ALL>
+static void run_coop(double *v, double *q, double *u, long n, double *sink) {
+  const long tiles = n / 256;
+  const long G = (tiles + T - 1) / T;
+  const float ms = timeit([&] { hipLaunchKernelGGL((k_coop<T, STORE_ALL>), dim3((unsigned)G), dim3(256), 0, 0, v, q, u, tiles, sink); }, 20);
+  const double bytes = 4.0 * 8.0 * (double)n;
+  printf("3R+1W cooperative tile loads + MFMA  tiles/workgroup=%d  store_all=%d  %.3f ms  %7.0f GB/s  %.3f of 8 TB/s\n", T, (int)STORE_ALL, ms, bytes / ms / 1e6, bytes / ms / 1e6 / 8000.0);
   fflush(stdout);
 }
 
@@ -111,6 +216,17 @@ static void panel_main(long rows, int p) {
   run_panel<double, NR, 16, WRITE, NTS>(NAME, v, q, u, n, sink); \
   run_panel<dbl2, NR, 2, WRITE, NTS>(NAME, v, q, u, n, sink); run_panel<dbl2, NR, 4, WRITE, NTS>(NAME, v, q, u, n, sink); \
   run_panel<dbl2, NR, 8, WRITE, NTS>(NAME, v, q, u, n, sink)
+  run_coop<4, false>(v, q, u, n, sink); run_coop<16, false>(v, q, u, n, sink); run_coop<64, false>(v, q, u, n, sink);
+  run_coop<4, true>(v, q, u, n, sink); run_coop<16, true>(v, q, u, n, sink); run_coop<64, true>(v, q, u, n, sink);
+  run_tilewalk<256, 2, false>(v, q, u, n); run_tilewalk<256, 2, true>(v, q, u, n); run_tilewalk<256, 1, true>(v, q, u, n); run_tilewalk<256, 4, true>(v, q, u, n);
+  run_tilewalk<32, 2, true>(v, q, u, n); run_tilewalk<16, 1, true>(v, q, u, n); run_tilewalk<1024, 2, true>(v, q, u, n);
+  run_tilewalk<16, 1, true, 64>(v, q, u, n); run_tilewalk<16, 1, true, 128>(v, q, u, n); run_tilewalk<32, 2, true, 64>(v, q, u, n); run_tilewalk<256, 2, true, 64>(v, q, u, n);
+  run_tilewalk<256, 2, true, 256, 1>(v, q, u, n); run_tilewalk<32, 2, true, 256, 1>(v, q, u, n); run_tilewalk<16, 1, true, 64, 1>(v, q, u, n);
+  // the BLAS-1 kernels' shape: one or two 16-byte elements per thread, non-temporal loads and stores
+#define NTL(NAME, NR, WRITE) \
+  run_panel<dbl2, NR, 1, WRITE, 2>(NAME " ntl", v, q, u, n, sink); run_panel<dbl2, NR, 2, WRITE, 2>(NAME " ntl", v, q, u, n, sink); \
+  run_panel<double, NR, 1, WRITE, 2>(NAME " ntl", v, q, u, n, sink); run_panel<double, NR, 4, WRITE, 2>(NAME " ntl", v, q, u, n, sink)
+  NTL("1R+1W", 1, true); NTL("2R", 2, false); NTL("2R+1W", 2, true); NTL("3R", 3, false); NTL("3R+1W", 3, true);
   BOTH("1R+1W", 1, true, false);          // in place
   BOTH("1R+1W", 1, true, true);
   BOTH("2R", 2, false, false);
