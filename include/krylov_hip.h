@@ -110,6 +110,15 @@ int khip_csr_shape(const khip_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
  * codes operators of at least 4 M entries (smaller ones are latency bound and keep the int32 stream), 2 codes whatever the
  * size, 16 forces two-byte codes, 0 keeps the int32 stream (environment variable KHIP_SPMV_CODES sets the initial value).  ref: the product is kmul!(y, A, x), src/krylov_utils.jl:305. */
 int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
+/* The SLICED form of a handle with 8-bit codes (csrc/colcode.hip csr_build_sell, read by spmv_sell_kernel): the entries of every 64
+ * consecutive rows stored a second time transposed -- per slice, per lane, W = ceil(L / 8) words of eight codes then L values
+ * (L = longest row of the slice; a unit = 64 words = 512 bytes) -- so that every lane loads the entries of its own row with
+ * coalesced 8-byte loads: no LDS window and no barrier in the row walk.  Built by the first khip_spmv that can use it when the
+ * padding costs at most 12 % (ctx option "spmv_sell": 2 default = non-temporal loads of the matrix words, 1 = default policy,
+ * 0 = off: the coded CSR stream).  *state = 1 built, 0 not tried, -1 not usable; *units_per_slice > 0: every slice is padded to
+ * that many units (no offset array), 0: per-slice offsets; *total_units: units stored.  y and the fused dots are bit-identical to
+ * the coded CSR kernel's.  khip_spmv_bytes_stored counts 512 B per unit (+ 4 B per slice of offsets) while the form is in use. */
+int khip_csr_sell_info(const khip_csr *A, int *state, int *units_per_slice, int64_t *total_units);
 /* Block-delta column stream of the stream SpMV (operators that are not stencils: more than 2048 diagonals; built at the first
  * product that can use it, ctx option "spmv_delta"): bits = 8 / 16 (32: not in use), rows = rows per block, escapes = entries
  * that stay int32 (6 B each).  khip_spmv_bytes_stored counts what that kernel streams. */

@@ -74,7 +74,110 @@ __global__ __launch_bounds__(kBlock) void code_assign_kernel(const int32_t *rowp
   }
 }
 
+// ---------------------------------------------------------------- sliced form (spmv_sell_kernel) ----
+// The coded kernel reads the CSR value / code streams of a row block coalesced, parks them in LDS and lets lane i walk row i out of
+// LDS: rowptr -> window loads -> barrier -> LDS reads -> gathers is one dependent chain per workgroup.  Here the SAME entries, in the
+// SAME order per row, are stored a second time transposed per 64-row slice, so that lane l reads entry k of its own row with a
+// coalesced 8-byte load (512 contiguous bytes per wave instruction): slice s starts at unit off[s] (a unit = 64 words of 8 bytes);
+// its first W = ceil(L / 8) units hold, per lane, eight 1-byte codes per word (0xFF = the row has no such entry), the next L units
+// the values (L = longest row of the slice).  64 B per row for the 7-point operator (7 values + one code word) where CSR + codes
+// + row pointer is 67.  y is bit-identical (stored order, one rounded multiply and one rounded add per entry).
+constexpr double kSellMaxPad = 1.12;       // slots / entries above which the sliced copy is not built
+constexpr double kSellUniformPad = 1.02;   // ... and below which every slice is padded to the longest one (no offset array)
+
+__global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowptr, int64_t m, int64_t slices, int32_t *units) {
+  const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (s >= slices) return;
+  int L = 0;
+  const int64_t r0 = s * 64, r1 = (r0 + 64 < m) ? r0 + 64 : m;
+  int32_t prev = rowptr[r0];
+  for (int64_t r = r0; r < r1; ++r) {
+    const int32_t nxt = rowptr[r + 1];
+    L = (nxt - prev > L) ? nxt - prev : L;
+    prev = nxt;
+  }
+  units[s] = L > 0 ? L + (L + 7) / 8 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr, const double *val, const uint8_t *code, int64_t m,
+                                                           int64_t slices, const uint32_t *off, int uniform_units,
+                                                           unsigned long long *sell) {
+  const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // rows of the last slice beyond m are written too (no entry)
+  if (row >= slices * 64) return;
+  const int64_t s = row >> 6;
+  const int lane = (int)(row & 63);
+  const int64_t o0 = uniform_units ? s * uniform_units : (int64_t)off[s];
+  const int T = uniform_units ? uniform_units : (int)(off[s + 1] - off[s]);
+  if (T == 0) return;
+  const int W = (T + 8) / 9, L = T - W;
+  const int32_t q0 = row < m ? rowptr[row] : 0;
+  const int len = row < m ? rowptr[row + 1] - q0 : 0;
+  unsigned long long *base = sell + (size_t)o0 * 64 + lane;
+  for (int w = 0; w < W; ++w) {
+    unsigned long long word = 0;
+    for (int u = 0; u < 8; ++u) {
+      const int k = 8 * w + u;
+      const unsigned long long c = k < len ? (unsigned long long)code[q0 + k] : 0xFFull;
+      word |= c << (8 * u);
+    }
+    base[(size_t)w * 64] = word;
+  }
+  for (int k = 0; k < L; ++k) base[(size_t)(W + k) * 64] = k < len ? (unsigned long long)__double_as_longlong(val[q0 + k]) : 0ull;
+}
+
+void csr_free_sell(khip_csr *A) {
+  (void)hipFree(A->sell); (void)hipFree(A->sell_off);
+  A->sell = nullptr; A->sell_off = nullptr;
+  A->sell_units = 0; A->sell_total_units = 0; A->sell_state = 0;
+}
+
+int csr_build_sell(khip_ctx *ctx, khip_csr *A) {
+  csr_free_sell(A);
+  A->sell_state = -1;
+  const int64_t m = A->m;
+  if (A->code_state != 1 || A->code_bits != 8 || A->code_T > 255 || m == 0 || A->nnz == 0 || A->max_row_nnz > 64) return KHIP_OK;
+  const int64_t slices = (m + 63) / 64;
+  int32_t *units_d = nullptr;
+  KHIP_CHECK_HIP(hipMalloc(&units_d, sizeof(int32_t) * (size_t)slices));
+  struct Scratch { int32_t *&p; ~Scratch() { (void)hipFree(p); } } scratch{units_d};
+  hipLaunchKernelGGL(sell_units_kernel, dim3((unsigned)((slices + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, m, slices, units_d);
+  KHIP_CHECK_HIP(hipGetLastError());
+  std::vector<int32_t> units((size_t)slices);
+  KHIP_CHECK_HIP(hipMemcpyAsync(units.data(), units_d, sizeof(int32_t) * (size_t)slices, hipMemcpyDeviceToHost, ctx->stream));
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  int64_t total = 0, slots = 0;
+  int umax = 0;
+  for (int32_t u : units) { total += u; const int W = (u + 8) / 9; slots += (int64_t)(u - W) * 64; umax = u > umax ? u : umax; }
+  if (slots > (int64_t)(kSellMaxPad * (double)A->nnz) + 4096) return KHIP_OK;          // too much padding: stays on the CSR stream
+  const int Wmax = (umax + 8) / 9;
+  const bool uniform = (int64_t)(umax - Wmax) * 64 * slices <= (int64_t)(kSellUniformPad * (double)A->nnz) + 4096;
+  if (uniform) total = (int64_t)umax * slices;
+  if (total >= ((int64_t)1 << 32)) return KHIP_OK;
+  bool keep = false;
+  struct Guard { khip_csr *A; bool &keep; ~Guard() { if (!keep) { csr_free_sell(A); A->sell_state = -1; } } } guard{A, keep};
+  if (!uniform) {
+    std::vector<uint32_t> off((size_t)slices + 1);
+    uint32_t run = 0;
+    for (int64_t s = 0; s < slices; ++s) { off[(size_t)s] = run; run += (uint32_t)units[(size_t)s]; }
+    off[(size_t)slices] = run;
+    KHIP_CHECK_HIP(hipMalloc(&A->sell_off, sizeof(uint32_t) * ((size_t)slices + 1)));
+    KHIP_CHECK_HIP(hipMemcpyAsync(A->sell_off, off.data(), sizeof(uint32_t) * ((size_t)slices + 1), hipMemcpyHostToDevice, ctx->stream));
+    KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));                                  // `off` dies with this scope
+  }
+  KHIP_CHECK_HIP(hipMalloc(&A->sell, sizeof(unsigned long long) * 64 * (size_t)(total + 1)));
+  hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((slices * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->val,
+                     (const uint8_t *)A->code, m, slices, A->sell_off, uniform ? umax : 0, A->sell);
+  KHIP_CHECK_HIP(hipGetLastError());
+  KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  keep = true;
+  A->sell_units = uniform ? umax : 0;
+  A->sell_total_units = total;
+  A->sell_state = 1;
+  return KHIP_OK;
+}
+
 void csr_free_codes(khip_csr *A) {
+  csr_free_sell(A);                          // the sliced form carries the codes
   (void)hipFree(A->code); (void)hipFree(A->code_tab);
   A->code = nullptr; A->code_tab = nullptr;
   A->code_T = 0; A->code_bits = 0; A->code_state = 0;

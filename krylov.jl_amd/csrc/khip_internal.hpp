@@ -94,6 +94,7 @@ struct Tuning {
   int spmv_blockptr = 1;    // use the L2-resident block-pointer table in the stream kernel
   int spmv_pipe = 0;        // staged kernel: software-pipelined form with this many consecutive row blocks per workgroup (0 = one block per workgroup, no pipeline; measured no faster: profiles/r02b_sweep_pipe.log)
   int cg_setup_fused = 1;   // cg! (fused paths, M = I, no warm start): x = 0, r = p = b, gamma = b.b in one pass (khip_cg_setup) instead of four primitives
+  int spmv_sell = 2;        // coded operators with 8-bit codes: the sliced (64-row transposed) form -- every lane loads its own row's entries with coalesced 8-byte loads, no LDS window, no barrier in the row walk (1: default load policy, 2: non-temporal loads of the matrix words, 0: off = spmv_code_kernel); 512^3: 2.21 -> 1.97-2.00 ms fused, CG 275 -> 290-297 it/s (profiles/r06ap, r06aq)
   int spmv_stream_nt = 0;   // 16-byte-load stream kernel: matrix stream loaded with the non-temporal policy
   int spmv_blk_pub = 0;     // fused dots of the staged / coded / delta SpMV kernels: 1 = workgroup-level fold in LDS, one wave runs the double-double tree (block_publish); measured equal to the per-wave trees (profiles/r04b_sweep_headline.log): off
   int spmv_delta = 0;       // stream kernel: block-delta column stream (coldelta.hip: 1 or 2 B per entry + 6 B per escape) -- 0: never (default: 18 % fewer bytes but no faster on the banded + random operator, slower on stencils; profiles/r04a_sweep_delta.log); 1: operators of >= 4 M entries where it saves at least a sixth of the column bytes; 2: whatever the size; 8 / 16: that width, always
@@ -247,6 +248,14 @@ struct khip_csr {
   int code_T = 0;                      // distinct (column - row) offsets
   void *code = nullptr;                // uint8_t / uint16_t [nnz + pad]
   int32_t *code_tab = nullptr;         // [code_T], ascending
+  // optional SLICED form of the coded operator (colcode.hip csr_build_sell, built on the first product that can use it): the entries of
+  // every 64 consecutive rows transposed so that lane l of a wave finds entry k of ITS row at word (W + k) * 64 + l of the slice --
+  // W = ceil(L / 8) words of eight 1-byte codes per row first (0xFF = no entry), then L = longest row of the slice words of values
+  int sell_state = 0;                  // 0 = not tried, 1 = built, -1 = tried, not usable / not worth the padding
+  unsigned long long *sell = nullptr;  // 64-bit words, 64 per unit
+  uint32_t *sell_off = nullptr;        // [slices + 1] first unit of every slice (null: every slice has sell_units units)
+  int sell_units = 0;                  // uniform slices: W + L of every slice (0: per-slice offsets)
+  int64_t sell_total_units = 0;
   // optional block-delta column stream of the stream SpMV (coldelta.hip, built on the first product that can use it)
   int delta_state = 0;                 // 0 = not tried, 1 = built, -1 = tried, not usable / not worth it
   int delta_bits = 0;                  // 8 or 16
@@ -347,6 +356,8 @@ void csr_free_delta(khip_csr *A);                  // coldelta.hip
 int csr_build_delta(khip_ctx *ctx, khip_csr *A, int rows);   // coldelta.hip: sets A->delta_state to 1 or -1
 void csr_free_codes(khip_csr *A);                  // colcode.hip
 int csr_build_codes(khip_ctx *ctx, khip_csr *A);   // colcode.hip: sets A->code_state to 1 or -1
+void csr_free_sell(khip_csr *A);                   // colcode.hip
+int csr_build_sell(khip_ctx *ctx, khip_csr *A);    // colcode.hip: sets A->sell_state to 1 or -1 (needs 8-bit codes)
 int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,
                    double *X);   // panel.hip
 int panel_tsqr_r(khip_ctx *ctx, int64_t n, int p, const double *Q, double *R_host_rowmajor);   // panel.hip: R factor by TSQR

@@ -457,6 +457,91 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
   }
 }
 
+// ---------------------------------------------------------------- coded columns, sliced rows ----
+// The coded operator in its sliced form (colcode.hip csr_build_sell): lane i owns row r0 + i as in spmv_code_kernel -- same row
+// blocks, same workgroups, same partial slots, so the fused dot's partials are the SAME numbers -- but it loads the entries of its
+// row itself: one 64-bit word of eight codes and up to eight values per step, each a coalesced 8-byte load (entry k of the 64 rows
+// of a slice is 512 contiguous bytes).  No LDS window, no barrier and no row pointer in the row walk: the only dependent hop is
+// code word -> table lookup (LDS) -> x gather.  Products in stored order, one rounded multiply and one rounded add per entry:
+// y is bit-identical to every other kernel.
+template <bool DOT, bool COMP, bool DIST, bool NTM>
+__global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs ra) {
+  if (seq_skip(a.stop_seq, a.seq)) return;
+  const int ROWS = a.stage_rows;
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_stage[];
+  // [block_publish scratch][diagonal table, 256 entries]: the scratch must not overlay the table, no barrier separates the row walks
+  // of different waves from the publish
+  const size_t pub = (DOT && a.blk_pub) ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;
+  int32_t *s_tab = reinterpret_cast<int32_t *>(s_stage + pub);
+  const int tid = threadIdx.x;
+  const int64_t nrows = a.row_hi - a.row_lo - a.hole_len;
+  const int64_t nrb = (nrows + ROWS - 1) / ROWS;
+  const int tpb = a.tiles_per_block > 0 ? a.tiles_per_block : 1;
+  const int cid = chunk_id(blockIdx.x, gridDim.x, a.xcd_remap, a.sweep_s, a.sweep_w);
+  const int64_t rb_begin = (int64_t)cid * tpb;
+  const int64_t rb_end = (rb_begin + tpb < nrb) ? rb_begin + tpb : nrb;
+  dd dacc[2];
+  dacc[0] = dd{0.0, 0.0};
+  dacc[1] = dd{0.0, 0.0};
+  for (int i = tid; i < 256; i += kBlock) s_tab[i] = i < a.code_T ? a.code_tab[i] : 0;
+  __syncthreads();
+  for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
+    int64_t r0 = a.row_lo + rb * ROWS;
+    if (r0 >= a.hole_lo) r0 += a.hole_len;   // the second range of a two-range launch
+    const int nr = (int)((a.row_hi - r0) < ROWS ? (a.row_hi - r0) : ROWS);
+    if (tid < nr) {
+      const int64_t rowl = r0 + tid;
+      const int32_t row = (int32_t)rowl;
+      const int64_t sl = rowl >> 6;
+      int64_t o0;
+      int T;
+      if (a.sell_units) { o0 = sl * a.sell_units; T = a.sell_units; }
+      else { const uint32_t b0 = a.sell_off[sl], b1 = a.sell_off[sl + 1]; o0 = (int64_t)b0; T = (int)(b1 - b0); }
+      const int W = (T + 8) / 9, L = T - W;
+      const unsigned long long *base = a.sell + (size_t)o0 * 64 + (rowl & 63);
+      double acc = 0.0, wv = 0.0;
+      if (DOT) wv = a.dotw[rowl];                 // in flight beside the row's entries (2.06 -> 1.97 ms fused at 512^3, profiles/r06ap/aq)
+      for (int w = 0; w < W; ++w) {
+        const unsigned long long cw = ld<NTM>(base + (size_t)w * 64);
+        const unsigned long long *vb = base + (size_t)(W + 8 * w) * 64;
+        const int left = L - 8 * w;            // >= 1
+        double vv[8], xx[8];
+        int32_t cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = (u < left) ? __longlong_as_double((long long)ld<NTM>(vb + (size_t)u * 64)) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cc[u] = (int32_t)((cw >> (8 * u)) & 0xFFull);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xx[u] = 0.0;
+          if (cc[u] != 0xFF) xx[u] = gather_x<DIST>(a, row + s_tab[cc[u]]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (cc[u] != 0xFF) {
+            const double prod = vv[u] * xx[u];
+            acc = acc + prod;
+          }
+        }
+      }
+      store_y(a, rowl, acc);
+      if (DOT) {
+        acc_prod<COMP>(dacc[0], wv, acc);
+        if (a.dot_sq == 1) acc_prod<COMP>(dacc[1], acc, acc);
+        else if (a.dot_sq == 2) acc_prod<COMP>(dacc[1], wv, wv);
+      }
+    }
+  }
+  if (DOT) {
+    if (a.blk_pub) {
+      dd *s_red = reinterpret_cast<dd *>(s_stage);
+      if (a.dot_sq) block_publish<2>(dacc, ra, s_red);
+      else block_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra, s_red);
+    } else if (a.dot_sq) wave_publish<2>(dacc, ra);
+    else wave_publish<1>(reinterpret_cast<dd (&)[1]>(dacc), ra);
+  }
+}
+
 // ---------------------------------------------------------------- staged rows, software-pipelined ----
 // The staged kernels above run one dependent chain per workgroup -- row pointers -> window (val + columns) -> x gathers
 // -> y -- and only the middle link carries the bulk of the bytes: with 8 workgroups per CU about 40 % of them have their
@@ -1113,6 +1198,16 @@ static void launch_code_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra,
 #undef KHIP_L
 }
 
+static void launch_sell_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp, bool dist) {
+  const size_t pub = dot && a.blk_pub ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;
+  const size_t lds = pub + 4u * 256u;
+#define KHIP_L(DOT, COMP, DIST) \
+  do { if (ctx->tune.spmv_sell == 2) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
+       else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } while (0)
+  KHIP_DISPATCH_DCD(KHIP_L);
+#undef KHIP_L
+}
+
 template <typename CODE>
 static void launch_pipe_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp,
                             bool dist) {
@@ -1265,6 +1360,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256; a.max_row = 0;
+  a.sell = nullptr; a.sell_off = nullptr; a.sell_units = 0;
   a.blk_pub = ctx->tune.spmv_blk_pub;
   a.stream_nt = ctx->tune.spmv_stream_nt;
   a.dcode = nullptr; a.dbase = nullptr; a.desc_ptr = nullptr; a.desc_pos = nullptr; a.desc_col = nullptr;
@@ -1388,6 +1484,9 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     if (coded) { a.code = Am->code; a.code_tab = Am->code_tab; a.code_T = Am->code_T; }
     a.stage_rows = rows;
     a.max_row = (int)A->max_row_nnz;
+    // sliced form of the coded operator (csr_build_sell): built once per handle, at the first product that gets here with spmv_sell on
+    if (coded && ctx->tune.spmv_sell && Am->code_bits == 8 && Am->sell_state == 0 && ctx->tune.spmv_pipe <= 0) optional_build(csr_build_sell(ctx, Am));
+    const bool sliced = coded && ctx->tune.spmv_sell && Am->sell_state == 1 && ctx->tune.spmv_pipe <= 0;
     // software-pipelined form: needs one window per row block
     const bool pipe = ctx->tune.spmv_pipe > 0 && !nt && !a.fake_gather && A->nnz > 0 && A->max_row_nnz >= 1 &&
                       (int64_t)rows * A->max_row_nnz + 3 <= 2048 && ctx->tune.spmv_cap == 0;
@@ -1400,6 +1499,10 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       if (!coded) launch_pipe_cfg<int32_t>(ctx, a, ra, grid, dot, comp, dist);
       else if (Am->code_bits == 8) launch_pipe_cfg<uint8_t>(ctx, a, ra, grid, dot, comp, dist);
       else launch_pipe_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
+      rows = 0;      // launched
+    } else if (coded && sliced) {
+      a.sell = Am->sell; a.sell_off = Am->sell_off; a.sell_units = Am->sell_units;
+      launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (coded) {
       if (Am->code_bits == 8) launch_code_cfg<uint8_t>(ctx, a, ra, grid, dot, comp, dist);

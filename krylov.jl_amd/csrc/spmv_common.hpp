@@ -48,6 +48,10 @@ struct SpmvArgs {
   const void *code;          // uint8_t[nnz + pad] or uint16_t[nnz + pad]
   const int32_t *code_tab;   // sorted distinct (column - row) offsets, code_T entries
   int code_T;
+  // sliced form of the coded operator (csr_build_sell): 64-row slices, per slice W code words then L value words per lane
+  const unsigned long long *sell;
+  const uint32_t *sell_off;  // first unit (64 words) of every slice; null: sell_units units per slice
+  int sell_units;
   // block-delta column stream (coldelta.hip): col = dbase[block] + dcode[k]; all-ones code = escape
   const void *dcode;         // uint8_t[nnz + pad] or uint16_t[nnz + pad]
   const int32_t *dbase;      // base column of every row block

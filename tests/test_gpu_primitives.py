@@ -824,9 +824,10 @@ def test_spmv_coded_columns_bit_exact(K, ctx, oracle, kind, n1, bits, diags):
     x = _vec(rng, A.n)
     y_ref = A.matvec(x)
     dx = ctx.array(x)
-    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel")}
+    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel", "spmv_sell")}
     try:
         ctx.set_option("spmv_kernel", 4)            # the 27-point operator would take the ordered kernel by default
+        ctx.set_option("spmv_sell", 0)              # the coded CSR stream itself (the sliced form: test_spmv_sliced_form_bit_exact)
         ctx.set_option("spmv_codes", 1)             # the default: only operators of >= 4 M entries get the coded stream
         dS = K.CsrMatrix.stencil(ctx, kind, n1)
         dS.matvec(dx, ctx.zeros(A.n))
@@ -847,6 +848,59 @@ def test_spmv_coded_columns_bit_exact(K, ctx, oracle, kind, n1, bits, diags):
             stored = dA.spmv_bytes_stored
             want = (8 + (want_bits // 8)) * A.nnz + 4 * (A.n + 1) + 16 * A.n
             assert stored == want and dA.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+
+
+@pytest.mark.parametrize("kind,n1", [("poisson", 20), ("poisson", 37), ("kron_unsymmetric", 12), ("stencil27", 9), ("stencil27", 21)])
+def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
+    """The sliced form of a coded operator (csrc/colcode.hip csr_build_sell + spmv_sell_kernel: every 64 rows transposed, a lane
+    loads its own row's codes and values with coalesced 8-byte loads; ctx option spmv_sell = 1 / 2, 2 the default): y equals the
+    oracle's serial loop bit for bit, the fused dots equal the coded CSR kernel's bit for bit (same rows per lane, same partials),
+    for 1 / 2 / 3 row blocks per workgroup, uniform and per-slice-offset layouts, row counts that are no multiple of 64."""
+    gen = {"poisson": oracle.poisson3d, "kron_unsymmetric": oracle.kron_unsymmetric, "stencil27": oracle.stencil27_unsym}[kind]
+    A = gen(n1)
+    rng = np.random.default_rng(78)
+    x = _vec(rng, A.n)
+    y_ref = A.matvec(x)
+    dx = ctx.array(x)
+    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel", "spmv_sell", "spmv_tiles", "spmv_blk_pub")}
+    try:
+        ctx.set_option("spmv_kernel", 4); ctx.set_option("spmv_codes", 2)
+        ref = {}
+        layouts = set()
+        for sell in (0, 1, 2):
+            for tiles in (1, 2, 3):
+                for pub in (1, 0):
+                    ctx.set_option("spmv_sell", sell); ctx.set_option("spmv_tiles", tiles); ctx.set_option("spmv_blk_pub", pub)
+                    dA = K.CsrMatrix.stencil(ctx, kind, n1)
+                    assert dA.sell_info == (0, 0, 0)                        # nothing is built before the first product
+                    dy = ctx.zeros(A.n)
+                    dA.matvec(dx, dy)
+                    assert np.array_equal(dy.to_host(), y_ref), (kind, sell, tiles, pub)
+                    st, upl, total = dA.sell_info
+                    assert st == (1 if sell else 0) and dA.code_info[0] == 8
+                    dy2 = ctx.zeros(A.n)
+                    d = K.spmv_dot(dA, dx, dy2)
+                    d2 = K.spmv_dot2(dA, dx, dy2)
+                    assert np.array_equal(dy2.to_host(), y_ref)
+                    key = (tiles, pub)
+                    if sell == 0: ref[key] = (d, d2)
+                    else: assert (d, d2) == ref[key], (kind, sell, tiles, pub)     # the SAME partials: bit-identical reductions
+                    slices = (A.n + 63) // 64
+                    if sell:
+                        layouts.add(upl > 0)
+                        assert total == (upl * slices if upl else total) and total >= slices
+                        want = 512 * total + (0 if upl else 4 * (slices + 1)) + 16 * A.n
+                    else:
+                        want = 9 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+                    assert dA.spmv_bytes_stored == want and dA.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+        # an operator the sliced form does not take (two-byte codes): the coded CSR stream, silently
+        ctx.set_option("spmv_sell", 2); ctx.set_option("spmv_codes", 16); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
+        dB = K.CsrMatrix.stencil(ctx, kind, n1)
+        dy = ctx.zeros(A.n); dB.matvec(dx, dy)
+        assert np.array_equal(dy.to_host(), y_ref) and dB.sell_info[0] == 0 and dB.code_info[0] == 16
     finally:
         for k, v in saved.items():
             ctx.set_option(k, v)
