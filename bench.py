@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PARITY_ITERS = 100          # iterations of the oracle history (tests/golden/oracle_cfg2_cg512.json)
-PMC_PROFILE = "r06_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
+PMC_PROFILE = "r06s_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
 
 
@@ -715,12 +715,18 @@ def main():
         avg_spmv_ms = spmv_ms / max(args.steps, 1)                    # all SpMV launches of one iteration
         spmv_gbps = spmv_bytes_local / (avg_spmv_ms * 1e-3) / 1e9 if avg_spmv_ms > 0 else 0.0
         moved_gbps = spmv_bytes_moved / (avg_spmv_ms * 1e-3) / 1e9 if avg_spmv_ms > 0 else 0.0
-        kern = "spmv_template_kernel" if templates else ("spmv_code_kernel" if code_bits != 32 else "spmv_stage_kernel")
+        sliced = code_bits == 8 and A.sell_info[0] == 1 and ctx.get_option("spmv_sell") != 0     # the sliced form of the coded operator is in use
+        kern = "spmv_template_kernel" if templates else ("spmv_sell_kernel" if sliced else ("spmv_code_kernel" if code_bits != 32 else "spmv_stage_kernel"))
         pmc_key = {8: "spmv_code_kernel<unsigned char, true, true", 16: "spmv_code_kernel<unsigned short, true, true",
                    32: "spmv_stage_kernel<256, false, true, true"}[code_bits]
+        if sliced:
+            pmc_key = "spmv_sell_kernel<true, true"
         traffic, traffic_note = pmc_traffic(n1, pmc_key) if (world == 1 and not templates) else (None, "single-GPU CSR runs only")
         col_note = ("int32 columns" if code_bits == 32 else
                     f"{code_bits}-bit diagonal codes ({code_diags} distinct column - row offsets, csrc/colcode.hip)")
+        if sliced:
+            col_note += ("; values and codes read from the sliced copy of the operator (every 64 rows transposed: per row one word of eight codes + "
+                         "its values, 64 B per 7-entry row; khip_csr_sell_info " + str(list(A.sell_info)) + ")")
         out = {
             "metric": "cg_iters_per_sec_poisson3d_csr_512cubed",
             "value": its, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
