@@ -683,7 +683,10 @@ def main():
             avg32 = ms32 / max(it32, 1)
             int32_leg = {"NOT_THE_HEADLINE": "same operator, same fused cg! iteration, ctx option spmv_codes = 0: the staged SpMV reads the "
                                              "int32 column stream (12 B per entry) -- the general-CSR kernel, for the '>= 70 % on CSR SpMV' target",
-                         "bound": "hbm", "kernel": f"SpMV kernel {A.spmv_kernel_choice} (4 = spmv_stage_kernel) fused with p.Ap, int32 columns",
+                         "bound": "hbm", "kernel": (f"SpMV kernel {A.spmv_kernel_choice} (4 = the staged family: " +
+                                                    ("spmv_sell_kernel on the sliced copy with int32 columns, khip_csr_sell32_info " + str(list(A.sell32_info))
+                                                     if A.sell32_info[0] == 1 and ctx.get_option("spmv_sell") else "spmv_stage_kernel") +
+                                                    ") fused with p.Ap, int32 columns"),
                          "achieved": A.spmv_bytes / (avg32 * 1e-3) / 1e9 if avg32 > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (A.spmv_bytes / (avg32 * 1e-3) / 1e9 / HBM_PEAK_GBPS) if avg32 > 0 else 0.0,
                          "bytes_per_launch": A.spmv_bytes, "avg_ms": avg32, "launches_per_iteration": l32 / max(it32, 1),

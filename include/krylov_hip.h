@@ -119,6 +119,12 @@ int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
  * that many units (no offset array), 0: per-slice offsets; *total_units: units stored.  y and the fused dots are bit-identical to
  * the coded CSR kernel's.  khip_spmv_bytes_stored counts 512 B per unit (+ 4 B per slice of offsets) while the form is in use. */
 int khip_csr_sell_info(const khip_csr *A, int *state, int *units_per_slice, int64_t *total_units);
+/* The same for the int32 column stream -- operators that are not coded (more than 2048 diagonals, fewer than 4 M entries under
+ * "spmv_codes" = 1, or "spmv_codes" = 0) with short rows (the staged kernel's operators: at most 12 entries per row on average):
+ * per slice, per lane, ceil(L / 2) words of two int32 columns (-1 = no entry) then L values; same padding rule, same size rule as
+ * the codes (at least 4 M entries unless "spmv_codes" = 2 or "spmv_sell" >= 3), same option.  y and the fused dots are
+ * bit-identical to the staged CSR kernel's. */
+int khip_csr_sell32_info(const khip_csr *A, int *state, int *units_per_slice, int64_t *total_units);
 /* Block-delta column stream of the stream SpMV (operators that are not stencils: more than 2048 diagonals; built at the first
  * product that can use it, ctx option "spmv_delta"): bits = 8 / 16 (32: not in use), rows = rows per block, escapes = entries
  * that stay int32 (6 B each).  khip_spmv_bytes_stored counts what that kernel streams. */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "khip_spmv_bytes": (_int, [_vp, C.POINTER(_i64)]),
     "khip_csr_code_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "khip_csr_sell_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "khip_csr_sell32_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "khip_spmv_kernel_info": (_int, [_vp, _vp, C.POINTER(C.c_int)]),
     "khip_csr_delta_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "khip_csr_tile_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
@@ -708,6 +709,13 @@ class CsrMatrix:
         csr_build_sell): state 1 = built and read by spmv_sell_kernel, 0 = not tried, -1 = not usable."""
         st, u, t = C.c_int(), C.c_int(), C.c_int64()
         _ck(lib().khip_csr_sell_info(self._h, C.byref(st), C.byref(u), C.byref(t)))
+        return st.value, u.value, t.value
+
+    @property
+    def sell32_info(self):
+        """(state, units_per_slice, total_units) of the sliced form with int32 columns (khip_csr_sell32_info)."""
+        st, u, t = C.c_int(), C.c_int(), C.c_int64()
+        _ck(lib().khip_csr_sell32_info(self._h, C.byref(st), C.byref(u), C.byref(t)))
         return st.value, u.value, t.value
 
     @property

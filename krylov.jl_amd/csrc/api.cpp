@@ -383,6 +383,14 @@ int khip_csr_sell_info(const khip_csr *A, int *state, int *units_per_slice, int6
   return KHIP_OK;
 }
 
+int khip_csr_sell32_info(const khip_csr *A, int *state, int *units_per_slice, int64_t *total_units) {
+  KHIP_REQUIRE(A, "csr_sell32_info: null handle");
+  if (state) *state = A->sell32_state;
+  if (units_per_slice) *units_per_slice = A->sell32_state == 1 ? A->sell32_units : 0;
+  if (total_units) *total_units = A->sell32_state == 1 ? A->sell32_total_units : 0;
+  return KHIP_OK;
+}
+
 int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals) {
   KHIP_REQUIRE(A, "csr_code_info: null handle");
   if (bits) *bits = A->code_state == 1 ? A->code_bits : 32;
@@ -498,10 +506,15 @@ int khip_spmv_dot2(khip_ctx *ctx, const khip_csr *A, const double *x, double *y,
 int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes) {
   KHIP_REQUIRE(A && bytes, "spmv_bytes_stored: null argument");
   const int64_t ncols_read = A->dist ? A->m + A->n_ghost : A->n;
+  const int sell_opt = A->ctx ? A->ctx->tune.spmv_sell : 0, codes_opt = A->ctx ? A->ctx->tune.spmv_codes : 1;
+  const bool coded = A->code_state == 1 && codes_opt != 0;               // what launch_spmv reads under the context's CURRENT options
+  const int64_t slices = (A->m + 63) / 64;
   if (A->tmpl_id) *bytes = 2 * A->m + 8 * ncols_read + 8 * A->m;        // template id + x + y
-  else if (A->code_state == 1 && A->sell_state == 1 && A->ctx && A->ctx->tune.spmv_sell)   // sliced form: 512 B per unit (+ 4 B per slice of offsets)
-    *bytes = 512 * A->sell_total_units + (A->sell_off ? 4 * ((A->m + 63) / 64 + 1) : 0) + 8 * ncols_read + 8 * A->m;
-  else if (A->code_state == 1)                                          // coded columns (colcode.hip): 1 or 2 B per entry
+  else if (coded && A->sell_state == 1 && sell_opt)                     // sliced form of the coded operator: 512 B per unit (+ 4 B per slice of offsets)
+    *bytes = 512 * A->sell_total_units + (A->sell_off ? 4 * (slices + 1) : 0) + 8 * ncols_read + 8 * A->m;
+  else if (!coded && A->sell32_state == 1 && sell_opt)                  // sliced form with int32 columns
+    *bytes = 512 * A->sell32_total_units + (A->sell32_off ? 4 * (slices + 1) : 0) + 8 * ncols_read + 8 * A->m;
+  else if (coded)                                                       // coded columns (colcode.hip): 1 or 2 B per entry
     *bytes = (8 + A->code_bits / 8) * A->nnz + 4 * (A->m + 1) + 8 * ncols_read + 8 * A->m;
   else if (A->delta_state == 1)                                         // block-delta columns (coldelta.hip): codes + 6 B per escape + 8 B per block
     *bytes = (8 + A->delta_bits / 8) * A->nnz + 6 * A->delta_esc + 8 * ((A->m + A->delta_rows - 1) / A->delta_rows) +

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void code_assign_kernel(const int32_t *rowp
 constexpr double kSellMaxPad = 1.12;       // slots / entries above which the sliced copy is not built
 constexpr double kSellUniformPad = 1.02;   // ... and below which every slice is padded to the longest one (no offset array)
 
-__global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowptr, int64_t m, int64_t slices, int32_t *units) {
+__global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowptr, int64_t m, int64_t slices, int32_t *units, int cols32) {
   const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (s >= slices) return;
   int L = 0;
@@ -96,10 +96,13 @@ __global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowpt
     L = (nxt - prev > L) ? nxt - prev : L;
     prev = nxt;
   }
-  units[s] = L > 0 ? L + (L + 7) / 8 : 0;
+  units[s] = L > 0 ? L + (cols32 ? (L + 1) / 2 : (L + 7) / 8) : 0;
 }
 
-__global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr, const double *val, const uint8_t *code, int64_t m,
+// words per row ahead of the values for T units of a slice: code words (T = L + ceil(L / 8)) or column words (T = L + ceil(L / 2))
+__host__ __device__ __forceinline__ int sell_head_words(int T, int cols32) { return cols32 ? (T + 2) / 3 : (T + 8) / 9; }
+
+__global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr, const double *val, const uint8_t *code, const int32_t *col, int64_t m,
                                                            int64_t slices, const uint32_t *off, int uniform_units,
                                                            unsigned long long *sell) {
   const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // rows of the last slice beyond m are written too (no entry)
@@ -109,16 +112,23 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr
   const int64_t o0 = uniform_units ? s * uniform_units : (int64_t)off[s];
   const int T = uniform_units ? uniform_units : (int)(off[s + 1] - off[s]);
   if (T == 0) return;
-  const int W = (T + 8) / 9, L = T - W;
+  const int cols32 = col != nullptr;
+  const int W = sell_head_words(T, cols32), L = T - W;
   const int32_t q0 = row < m ? rowptr[row] : 0;
   const int len = row < m ? rowptr[row + 1] - q0 : 0;
   unsigned long long *base = sell + (size_t)o0 * 64 + lane;
   for (int w = 0; w < W; ++w) {
     unsigned long long word = 0;
-    for (int u = 0; u < 8; ++u) {
-      const int k = 8 * w + u;
-      const unsigned long long c = k < len ? (unsigned long long)code[q0 + k] : 0xFFull;
-      word |= c << (8 * u);
+    if (cols32) {
+      const unsigned long long c0 = 2 * w < len ? (unsigned long long)(uint32_t)col[q0 + 2 * w] : 0xFFFFFFFFull;
+      const unsigned long long c1 = 2 * w + 1 < len ? (unsigned long long)(uint32_t)col[q0 + 2 * w + 1] : 0xFFFFFFFFull;
+      word = c0 | (c1 << 32);
+    } else {
+      for (int u = 0; u < 8; ++u) {
+        const int k = 8 * w + u;
+        const unsigned long long c = k < len ? (unsigned long long)code[q0 + k] : 0xFFull;
+        word |= c << (8 * u);
+      }
     }
     base[(size_t)w * 64] = word;
   }
@@ -131,53 +141,69 @@ void csr_free_sell(khip_csr *A) {
   A->sell_units = 0; A->sell_total_units = 0; A->sell_state = 0;
 }
 
-int csr_build_sell(khip_ctx *ctx, khip_csr *A) {
-  csr_free_sell(A);
-  A->sell_state = -1;
+void csr_free_sell32(khip_csr *A) {
+  (void)hipFree(A->sell32); (void)hipFree(A->sell32_off);
+  A->sell32 = nullptr; A->sell32_off = nullptr;
+  A->sell32_units = 0; A->sell32_total_units = 0; A->sell32_state = 0;
+}
+
+// cols32 = false: code words (needs the 8-bit codes); true: int32 column words
+static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
+  if (cols32) csr_free_sell32(A); else csr_free_sell(A);
+  int &state = cols32 ? A->sell32_state : A->sell_state;
+  unsigned long long *&words = cols32 ? A->sell32 : A->sell;
+  uint32_t *&offs = cols32 ? A->sell32_off : A->sell_off;
+  state = -1;
   const int64_t m = A->m;
-  if (A->code_state != 1 || A->code_bits != 8 || A->code_T > 255 || m == 0 || A->nnz == 0 || A->max_row_nnz > 64) return KHIP_OK;
+  if (m == 0 || A->nnz == 0 || A->max_row_nnz > 64) return KHIP_OK;
+  if (!cols32 && (A->code_state != 1 || A->code_bits != 8 || A->code_T > 255)) return KHIP_OK;
   const int64_t slices = (m + 63) / 64;
   int32_t *units_d = nullptr;
   KHIP_CHECK_HIP(hipMalloc(&units_d, sizeof(int32_t) * (size_t)slices));
   struct Scratch { int32_t *&p; ~Scratch() { (void)hipFree(p); } } scratch{units_d};
-  hipLaunchKernelGGL(sell_units_kernel, dim3((unsigned)((slices + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, m, slices, units_d);
+  hipLaunchKernelGGL(sell_units_kernel, dim3((unsigned)((slices + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, m, slices, units_d, cols32 ? 1 : 0);
   KHIP_CHECK_HIP(hipGetLastError());
   std::vector<int32_t> units((size_t)slices);
   KHIP_CHECK_HIP(hipMemcpyAsync(units.data(), units_d, sizeof(int32_t) * (size_t)slices, hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   int64_t total = 0, slots = 0;
   int umax = 0;
-  for (int32_t u : units) { total += u; const int W = (u + 8) / 9; slots += (int64_t)(u - W) * 64; umax = u > umax ? u : umax; }
+  for (int32_t u : units) { total += u; const int W = sell_head_words(u, cols32); slots += (int64_t)(u - W) * 64; umax = u > umax ? u : umax; }
   if (slots > (int64_t)(kSellMaxPad * (double)A->nnz) + 4096) return KHIP_OK;          // too much padding: stays on the CSR stream
-  const int Wmax = (umax + 8) / 9;
+  const int Wmax = sell_head_words(umax, cols32);
   const bool uniform = (int64_t)(umax - Wmax) * 64 * slices <= (int64_t)(kSellUniformPad * (double)A->nnz) + 4096;
   if (uniform) total = (int64_t)umax * slices;
   if (total >= ((int64_t)1 << 32)) return KHIP_OK;
   bool keep = false;
-  struct Guard { khip_csr *A; bool &keep; ~Guard() { if (!keep) { csr_free_sell(A); A->sell_state = -1; } } } guard{A, keep};
+  struct Guard { khip_csr *A; bool cols32; int &state; bool &keep;
+                 ~Guard() { if (!keep) { if (cols32) csr_free_sell32(A); else csr_free_sell(A); state = -1; } } } guard{A, cols32, state, keep};
   if (!uniform) {
     std::vector<uint32_t> off((size_t)slices + 1);
     uint32_t run = 0;
     for (int64_t s = 0; s < slices; ++s) { off[(size_t)s] = run; run += (uint32_t)units[(size_t)s]; }
     off[(size_t)slices] = run;
-    KHIP_CHECK_HIP(hipMalloc(&A->sell_off, sizeof(uint32_t) * ((size_t)slices + 1)));
-    KHIP_CHECK_HIP(hipMemcpyAsync(A->sell_off, off.data(), sizeof(uint32_t) * ((size_t)slices + 1), hipMemcpyHostToDevice, ctx->stream));
+    KHIP_CHECK_HIP(hipMalloc(&offs, sizeof(uint32_t) * ((size_t)slices + 1)));
+    KHIP_CHECK_HIP(hipMemcpyAsync(offs, off.data(), sizeof(uint32_t) * ((size_t)slices + 1), hipMemcpyHostToDevice, ctx->stream));
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));                                  // `off` dies with this scope
   }
-  KHIP_CHECK_HIP(hipMalloc(&A->sell, sizeof(unsigned long long) * 64 * (size_t)(total + 1)));
+  KHIP_CHECK_HIP(hipMalloc(&words, sizeof(unsigned long long) * 64 * (size_t)(total + 1)));
   hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((slices * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->val,
-                     (const uint8_t *)A->code, m, slices, A->sell_off, uniform ? umax : 0, A->sell);
+                     (const uint8_t *)A->code, cols32 ? A->col : (const int32_t *)nullptr, m, slices, offs, uniform ? umax : 0, words);
   KHIP_CHECK_HIP(hipGetLastError());
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   keep = true;
-  A->sell_units = uniform ? umax : 0;
-  A->sell_total_units = total;
-  A->sell_state = 1;
+  (cols32 ? A->sell32_units : A->sell_units) = uniform ? umax : 0;
+  (cols32 ? A->sell32_total_units : A->sell_total_units) = total;
+  state = 1;
   return KHIP_OK;
 }
 
+int csr_build_sell(khip_ctx *ctx, khip_csr *A) { return build_sell_form(ctx, A, false); }
+int csr_build_sell32(khip_ctx *ctx, khip_csr *A) { return build_sell_form(ctx, A, true); }
+
 void csr_free_codes(khip_csr *A) {
   csr_free_sell(A);                          // the sliced form carries the codes
+  csr_free_sell32(A);                        // ... and its int32 twin the columns (called wherever the columns change, and by destroy)
   (void)hipFree(A->code); (void)hipFree(A->code_tab);
   A->code = nullptr; A->code_tab = nullptr;
   A->code_T = 0; A->code_bits = 0; A->code_state = 0;

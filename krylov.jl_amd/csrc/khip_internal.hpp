@@ -256,6 +256,13 @@ struct khip_csr {
   uint32_t *sell_off = nullptr;        // [slices + 1] first unit of every slice (null: every slice has sell_units units)
   int sell_units = 0;                  // uniform slices: W + L of every slice (0: per-slice offsets)
   int64_t sell_total_units = 0;
+  // ... and the same for the int32 column stream (operators that are not coded, or spmv_codes = 0): W = ceil(L / 2) words of two
+  // int32 columns per row (-1 = no entry), then L values
+  int sell32_state = 0;
+  unsigned long long *sell32 = nullptr;
+  uint32_t *sell32_off = nullptr;
+  int sell32_units = 0;
+  int64_t sell32_total_units = 0;
   // optional block-delta column stream of the stream SpMV (coldelta.hip, built on the first product that can use it)
   int delta_state = 0;                 // 0 = not tried, 1 = built, -1 = tried, not usable / not worth it
   int delta_bits = 0;                  // 8 or 16
@@ -358,6 +365,8 @@ void csr_free_codes(khip_csr *A);                  // colcode.hip
 int csr_build_codes(khip_ctx *ctx, khip_csr *A);   // colcode.hip: sets A->code_state to 1 or -1
 void csr_free_sell(khip_csr *A);                   // colcode.hip
 int csr_build_sell(khip_ctx *ctx, khip_csr *A);    // colcode.hip: sets A->sell_state to 1 or -1 (needs 8-bit codes)
+void csr_free_sell32(khip_csr *A);                 // colcode.hip
+int csr_build_sell32(khip_ctx *ctx, khip_csr *A);  // colcode.hip: the sliced form with int32 columns; sets A->sell32_state to 1 or -1
 int panel_multi_nn(khip_ctx *ctx, int64_t n, int p, int k, const double *const *V_host, const double *Y_host, double beta,
                    double *X);   // panel.hip
 int panel_tsqr_r(khip_ctx *ctx, int64_t n, int p, const double *Q, double *R_host_rowmajor);   // panel.hip: R factor by TSQR

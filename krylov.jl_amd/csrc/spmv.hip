@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
 // of a slice is 512 contiguous bytes).  No LDS window, no barrier and no row pointer in the row walk: the only dependent hop is
 // code word -> table lookup (LDS) -> x gather.  Products in stored order, one rounded multiply and one rounded add per entry:
 // y is bit-identical to every other kernel.
-template <bool DOT, bool COMP, bool DIST, bool NTM>
+template <bool DOT, bool COMP, bool DIST, bool NTM, bool COLS32>
 __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs ra) {
   if (seq_skip(a.stop_seq, a.seq)) return;
   const int ROWS = a.stage_rows;
@@ -483,8 +483,10 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs r
   dd dacc[2];
   dacc[0] = dd{0.0, 0.0};
   dacc[1] = dd{0.0, 0.0};
-  for (int i = tid; i < 256; i += kBlock) s_tab[i] = i < a.code_T ? a.code_tab[i] : 0;
-  __syncthreads();
+  if (!COLS32) {
+    for (int i = tid; i < 256; i += kBlock) s_tab[i] = i < a.code_T ? a.code_tab[i] : 0;
+    __syncthreads();
+  }
   for (int64_t rb = rb_begin; rb < rb_end; ++rb) {
     int64_t r0 = a.row_lo + rb * ROWS;
     if (r0 >= a.hole_lo) r0 += a.hole_len;   // the second range of a two-range launch
@@ -497,28 +499,40 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs r
       int T;
       if (a.sell_units) { o0 = sl * a.sell_units; T = a.sell_units; }
       else { const uint32_t b0 = a.sell_off[sl], b1 = a.sell_off[sl + 1]; o0 = (int64_t)b0; T = (int)(b1 - b0); }
-      const int W = (T + 8) / 9, L = T - W;
+      const int W = COLS32 ? (T + 2) / 3 : (T + 8) / 9, L = T - W;
       const unsigned long long *base = a.sell + (size_t)o0 * 64 + (rowl & 63);
       double acc = 0.0, wv = 0.0;
       if (DOT) wv = a.dotw[rowl];                 // in flight beside the row's entries (2.06 -> 1.97 ms fused at 512^3, profiles/r06ap/aq)
-      for (int w = 0; w < W; ++w) {
-        const unsigned long long cw = ld<NTM>(base + (size_t)w * 64);
-        const unsigned long long *vb = base + (size_t)(W + 8 * w) * 64;
-        const int left = L - 8 * w;            // >= 1
+      for (int k0 = 0; k0 < L; k0 += 8) {      // eight entries per step: one code word, or four words of two int32 columns
+        const unsigned long long *vb = base + (size_t)(W + k0) * 64;
+        const int left = L - k0;               // >= 1
         double vv[8], xx[8];
         int32_t cc[8];
+        bool on[8];
+        if (COLS32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned long long cw = (2 * j < left) ? ld<NTM>(base + (size_t)(k0 / 2 + j) * 64) : ~0ull;
+            cc[2 * j] = (int32_t)(uint32_t)(cw & 0xFFFFFFFFull);
+            cc[2 * j + 1] = (int32_t)(uint32_t)(cw >> 32);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) on[u] = cc[u] != -1;
+        } else {
+          const unsigned long long cw = ld<NTM>(base + (size_t)(k0 / 8) * 64);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int c = (int)((cw >> (8 * u)) & 0xFFull); on[u] = c != 0xFF; cc[u] = row + s_tab[c]; }
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) vv[u] = (u < left) ? __longlong_as_double((long long)ld<NTM>(vb + (size_t)u * 64)) : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cc[u] = (int32_t)((cw >> (8 * u)) & 0xFFull);
-#pragma unroll
         for (int u = 0; u < 8; ++u) {
           xx[u] = 0.0;
-          if (cc[u] != 0xFF) xx[u] = gather_x<DIST>(a, row + s_tab[cc[u]]);
+          if (on[u]) xx[u] = gather_x<DIST>(a, cc[u]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          if (cc[u] != 0xFF) {
+          if (on[u]) {
             const double prod = vv[u] * xx[u];
             acc = acc + prod;
           }
@@ -1202,8 +1216,11 @@ static void launch_sell_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra,
   const size_t pub = dot && a.blk_pub ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;
   const size_t lds = pub + 4u * 256u;
 #define KHIP_L(DOT, COMP, DIST) \
-  do { if (ctx->tune.spmv_sell == 2) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
-       else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } while (0)
+  do { const bool ntm = ctx->tune.spmv_sell == 2; \
+       if (a.sell_cols) { if (ntm) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, true, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
+                          else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, false, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } \
+       else { if (ntm) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, true, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
+              else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, false, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } } while (0)
   KHIP_DISPATCH_DCD(KHIP_L);
 #undef KHIP_L
 }
@@ -1360,7 +1377,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256; a.max_row = 0;
-  a.sell = nullptr; a.sell_off = nullptr; a.sell_units = 0;
+  a.sell = nullptr; a.sell_off = nullptr; a.sell_units = 0; a.sell_cols = 0;
   a.blk_pub = ctx->tune.spmv_blk_pub;
   a.stream_nt = ctx->tune.spmv_stream_nt;
   a.dcode = nullptr; a.dbase = nullptr; a.desc_ptr = nullptr; a.desc_pos = nullptr; a.desc_col = nullptr;
@@ -1487,6 +1504,12 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     // sliced form of the coded operator (csr_build_sell): built once per handle, at the first product that gets here with spmv_sell on
     if (coded && ctx->tune.spmv_sell && Am->code_bits == 8 && Am->sell_state == 0 && ctx->tune.spmv_pipe <= 0) optional_build(csr_build_sell(ctx, Am));
     const bool sliced = coded && ctx->tune.spmv_sell && Am->sell_state == 1 && ctx->tune.spmv_pipe <= 0;
+    // ... and of the int32 column stream, for operators that are not coded (or with spmv_codes = 0); the same size rule as the codes:
+    // below 4 M entries an iteration is latency bound and the handle keeps one copy of its entries
+    const bool try32 = !coded && ctx->tune.spmv_sell && !nt && !a.fake_gather && ctx->tune.spmv_pipe <= 0 && rows == 256 &&
+                       (ctx->tune.spmv_codes == 2 || ctx->tune.spmv_sell >= 3 || A->nnz >= ((int64_t)1 << 22));
+    if (try32 && Am->sell32_state == 0) optional_build(csr_build_sell32(ctx, Am));
+    const bool sliced32 = try32 && Am->sell32_state == 1;
     // software-pipelined form: needs one window per row block
     const bool pipe = ctx->tune.spmv_pipe > 0 && !nt && !a.fake_gather && A->nnz > 0 && A->max_row_nnz >= 1 &&
                       (int64_t)rows * A->max_row_nnz + 3 <= 2048 && ctx->tune.spmv_cap == 0;
@@ -1501,7 +1524,11 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       else launch_pipe_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (coded && sliced) {
-      a.sell = Am->sell; a.sell_off = Am->sell_off; a.sell_units = Am->sell_units;
+      a.sell = Am->sell; a.sell_off = Am->sell_off; a.sell_units = Am->sell_units; a.sell_cols = 0;
+      launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
+      rows = 0;      // launched
+    } else if (sliced32) {
+      a.sell = Am->sell32; a.sell_off = Am->sell32_off; a.sell_units = Am->sell32_units; a.sell_cols = 1;
       launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (coded) {

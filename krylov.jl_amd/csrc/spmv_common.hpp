@@ -52,6 +52,7 @@ struct SpmvArgs {
   const unsigned long long *sell;
   const uint32_t *sell_off;  // first unit (64 words) of every slice; null: sell_units units per slice
   int sell_units;
+  int sell_cols;             // 0: code words (eight 1-byte codes), 1: column words (two int32 columns)
   // block-delta column stream (coldelta.hip): col = dbase[block] + dcode[k]; all-ones code = escape
   const void *dcode;         // uint8_t[nnz + pad] or uint16_t[nnz + pad]
   const int32_t *dbase;      // base column of every row block

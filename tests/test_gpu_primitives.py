@@ -896,6 +896,24 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
                     else:
                         want = 9 * A.nnz + 4 * (A.n + 1) + 16 * A.n
                     assert dA.spmv_bytes_stored == want and dA.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+        # the int32 column stream (spmv_codes = 0): its sliced form (two columns per word) against the staged CSR kernel
+        ctx.set_option("spmv_codes", 0); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
+        ref32 = None
+        for sell in (0, 3, 1):                       # 3: whatever the size (the default takes operators of >= 4 M entries)
+            ctx.set_option("spmv_sell", sell)
+            dC = K.CsrMatrix.stencil(ctx, kind, n1)
+            dy = ctx.zeros(A.n); dC.matvec(dx, dy)
+            assert np.array_equal(dy.to_host(), y_ref), (kind, "int32", sell)
+            dd_ = (K.spmv_dot(dC, dx, dy), K.spmv_dot2(dC, dx, dy))
+            ref32 = dd_ if ref32 is None else ref32
+            assert dd_ == ref32 and dC.code_info == (32, 0) and dC.sell_info[0] == 0
+            taken = sell == 3 and int(np.diff(A.rowptr).max()) <= 8   # the staged kernel with 256-row blocks (256 x longest row <= 2048)
+            assert dC.sell32_info[0] == (1 if taken else 0), (kind, sell, dC.sell32_info)
+            if taken:
+                st, upl, total = dC.sell32_info
+                assert dC.spmv_bytes_stored == 512 * total + (0 if upl else 4 * ((A.n + 63) // 64 + 1)) + 16 * A.n
+            else:
+                assert dC.spmv_bytes_stored == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
         # an operator the sliced form does not take (two-byte codes): the coded CSR stream, silently
         ctx.set_option("spmv_sell", 2); ctx.set_option("spmv_codes", 16); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
         dB = K.CsrMatrix.stencil(ctx, kind, n1)
