@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PARITY_ITERS = 100          # iterations of the oracle history (tests/golden/oracle_cfg2_cg512.json)
-PMC_PROFILE = "r06s_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
+PMC_PROFILE = "r06t_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
 
 
@@ -723,7 +723,7 @@ def main():
         pmc_key = {8: "spmv_code_kernel<unsigned char, true, true", 16: "spmv_code_kernel<unsigned short, true, true",
                    32: "spmv_stage_kernel<256, false, true, true"}[code_bits]
         if sliced:
-            pmc_key = "spmv_sell_kernel<true, true"
+            pmc_key = "spmv_sell_kernel<true, true, false, " + ("true" if ctx.get_option("spmv_sell") == 2 else "false") + ", false>"   # DOT, COMP, DIST, non-temporal, int32 columns
         traffic, traffic_note = pmc_traffic(n1, pmc_key) if (world == 1 and not templates) else (None, "single-GPU CSR runs only")
         col_note = ("int32 columns" if code_bits == 32 else
                     f"{code_bits}-bit diagonal codes ({code_diags} distinct column - row offsets, csrc/colcode.hip)")
