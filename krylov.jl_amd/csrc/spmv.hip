@@ -1470,9 +1470,22 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     }
 #undef KHIP_ROWS
   } else if (kernel == 4) {
+    khip_csr *Am = const_cast<khip_csr *>(A);
+    // spmv_codes: 1 = coded stream for operators large enough to be bandwidth bound (>= 4 M entries: below that an iteration is
+    // latency bound and the table lookup costs ~5 %, profiles/r02_bench_sizes.jsonl), 2 = whenever the operator qualifies,
+    // 16 = two-byte codes, 0 = never
+    const bool try_codes = ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && !nt && !a.fake_gather;
+    // coded column stream (colcode.hip): built once per handle, at the first product that gets here
+    if (try_codes && Am->code_state == 0) optional_build(csr_build_codes(ctx, Am));
+    const bool coded = try_codes && Am->code_state == 1;
+    // sliced form of the coded operator (csr_build_sell): built once per handle, at the first product that gets here with spmv_sell on
+    if (coded && ctx->tune.spmv_sell && Am->code_bits == 8 && Am->sell_state == 0 && ctx->tune.spmv_pipe <= 0) optional_build(csr_build_sell(ctx, Am));
+    const bool sliced = coded && ctx->tune.spmv_sell && Am->sell_state == 1 && ctx->tune.spmv_pipe <= 0;
     int rows = ctx->tune.spmv_rows;
     if (rows != 256 && rows != 128 && rows != 64 && rows != 32) rows = 256;
-    while (rows > 32 && rows * A->mean_row_nnz > 2048.0) rows >>= 1;
+    // the LDS window of the staged / coded kernels holds a whole row block: fewer rows per block for longer rows (three quarters of the
+    // lanes idle in the row walk at 27 entries per row).  The sliced form has no window: one row per lane whatever the row length.
+    if (!sliced) while (rows > 32 && rows * A->mean_row_nnz > 2048.0) rows >>= 1;
     // row blocks per workgroup: with a fused dot, two -- the double-double tree at a workgroup's end is ~0.1 us of dependent
     // fp64 latency on a 2.5 us lifetime, and it is paid once per workgroup whatever it covered: 2.19 -> 2.10 ms fused at 512^3,
     // the plain product is unchanged and four blocks per workgroup cost more than they save (profiles/r04b_sweep_headline.log)
@@ -1490,20 +1503,9 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
     ra = make_red_args(ctx, dot ? dot_slot : 0); ra.wave_offset = *wave_cursor;
 #define KHIP_STG(R) do { if (nt) launch_stage_cfg<R, true>(ctx, a, ra, grid, dot, comp, dist); \
                          else launch_stage_cfg<R, false>(ctx, a, ra, grid, dot, comp, dist); } while (0)
-    khip_csr *Am = const_cast<khip_csr *>(A);
-    // spmv_codes: 1 = coded stream for operators large enough to be bandwidth bound (>= 4 M entries: below that an iteration is
-    // latency bound and the table lookup costs ~5 %, profiles/r02_bench_sizes.jsonl), 2 = whenever the operator qualifies,
-    // 16 = two-byte codes, 0 = never
-    const bool try_codes = ctx->tune.spmv_codes && (ctx->tune.spmv_codes != 1 || A->nnz >= ((int64_t)1 << 22)) && !nt && !a.fake_gather;
-    // coded column stream (colcode.hip): built once per handle, at the first product that gets here
-    if (try_codes && Am->code_state == 0) optional_build(csr_build_codes(ctx, Am));
-    const bool coded = try_codes && Am->code_state == 1;
     if (coded) { a.code = Am->code; a.code_tab = Am->code_tab; a.code_T = Am->code_T; }
     a.stage_rows = rows;
     a.max_row = (int)A->max_row_nnz;
-    // sliced form of the coded operator (csr_build_sell): built once per handle, at the first product that gets here with spmv_sell on
-    if (coded && ctx->tune.spmv_sell && Am->code_bits == 8 && Am->sell_state == 0 && ctx->tune.spmv_pipe <= 0) optional_build(csr_build_sell(ctx, Am));
-    const bool sliced = coded && ctx->tune.spmv_sell && Am->sell_state == 1 && ctx->tune.spmv_pipe <= 0;
     // ... and of the int32 column stream, for operators that are not coded (or with spmv_codes = 0); the same size rule as the codes:
     // below 4 M entries an iteration is latency bound and the handle keeps one copy of its entries
     const bool try32 = !coded && ctx->tune.spmv_sell && !nt && !a.fake_gather && ctx->tune.spmv_pipe <= 0 && rows == 256 &&

@@ -858,7 +858,9 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
     """The sliced form of a coded operator (csrc/colcode.hip csr_build_sell + spmv_sell_kernel: every 64 rows transposed, a lane
     loads its own row's codes and values with coalesced 8-byte loads; ctx option spmv_sell = 1 / 2, 2 the default): y equals the
     oracle's serial loop bit for bit, the fused dots equal the coded CSR kernel's bit for bit (same rows per lane, same partials),
-    for 1 / 2 / 3 row blocks per workgroup, uniform and per-slice-offset layouts, row counts that are no multiple of 64."""
+    for 1 / 2 / 3 row blocks per workgroup, uniform and per-slice-offset layouts, row counts that are no multiple of 64.  (Rows too long
+    for 256 of them in the coded kernel's LDS window -- the 27-point operator -- keep 256-row blocks in the sliced form, which has no
+    window: other partials there, the dots agree to rounding.)"""
     gen = {"poisson": oracle.poisson3d, "kron_unsymmetric": oracle.kron_unsymmetric, "stencil27": oracle.stencil27_unsym}[kind]
     A = gen(n1)
     rng = np.random.default_rng(78)
@@ -870,6 +872,7 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
         ctx.set_option("spmv_kernel", 4); ctx.set_option("spmv_codes", 2)
         ref = {}
         layouts = set()
+        same_blocks = 256.0 * A.nnz / A.n <= 2048.0          # both forms walk 256-row blocks (spmv.hip launch_spmv)
         for sell in (0, 1, 2):
             for tiles in (1, 2, 3):
                 for pub in (1, 0):
@@ -887,7 +890,10 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
                     assert np.array_equal(dy2.to_host(), y_ref)
                     key = (tiles, pub)
                     if sell == 0: ref[key] = (d, d2)
-                    else: assert (d, d2) == ref[key], (kind, sell, tiles, pub)     # the SAME partials: bit-identical reductions
+                    elif same_blocks: assert (d, d2) == ref[key], (kind, sell, tiles, pub)     # the SAME partials: bit-identical reductions
+                    else:             # longer rows: the coded kernel's LDS window takes 64-row blocks, the sliced form 256 -- other partials
+                        for got, want in zip((d, d2[0], d2[1]), (ref[key][0],) + tuple(ref[key][1])):
+                            assert abs(got - want) <= 4 * EPS * abs(want)
                     slices = (A.n + 63) // 64
                     if sell:
                         layouts.add(upl > 0)
