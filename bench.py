@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PARITY_ITERS = 100          # iterations of the oracle history (tests/golden/oracle_cfg2_cg512.json)
-PMC_PROFILE = "r06t_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
+PMC_PROFILE = "r06end_spmv_pmc.json"   # rocprofv3 counter passes of this round's kernels (tools/gpu_prof.sh)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
 
 
