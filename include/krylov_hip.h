@@ -119,6 +119,10 @@ int khip_csr_code_info(const khip_csr *A, int *bits, int *diagonals);
  * that many units (no offset array), 0: per-slice offsets; *total_units: units stored.  y and the fused dots are bit-identical to
  * the coded CSR kernel's.  khip_spmv_bytes_stored counts 512 B per unit (+ 4 B per slice of offsets) while the form is in use. */
 int khip_csr_sell_info(const khip_csr *A, int *state, int *units_per_slice, int64_t *total_units);
+/* *narrow = 1 when the sliced form keeps 4-bit codes: operators with at most 15 diagonals and at most 8 entries per row store ONE
+ * 32-bit word of eight codes per row (indexed by the row) and the slices hold values only -- 60 instead of 64 B per 7-point row
+ * (ctx option "spmv_sell_narrow" = 1; default 0: it measured 8-10 % slower than the byte-coded words at 512^3, whose slices are 4 KB blocks). */
+int khip_csr_sell_narrow(const khip_csr *A, int *narrow);
 /* The same for the int32 column stream -- operators that are not coded (more than 2048 diagonals, fewer than 4 M entries under
  * "spmv_codes" = 1, or "spmv_codes" = 0) with short rows (the staged kernel's operators: at most 12 entries per row on average):
  * per slice, per lane, ceil(L / 2) words of two int32 columns (-1 = no entry) then L values; same padding rule, same size rule as

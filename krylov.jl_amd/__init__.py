@@ -94,6 +94,7 @@ SIGNATURES = {
     "khip_csr_code_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "khip_csr_sell_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "khip_csr_sell32_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "khip_csr_sell_narrow": (_int, [_vp, C.POINTER(C.c_int)]),
     "khip_spmv_kernel_info": (_int, [_vp, _vp, C.POINTER(C.c_int)]),
     "khip_csr_delta_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_i64)]),
     "khip_csr_tile_info": (_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64),
@@ -710,6 +711,13 @@ class CsrMatrix:
         st, u, t = C.c_int(), C.c_int(), C.c_int64()
         _ck(lib().khip_csr_sell_info(self._h, C.byref(st), C.byref(u), C.byref(t)))
         return st.value, u.value, t.value
+
+    @property
+    def sell_narrow(self) -> bool:
+        """True when the sliced form keeps eight 4-bit codes per row in one 32-bit word (khip_csr_sell_narrow)."""
+        v = C.c_int()
+        _ck(lib().khip_csr_sell_narrow(self._h, C.byref(v)))
+        return bool(v.value)
 
     @property
     def sell32_info(self):

@@ -161,7 +161,7 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
       {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}, {"comm_priority", &t.comm_priority}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_delta", &t.spmv_delta}, {"spmv_blk_pub", &t.spmv_blk_pub}, {"spmv_stream_nt", &t.spmv_stream_nt}, {"spmv_sell", &t.spmv_sell}, {"cg_setup_fused", &t.cg_setup_fused}, {"spmv_wide", &t.spmv_wide}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_slide", &t.spmm_tile_slide}, {"spmm_tile_ahead", &t.spmm_tile_ahead}, {"spmm_tile_xcd", &t.spmm_tile_xcd}, {"spmm_tile_dbuf", &t.spmm_tile_dbuf}, {"spmm_tile_pair", &t.spmm_tile_pair}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
+      {"profile_spmv", &t.profile_spmv}, {"comm_priority", &t.comm_priority}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_delta", &t.spmv_delta}, {"spmv_blk_pub", &t.spmv_blk_pub}, {"spmv_stream_nt", &t.spmv_stream_nt}, {"spmv_sell", &t.spmv_sell}, {"spmv_sell_narrow", &t.spmv_sell_narrow}, {"cg_setup_fused", &t.cg_setup_fused}, {"spmv_wide", &t.spmv_wide}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_slide", &t.spmm_tile_slide}, {"spmm_tile_ahead", &t.spmm_tile_ahead}, {"spmm_tile_xcd", &t.spmm_tile_xcd}, {"spmm_tile_dbuf", &t.spmm_tile_dbuf}, {"spmm_tile_pair", &t.spmm_tile_pair}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;
@@ -383,6 +383,12 @@ int khip_csr_sell_info(const khip_csr *A, int *state, int *units_per_slice, int6
   return KHIP_OK;
 }
 
+int khip_csr_sell_narrow(const khip_csr *A, int *narrow) {
+  KHIP_REQUIRE(A && narrow, "csr_sell_narrow: null argument");
+  *narrow = (A->sell_state == 1 && A->sell_c4) ? 1 : 0;
+  return KHIP_OK;
+}
+
 int khip_csr_sell32_info(const khip_csr *A, int *state, int *units_per_slice, int64_t *total_units) {
   KHIP_REQUIRE(A, "csr_sell32_info: null handle");
   if (state) *state = A->sell32_state;
@@ -510,8 +516,8 @@ int khip_spmv_bytes_stored(const khip_csr *A, int64_t *bytes) {
   const bool coded = A->code_state == 1 && codes_opt != 0;               // what launch_spmv reads under the context's CURRENT options
   const int64_t slices = (A->m + 63) / 64;
   if (A->tmpl_id) *bytes = 2 * A->m + 8 * ncols_read + 8 * A->m;        // template id + x + y
-  else if (coded && A->sell_state == 1 && sell_opt)                     // sliced form of the coded operator: 512 B per unit (+ 4 B per slice of offsets)
-    *bytes = 512 * A->sell_total_units + (A->sell_off ? 4 * (slices + 1) : 0) + 8 * ncols_read + 8 * A->m;
+  else if (coded && A->sell_state == 1 && sell_opt)                     // sliced form of the coded operator: 512 B per unit (+ 4 B per slice of offsets, + 4 B per row of narrow codes)
+    *bytes = 512 * A->sell_total_units + (A->sell_off ? 4 * (slices + 1) : 0) + (A->sell_c4 ? 4 * 64 * slices : 0) + 8 * ncols_read + 8 * A->m;
   else if (!coded && A->sell32_state == 1 && sell_opt)                  // sliced form with int32 columns
     *bytes = 512 * A->sell32_total_units + (A->sell32_off ? 4 * (slices + 1) : 0) + 8 * ncols_read + 8 * A->m;
   else if (coded)                                                       // coded columns (colcode.hip): 1 or 2 B per entry

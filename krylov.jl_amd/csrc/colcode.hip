@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void code_assign_kernel(const int32_t *rowp
 constexpr double kSellMaxPad = 1.12;       // slots / entries above which the sliced copy is not built
 constexpr double kSellUniformPad = 1.02;   // ... and below which every slice is padded to the longest one (no offset array)
 
-__global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowptr, int64_t m, int64_t slices, int32_t *units, int cols32) {
+__global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowptr, int64_t m, int64_t slices, int32_t *units, int mode) {
   const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (s >= slices) return;
   int L = 0;
@@ -96,26 +96,32 @@ __global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowpt
     L = (nxt - prev > L) ? nxt - prev : L;
     prev = nxt;
   }
-  units[s] = L > 0 ? L + (cols32 ? (L + 1) / 2 : (L + 7) / 8) : 0;
+  units[s] = L > 0 ? L + (mode == 2 ? 0 : (mode == 1 ? (L + 1) / 2 : (L + 7) / 8)) : 0;      // mode 0: 8-bit code words, 1: int32 column words, 2: values only (narrow codes live in their own array)
 }
 
 // words per row ahead of the values for T units of a slice: code words (T = L + ceil(L / 8)) or column words (T = L + ceil(L / 2))
-__host__ __device__ __forceinline__ int sell_head_words(int T, int cols32) { return cols32 ? (T + 2) / 3 : (T + 8) / 9; }
+__host__ __device__ __forceinline__ int sell_head_words(int T, int mode) { return mode == 2 ? 0 : (mode == 1 ? (T + 2) / 3 : (T + 8) / 9); }
 
 __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr, const double *val, const uint8_t *code, const int32_t *col, int64_t m,
                                                            int64_t slices, const uint32_t *off, int uniform_units,
-                                                           unsigned long long *sell) {
+                                                           unsigned long long *sell, uint32_t *c4) {
   const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // rows of the last slice beyond m are written too (no entry)
   if (row >= slices * 64) return;
   const int64_t s = row >> 6;
   const int lane = (int)(row & 63);
   const int64_t o0 = uniform_units ? s * uniform_units : (int64_t)off[s];
   const int T = uniform_units ? uniform_units : (int)(off[s + 1] - off[s]);
-  if (T == 0) return;
   const int cols32 = col != nullptr;
-  const int W = sell_head_words(T, cols32), L = T - W;
+  const int mode = c4 ? 2 : cols32;
   const int32_t q0 = row < m ? rowptr[row] : 0;
   const int len = row < m ? rowptr[row + 1] - q0 : 0;
+  if (c4) {                                   // eight 4-bit codes, 0xF = no entry
+    uint32_t word = 0;
+    for (int u = 0; u < 8; ++u) word |= (u < len ? (uint32_t)code[q0 + u] : 0xFu) << (4 * u);
+    c4[row] = word;
+  }
+  if (T == 0) return;
+  const int W = sell_head_words(T, mode), L = T - W;
   unsigned long long *base = sell + (size_t)o0 * 64 + lane;
   for (int w = 0; w < W; ++w) {
     unsigned long long word = 0;
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr
 }
 
 void csr_free_sell(khip_csr *A) {
-  (void)hipFree(A->sell); (void)hipFree(A->sell_off);
-  A->sell = nullptr; A->sell_off = nullptr;
+  (void)hipFree(A->sell); (void)hipFree(A->sell_off); (void)hipFree(A->sell_c4);
+  A->sell = nullptr; A->sell_off = nullptr; A->sell_c4 = nullptr;
   A->sell_units = 0; A->sell_total_units = 0; A->sell_state = 0;
 }
 
@@ -157,20 +163,22 @@ static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
   const int64_t m = A->m;
   if (m == 0 || A->nnz == 0 || A->max_row_nnz > 64) return KHIP_OK;
   if (!cols32 && (A->code_state != 1 || A->code_bits != 8 || A->code_T > 255)) return KHIP_OK;
+  const bool narrow = !cols32 && ctx->tune.spmv_sell_narrow && A->code_T <= 15 && A->max_row_nnz <= 8;
+  const int mode = narrow ? 2 : (cols32 ? 1 : 0);
   const int64_t slices = (m + 63) / 64;
   int32_t *units_d = nullptr;
   KHIP_CHECK_HIP(hipMalloc(&units_d, sizeof(int32_t) * (size_t)slices));
   struct Scratch { int32_t *&p; ~Scratch() { (void)hipFree(p); } } scratch{units_d};
-  hipLaunchKernelGGL(sell_units_kernel, dim3((unsigned)((slices + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, m, slices, units_d, cols32 ? 1 : 0);
+  hipLaunchKernelGGL(sell_units_kernel, dim3((unsigned)((slices + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, m, slices, units_d, mode);
   KHIP_CHECK_HIP(hipGetLastError());
   std::vector<int32_t> units((size_t)slices);
   KHIP_CHECK_HIP(hipMemcpyAsync(units.data(), units_d, sizeof(int32_t) * (size_t)slices, hipMemcpyDeviceToHost, ctx->stream));
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   int64_t total = 0, slots = 0;
   int umax = 0;
-  for (int32_t u : units) { total += u; const int W = sell_head_words(u, cols32); slots += (int64_t)(u - W) * 64; umax = u > umax ? u : umax; }
+  for (int32_t u : units) { total += u; const int W = sell_head_words(u, mode); slots += (int64_t)(u - W) * 64; umax = u > umax ? u : umax; }
   if (slots > (int64_t)(kSellMaxPad * (double)A->nnz) + 4096) return KHIP_OK;          // too much padding: stays on the CSR stream
-  const int Wmax = sell_head_words(umax, cols32);
+  const int Wmax = sell_head_words(umax, mode);
   const bool uniform = (int64_t)(umax - Wmax) * 64 * slices <= (int64_t)(kSellUniformPad * (double)A->nnz) + 4096;
   if (uniform) total = (int64_t)umax * slices;
   if (total >= ((int64_t)1 << 32)) return KHIP_OK;
@@ -187,8 +195,9 @@ static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
     KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));                                  // `off` dies with this scope
   }
   KHIP_CHECK_HIP(hipMalloc(&words, sizeof(unsigned long long) * 64 * (size_t)(total + 1)));
+  if (narrow) KHIP_CHECK_HIP(hipMalloc(&A->sell_c4, sizeof(uint32_t) * 64 * (size_t)slices));
   hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((slices * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->val,
-                     (const uint8_t *)A->code, cols32 ? A->col : (const int32_t *)nullptr, m, slices, offs, uniform ? umax : 0, words);
+                     (const uint8_t *)A->code, cols32 ? A->col : (const int32_t *)nullptr, m, slices, offs, uniform ? umax : 0, words, narrow ? A->sell_c4 : (uint32_t *)nullptr);
   KHIP_CHECK_HIP(hipGetLastError());
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   keep = true;

@@ -464,7 +464,8 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
 // of a slice is 512 contiguous bytes).  No LDS window, no barrier and no row pointer in the row walk: the only dependent hop is
 // code word -> table lookup (LDS) -> x gather.  Products in stored order, one rounded multiply and one rounded add per entry:
 // y is bit-identical to every other kernel.
-template <bool DOT, bool COMP, bool DIST, bool NTM, bool COLS32>
+// C4: narrow codes -- eight 4-bit codes per row in one 32-bit word indexed by the row, the slices hold values only
+template <bool DOT, bool COMP, bool DIST, bool NTM, bool COLS32, bool C4>
 __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs ra) {
   if (seq_skip(a.stop_seq, a.seq)) return;
   const int ROWS = a.stage_rows;
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs r
       int T;
       if (a.sell_units) { o0 = sl * a.sell_units; T = a.sell_units; }
       else { const uint32_t b0 = a.sell_off[sl], b1 = a.sell_off[sl + 1]; o0 = (int64_t)b0; T = (int)(b1 - b0); }
-      const int W = COLS32 ? (T + 2) / 3 : (T + 8) / 9, L = T - W;
+      const int W = C4 ? 0 : (COLS32 ? (T + 2) / 3 : (T + 8) / 9), L = T - W;
       const unsigned long long *base = a.sell + (size_t)o0 * 64 + (rowl & 63);
       double acc = 0.0, wv = 0.0;
       if (DOT) wv = a.dotw[rowl];                 // in flight beside the row's entries (2.06 -> 1.97 ms fused at 512^3, profiles/r06ap/aq)
@@ -518,6 +519,10 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs r
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) on[u] = cc[u] != -1;
+        } else if (C4) {
+          const uint32_t cw = ld<NTM>(a.sell_c4 + rowl);          // L <= 8: one step
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int c = (int)((cw >> (4 * u)) & 0xFu); on[u] = c != 0xF; cc[u] = row + s_tab[c]; }
         } else {
           const unsigned long long cw = ld<NTM>(base + (size_t)(k0 / 8) * 64);
 #pragma unroll
@@ -1215,14 +1220,15 @@ static void launch_code_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra,
 static void launch_sell_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp, bool dist) {
   const size_t pub = dot && a.blk_pub ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;
   const size_t lds = pub + 4u * 256u;
+#define KHIP_SELL(DOT, COMP, DIST, NTM, COLS32, C4) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, COLS32, C4>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra)
 #define KHIP_L(DOT, COMP, DIST) \
   do { const bool ntm = ctx->tune.spmv_sell == 2; \
-       if (a.sell_cols) { if (ntm) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, true, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
-                          else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, false, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } \
-       else { if (ntm) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, true, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
-              else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, false, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } } while (0)
+       if (a.sell_cols) { if (ntm) KHIP_SELL(DOT, COMP, DIST, true, true, false); else KHIP_SELL(DOT, COMP, DIST, false, true, false); } \
+       else if (a.sell_c4) { if (ntm) KHIP_SELL(DOT, COMP, DIST, true, false, true); else KHIP_SELL(DOT, COMP, DIST, false, false, true); } \
+       else { if (ntm) KHIP_SELL(DOT, COMP, DIST, true, false, false); else KHIP_SELL(DOT, COMP, DIST, false, false, false); } } while (0)
   KHIP_DISPATCH_DCD(KHIP_L);
 #undef KHIP_L
+#undef KHIP_SELL
 }
 
 template <typename CODE>
@@ -1377,7 +1383,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256; a.max_row = 0;
-  a.sell = nullptr; a.sell_off = nullptr; a.sell_units = 0; a.sell_cols = 0;
+  a.sell = nullptr; a.sell_off = nullptr; a.sell_units = 0; a.sell_cols = 0; a.sell_c4 = nullptr;
   a.blk_pub = ctx->tune.spmv_blk_pub;
   a.stream_nt = ctx->tune.spmv_stream_nt;
   a.dcode = nullptr; a.dbase = nullptr; a.desc_ptr = nullptr; a.desc_pos = nullptr; a.desc_col = nullptr;
@@ -1526,7 +1532,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       else launch_pipe_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (coded && sliced) {
-      a.sell = Am->sell; a.sell_off = Am->sell_off; a.sell_units = Am->sell_units; a.sell_cols = 0;
+      a.sell = Am->sell; a.sell_off = Am->sell_off; a.sell_units = Am->sell_units; a.sell_cols = 0; a.sell_c4 = Am->sell_c4;
       launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (sliced32) {

@@ -867,9 +867,10 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
     x = _vec(rng, A.n)
     y_ref = A.matvec(x)
     dx = ctx.array(x)
-    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel", "spmv_sell", "spmv_tiles", "spmv_blk_pub")}
+    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel", "spmv_sell", "spmv_tiles", "spmv_blk_pub", "spmv_sell_narrow")}
     try:
         ctx.set_option("spmv_kernel", 4); ctx.set_option("spmv_codes", 2)
+        ctx.set_option("spmv_sell_narrow", 1)          # the 4-bit code words where the operator allows them (off by default: slower)
         ref = {}
         layouts = set()
         same_blocks = 256.0 * A.nnz / A.n <= 2048.0          # both forms walk 256-row blocks (spmv.hip launch_spmv)
@@ -883,6 +884,7 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
                     dA.matvec(dx, dy)
                     assert np.array_equal(dy.to_host(), y_ref), (kind, sell, tiles, pub)
                     st, upl, total = dA.sell_info
+                    diags = dA.code_info[1]
                     assert st == (1 if sell else 0) and dA.code_info[0] == 8
                     dy2 = ctx.zeros(A.n)
                     d = K.spmv_dot(dA, dx, dy2)
@@ -898,10 +900,22 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
                     if sell:
                         layouts.add(upl > 0)
                         assert total == (upl * slices if upl else total) and total >= slices
-                        want = 512 * total + (0 if upl else 4 * (slices + 1)) + 16 * A.n
+                        narrow = diags <= 15 and int(np.diff(A.rowptr).max()) <= 8          # eight 4-bit codes per row in one word
+                        assert dA.sell_narrow == narrow
+                        want = 512 * total + (0 if upl else 4 * (slices + 1)) + (256 * slices if narrow else 0) + 16 * A.n
                     else:
                         want = 9 * A.nnz + 4 * (A.n + 1) + 16 * A.n
                     assert dA.spmv_bytes_stored == want and dA.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+        # narrow codes off: the byte-coded words, same results
+        ctx.set_option("spmv_codes", 2); ctx.set_option("spmv_sell", 2); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
+        got = {}
+        for nar in (1, 0):
+            ctx.set_option("spmv_sell_narrow", nar)
+            dN = K.CsrMatrix.stencil(ctx, kind, n1)
+            dy = ctx.zeros(A.n); dN.matvec(dx, dy)
+            assert np.array_equal(dy.to_host(), y_ref) and (not dN.sell_narrow or nar == 1)
+            got[nar] = (K.spmv_dot(dN, dx, dy), K.spmv_dot2(dN, dx, dy))
+        assert got[0] == got[1]
         # the int32 column stream (spmv_codes = 0): its sliced form (two columns per word) against the staged CSR kernel
         ctx.set_option("spmv_codes", 0); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
         ref32 = None
