@@ -161,7 +161,7 @@ static int *tuning_field(khip_ctx *ctx, const char *key) {
       {"spmv_kernel", &t.spmv_kernel}, {"spmv_rows", &t.spmv_rows}, {"spmv_vec", &t.spmv_vec},
       {"spmv_nt", &t.spmv_nt},         {"spmv_xcd", &t.spmv_xcd},   {"spmv_lanes", &t.spmv_lanes},
       {"compensated", &t.compensated}, {"nt_min_elems", &t.nt_min_elems}, {"overlap_halo", &t.overlap_halo},
-      {"profile_spmv", &t.profile_spmv}, {"comm_priority", &t.comm_priority}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_delta", &t.spmv_delta}, {"spmv_blk_pub", &t.spmv_blk_pub}, {"spmv_stream_nt", &t.spmv_stream_nt}, {"spmv_sell", &t.spmv_sell}, {"spmv_sell_narrow", &t.spmv_sell_narrow}, {"cg_setup_fused", &t.cg_setup_fused}, {"spmv_wide", &t.spmv_wide}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_slide", &t.spmm_tile_slide}, {"spmm_tile_ahead", &t.spmm_tile_ahead}, {"spmm_tile_xcd", &t.spmm_tile_xcd}, {"spmm_tile_dbuf", &t.spmm_tile_dbuf}, {"spmm_tile_pair", &t.spmm_tile_pair}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
+      {"profile_spmv", &t.profile_spmv}, {"comm_priority", &t.comm_priority}, {"spmv_persist", &t.spmv_persist}, {"spmv_nty", &t.spmv_nty}, {"spmv_dot_early", &t.spmv_dot_early}, {"spmv_blockptr", &t.spmv_blockptr}, {"spmv_codes", &t.spmv_codes}, {"spmv_delta", &t.spmv_delta}, {"spmv_blk_pub", &t.spmv_blk_pub}, {"spmv_stream_nt", &t.spmv_stream_nt}, {"spmv_sell", &t.spmv_sell}, {"spmv_sell_narrow", &t.spmv_sell_narrow}, {"spmv_sell_pair", &t.spmv_sell_pair}, {"cg_setup_fused", &t.cg_setup_fused}, {"spmv_wide", &t.spmv_wide}, {"spmv_pipe", &t.spmv_pipe}, {"spmv_fake_gather", &t.spmv_fake_gather}, {"spmv_tiles", &t.spmv_tiles}, {"spmv_lds_pad", &t.spmv_lds_pad}, {"spmv_cap", &t.spmv_cap}, {"spmv_template", &t.spmv_template}, {"spmv_sweep_s", &t.spmv_sweep_s}, {"spmv_sweep_w", &t.spmv_sweep_w}, {"spmv_tmpl_rows", &t.spmv_tmpl_rows}, {"mgs_keep", &t.mgs_keep}, {"spmm_sweep", &t.spmm_sweep}, {"spmm_win_sweep", &t.spmm_win_sweep}, {"spmm_wide", &t.spmm_wide}, {"panel_fuse", &t.panel_fuse}, {"panel_signs", &t.panel_signs}, {"panel_qr_tsqr", &t.panel_qr_tsqr}, {"panel_a_lds", &t.panel_a_lds}, {"panel_nt", &t.panel_nt}, {"gmres_sstep", &t.gmres_sstep}, {"panel_multi_tiles", &t.panel_multi_tiles}, {"ilu_blocks", &t.ilu_blocks}, {"halo_mode", &t.halo_mode}, {"halo_gather_pct", &t.halo_gather_pct}, {"spmm_window", &t.spmm_window}, {"spmm_tile", &t.spmm_tile}, {"spmm_tile_exp", &t.spmm_tile_exp}, {"spmm_tile_nt", &t.spmm_tile_nt}, {"spmm_tile_slices", &t.spmm_tile_slices}, {"spmm_tile_pencil", &t.spmm_tile_pencil}, {"spmm_tile_slide", &t.spmm_tile_slide}, {"spmm_tile_ahead", &t.spmm_tile_ahead}, {"spmm_tile_xcd", &t.spmm_tile_xcd}, {"spmm_tile_dbuf", &t.spmm_tile_dbuf}, {"spmm_tile_pair", &t.spmm_tile_pair}, {"spmm_tile_waves", &t.spmm_tile_waves}, {"spmm_tile_grid", &t.spmm_tile_grid}, {"spmm_tile_shape", &t.spmm_tile_shape}, {"spmm_window_grid", &t.spmm_window_grid}, {"spmm_sweep_s", &t.spmm_sweep_s}, {"spmm_sweep_w", &t.spmm_sweep_w}, {"red_u", &t.red_u}, {"hist_window", &t.hist_window}};
   for (auto &e : tab)
     if (strcmp(e.k, key) == 0) return e.p;
   return nullptr;

@@ -96,15 +96,15 @@ __global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowpt
     L = (nxt - prev > L) ? nxt - prev : L;
     prev = nxt;
   }
-  units[s] = L > 0 ? L + (mode == 2 ? 0 : (mode == 1 ? (L + 1) / 2 : (L + 7) / 8)) : 0;      // mode 0: 8-bit code words, 1: int32 column words, 2: values only (narrow codes live in their own array)
+  units[s] = L > 0 ? (mode == 3 ? 2 * ((L + 2) / 2) : L + (mode == 2 ? 0 : (mode == 1 ? (L + 1) / 2 : (L + 7) / 8))) : 0;      // mode 0: 8-bit code words, 1: int32 column words, 2: values only (narrow codes live in their own array), 3: one code word + values, an even number of words (16-byte pairs; L <= 8)
 }
 
 // words per row ahead of the values for T units of a slice: code words (T = L + ceil(L / 8)) or column words (T = L + ceil(L / 2))
-__host__ __device__ __forceinline__ int sell_head_words(int T, int mode) { return mode == 2 ? 0 : (mode == 1 ? (T + 2) / 3 : (T + 8) / 9); }
+__host__ __device__ __forceinline__ int sell_head_words(int T, int mode) { return mode == 3 ? (T > 0 ? 1 : 0) : (mode == 2 ? 0 : (mode == 1 ? (T + 2) / 3 : (T + 8) / 9)); }
 
 __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr, const double *val, const uint8_t *code, const int32_t *col, int64_t m,
                                                            int64_t slices, const uint32_t *off, int uniform_units,
-                                                           unsigned long long *sell, uint32_t *c4) {
+                                                           unsigned long long *sell, uint32_t *c4, int pair) {
   const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // rows of the last slice beyond m are written too (no entry)
   if (row >= slices * 64) return;
   const int64_t s = row >> 6;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr
   const int64_t o0 = uniform_units ? s * uniform_units : (int64_t)off[s];
   const int T = uniform_units ? uniform_units : (int)(off[s + 1] - off[s]);
   const int cols32 = col != nullptr;
-  const int mode = c4 ? 2 : cols32;
+  const int mode = pair ? 3 : (c4 ? 2 : cols32);
   const int32_t q0 = row < m ? rowptr[row] : 0;
   const int len = row < m ? rowptr[row + 1] - q0 : 0;
   if (c4) {                                   // eight 4-bit codes, 0xF = no entry
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr
   if (T == 0) return;
   const int W = sell_head_words(T, mode), L = T - W;
   unsigned long long *base = sell + (size_t)o0 * 64 + lane;
+  // word w of this lane: plain layout (w * 64 + lane); pair layout ((w / 2) * 64 + lane) * 2 + (w & 1)
+  auto slot = [&](int w) -> unsigned long long & { return pair ? sell[(size_t)o0 * 64 + ((size_t)(w >> 1) * 64 + lane) * 2 + (w & 1)] : base[(size_t)w * 64]; };
   for (int w = 0; w < W; ++w) {
     unsigned long long word = 0;
     if (cols32) {
@@ -136,14 +138,14 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr
         word |= c << (8 * u);
       }
     }
-    base[(size_t)w * 64] = word;
+    slot(w) = word;
   }
-  for (int k = 0; k < L; ++k) base[(size_t)(W + k) * 64] = k < len ? (unsigned long long)__double_as_longlong(val[q0 + k]) : 0ull;
+  for (int k = 0; k < L; ++k) slot(W + k) = k < len ? (unsigned long long)__double_as_longlong(val[q0 + k]) : 0ull;
 }
 
 void csr_free_sell(khip_csr *A) {
   (void)hipFree(A->sell); (void)hipFree(A->sell_off); (void)hipFree(A->sell_c4);
-  A->sell = nullptr; A->sell_off = nullptr; A->sell_c4 = nullptr;
+  A->sell = nullptr; A->sell_off = nullptr; A->sell_c4 = nullptr; A->sell_pair = 0;
   A->sell_units = 0; A->sell_total_units = 0; A->sell_state = 0;
 }
 
@@ -164,7 +166,8 @@ static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
   if (m == 0 || A->nnz == 0 || A->max_row_nnz > 64) return KHIP_OK;
   if (!cols32 && (A->code_state != 1 || A->code_bits != 8 || A->code_T > 255)) return KHIP_OK;
   const bool narrow = !cols32 && ctx->tune.spmv_sell_narrow && A->code_T <= 15 && A->max_row_nnz <= 8;
-  const int mode = narrow ? 2 : (cols32 ? 1 : 0);
+  const bool pair = !cols32 && !narrow && ctx->tune.spmv_sell_pair && A->max_row_nnz <= 8;
+  const int mode = pair ? 3 : (narrow ? 2 : (cols32 ? 1 : 0));
   const int64_t slices = (m + 63) / 64;
   int32_t *units_d = nullptr;
   KHIP_CHECK_HIP(hipMalloc(&units_d, sizeof(int32_t) * (size_t)slices));
@@ -197,12 +200,13 @@ static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
   KHIP_CHECK_HIP(hipMalloc(&words, sizeof(unsigned long long) * 64 * (size_t)(total + 1)));
   if (narrow) KHIP_CHECK_HIP(hipMalloc(&A->sell_c4, sizeof(uint32_t) * 64 * (size_t)slices));
   hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((slices * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->val,
-                     (const uint8_t *)A->code, cols32 ? A->col : (const int32_t *)nullptr, m, slices, offs, uniform ? umax : 0, words, narrow ? A->sell_c4 : (uint32_t *)nullptr);
+                     (const uint8_t *)A->code, cols32 ? A->col : (const int32_t *)nullptr, m, slices, offs, uniform ? umax : 0, words, narrow ? A->sell_c4 : (uint32_t *)nullptr, pair ? 1 : 0);
   KHIP_CHECK_HIP(hipGetLastError());
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   keep = true;
   (cols32 ? A->sell32_units : A->sell_units) = uniform ? umax : 0;
   (cols32 ? A->sell32_total_units : A->sell_total_units) = total;
+  if (!cols32) A->sell_pair = pair ? 1 : 0;
   state = 1;
   return KHIP_OK;
 }

@@ -465,7 +465,8 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
 // code word -> table lookup (LDS) -> x gather.  Products in stored order, one rounded multiply and one rounded add per entry:
 // y is bit-identical to every other kernel.
 // C4: narrow codes -- eight 4-bit codes per row in one 32-bit word indexed by the row, the slices hold values only
-template <bool DOT, bool COMP, bool DIST, bool NTM, bool COLS32, bool C4>
+// PAIR: rows of at most 8 entries, the code word and the values of a row in 16-byte pairs (element e of lane l = words 2e, 2e + 1)
+template <bool DOT, bool COMP, bool DIST, bool NTM, bool COLS32, bool C4, bool PAIR>
 __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs ra) {
   if (seq_skip(a.stop_seq, a.seq)) return;
   const int ROWS = a.stage_rows;
@@ -500,10 +501,35 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs r
       int T;
       if (a.sell_units) { o0 = sl * a.sell_units; T = a.sell_units; }
       else { const uint32_t b0 = a.sell_off[sl], b1 = a.sell_off[sl + 1]; o0 = (int64_t)b0; T = (int)(b1 - b0); }
-      const int W = C4 ? 0 : (COLS32 ? (T + 2) / 3 : (T + 8) / 9), L = T - W;
+      const int W = PAIR ? (T > 0 ? 1 : 0) : (C4 ? 0 : (COLS32 ? (T + 2) / 3 : (T + 8) / 9)), L = T - W;
       const unsigned long long *base = a.sell + (size_t)o0 * 64 + (rowl & 63);
       double acc = 0.0, wv = 0.0;
       if (DOT) wv = a.dotw[rowl];                 // in flight beside the row's entries (2.06 -> 1.97 ms fused at 512^3, profiles/r06ap/aq)
+      if (PAIR) {                                // T = 8 or 10 words: four or five 16-byte loads bring the whole row
+        const dbl2 *pb = reinterpret_cast<const dbl2 *>(a.sell + (size_t)o0 * 64) + (rowl & 63);
+        dbl2 el[5];
+#pragma unroll
+        for (int e = 0; e < 5; ++e) el[e] = (2 * e < T) ? ld<NTM>(pb + (size_t)e * 64) : dbl2{0.0, 0.0};
+        const unsigned long long cw = (unsigned long long)__double_as_longlong(el[0].x);
+        double vv[8], xx[8];
+        int32_t cc[8];
+        bool on[8];
+        vv[0] = el[0].y; vv[1] = el[1].x; vv[2] = el[1].y; vv[3] = el[2].x; vv[4] = el[2].y; vv[5] = el[3].x; vv[6] = el[3].y; vv[7] = el[4].x;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int c = (int)((cw >> (8 * u)) & 0xFFull); on[u] = T > 0 && c != 0xFF; cc[u] = row + s_tab[c]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xx[u] = 0.0;
+          if (on[u]) xx[u] = gather_x<DIST>(a, cc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (on[u]) {
+            const double prod = vv[u] * xx[u];
+            acc = acc + prod;
+          }
+        }
+      } else
       for (int k0 = 0; k0 < L; k0 += 8) {      // eight entries per step: one code word, or four words of two int32 columns
         const unsigned long long *vb = base + (size_t)(W + k0) * 64;
         const int left = L - k0;               // >= 1
@@ -1220,7 +1246,9 @@ static void launch_code_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra,
 static void launch_sell_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra, unsigned grid, bool dot, bool comp, bool dist) {
   const size_t pub = dot && a.blk_pub ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;
   const size_t lds = pub + 4u * 256u;
-#define KHIP_SELL(DOT, COMP, DIST, NTM, COLS32, C4) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, COLS32, C4>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra)
+#define KHIP_SELL(DOT, COMP, DIST, NTM, COLS32, C4) \
+  do { if (a.sell_pair) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, false, false, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
+       else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, COLS32, C4, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } while (0)
 #define KHIP_L(DOT, COMP, DIST) \
   do { const bool ntm = ctx->tune.spmv_sell == 2; \
        if (a.sell_cols) { if (ntm) KHIP_SELL(DOT, COMP, DIST, true, true, false); else KHIP_SELL(DOT, COMP, DIST, false, true, false); } \
@@ -1383,7 +1411,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
   a.nnz_bound = A->nnz + kPad;
   a.fake_gather = ctx->tune.spmv_fake_gather;
   a.code = nullptr; a.code_tab = nullptr; a.code_T = 0; a.stage_rows = 256; a.max_row = 0;
-  a.sell = nullptr; a.sell_off = nullptr; a.sell_units = 0; a.sell_cols = 0; a.sell_c4 = nullptr;
+  a.sell = nullptr; a.sell_off = nullptr; a.sell_units = 0; a.sell_cols = 0; a.sell_c4 = nullptr; a.sell_pair = 0;
   a.blk_pub = ctx->tune.spmv_blk_pub;
   a.stream_nt = ctx->tune.spmv_stream_nt;
   a.dcode = nullptr; a.dbase = nullptr; a.desc_ptr = nullptr; a.desc_pos = nullptr; a.desc_col = nullptr;
@@ -1532,11 +1560,11 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       else launch_pipe_cfg<uint16_t>(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (coded && sliced) {
-      a.sell = Am->sell; a.sell_off = Am->sell_off; a.sell_units = Am->sell_units; a.sell_cols = 0; a.sell_c4 = Am->sell_c4;
+      a.sell = Am->sell; a.sell_off = Am->sell_off; a.sell_units = Am->sell_units; a.sell_cols = 0; a.sell_c4 = Am->sell_c4; a.sell_pair = Am->sell_pair;
       launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (sliced32) {
-      a.sell = Am->sell32; a.sell_off = Am->sell32_off; a.sell_units = Am->sell32_units; a.sell_cols = 1;
+      a.sell = Am->sell32; a.sell_off = Am->sell32_off; a.sell_units = Am->sell32_units; a.sell_cols = 1; a.sell_pair = 0; a.sell_c4 = nullptr;
       launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (coded) {

@@ -53,6 +53,7 @@ struct SpmvArgs {
   const uint32_t *sell_off;  // first unit (64 words) of every slice; null: sell_units units per slice
   int sell_units;
   int sell_cols;             // 0: code words (eight 1-byte codes), 1: column words (two int32 columns)
+  int sell_pair;             // the words of a row interleaved in 16-byte pairs (rows of at most 8 entries, one code word)
   const uint32_t *sell_c4;   // narrow codes: eight 4-bit codes per row in one word indexed by the row (the slices hold values only); null otherwise
   // block-delta column stream (coldelta.hip): col = dbase[block] + dcode[k]; all-ones code = escape
   const void *dcode;         // uint8_t[nnz + pad] or uint16_t[nnz + pad]

@@ -12,6 +12,5 @@ PY
 }
 for rep in 1 2 3; do
 run
-run --opt spmv_sell_narrow=0
-run --opt spmv_sell=0
+run --opt spmv_sell_pair=0
 done
