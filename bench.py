@@ -723,7 +723,7 @@ def main():
         pmc_key = {8: "spmv_code_kernel<unsigned char, true, true", 16: "spmv_code_kernel<unsigned short, true, true",
                    32: "spmv_stage_kernel<256, false, true, true"}[code_bits]
         if sliced:
-            pmc_key = "spmv_sell_kernel<true, true, false, " + ("true" if ctx.get_option("spmv_sell") == 2 else "false") + ", false, false>"   # DOT, COMP, DIST, non-temporal, int32 columns, narrow codes
+            pmc_key = "spmv_sell_kernel<true, true, false, " + ("true" if ctx.get_option("spmv_sell") == 2 else "false") + ", false, "   # DOT, COMP, DIST, non-temporal loads, int32 columns = false; the layout flags (narrow codes, 16-byte pairs) follow
         traffic, traffic_note = pmc_traffic(n1, pmc_key) if (world == 1 and not templates) else (None, "single-GPU CSR runs only")
         col_note = ("int32 columns" if code_bits == 32 else
                     f"{code_bits}-bit diagonal codes ({code_diags} distinct column - row offsets, csrc/colcode.hip)")

@@ -10,7 +10,7 @@
 #   2. Method specialisations of `cg!`, `gmres!`, `bicgstab!` and `block_gmres!` for workspaces whose storage type is
 #      `HIPVector` / `HIPMatrix` and an operator that is a `HIPCsr`.  They hand the device pointers of the WORKSPACE'S OWN
 #      vectors to the library (`khip_*_workspace_adopt`, include/krylov_hip.h) and run its fused, device-resident loop on them
-#      (`khip_*_solve`; 290-308 it/s for cg! at 512^3): `solution(ws) === ws.x`, `ws.stats` is filled as the generic method fills
+#      (`khip_*_solve`; 310-316 it/s for cg! at 512^3): `solution(ws) === ws.x`, `ws.stats` is filled as the generic method fills
 #      it, nothing is copied.
 #
 #      EVERY entry point of the reference reaches them.  `cg(A, b)`, `krylov_solve(Val(:cg), A, b)`, `krylov_solve!(ws, A, b)`

@@ -82,8 +82,8 @@ __global__ __launch_bounds__(kBlock) void code_assign_kernel(const int32_t *rowp
 // its first W = ceil(L / 8) units hold, per lane, eight 1-byte codes per word (0xFF = the row has no such entry), the next L units
 // the values (L = longest row of the slice).  64 B per row for the 7-point operator (7 values + one code word) where CSR + codes
 // + row pointer is 67.  y is bit-identical (stored order, one rounded multiply and one rounded add per entry).
-constexpr double kSellMaxPad = 1.12;       // slots / entries above which the sliced copy is not built
-constexpr double kSellUniformPad = 1.02;   // ... and below which every slice is padded to the longest one (no offset array)
+constexpr double kSellMaxPad = 1.20;       // bytes of the sliced copy / bytes of the CSR stream it replaces above which it is not built
+constexpr double kSellUniformPad = 1.02;   // padding every slice to the longest one may cost this much (then there is no offset array)
 
 __global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowptr, int64_t m, int64_t slices, int32_t *units, int mode) {
   const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -96,15 +96,22 @@ __global__ __launch_bounds__(kBlock) void sell_units_kernel(const int32_t *rowpt
     L = (nxt - prev > L) ? nxt - prev : L;
     prev = nxt;
   }
-  units[s] = L > 0 ? (mode == 3 ? 2 * ((L + 2) / 2) : L + (mode == 2 ? 0 : (mode == 1 ? (L + 1) / 2 : (L + 7) / 8))) : 0;      // mode 0: 8-bit code words, 1: int32 column words, 2: values only (narrow codes live in their own array), 3: one code word + values, an even number of words (16-byte pairs; L <= 8)
+  const int Lp = L + (L & 1);                // pair layouts: an even number of value words ...
+  const int h4 = (Lp / 2) + ((Lp / 2) & 1), h5 = ((L + 7) / 8) + (((L + 7) / 8) & 1);      // ... behind an even number of column / code words
+  units[s] = L > 0 ? (mode == 5 ? Lp + h5 : (mode == 4 ? Lp + h4 : (mode == 3 ? 2 * ((L + 2) / 2) : L + (mode == 2 ? 0 : (mode == 1 ? (L + 1) / 2 : (L + 7) / 8))))) : 0;      // mode 0: 8-bit code words, 1: int32 column words, 2: values only (narrow codes live in their own array), 3: one code word + values, an even number of words (16-byte pairs; L <= 8), 4 / 5: int32 column words / code words padded to an even count, then the values padded to an even count (16-byte pairs, any L)
 }
 
 // words per row ahead of the values for T units of a slice: code words (T = L + ceil(L / 8)) or column words (T = L + ceil(L / 2))
-__host__ __device__ __forceinline__ int sell_head_words(int T, int mode) { return mode == 3 ? (T > 0 ? 1 : 0) : (mode == 2 ? 0 : (mode == 1 ? (T + 2) / 3 : (T + 8) / 9)); }
+__host__ __device__ __forceinline__ int sell_head_words(int T, int mode) {
+  if (T <= 0) return 0;
+  if (mode == 5) return T <= 18 ? 2 : (T <= 36 ? 4 : (T <= 54 ? 6 : 8));       // T = Lp + even(ceil(Lp / 8)), Lp even <= 64: disjoint ranges
+  if (mode == 4) return 2 * ((T - 4) / 6) + 2;                                 // T = Lp + even(Lp / 2)
+  return mode == 3 ? 1 : (mode == 2 ? 0 : (mode == 1 ? (T + 2) / 3 : (T + 8) / 9));
+}
 
 __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr, const double *val, const uint8_t *code, const int32_t *col, int64_t m,
                                                            int64_t slices, const uint32_t *off, int uniform_units,
-                                                           unsigned long long *sell, uint32_t *c4, int pair) {
+                                                           unsigned long long *sell, uint32_t *c4, int mode) {
   const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // rows of the last slice beyond m are written too (no entry)
   if (row >= slices * 64) return;
   const int64_t s = row >> 6;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void sell_fill_kernel(const int32_t *rowptr
   const int64_t o0 = uniform_units ? s * uniform_units : (int64_t)off[s];
   const int T = uniform_units ? uniform_units : (int)(off[s + 1] - off[s]);
   const int cols32 = col != nullptr;
-  const int mode = pair ? 3 : (c4 ? 2 : cols32);
+  const bool pair = mode >= 3;
   const int32_t q0 = row < m ? rowptr[row] : 0;
   const int len = row < m ? rowptr[row + 1] - q0 : 0;
   if (c4) {                                   // eight 4-bit codes, 0xF = no entry
@@ -152,7 +159,7 @@ void csr_free_sell(khip_csr *A) {
 void csr_free_sell32(khip_csr *A) {
   (void)hipFree(A->sell32); (void)hipFree(A->sell32_off);
   A->sell32 = nullptr; A->sell32_off = nullptr;
-  A->sell32_units = 0; A->sell32_total_units = 0; A->sell32_state = 0;
+  A->sell32_units = 0; A->sell32_total_units = 0; A->sell32_state = 0; A->sell32_pair = 0;
 }
 
 // cols32 = false: code words (needs the 8-bit codes); true: int32 column words
@@ -166,8 +173,10 @@ static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
   if (m == 0 || A->nnz == 0 || A->max_row_nnz > 64) return KHIP_OK;
   if (!cols32 && (A->code_state != 1 || A->code_bits != 8 || A->code_T > 255)) return KHIP_OK;
   const bool narrow = !cols32 && ctx->tune.spmv_sell_narrow && A->code_T <= 15 && A->max_row_nnz <= 8;
-  const bool pair = !cols32 && !narrow && ctx->tune.spmv_sell_pair && A->max_row_nnz <= 8;
-  const int mode = pair ? 3 : (narrow ? 2 : (cols32 ? 1 : 0));
+  const bool pair = !narrow && ctx->tune.spmv_sell_pair;
+  // int32 columns: the pair layout costs 96 instead of 88 B per 7-point row and measured no faster (plain 2.36 against 2.27 ms, fused 2.44
+  // against 2.41 at 512^3, profiles/r06aw): only with spmv_sell_pair = 2
+  const int mode = cols32 ? ((pair && ctx->tune.spmv_sell_pair >= 2) ? 4 : 1) : (narrow ? 2 : (pair ? (A->max_row_nnz <= 8 ? 3 : 5) : 0));
   const int64_t slices = (m + 63) / 64;
   int32_t *units_d = nullptr;
   KHIP_CHECK_HIP(hipMalloc(&units_d, sizeof(int32_t) * (size_t)slices));
@@ -180,9 +189,10 @@ static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
   int64_t total = 0, slots = 0;
   int umax = 0;
   for (int32_t u : units) { total += u; const int W = sell_head_words(u, mode); slots += (int64_t)(u - W) * 64; umax = u > umax ? u : umax; }
-  if (slots > (int64_t)(kSellMaxPad * (double)A->nnz) + 4096) return KHIP_OK;          // too much padding: stays on the CSR stream
-  const int Wmax = sell_head_words(umax, mode);
-  const bool uniform = (int64_t)(umax - Wmax) * 64 * slices <= (int64_t)(kSellUniformPad * (double)A->nnz) + 4096;
+  (void)slots;
+  const double ref_bytes = (cols32 ? 12.0 : 9.0) * (double)A->nnz + 4.0 * (double)m;    // the CSR stream this copy replaces
+  if (512.0 * (double)total > kSellMaxPad * ref_bytes + 65536.0) return KHIP_OK;       // too much padding: stays on the CSR stream
+  const bool uniform = (double)umax * (double)slices <= kSellUniformPad * (double)total + 8.0;
   if (uniform) total = (int64_t)umax * slices;
   if (total >= ((int64_t)1 << 32)) return KHIP_OK;
   bool keep = false;
@@ -200,13 +210,13 @@ static int build_sell_form(khip_ctx *ctx, khip_csr *A, bool cols32) {
   KHIP_CHECK_HIP(hipMalloc(&words, sizeof(unsigned long long) * 64 * (size_t)(total + 1)));
   if (narrow) KHIP_CHECK_HIP(hipMalloc(&A->sell_c4, sizeof(uint32_t) * 64 * (size_t)slices));
   hipLaunchKernelGGL(sell_fill_kernel, dim3((unsigned)((slices * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, ctx->stream, A->rowptr, A->val,
-                     (const uint8_t *)A->code, cols32 ? A->col : (const int32_t *)nullptr, m, slices, offs, uniform ? umax : 0, words, narrow ? A->sell_c4 : (uint32_t *)nullptr, pair ? 1 : 0);
+                     (const uint8_t *)A->code, cols32 ? A->col : (const int32_t *)nullptr, m, slices, offs, uniform ? umax : 0, words, narrow ? A->sell_c4 : (uint32_t *)nullptr, mode);
   KHIP_CHECK_HIP(hipGetLastError());
   KHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   keep = true;
   (cols32 ? A->sell32_units : A->sell_units) = uniform ? umax : 0;
   (cols32 ? A->sell32_total_units : A->sell_total_units) = total;
-  if (!cols32) A->sell_pair = pair ? 1 : 0;
+  if (cols32) A->sell32_pair = mode == 4 ? 2 : 0; else A->sell_pair = mode == 3 ? 1 : (mode == 5 ? 2 : 0);
   state = 1;
   return KHIP_OK;
 }

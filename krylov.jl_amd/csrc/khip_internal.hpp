@@ -95,7 +95,7 @@ struct Tuning {
   int spmv_pipe = 0;        // staged kernel: software-pipelined form with this many consecutive row blocks per workgroup (0 = one block per workgroup, no pipeline; measured no faster: profiles/r02b_sweep_pipe.log)
   int cg_setup_fused = 1;   // cg! (fused paths, M = I, no warm start): x = 0, r = p = b, gamma = b.b in one pass (khip_cg_setup) instead of four primitives
   int spmv_sell = 2;        // coded operators with 8-bit codes: the sliced (64-row transposed) form -- every lane loads its own row's entries with coalesced 8-byte loads, no LDS window, no barrier in the row walk (1: default load policy, 2: non-temporal loads of the matrix words, 0: off = spmv_code_kernel); 512^3: 2.21 -> 1.97-2.00 ms fused, CG 275 -> 290-297 it/s (profiles/r06ap, r06aq)
-  int spmv_sell_pair = 1;   // sliced form of a coded operator with at most 8 entries per row: the row's words in 16-byte pairs (half the vector-memory instructions of the matrix stream)
+  int spmv_sell_pair = 1;   // sliced form of a coded operator: the row's words in 16-byte pairs (half the vector-memory instructions of the matrix stream): 7-point 512^3 fused 1.92-2.00 -> 1.77-1.84 ms, 27-point 216^3 plain 0.53 -> 0.49 ms; 2 = for the int32 form too (96 instead of 88 B per 7-point row: no gain, off)
   int spmv_sell_narrow = 0; // sliced form: 1 = 4-bit codes in one 32-bit word per row where the operator allows (<= 15 diagonals, <= 8 entries per row): 60 instead of 64 B per 7-point row -- and 8-10 % SLOWER at 512^3 (fused 2.13-2.15 against 1.93-1.98 ms: slices of 7 units are no longer 4 KB blocks, and the codes are a second stream of 256-byte wave loads; profiles/r06au_spmv_sell_narrow_ab.log): off
   int spmv_stream_nt = 0;   // 16-byte-load stream kernel: matrix stream loaded with the non-temporal policy
   int spmv_blk_pub = 0;     // fused dots of the staged / coded / delta SpMV kernels: 1 = workgroup-level fold in LDS, one wave runs the double-double tree (block_publish); measured equal to the per-wave trees (profiles/r04b_sweep_headline.log): off
@@ -258,7 +258,8 @@ struct khip_csr {
   uint32_t *sell_off = nullptr;        // [slices + 1] first unit of every slice (null: every slice has sell_units units)
   int sell_units = 0;                  // uniform slices: W + L of every slice (0: per-slice offsets)
   int64_t sell_total_units = 0;
-  int sell_pair = 0;                   // 1: rows of at most 8 entries, the words of a row (code word, values) interleaved in PAIRS: lane l's words 2e, 2e + 1 are one 16-byte element at (e * 64 + l) of the slice -- 16-byte lane loads
+  int sell32_pair = 0;                 // the int32 form in 16-byte pairs (2: general pair layout, see sell_pair)
+  int sell_pair = 0;                   // 2: general pair layout -- head words (codes / columns) padded to an even count, then the values padded to an even count, lane l's words 2e, 2e + 1 one 16-byte element; 1: rows of at most 8 entries, the words of a row (code word, values) interleaved in PAIRS: lane l's words 2e, 2e + 1 are one 16-byte element at (e * 64 + l) of the slice -- 16-byte lane loads
   uint32_t *sell_c4 = nullptr;         // narrow codes (at most 15 diagonals, rows of at most 8 entries): ONE 32-bit word of eight 4-bit codes per row (0xF = no entry), indexed by the row; the slices then hold values only
   // ... and the same for the int32 column stream (operators that are not coded, or spmv_codes = 0): W = ceil(L / 2) words of two
   // int32 columns per row (-1 = no entry), then L values

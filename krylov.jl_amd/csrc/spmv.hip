@@ -466,7 +466,8 @@ __global__ __launch_bounds__(kBlock) void spmv_code_kernel(SpmvArgs a, RedArgs r
 // y is bit-identical to every other kernel.
 // C4: narrow codes -- eight 4-bit codes per row in one 32-bit word indexed by the row, the slices hold values only
 // PAIR: rows of at most 8 entries, the code word and the values of a row in 16-byte pairs (element e of lane l = words 2e, 2e + 1)
-template <bool DOT, bool COMP, bool DIST, bool NTM, bool COLS32, bool C4, bool PAIR>
+// PAIRG: the general pair layout -- an even number of head words (codes or columns), then an even number of value words; any row length
+template <bool DOT, bool COMP, bool DIST, bool NTM, bool COLS32, bool C4, bool PAIR, bool PAIRG>
 __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs ra) {
   if (seq_skip(a.stop_seq, a.seq)) return;
   const int ROWS = a.stage_rows;
@@ -501,7 +502,9 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs r
       int T;
       if (a.sell_units) { o0 = sl * a.sell_units; T = a.sell_units; }
       else { const uint32_t b0 = a.sell_off[sl], b1 = a.sell_off[sl + 1]; o0 = (int64_t)b0; T = (int)(b1 - b0); }
-      const int W = PAIR ? (T > 0 ? 1 : 0) : (C4 ? 0 : (COLS32 ? (T + 2) / 3 : (T + 8) / 9)), L = T - W;
+      const int W = T <= 0 ? 0 : (PAIRG ? (COLS32 ? 2 * ((T - 4) / 6) + 2 : (T <= 18 ? 2 : (T <= 36 ? 4 : (T <= 54 ? 6 : 8))))
+                                        : (PAIR ? 1 : (C4 ? 0 : (COLS32 ? (T + 2) / 3 : (T + 8) / 9))));
+      const int L = T - W;
       const unsigned long long *base = a.sell + (size_t)o0 * 64 + (rowl & 63);
       double acc = 0.0, wv = 0.0;
       if (DOT) wv = a.dotw[rowl];                 // in flight beside the row's entries (2.06 -> 1.97 ms fused at 512^3, profiles/r06ap/aq)
@@ -527,6 +530,48 @@ __global__ __launch_bounds__(kBlock) void spmv_sell_kernel(SpmvArgs a, RedArgs r
           if (on[u]) {
             const double prod = vv[u] * xx[u];
             acc = acc + prod;
+          }
+        }
+      } else if (PAIRG) {                        // eight entries per step: four 16-byte value loads + half a code element, or two column elements
+        const dbl2 *pb = reinterpret_cast<const dbl2 *>(a.sell + (size_t)o0 * 64) + (rowl & 63);
+        dbl2 ce = dbl2{0.0, 0.0};
+        for (int k0 = 0; k0 < L; k0 += 8) {
+          const int left = L - k0;               // >= 2, even
+          double vv[8], xx[8];
+          int32_t cc[8];
+          bool on[8];
+          if (COLS32) {
+            const dbl2 c0 = ld<NTM>(pb + (size_t)(k0 / 4) * 64);
+            const dbl2 c1 = (4 < left) ? ld<NTM>(pb + (size_t)(k0 / 4 + 1) * 64) : dbl2{0.0, 0.0};
+            const unsigned long long w0 = (unsigned long long)__double_as_longlong(c0.x), w1 = (unsigned long long)__double_as_longlong(c0.y);
+            const unsigned long long w2 = (4 < left) ? (unsigned long long)__double_as_longlong(c1.x) : ~0ull, w3 = (4 < left) ? (unsigned long long)__double_as_longlong(c1.y) : ~0ull;
+            cc[0] = (int32_t)(uint32_t)w0; cc[1] = (int32_t)(uint32_t)(w0 >> 32); cc[2] = (int32_t)(uint32_t)w1; cc[3] = (int32_t)(uint32_t)(w1 >> 32);
+            cc[4] = (int32_t)(uint32_t)w2; cc[5] = (int32_t)(uint32_t)(w2 >> 32); cc[6] = (int32_t)(uint32_t)w3; cc[7] = (int32_t)(uint32_t)(w3 >> 32);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) on[u] = u < left && cc[u] != -1;
+          } else {
+            const int w = k0 >> 3;
+            if ((w & 1) == 0) ce = ld<NTM>(pb + (size_t)(w >> 1) * 64);
+            const unsigned long long cw = (unsigned long long)__double_as_longlong((w & 1) ? ce.y : ce.x);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int c = (int)((cw >> (8 * u)) & 0xFFull); on[u] = c != 0xFF; cc[u] = row + s_tab[c]; }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const dbl2 v = (2 * j < left) ? ld<NTM>(pb + (size_t)((W + k0) / 2 + j) * 64) : dbl2{0.0, 0.0};
+            vv[2 * j] = v.x; vv[2 * j + 1] = v.y;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            xx[u] = 0.0;
+            if (on[u]) xx[u] = gather_x<DIST>(a, cc[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (on[u]) {
+              const double prod = vv[u] * xx[u];
+              acc = acc + prod;
+            }
           }
         }
       } else
@@ -1247,8 +1292,9 @@ static void launch_sell_cfg(khip_ctx *ctx, const SpmvArgs &a, const RedArgs &ra,
   const size_t pub = dot && a.blk_pub ? sizeof(dd) * (size_t)kBlock * (a.dot_sq ? 2u : 1u) : 0u;
   const size_t lds = pub + 4u * 256u;
 #define KHIP_SELL(DOT, COMP, DIST, NTM, COLS32, C4) \
-  do { if (a.sell_pair) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, false, false, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
-       else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, COLS32, C4, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } while (0)
+  do { if (a.sell_pair == 1) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, false, false, true, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
+       else if (a.sell_pair == 2) hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, COLS32, false, false, true>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); \
+       else hipLaunchKernelGGL((spmv_sell_kernel<DOT, COMP, DIST, NTM, COLS32, C4, false, false>), dim3(grid), dim3(kBlock), lds, ctx->stream, a, ra); } while (0)
 #define KHIP_L(DOT, COMP, DIST) \
   do { const bool ntm = ctx->tune.spmv_sell == 2; \
        if (a.sell_cols) { if (ntm) KHIP_SELL(DOT, COMP, DIST, true, true, false); else KHIP_SELL(DOT, COMP, DIST, false, true, false); } \
@@ -1564,7 +1610,7 @@ int launch_spmv(khip_ctx *ctx, const khip_csr *A, const double *x, double *y, in
       launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (sliced32) {
-      a.sell = Am->sell32; a.sell_off = Am->sell32_off; a.sell_units = Am->sell32_units; a.sell_cols = 1; a.sell_pair = 0; a.sell_c4 = nullptr;
+      a.sell = Am->sell32; a.sell_off = Am->sell32_off; a.sell_units = Am->sell32_units; a.sell_cols = 1; a.sell_pair = Am->sell32_pair; a.sell_c4 = nullptr;
       launch_sell_cfg(ctx, a, ra, grid, dot, comp, dist);
       rows = 0;      // launched
     } else if (coded) {

@@ -867,7 +867,7 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
     x = _vec(rng, A.n)
     y_ref = A.matvec(x)
     dx = ctx.array(x)
-    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel", "spmv_sell", "spmv_tiles", "spmv_blk_pub", "spmv_sell_narrow")}
+    saved = {k: ctx.get_option(k) for k in ("spmv_codes", "spmv_kernel", "spmv_sell", "spmv_tiles", "spmv_blk_pub", "spmv_sell_narrow", "spmv_sell_pair")}
     try:
         ctx.set_option("spmv_kernel", 4); ctx.set_option("spmv_codes", 2)
         ctx.set_option("spmv_sell_narrow", 1)          # the 4-bit code words where the operator allows them (off by default: slower)
@@ -908,19 +908,20 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
                     assert dA.spmv_bytes_stored == want and dA.spmv_bytes == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
         # narrow codes off: the byte-coded words, same results
         ctx.set_option("spmv_codes", 2); ctx.set_option("spmv_sell", 2); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
-        got = {}
-        for nar in (1, 0):
-            ctx.set_option("spmv_sell_narrow", nar)
+        got = []
+        for nar, pair in ((1, 1), (0, 1), (0, 0)):         # 4-bit code words | the row's words in 16-byte pairs (the default) | plain 8-byte words
+            ctx.set_option("spmv_sell_narrow", nar); ctx.set_option("spmv_sell_pair", pair)
             dN = K.CsrMatrix.stencil(ctx, kind, n1)
             dy = ctx.zeros(A.n); dN.matvec(dx, dy)
-            assert np.array_equal(dy.to_host(), y_ref) and (not dN.sell_narrow or nar == 1)
-            got[nar] = (K.spmv_dot(dN, dx, dy), K.spmv_dot2(dN, dx, dy))
-        assert got[0] == got[1]
+            assert np.array_equal(dy.to_host(), y_ref) and (not dN.sell_narrow or nar == 1) and dN.sell_info[0] == 1
+            got.append((K.spmv_dot(dN, dx, dy), K.spmv_dot2(dN, dx, dy)))
+        assert got[0] == got[1] == got[2]
+        ctx.set_option("spmv_sell_narrow", 0); ctx.set_option("spmv_sell_pair", 1)
         # the int32 column stream (spmv_codes = 0): its sliced form (two columns per word) against the staged CSR kernel
         ctx.set_option("spmv_codes", 0); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
         ref32 = None
-        for sell in (0, 3, 1):                       # 3: whatever the size (the default takes operators of >= 4 M entries)
-            ctx.set_option("spmv_sell", sell)
+        for sell, pair in ((0, 1), (3, 1), (3, 2), (1, 1)):     # sell 3: whatever the size (the default takes operators of >= 4 M entries); pair 2: the int32 form in 16-byte pairs too
+            ctx.set_option("spmv_sell", sell); ctx.set_option("spmv_sell_pair", pair)
             dC = K.CsrMatrix.stencil(ctx, kind, n1)
             dy = ctx.zeros(A.n); dC.matvec(dx, dy)
             assert np.array_equal(dy.to_host(), y_ref), (kind, "int32", sell)
@@ -934,6 +935,7 @@ def test_spmv_sliced_form_bit_exact(K, ctx, oracle, kind, n1):
                 assert dC.spmv_bytes_stored == 512 * total + (0 if upl else 4 * ((A.n + 63) // 64 + 1)) + 16 * A.n
             else:
                 assert dC.spmv_bytes_stored == 12 * A.nnz + 4 * (A.n + 1) + 16 * A.n
+        ctx.set_option("spmv_sell_pair", 1)
         # an operator the sliced form does not take (two-byte codes): the coded CSR stream, silently
         ctx.set_option("spmv_sell", 2); ctx.set_option("spmv_codes", 16); ctx.set_option("spmv_tiles", 0); ctx.set_option("spmv_blk_pub", 1)
         dB = K.CsrMatrix.stencil(ctx, kind, n1)
