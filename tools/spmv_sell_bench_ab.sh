@@ -10,7 +10,8 @@ o = json.loads(sys.argv[1]); r = o["roofline"]
 print(f"{sys.argv[2]:60s} {o['value']:7.2f} it/s  {o['ms_per_step']:.4f} ms/it  spmv {r['avg_ms']:.4f} ms  frac {r['frac']:.3f}  parity {o['parity']['ok']} self {o.get('self_consistency', {}).get('max_rel_dev')}")
 PY
 }
-for rep in 1 2 3; do
+for rep in 1 2; do
 run
 run --opt spmv_sell_pair=0
+run --opt spmv_sell=0
 done
